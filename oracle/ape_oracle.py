@@ -1,0 +1,439 @@
+"""CPU oracle for the arm-pose inference path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A numpy restatement of the per-frame path of wear_mocap_ape (reference cited as
+``<file>:<line>`` relative to ``/root/reference/src/wear_mocap_ape``):
+
+    window of IMU features -> z-score -> L-layer LSTM + linear head -> de-normalise
+    -> 6D-rotation -> quaternion, hips sin/cos -> quaternion, forward kinematics
+    -> 25-float joint message (quaternion averaging when there are several rows).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this module, and only as the checker / the timed CPU baseline.  The product
+package (``arm-pose-estimation_amd/``) never imports it and has no CPU fallback.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function below
+against golden vectors produced by importing the reference itself in the build
+container (``tests/golden/gen_golden.py``; the reference ships no tests or vectors of
+its own).
+
+Third-party arithmetic the reference delegates to (setup.cfg:22-30, both unpinned):
+  * ``torch.nn.LSTM`` / ``torch.nn.Linear`` (nn_models.py:169-174,188-189).  Restated here
+    from the published LSTM equations (gate order i,f,g,o; both biases added; h0=c0=0)
+    as ``lstm_forward``; ``torch_reference_model`` builds the very same torch modules
+    for the "reference-equivalent" CPU baseline (torch IS the dependency).
+  * ``numpy.linalg.eigh`` for rotation-matrix -> quaternion (transformations.py:538).
+    ``rotmat_to_quat_eigh`` keeps that route; ``rotmat_to_quat_closed`` is the
+    closed-form (Shepperd) equivalent the HIP kernel uses.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# model configurations (data_deploy/nn/<hash>/results.json of the three deployed models)
+# --------------------------------------------------------------------------------------
+LAYOUT_ORI_CAL_LARM_UARM_HIPS = 0      # 14 targets -> est[21]   (estimate_joints.py:48-71)
+LAYOUT_ORI_CAL_LARM_UARM = 1           # 12 targets -> est[14]   (estimate_joints.py:74-92)
+LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS = 2  # 20 targets -> est[21]   (estimate_joints.py:20-45)
+
+LAYOUT_NUM_TARGETS = {0: 14, 1: 12, 2: 20}
+LAYOUT_EST_WIDTH = {0: 21, 1: 14, 2: 21}
+
+MODEL_CONFIGS = {
+    # name: I, H, L, O, deployed T, target layout
+    "pocket": dict(I=22, H=256, L=2, O=14, T=6, layout=LAYOUT_ORI_CAL_LARM_UARM_HIPS),
+    "watch": dict(I=20, H=256, L=2, O=12, T=8, layout=LAYOUT_ORI_CAL_LARM_UARM),
+    "uarm": dict(I=38, H=128, L=3, O=12, T=6, layout=LAYOUT_ORI_CAL_LARM_UARM),
+}
+
+# estimator.py:57-68 with bone_map.py:42-45 defaults: [larm_vec, uarm_vec, uarm_orig_rh]
+DEFAULT_BODY = np.array([[-0.22, 0.0, 0.0, -0.26, 0.0, 0.0, -0.1704612, 0.4309841, -0.00670862]])
+
+
+# --------------------------------------------------------------------------------------
+# weights: seeded synthetic state_dict in the reference's key layout (nn_models.py:160-178)
+# --------------------------------------------------------------------------------------
+def state_dict_keys(L: int) -> List[str]:
+    keys = []
+    for k in range(L):
+        keys += [f"lstm.weight_ih_l{k}", f"lstm.weight_hh_l{k}", f"lstm.bias_ih_l{k}", f"lstm.bias_hh_l{k}"]
+    keys += ["output_layer.weight", "output_layer.bias"]
+    return keys
+
+
+def make_state_dict(I: int, H: int, L: int, O: int, seed: int) -> Dict[str, np.ndarray]:
+    """Uniform(-1/sqrt(H), 1/sqrt(H)) float32 tensors drawn from numpy's PCG64 stream
+    (platform-stable), in ``state_dict_keys`` order.  The trained checkpoints are absent
+    from the reference snapshot (.MISSING_LARGE_BLOBS), so parity is defined on
+    (weights, window) -> outputs with these weights."""
+    rng = np.random.default_rng(seed)
+    bound = 1.0 / math.sqrt(H)
+    shapes = {}
+    for k in range(L):
+        shapes[f"lstm.weight_ih_l{k}"] = (4 * H, I if k == 0 else H)
+        shapes[f"lstm.weight_hh_l{k}"] = (4 * H, H)
+        shapes[f"lstm.bias_ih_l{k}"] = (4 * H,)
+        shapes[f"lstm.bias_hh_l{k}"] = (4 * H,)
+    shapes["output_layer.weight"] = (O, H)
+    shapes["output_layer.bias"] = (O,)
+    sd = {}
+    for key in state_dict_keys(L):
+        sd[key] = rng.uniform(-bound, bound, size=shapes[key]).astype(np.float32)
+    return sd
+
+
+def state_dict_digest(sd: Dict[str, np.ndarray]) -> np.ndarray:
+    """float64 [n_keys, 3]: (sum, sum of squares, first element) per tensor -- stored with
+    the goldens so a test can prove it regenerated the very same weights."""
+    rows = []
+    for key in sorted(sd):
+        a = np.asarray(sd[key], dtype=np.float64)
+        rows.append([a.sum(), np.square(a).sum(), a.reshape(-1)[0]])
+    return np.array(rows)
+
+
+# --------------------------------------------------------------------------------------
+# LSTM + head (nn_models.py:180-189; torch.nn.LSTM equations)
+# --------------------------------------------------------------------------------------
+def _sigmoid(v):
+    return 1.0 / (1.0 + np.exp(-v))
+
+
+def lstm_forward(sd: Dict[str, np.ndarray], x: np.ndarray,
+                 masks: Optional[Sequence[np.ndarray]] = None,
+                 dtype=np.float32) -> np.ndarray:
+    """x [B,T,I] -> y [B,T,O].  Zero initial state per call (nn_models.py:188 with hs=None).
+
+    ``masks``: optional list of L-1 arrays [B,T,H] multiplied onto the output sequence of
+    layers 0..L-2 (already holding 0 or 1/(1-p)) -- inter-layer dropout of
+    ``torch.nn.LSTM(dropout=p)`` in train mode, which is what
+    ``monte_carlo_predictions`` switches on (nn_models.py:204)."""
+    L = sum(1 for k in sd if k.startswith("lstm.weight_ih_l"))
+    seq = np.asarray(x, dtype=dtype)
+    B, T, _ = seq.shape
+    for k in range(L):
+        w_ih = sd[f"lstm.weight_ih_l{k}"].astype(dtype)
+        w_hh = sd[f"lstm.weight_hh_l{k}"].astype(dtype)
+        b_ih = sd[f"lstm.bias_ih_l{k}"].astype(dtype)
+        b_hh = sd[f"lstm.bias_hh_l{k}"].astype(dtype)
+        H = w_hh.shape[1]
+        h = np.zeros((B, H), dtype=dtype)
+        c = np.zeros((B, H), dtype=dtype)
+        out = np.empty((B, T, H), dtype=dtype)
+        for t in range(T):
+            pre = (seq[:, t, :] @ w_ih.T + b_ih) + (h @ w_hh.T + b_hh)
+            gi = _sigmoid(pre[:, 0 * H:1 * H])
+            gf = _sigmoid(pre[:, 1 * H:2 * H])
+            gg = np.tanh(pre[:, 2 * H:3 * H])
+            go = _sigmoid(pre[:, 3 * H:4 * H])
+            c = gf * c + gi * gg
+            h = go * np.tanh(c)
+            out[:, t, :] = h
+        if masks is not None and k < L - 1:
+            out = out * np.asarray(masks[k], dtype=dtype)
+        seq = out
+    w_o = sd["output_layer.weight"].astype(dtype)
+    b_o = sd["output_layer.bias"].astype(dtype)
+    return seq @ w_o.T + b_o
+
+
+def torch_reference_model(sd: Dict[str, np.ndarray], dropout: float = 0.2):
+    """The third-party modules the reference instantiates (nn_models.py:169-174):
+    ``torch.nn.LSTM(I,H,L,batch_first=True,dropout)`` + ``torch.nn.Linear(H,O)``, loaded
+    with ``sd``.  Returns ``f(x_f32[B,T,I]) -> y[B,T,O]`` running on torch-CPU in eval mode.
+    Used as the "reference-equivalent" CPU baseline in bench.py."""
+    import torch
+
+    L = sum(1 for k in sd if k.startswith("lstm.weight_ih_l"))
+    H = sd["lstm.weight_hh_l0"].shape[1]
+    I = sd["lstm.weight_ih_l0"].shape[1]
+    O = sd["output_layer.weight"].shape[0]
+    lstm = torch.nn.LSTM(I, hidden_size=H, num_layers=L, batch_first=True, dropout=dropout if L > 1 else 0.0)
+    head = torch.nn.Linear(H, O)
+    with torch.no_grad():
+        for k in range(L):
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                getattr(lstm, f"{nm}_l{k}").copy_(torch.from_numpy(sd[f"lstm.{nm}_l{k}"]))
+        head.weight.copy_(torch.from_numpy(sd["output_layer.weight"]))
+        head.bias.copy_(torch.from_numpy(sd["output_layer.bias"]))
+    lstm.eval()
+    head.eval()
+
+    def run(x: np.ndarray) -> np.ndarray:
+        with torch.no_grad():
+            seq, _ = lstm(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)))
+            return head(seq).numpy()
+
+    return run
+
+
+# --------------------------------------------------------------------------------------
+# quaternion / rotation algebra (utility/transformations.py), batched over rows
+# --------------------------------------------------------------------------------------
+def quat_mul(p: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """Hamilton product of [...,4] arrays, [w,x,y,z] (transformations.py:129-149)."""
+    pw, px, py, pz = np.moveaxis(np.asarray(p, dtype=np.float64), -1, 0)
+    qw, qx, qy, qz = np.moveaxis(np.asarray(q, dtype=np.float64), -1, 0)
+    return np.stack([
+        pw * qw - px * qx - py * qy - pz * qz,
+        pw * qx + px * qw + py * qz - pz * qy,
+        pw * qy - px * qz + py * qw + pz * qx,
+        pw * qz + px * qy - py * qx + pz * qw,
+    ], axis=-1)
+
+
+def quat_rotate(q: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """v' = vector part of q (0,v) q*  (transformations.py:83-126).  q [...,4], v [...,3]
+    broadcast against each other."""
+    q = np.asarray(q, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    batch = np.broadcast_shapes(q.shape[:-1], v.shape[:-1])
+    q = np.broadcast_to(q, batch + (4,))
+    pure = np.concatenate([np.zeros(batch + (1,)), np.broadcast_to(v, batch + (3,))], axis=-1)
+    conj = q * np.array([1.0, -1.0, -1.0, -1.0])
+    return quat_mul(quat_mul(q, pure), conj)[..., 1:]
+
+
+def six_drr_to_rotmat(s: np.ndarray) -> np.ndarray:
+    """[N,6] = [m11,m12,m21,m22,m31,m32] -> [N,9] row-major R whose columns are the
+    Gram-Schmidt basis b1,b2,b3 (transformations.py:602-637).  No zero-norm guard, as in
+    the reference: a degenerate input yields NaN."""
+    s = np.asarray(s, dtype=np.float64)
+    a1 = s[:, [0, 2, 4]]
+    a2 = s[:, [1, 3, 5]]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        b1 = a1 / np.linalg.norm(a1, axis=1, keepdims=True)
+        u2 = a2 - np.sum(b1 * a2, axis=1, keepdims=True) * b1
+        b2 = u2 / np.linalg.norm(u2, axis=1, keepdims=True)
+    b3 = np.cross(b1, b2, axis=1)
+    return np.stack([b1[:, 0], b2[:, 0], b3[:, 0],
+                     b1[:, 1], b2[:, 1], b3[:, 1],
+                     b1[:, 2], b2[:, 2], b3[:, 2]], axis=1)
+
+
+def rotmat_to_quat_eigh(r9: np.ndarray) -> np.ndarray:
+    """Reference route (transformations.py:521-545,575-584): per row, the eigenvector of the
+    largest eigenvalue of the symmetric 4x4 K/3 matrix (lower triangle filled), reordered
+    to [w,x,y,z], sign flipped so that w >= 0.  numpy.linalg.eigh does the arithmetic."""
+    r9 = np.asarray(r9, dtype=np.float64)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = r9.T
+    z = np.zeros_like(m00)
+    k = np.stack([
+        np.stack([m00 - m11 - m22, z, z, z], axis=-1),
+        np.stack([m01 + m10, m11 - m00 - m22, z, z], axis=-1),
+        np.stack([m02 + m20, m12 + m21, m22 - m00 - m11, z], axis=-1),
+        np.stack([m21 - m12, m02 - m20, m10 - m01, m00 + m11 + m22], axis=-1),
+    ], axis=-2) / 3.0
+    out = np.empty((r9.shape[0], 4))
+    for n in range(r9.shape[0]):  # one LAPACK call per row, like the reference
+        vals, vecs = np.linalg.eigh(k[n])
+        q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+        out[n] = -q if q[0] < 0 else q
+    return out
+
+
+def rotmat_to_quat_closed(r9: np.ndarray) -> np.ndarray:
+    """Closed-form equivalent for proper rotation matrices (what the HIP kernel computes):
+    pick the largest of (trace, m00, m11, m22) as the pivot (Shepperd), then flip to w >= 0."""
+    r9 = np.asarray(r9, dtype=np.float64)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = r9.T
+    tr = m00 + m11 + m22
+    out = np.empty((r9.shape[0], 4))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for n in range(r9.shape[0]):
+            cand = (tr[n], m00[n], m11[n], m22[n])
+            p = int(np.argmax(cand)) if not np.any(np.isnan(cand)) else 0
+            if p == 0:
+                s = math.sqrt(tr[n] + 1.0) * 2.0 if tr[n] + 1.0 >= 0 else float("nan")
+                q = (0.25 * s, (m21[n] - m12[n]) / s, (m02[n] - m20[n]) / s, (m10[n] - m01[n]) / s)
+            elif p == 1:
+                s = math.sqrt(1.0 + m00[n] - m11[n] - m22[n]) * 2.0
+                q = ((m21[n] - m12[n]) / s, 0.25 * s, (m01[n] + m10[n]) / s, (m02[n] + m20[n]) / s)
+            elif p == 2:
+                s = math.sqrt(1.0 + m11[n] - m00[n] - m22[n]) * 2.0
+                q = ((m02[n] - m20[n]) / s, (m01[n] + m10[n]) / s, 0.25 * s, (m12[n] + m21[n]) / s)
+            else:
+                s = math.sqrt(1.0 + m22[n] - m00[n] - m11[n]) * 2.0
+                q = ((m10[n] - m01[n]) / s, (m02[n] + m20[n]) / s, (m12[n] + m21[n]) / s, 0.25 * s)
+            q = np.array(q)
+            out[n] = -q if q[0] < 0 else q
+    return out
+
+
+def six_drr_to_quat(s: np.ndarray, route: str = "eigh") -> np.ndarray:
+    """transformations.py:471-473."""
+    r9 = six_drr_to_rotmat(s)
+    return rotmat_to_quat_eigh(r9) if route == "eigh" else rotmat_to_quat_closed(r9)
+
+
+def hips_sin_cos_to_quat(sn: np.ndarray, cs: np.ndarray) -> np.ndarray:
+    """y = atan2(sin, cos); quaternion of a pure y rotation = [cos(y/2), 0, sin(y/2), 0]
+    (transformations.py:177-179 through the general euler formula :152-174 with x=z=0)."""
+    y = np.arctan2(np.asarray(sn, dtype=np.float64), np.asarray(cs, dtype=np.float64))
+    half = 0.5 * y
+    zero = np.zeros_like(half)
+    return np.stack([np.cos(half), zero, np.sin(half), zero], axis=-1)
+
+
+def average_quaternions(qs: np.ndarray) -> np.ndarray:
+    """Sign-aligned mean (transformations.py:32-51): row 0 is the reference direction, a row
+    whose dot product with it is < 0.0 is subtracted instead of added; weights 1/N;
+    rows accumulated in order; result normalised."""
+    qs = np.asarray(qs, dtype=np.float64)
+    w = 1 / len(qs)
+    acc = qs[0] * w
+    for row in qs[1:]:
+        acc = acc + row * (-w if float(np.dot(row, qs[0])) < 0.0 else w)
+    return acc / np.linalg.norm(acc)
+
+
+# --------------------------------------------------------------------------------------
+# forward kinematics: NN targets -> est rows (estimate/estimate_joints.py)
+# --------------------------------------------------------------------------------------
+def arm_pose_from_targets(preds: np.ndarray, body: np.ndarray, layout: int, route: str = "eigh") -> np.ndarray:
+    """estimate_joints.py:16-17 dispatch.  preds f64 [N,O]; body [1,9] =
+    [larm_vec, uarm_vec, uarm_orig_rh]; returns est [N, 21 | 14 | 21]."""
+    preds = np.asarray(preds, dtype=np.float64)
+    body = np.asarray(body, dtype=np.float64).reshape(1, 9)
+    larm_vec, uarm_vec, uarm_orig_rh = body[:, 0:3], body[:, 3:6], body[:, 6:9]
+    if layout == LAYOUT_ORI_CAL_LARM_UARM_HIPS:          # estimate_joints.py:48-71
+        uarm_q = six_drr_to_quat(preds[:, 6:12], route)
+        larm_q = six_drr_to_quat(preds[:, 0:6], route)
+        hips_q = hips_sin_cos_to_quat(preds[:, 12], preds[:, 13])
+        uarm_o = quat_rotate(hips_q, uarm_orig_rh)
+        larm_o = quat_rotate(uarm_q, uarm_vec) + uarm_o
+        hand_o = quat_rotate(larm_q, larm_vec) + larm_o
+        return np.concatenate([hand_o, larm_o, uarm_o, larm_q, uarm_q, hips_q], axis=1)
+    if layout == LAYOUT_ORI_CAL_LARM_UARM:               # estimate_joints.py:74-92
+        uarm_q = six_drr_to_quat(preds[:, 6:12], route)
+        larm_q = six_drr_to_quat(preds[:, 0:6], route)
+        larm_o = quat_rotate(uarm_q, uarm_vec) + uarm_orig_rh
+        hand_o = quat_rotate(larm_q, larm_vec) + larm_o
+        return np.concatenate([hand_o, larm_o, larm_q, uarm_q], axis=1)
+    if layout == LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS:      # estimate_joints.py:20-45
+        uarm_q = six_drr_to_quat(preds[:, 12:18], route)
+        larm_q = six_drr_to_quat(preds[:, 3:9], route)
+        hips_q = hips_sin_cos_to_quat(preds[:, 18], preds[:, 19])
+        uarm_o = quat_rotate(hips_q, uarm_orig_rh)
+        return np.concatenate([preds[:, 0:3], preds[:, 9:12], uarm_o, larm_q, uarm_q, hips_q], axis=1)
+    raise KeyError(layout)
+
+
+# --------------------------------------------------------------------------------------
+# message composition: est rows -> 25 floats (estimate/compose_msg.py)
+# --------------------------------------------------------------------------------------
+def msg_from_est(est: np.ndarray, body: np.ndarray, layout: int) -> np.ndarray:
+    """compose_msg.py:13-14 dispatch.  Output layout (bit-exact bookkeeping):
+    [0:4] hand rot (= lower-arm quaternion, duplicated), [4:7] hand origin, [7:11] lower-arm
+    rot, [11:14] lower-arm origin, [14:18] upper-arm rot, [18:21] upper-arm origin,
+    [21:25] hips rot."""
+    est = np.asarray(est, dtype=np.float64)
+    body = np.asarray(body, dtype=np.float64).reshape(1, 9)
+    larm_vec, uarm_vec, uarm_orig_rh = body[0, 0:3], body[0, 3:6], body[0, 6:9]
+    many = est.shape[0] > 1
+    if layout == LAYOUT_ORI_CAL_LARM_UARM_HIPS:          # compose_msg.py:48-79
+        if many:
+            hips_q = average_quaternions(est[:, 17:21])
+            larm_q = average_quaternions(est[:, 9:13])
+            uarm_q = average_quaternions(est[:, 13:17])
+            uarm_o = quat_rotate(hips_q, uarm_orig_rh)
+            larm_o = quat_rotate(uarm_q, uarm_vec) + uarm_o
+            hand_o = quat_rotate(larm_q, larm_vec) + larm_o
+        else:
+            hand_o, larm_o, uarm_o = est[0, 0:3], est[0, 3:6], est[0, 6:9]
+            larm_q, uarm_q, hips_q = est[0, 9:13], est[0, 13:17], est[0, 17:21]
+    elif layout == LAYOUT_ORI_CAL_LARM_UARM:             # compose_msg.py:82-108
+        if many:
+            larm_q = average_quaternions(est[:, 6:10])
+            uarm_q = average_quaternions(est[:, 10:14])
+            larm_o = quat_rotate(uarm_q, uarm_vec) + uarm_orig_rh
+            hand_o = quat_rotate(larm_q, larm_vec) + larm_o
+        else:
+            hand_o, larm_o = est[0, 0:3], est[0, 3:6]
+            larm_q, uarm_q = est[0, 6:10], est[0, 10:14]
+        uarm_o = uarm_orig_rh
+        hips_q = np.array([1.0, 0.0, 0.0, 0.0])
+    elif layout == LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS:    # compose_msg.py:17-45
+        if many:
+            hips_q = average_quaternions(est[:, 17:21])
+            larm_q = average_quaternions(est[:, 9:13])
+            uarm_q = average_quaternions(est[:, 13:17])
+            uarm_o = est[:, 6:9].mean(axis=0)
+            larm_o = est[:, 3:6].mean(axis=0)
+            hand_o = est[:, 0:3].mean(axis=0)
+        else:
+            hand_o, larm_o, uarm_o = est[0, 0:3], est[0, 3:6], est[0, 6:9]
+            larm_q, uarm_q, hips_q = est[0, 9:13], est[0, 13:17], est[0, 17:21]
+    else:
+        raise KeyError(layout)
+    return np.concatenate([larm_q, hand_o, larm_q, larm_o, uarm_q, uarm_o, hips_q])
+
+
+def msg_with_mc_samples(msg: np.ndarray, est: np.ndarray, add_mc_samples: bool):
+    """estimator.py:130-137: with ``add_mc_samples`` the message becomes a python list and,
+    when there is more than one est row, every row's first six values (hand xyz, elbow
+    xyz) are appended -> length 25 + 6 N."""
+    if not add_mc_samples:
+        return msg
+    out = list(msg)
+    if est.shape[0] > 1:
+        for row in est:
+            out += list(row[:6])
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# window / smoothing bookkeeping (estimate/estimator.py:93-120)
+# --------------------------------------------------------------------------------------
+class WindowOracle:
+    """Sliding feature window and smoothing stack of ``Estimator``.
+
+    ``predict(xx_hist_normalised[T,I]) -> [n,O]`` is supplied by the caller (the model)."""
+
+    def __init__(self, seq_len: int, smooth: int, stats: Optional[dict], predict):
+        self.seq_len = max(1, seq_len)       # estimator.py:54
+        self.smooth = max(1, smooth)         # estimator.py:45
+        self.stats = stats
+        self.predict = predict
+        self.rows: List[np.ndarray] = []
+        self.preds: List[np.ndarray] = []
+
+    def reset(self):                         # estimator.py:88-91
+        self.rows, self.preds = [], []
+
+    def push(self, xx: np.ndarray) -> np.ndarray:
+        self.rows.append(xx)
+        while len(self.rows) < self.seq_len:      # cold start: pad with the NEWEST row (:96-97)
+            self.rows.append(xx)
+        del self.rows[:len(self.rows) - self.seq_len]   # trim oldest (:99-100)
+        hist = np.vstack(self.rows)
+        if self.stats is not None:                # f64 z-score (:103-104)
+            hist = (hist - self.stats["xx_m"]) / self.stats["xx_s"]
+        pred = self.predict(hist)
+        if self.stats is not None:                # f64 de-normalise (:108-109)
+            pred = pred * self.stats["yy_s"] + self.stats["yy_m"]
+        if self.smooth > 1:                       # smoothing stack (:112-118)
+            self.preds.append(pred)
+            while len(self.preds) < self.smooth:
+                self.preds.append(pred)
+            del self.preds[:len(self.preds) - self.smooth]
+            pred = np.vstack(self.preds)
+        return pred
+
+
+# --------------------------------------------------------------------------------------
+# whole batched path, as the HIP boundary exposes it
+# --------------------------------------------------------------------------------------
+def infer_windows(sd, stats, body, layout, x_raw: np.ndarray, route: str = "closed", use_torch: bool = False):
+    """x_raw f32 [B,T,I] (un-normalised features) -> (y f32 [B,O] normalised NN targets of the
+    last step, est f64 [B,W]).  dtype ladder as SURVEY appendix B.5: z-score in f64, cast
+    to f32, model in f32, de-normalise + FK in f64."""
+    xn = ((np.asarray(x_raw, dtype=np.float64) - stats["xx_m"]) / stats["xx_s"]).astype(np.float32)
+    y_all = torch_reference_model(sd)(xn) if use_torch else lstm_forward(sd, xn)
+    y = np.ascontiguousarray(y_all[:, -1, :])
+    pred = y.astype(np.float64) * stats["yy_s"] + stats["yy_m"]
+    est = arm_pose_from_targets(pred, body, layout, route)
+    return y, est

@@ -1,0 +1,50 @@
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parents[1]
+GOLDEN = REPO / "tests" / "golden"
+# the product package lives in a src-style directory, like the reference's src/wear_mocap_ape
+for p in (str(REPO), str(REPO / "arm-pose-estimation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(GOLDEN / name, allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def norm_stats():
+    import json
+    raw = json.loads((GOLDEN / "norm_stats.json").read_text())
+    return {k: {kk: np.array(vv) if kk[:2] in ("xx", "yy") else vv for kk, vv in v.items()} for k, v in raw.items()}

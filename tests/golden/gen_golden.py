@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen_golden.py
+
+What it does
+  * imports ``wear_mocap_ape`` from /root/reference/src (read-only);
+  * ``aenum`` (setup.cfg:23) is not installed here, so ``utility/names.py`` cannot import; an
+    in-process stand-in for ``aenum.Enum`` / ``aenum.NoAlias`` (recipe of SURVEY.md appendix A:
+    an ``enum.Enum`` whose class dict ignores ``_settings_``) is registered first.  It carries no
+    arithmetic; transformations.py and nn_models.py import without it;
+  * the trained checkpoints are absent (.MISSING_LARGE_BLOBS), so models are built from
+    results.json and loaded with the seeded synthetic weights of ``oracle.make_state_dict``
+    (numpy PCG64, platform-stable); tests regenerate the same weights from the seed and
+    compare ``state_dict_digest``;
+  * writes inputs + the reference's outputs as .npz/.json fixtures (data only).
+
+Also exports the three normalisation-stat pickles and the fields of the three results.json
+that the loader uses into the product package's ``data_deploy`` (model/config data).
+"""
+import enum
+import json
+import os
+import pickle
+import sys
+import types
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[2]
+REF_SRC = Path("/root/reference/src")
+OUT = REPO / "tests" / "golden"
+PKG_DEPLOY = REPO / "arm-pose-estimation_amd" / "wear_mocap_ape_amd" / "data_deploy"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REF_SRC))
+sys.path.insert(0, str(REPO))
+
+
+# ---- stand-in for the missing `aenum` dependency (no arithmetic) ------------------------
+class _IgnoreSettingsDict(enum._EnumDict):
+    def __setitem__(self, key, value):
+        if key == "_settings_":
+            return
+        super().__setitem__(key, value)
+
+
+class _Meta(enum.EnumMeta):
+    @classmethod
+    def __prepare__(mcs, cls, bases, **kw):
+        base = super().__prepare__(cls, bases, **kw)
+        d = _IgnoreSettingsDict()
+        d.__dict__.update(base.__dict__)
+        for k, v in base.items():
+            dict.__setitem__(d, k, v)
+        return d
+
+
+class _Enum(enum.Enum, metaclass=_Meta):
+    pass
+
+
+_m = types.ModuleType("aenum")
+_m.Enum = _Enum
+_m.NoAlias = object()
+sys.modules["aenum"] = _m
+
+import torch  # noqa: E402
+
+from oracle import ape_oracle as orc  # noqa: E402
+import wear_mocap_ape.config as ref_config  # noqa: E402
+import wear_mocap_ape.estimate.nn_models as ref_nn  # noqa: E402
+import wear_mocap_ape.utility.transformations as ref_ts  # noqa: E402
+from wear_mocap_ape.data_deploy.nn import deploy_models as ref_deploy  # noqa: E402
+from wear_mocap_ape.estimate import compose_msg as ref_msg  # noqa: E402
+from wear_mocap_ape.estimate import estimate_joints as ref_fk  # noqa: E402
+from wear_mocap_ape.utility import data_stats as ref_stats  # noqa: E402
+from wear_mocap_ape.utility.names import NNS_INPUTS, NNS_TARGETS  # noqa: E402
+
+HASHES = {
+    "pocket": ref_deploy.LSTM.WATCH_PHONE_POCKET.value,
+    "watch": ref_deploy.LSTM.WATCH_ONLY.value,
+    "uarm": ref_deploy.LSTM.WATCH_PHONE_UARM.value,
+}
+LAYOUT_OF = {
+    "ORI_CAL_LARM_UARM_HIPS": orc.LAYOUT_ORI_CAL_LARM_UARM_HIPS,
+    "ORI_CAL_LARM_UARM": orc.LAYOUT_ORI_CAL_LARM_UARM,
+    "ORI_POS_CAL_LARM_UARM_HIPS": orc.LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS,
+}
+
+
+def ref_params(name):
+    p = Path(ref_config.PATHS["deploy"]) / "nn" / HASHES[name] / "results.json"
+    return json.loads(p.read_text())
+
+
+def ref_model(name, seed, dropout=None):
+    """reference DropoutLSTM (nn_models.py:160) with the oracle's seeded weights."""
+    p = ref_params(name)
+    assert p["model"] == "DropoutLSTM"
+    model = ref_nn.DropoutLSTM(input_size=len(p["x_inputs_v"]), hidden_layer_size=p["hidden_layer_size"],
+                               hidden_layer_count=p["hidden_layer_count"], output_size=len(p["y_targets_v"]),
+                               dropout=p["dropout"] if dropout is None else dropout)
+    sd = orc.make_state_dict(len(p["x_inputs_v"]), p["hidden_layer_size"], p["hidden_layer_count"],
+                             len(p["y_targets_v"]), seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return model.eval(), p, sd
+
+
+def rand_unit_quats(rng, n):
+    q = rng.normal(size=(n, 4))
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+# ---- 1. norm stats + model config export ------------------------------------------------
+def export_stats_and_configs():
+    stats_out = {}
+    for name in HASHES:
+        p = ref_params(name)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            st = ref_stats.get_norm_stats(NNS_INPUTS[p["x_inputs_n"]], NNS_TARGETS[p["y_targets_n"]])
+        fname = f"{p['x_inputs_n']}_{p['y_targets_n']}.json"
+        plain = {k: np.asarray(st[k], dtype=np.float64).tolist() for k in ("xx_m", "xx_s", "yy_m", "yy_s")}
+        plain["x_inputs"] = list(NNS_INPUTS[p["x_inputs_n"]].value)
+        plain["y_targets"] = list(NNS_TARGETS[p["y_targets_n"]].value)
+        (PKG_DEPLOY / "data_stats").mkdir(parents=True, exist_ok=True)
+        (PKG_DEPLOY / "data_stats" / fname).write_text(json.dumps(plain, indent=1))
+        stats_out[name] = plain
+        keep = ("model", "hidden_layer_count", "hidden_layer_size", "dropout", "sequence_len", "normalize",
+                "hash", "y_targets_n", "x_inputs_n", "y_targets_v", "x_inputs_v")
+        d = PKG_DEPLOY / "nn" / HASHES[name]
+        d.mkdir(parents=True, exist_ok=True)
+        (d / "results.json").write_text(json.dumps({k: p[k] for k in keep}, indent=1))
+    (OUT / "norm_stats.json").write_text(json.dumps(stats_out, indent=1))
+    return stats_out
+
+
+# ---- 2. LSTM forward goldens ------------------------------------------------------------
+def gen_lstm(stats):
+    for name, cfg in orc.MODEL_CONFIGS.items():
+        blob = {}
+        for seed in (0, 1):
+            model, p, sd = ref_model(name, seed)
+            blob[f"digest_seed{seed}"] = orc.state_dict_digest(sd)
+            rng = np.random.default_rng(100 + seed)
+            for (B, T) in ((1, cfg["T"]), (5, cfg["T"]), (3, 64), (2, 1)):
+                x = rng.normal(size=(B, T, cfg["I"])).astype(np.float32)
+                with torch.no_grad():
+                    y = model(torch.from_numpy(x)).numpy()
+                blob[f"x_seed{seed}_B{B}_T{T}"] = x
+                blob[f"y_seed{seed}_B{B}_T{T}"] = y
+        np.savez_compressed(OUT / f"lstm_{name}.npz", **blob)
+
+
+# ---- 3. quaternion primitive goldens ------------------------------------------------------
+def edge_six_drr(rng, n):
+    """6D rows that stress the Gram-Schmidt / quaternion branches."""
+    rows = []
+    # exact rotation matrices of random quaternions, incl. rotations by ~pi (w ~ 0)
+    q = rand_unit_quats(rng, n)
+    q[: n // 4, 0] *= 1e-9
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    r9 = ref_ts.quat_to_rot_mat_1x9(q)
+    rows.append(r9[:, [0, 1, 3, 4, 6, 7]])
+    # un-normalised, non-orthogonal network-like outputs
+    rows.append(rng.normal(size=(n, 6)))
+    # nearly parallel columns
+    a = rng.normal(size=(n, 3))
+    b = a * rng.uniform(0.5, 2.0, size=(n, 1)) + 1e-4 * rng.normal(size=(n, 3))
+    rows.append(np.stack([a[:, 0], b[:, 0], a[:, 1], b[:, 1], a[:, 2], b[:, 2]], axis=1))
+    # axis-aligned: identity and 180-degree flips (trace = -1 pivots)
+    for diag in ((1, 1, 1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1)):
+        rows.append(np.array([[diag[0], 0, 0, diag[1], 0, 0]], dtype=np.float64))
+    rows.append(np.array([[0, 1, 0, 0, 1, 0.0], [0, 0, 1, 0, 0, 1.0], [0, -1, 1, 0, 0, 0.0]]))
+    return np.vstack(rows)
+
+
+def gen_quat_ops():
+    rng = np.random.default_rng(7)
+    six = edge_six_drr(rng, 40)
+    r9 = ref_ts.six_drr_1x6_to_rot_mat_1x9(six)
+    quat = ref_ts.rot_mat_1x9_to_quat(r9)
+    a, b = rand_unit_quats(rng, 50), rng.normal(size=(50, 4))
+    v = rng.normal(size=(50, 3))
+    sn, cs = rng.normal(size=60), rng.normal(size=60)
+    sn[:6] = [0.0, 0.0, 1e-300, -1e-12, 0.0, 1.0]
+    cs[:6] = [0.0, -1.0, 1e-300, -1.0, 1.0, 0.0]
+    avg_sets = []
+    for n in (2, 5, 60, 300):
+        base = rand_unit_quats(rng, 1)
+        qs = base + 0.2 * rng.normal(size=(n, 4))
+        qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+        qs[1::3] *= -1.0          # antipodal duplicates exercise the sign alignment
+        avg_sets.append(qs)
+    blob = dict(
+        six=six, rotmat=r9, quat=quat,
+        ham_a=a, ham_b=b, ham=ref_ts.hamilton_product(a, b),
+        rot_q=a, rot_v=v, rot_out=ref_ts.quat_rotate_vector(a, v),
+        rot_single_v=v[0], rot_single_out=ref_ts.quat_rotate_vector(a, v[0]),
+        hips_sin=sn, hips_cos=cs, hips_quat=ref_ts.hips_sin_cos_to_quat(sn, cs),
+    )
+    for i, qs in enumerate(avg_sets):
+        blob[f"avg_in_{i}"] = qs
+        blob[f"avg_out_{i}"] = ref_ts.average_quaternions(qs)
+    np.savez_compressed(OUT / "quat_ops.npz", **blob)
+
+
+# ---- 4. FK + message goldens ------------------------------------------------------------
+def gen_fk(stats):
+    rng = np.random.default_rng(11)
+    body_default = orc.DEFAULT_BODY
+    body_other = np.array([[-0.25, 0.0, 0.0, -0.3, 0.0, 0.0, -0.18, 0.45, 0.01]])
+    for tname, layout in LAYOUT_OF.items():
+        O = orc.LAYOUT_NUM_TARGETS[layout]
+        tgt = NNS_TARGETS[tname]
+        blob = {}
+        for tag, body in (("bd", body_default), ("bo", body_other)):
+            for N in (1, 7, 300):
+                if layout == orc.LAYOUT_ORI_CAL_LARM_UARM_HIPS:
+                    st = stats["pocket"]
+                    preds = np.array(st["yy_m"]) + 3.0 * np.array(st["yy_s"]) * rng.uniform(-1, 1, size=(N, O))
+                elif layout == orc.LAYOUT_ORI_CAL_LARM_UARM:
+                    st = stats["watch"]
+                    preds = np.array(st["yy_m"]) + 3.0 * np.array(st["yy_s"]) * rng.uniform(-1, 1, size=(N, O))
+                else:
+                    preds = rng.normal(size=(N, O))
+                if N == 300:   # splice edge-case 6D rows and degenerate hips into the big set
+                    e = edge_six_drr(rng, 20)
+                    lo, uo = {0: (0, 6), 1: (0, 6), 2: (3, 12)}[layout]
+                    preds[: len(e), lo:lo + 6] = e
+                    preds[: len(e), uo:uo + 6] = e[::-1]
+                    if layout != orc.LAYOUT_ORI_CAL_LARM_UARM:
+                        preds[0, -2:] = 0.0
+                        preds[1, -2:] = [0.0, -1.0]
+                        preds[2, -2:] = [1e-200, 1e-200]
+                est = ref_fk.arm_pose_from_nn_targets(preds, body, tgt)
+                msg = ref_msg.msg_from_nn_targets_est(est, body, tgt)
+                blob[f"preds_{tag}_N{N}"] = preds
+                blob[f"est_{tag}_N{N}"] = est
+                blob[f"msg_{tag}_N{N}"] = np.asarray(msg, dtype=np.float64)
+            blob[f"body_{tag}"] = body
+        np.savez_compressed(OUT / f"fk_layout{layout}.npz", **blob)
+
+
+# ---- 5. streaming traces through the reference Estimator subclasses ----------------------
+def synth_rows(rng, n_frames, width, lookup):
+    rows = rng.normal(size=(n_frames, width)).astype(np.float32)
+    rows[:, lookup["sw_dt"]] = 0.02
+    for pre in ("sw_rotvec", "sw_forward", "ph_rotvec", "ph_forward"):
+        if pre + "_w" in lookup:
+            idx = [lookup[f"{pre}_{c}"] for c in "wxyz"]
+            if pre.endswith("forward"):   # calibration quaternion: constant over a recording
+                rows[:, idx] = rand_unit_quats(rng, 1).astype(np.float32)
+            else:                          # smooth-ish random walk on the sphere
+                q = rand_unit_quats(rng, 1)
+                out = []
+                for _ in range(n_frames):
+                    q = q + 0.05 * rng.normal(size=(1, 4))
+                    q /= np.linalg.norm(q)
+                    out.append(q[0])
+                rows[:, idx] = np.array(out, dtype=np.float32)
+    rows[:, lookup["sw_pres"]] = 1000.0 + rng.normal(size=n_frames).astype(np.float32)
+    rows[:, lookup["sw_init_pres"]] = 1000.5
+    return rows
+
+
+def gen_stream_traces():
+    from wear_mocap_ape.data_types import messaging
+    from wear_mocap_ape.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+
+    classes = {
+        "pocket": (WatchPhonePocketNN, messaging.WATCH_PHONE_IMU_LOOKUP),
+        "watch": (WatchOnlyNN, messaging.WATCH_ONLY_IMU_LOOKUP),
+        "uarm": (WatchPhoneUarmNN, messaging.WATCH_PHONE_IMU_LOOKUP),
+    }
+    seed = 3
+    real_loader = ref_nn.load_deployed_model_from_hash
+
+    for name, (cls, lookup) in classes.items():
+        def fake_load(hash_str, _name=name):
+            # checkpoints are absent: same class + params as nn_models.py:390-408, seeded weights,
+            # dropout=0 so that the permanent lstm.train() of nn_models.py:204 stays deterministic
+            model, p, _ = ref_model(_name, seed, dropout=0.0)
+            return model, p
+
+        ref_nn.load_deployed_model_from_hash = fake_load
+        rng = np.random.default_rng(21)
+        rows = synth_rows(rng, 20, len(lookup), lookup)
+        blob = {"rows": rows, "weights_seed": np.array(seed)}
+        for smooth, mc in ((1, 1), (5, 1), (3, 4)):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                est = cls(model_hash=HASHES[name], smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
+            xs, preds, msgs = [], [], []
+            for row in rows:
+                xx = est.parse_row_to_xx(row)
+                pred = est.add_xx_to_row_hist_and_make_prediction(xx)
+                msg = est.msg_from_pred(pred, True)
+                xs.append(np.asarray(xx, dtype=np.float64))
+                preds.append(pred)
+                msgs.append(np.asarray(msg, dtype=np.float64))
+            tag = f"s{smooth}_mc{mc}"
+            blob[f"xx_{tag}"] = np.array(xs)
+            blob[f"xx_dtype_{tag}"] = np.array(str(np.asarray(est.parse_row_to_xx(rows[0])).dtype))
+            blob[f"pred_{tag}"] = np.array(preds)
+            blob[f"msg_{tag}"] = np.array(msgs)
+            blob[f"last_msg_{tag}"] = np.asarray(est.get_last_msg(), dtype=np.float64)
+            blob["body"] = est.body_measurements
+            blob["seq_len"] = np.array(est.sequence_len)
+        np.savez_compressed(OUT / f"stream_trace_{name}.npz", **blob)
+    ref_nn.load_deployed_model_from_hash = real_loader
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    stats = export_stats_and_configs()
+    gen_lstm(stats)
+    gen_quat_ops()
+    gen_fk(stats)
+    gen_stream_traces()
+    total = sum(f.stat().st_size for f in OUT.glob("*.np*")) + (OUT / "norm_stats.json").stat().st_size
+    print("golden fixtures written to", OUT, f"({total / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

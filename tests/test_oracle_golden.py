@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/ape_oracle.py) against golden vectors produced by the reference
+itself (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import ape_oracle as orc
+
+F64_TOL = 1e-12       # f64 numpy restatement vs f64 numpy reference
+LSTM_TOL = 2e-6       # f32 cell loop vs torch.lstm (SURVEY 3.3 measured 1.1e-8 at T=6; T=64 drifts)
+
+
+def quat_close(a, b, tol, sign_free_below=1e-4):
+    """strict where |w_ref| is clear of zero; sign-aware only where the reference w ~ 0."""
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    d_plus = np.abs(a - b).max(axis=1)
+    d_minus = np.abs(a + b).max(axis=1)
+    amb = np.abs(b[:, 0]) < sign_free_below
+    d = np.where(amb, np.minimum(d_plus, d_minus), d_plus)
+    return np.nanmax(d) <= tol, float(np.nanmax(d))
+
+
+# ---------------- primitives --------------------------------------------------------------
+def test_quat_primitives(golden):
+    g = golden("quat_ops.npz")
+    assert np.allclose(orc.quat_mul(g["ham_a"], g["ham_b"]), g["ham"], rtol=0, atol=F64_TOL)
+    assert np.allclose(orc.quat_rotate(g["rot_q"], g["rot_v"]), g["rot_out"], rtol=0, atol=F64_TOL)
+    assert np.allclose(orc.quat_rotate(g["rot_q"], g["rot_single_v"]), g["rot_single_out"], rtol=0, atol=F64_TOL)
+    hq = orc.hips_sin_cos_to_quat(g["hips_sin"], g["hips_cos"])
+    assert np.allclose(hq, g["hips_quat"], rtol=0, atol=F64_TOL)
+    # atan2(0, 0) = 0 -> identity; atan2(0, -1) = pi -> [cos(pi/2), 0, 1, 0]
+    assert np.array_equal(hq[0], [1.0, 0.0, 0.0, 0.0])
+    assert abs(hq[1, 2] - 1.0) < 1e-15
+
+
+def test_six_drr_to_rotmat(golden):
+    g = golden("quat_ops.npz")
+    r = orc.six_drr_to_rotmat(g["six"])
+    assert np.array_equal(np.isnan(r), np.isnan(g["rotmat"]))     # degenerate rows stay NaN
+    assert np.allclose(r, g["rotmat"], rtol=0, atol=F64_TOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("route", ["eigh", "closed"])
+def test_rotmat_to_quat(golden, route):
+    g = golden("quat_ops.npz")
+    ok_rows = ~np.isnan(g["quat"]).any(axis=1) & ~np.isnan(g["rotmat"]).any(axis=1)
+    fn = orc.rotmat_to_quat_eigh if route == "eigh" else orc.rotmat_to_quat_closed
+    q = fn(g["rotmat"][ok_rows])
+    ok, worst = quat_close(q, g["quat"][ok_rows], 1e-9 if route == "closed" else F64_TOL)
+    assert ok, worst
+    assert (q[:, 0] >= 0).all()                                    # w >= 0 convention
+
+
+def test_average_quaternions(golden):
+    g = golden("quat_ops.npz")
+    for i in range(4):
+        out = orc.average_quaternions(g[f"avg_in_{i}"])
+        assert np.allclose(out, g[f"avg_out_{i}"], rtol=0, atol=F64_TOL)
+
+
+# ---------------- LSTM --------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_lstm_forward(golden, name):
+    g = golden(f"lstm_{name}.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    for seed in (0, 1):
+        sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed)
+        assert np.array_equal(orc.state_dict_digest(sd), g[f"digest_seed{seed}"])
+        for (B, T) in ((1, cfg["T"]), (5, cfg["T"]), (3, 64), (2, 1)):
+            x, y_ref = g[f"x_seed{seed}_B{B}_T{T}"], g[f"y_seed{seed}_B{B}_T{T}"]
+            y = orc.lstm_forward(sd, x)
+            assert y.shape == y_ref.shape == (B, T, cfg["O"])
+            assert np.abs(y - y_ref).max() < LSTM_TOL
+            if (B, T) == (5, cfg["T"]):
+                yt = orc.torch_reference_model(sd)(x)      # the third-party dependency itself
+                assert np.abs(yt - y_ref).max() == 0.0
+
+
+def test_lstm_masks_are_interlayer_only():
+    cfg = orc.MODEL_CONFIGS["uarm"]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5)
+    x = np.random.default_rng(0).normal(size=(2, 4, cfg["I"])).astype(np.float32)
+    ones = [np.ones((2, 4, cfg["H"]), np.float32)] * (cfg["L"] - 1)
+    assert np.array_equal(orc.lstm_forward(sd, x, masks=ones), orc.lstm_forward(sd, x))
+    zeros = [np.zeros((2, 4, cfg["H"]), np.float32)] * (cfg["L"] - 1)
+    y0 = orc.lstm_forward(sd, x, masks=zeros)
+    # with layer-0 output zeroed the result no longer depends on x
+    assert np.array_equal(y0, orc.lstm_forward(sd, x * 0 + 1, masks=zeros))
+
+
+# ---------------- FK + message --------------------------------------------------------------
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("route", ["eigh", "closed"])
+def test_fk_and_msg(golden, layout, route):
+    g = golden(f"fk_layout{layout}.npz")
+    W = orc.LAYOUT_EST_WIDTH[layout]
+    qcols = {0: (9, 13, 17), 1: (6, 10), 2: (9, 13, 17)}[layout]
+    tol = F64_TOL if route == "eigh" else 1e-9
+    for tag in ("bd", "bo"):
+        body = g[f"body_{tag}"]
+        for N in (1, 7, 300):
+            preds, est_ref, msg_ref = g[f"preds_{tag}_N{N}"], g[f"est_{tag}_N{N}"], g[f"msg_{tag}_N{N}"]
+            est = orc.arm_pose_from_targets(preds, body, layout, route)
+            assert est.shape == (N, W)
+            good = ~np.isnan(est_ref).any(axis=1)
+            assert np.array_equal(good, ~np.isnan(est).any(axis=1))
+            for c in qcols:
+                ok, worst = quat_close(est[good, c:c + 4], est_ref[good, c:c + 4], tol)
+                assert ok, (layout, tag, N, c, worst)
+            # origins: strict wherever no quaternion of that row is sign-ambiguous
+            clear = good & (np.abs(est_ref[:, [c for c in qcols]]) > 1e-4).all(axis=1)
+            assert np.allclose(est[clear, :qcols[0]], est_ref[clear, :qcols[0]], rtol=0, atol=tol)
+            # message from the REFERENCE est rows (isolates compose_msg bookkeeping)
+            msg = orc.msg_from_est(est_ref[good] if N > 1 else est_ref, body, layout)
+            if N == 1 or good.all():
+                assert msg.shape == (25,)
+                assert np.allclose(msg, msg_ref, rtol=0, atol=F64_TOL, equal_nan=True)
+                assert np.array_equal(msg[0:4], msg[7:11])          # hand rot duplicates larm rot
+                if layout == 1:
+                    assert np.array_equal(msg[21:25], [1.0, 0.0, 0.0, 0.0])
+                    assert np.array_equal(msg[18:21], body[0, 6:9])
+
+
+# ---------------- streaming bookkeeping -------------------------------------------------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_stream_trace(golden, norm_stats, name):
+    g = golden(f"stream_trace_{name}.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], int(g["weights_seed"]))
+    stats = norm_stats[name]
+    body = g["body"]
+    assert int(g["seq_len"]) == cfg["T"]
+    for smooth, mc in ((1, 1), (5, 1), (3, 4)):
+        tag = f"s{smooth}_mc{mc}"
+
+        def predict(hist):
+            x = np.asarray(hist, dtype=np.float32)[None]
+            y = orc.lstm_forward(sd, np.repeat(x, mc, axis=0))        # nn_models.py:206
+            return y[:, -1, :]
+
+        win = orc.WindowOracle(cfg["T"], smooth, stats, predict)
+        for f, xx in enumerate(g[f"xx_{tag}"]):
+            xx = xx.astype(np.float32) if str(g[f"xx_dtype_{tag}"]) == "float32" else xx
+            pred = win.push(xx)
+            pred_ref = g[f"pred_{tag}"][f]
+            assert pred.shape == pred_ref.shape == (max(1, smooth if smooth > 1 else 1) * mc, cfg["O"])
+            assert np.abs(pred - pred_ref).max() < 5e-6
+            est = orc.arm_pose_from_targets(pred_ref, body, cfg["layout"], "eigh")
+            msg = orc.msg_with_mc_samples(orc.msg_from_est(est, body, cfg["layout"]), est, True)
+            msg_ref = g[f"msg_{tag}"][f]
+            n_rows = pred_ref.shape[0]
+            assert len(msg) == (25 + 6 * n_rows if n_rows > 1 else 25) == len(msg_ref)
+            assert np.allclose(np.asarray(msg), msg_ref, rtol=0, atol=1e-11)
