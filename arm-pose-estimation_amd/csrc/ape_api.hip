@@ -1,0 +1,358 @@
+// C ABI of libape_hip.so (see include/ape_hip.h).  Host side: handle, weight packing, checks,
+// kernel dispatch.  No CPU fallback: every compute entry point needs a gfx950 device.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ape_hip.h"
+#include "ape_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) return fail(APE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+int layout_targets(int layout) {
+    switch (layout) {
+        case APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS: return 14;
+        case APE_LAYOUT_ORI_CAL_LARM_UARM: return 12;
+        case APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: return 20;
+    }
+    return -1;
+}
+int layout_est_width(int layout) { return layout == APE_LAYOUT_ORI_CAL_LARM_UARM ? 14 : 21; }
+
+int check_dims(const ape_dims_t* d) {
+    if (!d) return fail(APE_ERR_INVALID_ARG, "dims is NULL");
+    if (d->input_size < 1 || d->input_size > APE_MAX_INPUT)
+        return fail(APE_ERR_UNSUPPORTED, "input_size %d outside 1..%d", d->input_size, APE_MAX_INPUT);
+    if (d->hidden_size != 128 && d->hidden_size != 256)
+        return fail(APE_ERR_UNSUPPORTED, "hidden_size %d: kernels are built for 128 and 256", d->hidden_size);
+    if (d->num_layers < 1 || d->num_layers > APE_MAX_LAYERS)
+        return fail(APE_ERR_UNSUPPORTED, "num_layers %d outside 1..%d", d->num_layers, APE_MAX_LAYERS);
+    if (d->output_size < 1 || d->output_size > APE_MAX_OUTPUT)
+        return fail(APE_ERR_UNSUPPORTED, "output_size %d outside 1..%d", d->output_size, APE_MAX_OUTPUT);
+    if (d->target_layout == APE_LAYOUT_NONE) return APE_OK;      // regressor only, no post-filter
+    const int want = layout_targets(d->target_layout);
+    if (want < 0) return fail(APE_ERR_INVALID_ARG, "unknown target_layout %d", d->target_layout);
+    if (want != d->output_size)
+        return fail(APE_ERR_INVALID_ARG, "target_layout %d needs output_size %d, got %d", d->target_layout, want,
+                    d->output_size);
+    return APE_OK;
+}
+
+int padded_input(int I) { return ((I + 31) / 32) * 32; }
+
+}  // namespace
+
+struct ape_model {
+    ape_dims_t dims{};
+    int KX = 0;
+    f32x4* wpack[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+    float* bias[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+    float* w_out = nullptr;
+    float* b_out = nullptr;
+    double* stats = nullptr;       // device: xx_m[I] xx_s[I] yy_m[O] yy_s[O]
+    bool has_weights = false, has_stats = false;
+    double body[9];
+    float* y_ws = nullptr;         // [cap, O] intermediate of ape_infer
+    int y_cap = 0;
+    std::string kernel_name;
+};
+
+extern "C" {
+
+int ape_abi_version(void) { return APE_ABI_VERSION; }
+const char* ape_last_error(void) { return g_err.c_str(); }
+
+int ape_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+size_t ape_weight_blob_floats(const ape_dims_t* d) {
+    if (check_dims(d) != APE_OK) return 0;
+    const size_t H = d->hidden_size, I = d->input_size, O = d->output_size;
+    size_t n = 0;
+    for (int l = 0; l < d->num_layers; ++l) n += 4 * H * (l == 0 ? I : H) + 4 * H * H + 8 * H;
+    return n + O * H + O;
+}
+
+double ape_flops_per_window(const ape_dims_t* d, int32_t T) {
+    if (check_dims(d) != APE_OK || T < 1) return 0.0;
+    const double H = d->hidden_size, I = d->input_size, O = d->output_size;
+    double step = 0;
+    for (int l = 0; l < d->num_layers; ++l) step += 2.0 * 4.0 * H * ((l == 0 ? I : H) + H);
+    return step * T + 2.0 * O * H;
+}
+
+int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
+    if (!out) return fail(APE_ERR_INVALID_ARG, "out_model is NULL");
+    *out = nullptr;
+    if (int rc = check_dims(dims)) return rc;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(APE_ERR_NO_DEVICE, "no HIP device visible: libape_hip has no CPU fallback");
+    }
+    if (dims->device < 0 || dims->device >= n) return fail(APE_ERR_INVALID_ARG, "device %d of %d", dims->device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dims->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(APE_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dims->device,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(dims->device));
+
+    ape_model* m = new (std::nothrow) ape_model();
+    if (!m) return fail(APE_ERR_HIP, "out of host memory");
+    m->dims = *dims;
+    m->KX = padded_input(dims->input_size);
+    const double def_body[9] = {-0.22, 0, 0, -0.26, 0, 0, -0.1704612, 0.4309841, -0.00670862};  // bone_map.py:42-45
+    memcpy(m->body, def_body, sizeof(def_body));
+    const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, I = dims->input_size;
+    const int NT = 4 * (H / 64);
+    hipError_t e = hipSuccess;
+    for (int l = 0; l < L && e == hipSuccess; ++l) {
+        const size_t Q = ((l == 0 ? m->KX : H) + H) / 16;
+        e = hipMalloc((void**)&m->wpack[l], 4 * Q * NT * 64 * sizeof(f32x4));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->bias[l], 4 * H * sizeof(float));
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (2 * I + 2 * O) * sizeof(double));
+    // the kernel may carve its largest LDS layout (with dropout buffers)
+    const size_t smem = ape_lstm_tile16_smem_bytes(H, L, m->KX, O, true);
+    if (e == hipSuccess && smem <= 160 * 1024) e = ape_prepare_lstm_tile16(H, L, smem);
+    else if (e == hipSuccess) e = ape_prepare_lstm_tile16(H, L, ape_lstm_tile16_smem_bytes(H, L, m->KX, O, false));
+    if (e != hipSuccess) {
+        ape_model_destroy(m);
+        return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
+    }
+    char nm[64];
+    snprintf(nm, sizeof(nm), "ape_lstm_tile16<%d, %d>", H, L);
+    m->kernel_name = nm;
+    *out = m;
+    return APE_OK;
+}
+
+int ape_model_destroy(ape_model_t* m) {
+    if (!m) return APE_OK;
+    (void)hipSetDevice(m->dims.device);
+    for (int l = 0; l < APE_MAX_LAYERS; ++l) {
+        if (m->wpack[l]) (void)hipFree(m->wpack[l]);
+        if (m->bias[l]) (void)hipFree(m->bias[l]);
+    }
+    if (m->w_out) (void)hipFree(m->w_out);
+    if (m->b_out) (void)hipFree(m->b_out);
+    if (m->stats) (void)hipFree(m->stats);
+    if (m->y_ws) (void)hipFree(m->y_ws);
+    delete m;
+    return APE_OK;
+}
+
+int ape_model_reserve(ape_model_t* m, int32_t max_batch) {
+    if (!m || max_batch < 1) return fail(APE_ERR_INVALID_ARG, "reserve: bad arguments");
+    if (max_batch <= m->y_cap) return APE_OK;
+    HIP_TRY(hipSetDevice(m->dims.device));
+    if (m->y_ws) { HIP_TRY(hipFree(m->y_ws)); m->y_ws = nullptr; m->y_cap = 0; }
+    HIP_TRY(hipMalloc((void**)&m->y_ws, (size_t)max_batch * m->dims.output_size * sizeof(float)));
+    m->y_cap = max_batch;
+    return APE_OK;
+}
+
+// Pack [W_ih | W_hh] of one layer into the order the kernel's waves stream it:
+//   packed[((w*Q + q)*NT + n)*64 + lane][j] = Wcat[gate*H + w*H/4 + u*16 + (lane&15)][16q + 4(lane>>4) + j]
+// with n = gate*UB + u, Wcat columns = input part zero-padded to KXl, then the recurrent part.
+int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
+    if (!m || !blob) return fail(APE_ERR_INVALID_ARG, "load_weights: NULL argument");
+    const size_t want = ape_weight_blob_floats(&m->dims);
+    if (n_floats != want) return fail(APE_ERR_INVALID_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
+    HIP_TRY(hipSetDevice(m->dims.device));
+    std::vector<float> host(n_floats);
+    HIP_TRY(hipMemcpy(host.data(), blob, n_floats * sizeof(float), hipMemcpyDefault));   // host or device source
+
+    const int H = m->dims.hidden_size, L = m->dims.num_layers, O = m->dims.output_size, I = m->dims.input_size;
+    const int UB = H / 64, NT = 4 * UB;
+    const float* cur = host.data();
+    for (int l = 0; l < L; ++l) {
+        const int in_l = (l == 0) ? I : H;
+        const int KXl = (l == 0) ? m->KX : H;
+        const int Q = (KXl + H) / 16;
+        const float* w_ih = cur;  cur += (size_t)4 * H * in_l;
+        const float* w_hh = cur;  cur += (size_t)4 * H * H;
+        const float* b_ih = cur;  cur += 4 * H;
+        const float* b_hh = cur;  cur += 4 * H;
+        std::vector<float> packed((size_t)4 * Q * NT * 64 * 4);
+        for (int w = 0; w < 4; ++w)
+            for (int q = 0; q < Q; ++q)
+                for (int n = 0; n < NT; ++n) {
+                    const int gate = n / UB, u = n % UB;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = gate * H + w * (H / 4) + u * 16 + (lane & 15);
+                        float* dst = &packed[((((size_t)w * Q + q) * NT + n) * 64 + lane) * 4];
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = 16 * q + 4 * (lane >> 4) + j;
+                            float v;
+                            if (k < KXl) v = (k < in_l) ? w_ih[(size_t)row * in_l + k] : 0.0f;
+                            else v = w_hh[(size_t)row * H + (k - KXl)];
+                            dst[j] = v;
+                        }
+                    }
+                }
+        std::vector<float> bsum(4 * H);
+        for (int i = 0; i < 4 * H; ++i) bsum[i] = b_ih[i] + b_hh[i];
+        HIP_TRY(hipMemcpy(m->wpack[l], packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m->bias[l], bsum.data(), bsum.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(m->w_out, cur, (size_t)O * H * sizeof(float), hipMemcpyHostToDevice));
+    cur += (size_t)O * H;
+    HIP_TRY(hipMemcpy(m->b_out, cur, O * sizeof(float), hipMemcpyHostToDevice));
+    m->has_weights = true;
+    return APE_OK;
+}
+
+int ape_model_set_norm_stats(ape_model_t* m, const double* xx_m, const double* xx_s, const double* yy_m,
+                             const double* yy_s) {
+    if (!m || !xx_m || !xx_s || !yy_m || !yy_s) return fail(APE_ERR_INVALID_ARG, "set_norm_stats: NULL argument");
+    const int I = m->dims.input_size, O = m->dims.output_size;
+    std::vector<double> h(2 * I + 2 * O);
+    memcpy(&h[0], xx_m, I * sizeof(double));
+    memcpy(&h[I], xx_s, I * sizeof(double));
+    memcpy(&h[2 * I], yy_m, O * sizeof(double));
+    memcpy(&h[2 * I + O], yy_s, O * sizeof(double));
+    HIP_TRY(hipSetDevice(m->dims.device));
+    HIP_TRY(hipMemcpy(m->stats, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    m->has_stats = true;
+    return APE_OK;
+}
+
+int ape_model_set_body(ape_model_t* m, const double body9[9]) {
+    if (!m || !body9) return fail(APE_ERR_INVALID_ARG, "set_body: NULL argument");
+    memcpy(m->body, body9, 9 * sizeof(double));
+    return APE_OK;
+}
+
+int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+                     const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream) {
+    if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
+    if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
+    if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
+    if ((flags & APE_FLAG_NORMALIZE_INPUT) && !m->has_stats)
+        return fail(APE_ERR_NOT_READY, "lstm_forward: NORMALIZE_INPUT without norm stats");
+    if ((flags & APE_FLAG_DROPOUT_MASKS) && (flags & APE_FLAG_DROPOUT_PHILOX))
+        return fail(APE_ERR_INVALID_ARG, "lstm_forward: choose one dropout mode");
+    if ((flags & APE_FLAG_DROPOUT_MASKS) && m->dims.num_layers > 1 && !masks_dev)
+        return fail(APE_ERR_INVALID_ARG, "lstm_forward: DROPOUT_MASKS without masks");
+    if ((flags & APE_FLAG_DROPOUT_PHILOX) && !(dropout_p >= 0.0f && dropout_p < 1.0f))
+        return fail(APE_ERR_INVALID_ARG, "lstm_forward: dropout_p %f outside [0,1)", dropout_p);
+    const int H = m->dims.hidden_size, L = m->dims.num_layers;
+    const bool drop = (flags & (APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) != 0;
+    if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
+        return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
+
+    LstmParams p{};
+    p.x = x_dev;
+    p.y = y_dev;
+    for (int l = 0; l < L; ++l) { p.wpack[l] = m->wpack[l]; p.bias[l] = m->bias[l]; }
+    p.w_out = m->w_out;
+    p.b_out = m->b_out;
+    p.xx_m = m->stats;
+    p.xx_s = m->stats + m->dims.input_size;
+    p.masks = masks_dev;
+    p.B = B; p.T = T; p.I = m->dims.input_size; p.O = m->dims.output_size; p.KX = m->KX;
+    p.flags = flags;
+    p.dropout_p = dropout_p;
+    p.seed = seed;
+    hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
+    return APE_OK;
+}
+
+int ape_fk(ape_model_t* m, const void* preds_dev, int32_t preds_dtype, int32_t N, int32_t denormalize, void* est_dev,
+           int32_t est_dtype, void* stream) {
+    if (!m || !preds_dev || !est_dev) return fail(APE_ERR_INVALID_ARG, "fk: NULL argument");
+    if (N < 1) return fail(APE_ERR_INVALID_ARG, "fk: N=%d must be >= 1", N);
+    if ((preds_dtype != APE_F32 && preds_dtype != APE_F64) || (est_dtype != APE_F32 && est_dtype != APE_F64))
+        return fail(APE_ERR_INVALID_ARG, "fk: unknown dtype selector");
+    if (m->dims.target_layout == APE_LAYOUT_NONE) return fail(APE_ERR_INVALID_ARG, "fk: model has no target layout");
+    if (denormalize && !m->has_stats) return fail(APE_ERR_NOT_READY, "fk: denormalize without norm stats");
+    FkParams p{};
+    p.preds = preds_dev;
+    p.est = est_dev;
+    if (denormalize) {
+        p.yy_m = m->stats + 2 * m->dims.input_size;
+        p.yy_s = p.yy_m + m->dims.output_size;
+    }
+    memcpy(p.body, m->body, sizeof(p.body));
+    p.N = N; p.O = m->dims.output_size; p.layout = m->dims.target_layout; p.W = layout_est_width(p.layout);
+    hipError_t e = ape_launch_fk(p, preds_dtype, est_dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "fk kernel launch failed: %s", hipGetErrorString(e));
+    return APE_OK;
+}
+
+int ape_msg_reduce(ape_model_t* m, const double* est_dev, int32_t N, double* msg_dev, void* stream) {
+    if (!m || !est_dev || !msg_dev) return fail(APE_ERR_INVALID_ARG, "msg_reduce: NULL argument");
+    if (N < 1) return fail(APE_ERR_INVALID_ARG, "msg_reduce: N=%d must be >= 1", N);
+    if (m->dims.target_layout == APE_LAYOUT_NONE) return fail(APE_ERR_INVALID_ARG, "msg_reduce: model has no target layout");
+    MsgParams p{};
+    p.est = est_dev;
+    p.msg = msg_dev;
+    memcpy(p.body, m->body, sizeof(p.body));
+    p.N = N; p.layout = m->dims.target_layout; p.W = layout_est_width(p.layout);
+    hipError_t e = ape_launch_msg_reduce(p, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "msg kernel launch failed: %s", hipGetErrorString(e));
+    return APE_OK;
+}
+
+int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags, float* y_dev, void* est_dev,
+              int32_t est_dtype, void* stream) {
+    if (!m || !x_dev || !est_dev) return fail(APE_ERR_INVALID_ARG, "infer: NULL argument");
+    if (flags & (APE_FLAG_ALL_STEPS | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX))
+        return fail(APE_ERR_INVALID_ARG, "infer: only NORMALIZE_INPUT is accepted (use ape_lstm_forward + ape_fk)");
+    float* y = y_dev;
+    if (!y) {
+        if (B > m->y_cap) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing((hipStream_t)stream, &st);
+            if (st != hipStreamCaptureStatusNone)
+                return fail(APE_ERR_CAPACITY, "infer: B=%d exceeds reserved %d during stream capture", B, m->y_cap);
+            if (int rc = ape_model_reserve(m, B)) return rc;
+        }
+        y = m->y_ws;
+    }
+    if (int rc = ape_lstm_forward(m, x_dev, B, T, flags, nullptr, 0.0f, 0, y, stream)) return rc;
+    // de-normalise exactly when the inputs were normalised (estimator.py:103-109: one switch)
+    return ape_fk(m, y, APE_F32, B, (flags & APE_FLAG_NORMALIZE_INPUT) ? 1 : 0, est_dev, est_dtype, stream);
+}
+
+const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
+    (void)B; (void)T;
+    return m ? m->kernel_name.c_str() : "";
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Internal declarations shared by the C-ABI (ape_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define APE_MAX_LAYERS 3
+#define APE_MAX_INPUT 64
+#define APE_MAX_OUTPUT 32
+#define APE_TILE_ROWS 16          // windows per workgroup in the batch-tile LSTM kernel
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Kernel arguments of the batch-tile LSTM kernel (passed by value).
+struct LstmParams {
+    const float* x;                     // [B,T,I]
+    float* y;                           // [B,O] or [B,T,O]
+    const f32x4* wpack[APE_MAX_LAYERS]; // per layer: MFMA-fragment-ordered [W_ih | W_hh]
+    const float* bias[APE_MAX_LAYERS];  // per layer [4H] = b_ih + b_hh
+    const float* w_out;                 // [O,H]
+    const float* b_out;                 // [O]
+    const double* xx_m;                 // [I] (device) or nullptr
+    const double* xx_s;                 // [I]
+    const float* masks;                 // [L-1,B,T,H] or nullptr
+    int B, T, I, O;
+    int KX;                             // input width padded to a multiple of 32
+    unsigned flags;
+    float dropout_p;
+    unsigned long long seed;
+};
+
+struct FkParams {
+    const void* preds;   // [N,O] f32 or f64
+    void* est;           // [N,W] f32 or f64
+    const double* yy_m;  // [O] device, or nullptr (no de-normalisation)
+    const double* yy_s;
+    double body[9];      // larm_vec, uarm_vec, uarm_orig_rh
+    int N, O, W, layout;
+};
+
+struct MsgParams {
+    const double* est;   // [N,W]
+    double* msg;         // [25]
+    double body[9];
+    int N, W, layout;
+};
+
+// launchers implemented in the .hip files --------------------------------------------------
+// returns hipSuccess or the launch error; `smem_bytes` out for diagnostics
+hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream);
+size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout);
+hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
+hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
+hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

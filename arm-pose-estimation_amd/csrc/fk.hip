@@ -1,0 +1,265 @@
+// Quaternion / forward-kinematics post-filter kernels for gfx950.
+//
+// ape_fk_kernel      replaces estimate_joints.arm_pose_from_nn_targets (reference
+//                    estimate/estimate_joints.py:16-92) incl. utility/transformations.py:
+//                    six_drr_1x6_to_rot_mat_1x9 (:602-637), rot_mat_to_quat (:521-545),
+//                    hips_sin_cos_to_quat (:177-179), quat_rotate_vector (:83-126),
+//                    hamilton_product (:129-149); optionally the `pred*yy_s+yy_m` of
+//                    estimate/estimator.py:108-109 in front of it.
+// ape_msg_kernel     replaces compose_msg.msg_from_nn_targets_est (estimate/compose_msg.py:13-108)
+//                    incl. average_quaternions (transformations.py:32-51).
+//
+// The reference does this arithmetic in float64 (numpy), so both kernels compute in float64
+// whatever the storage type: the work is a few hundred flops per row and HBM/latency bound.
+// One thread per row; rows move HBM <-> LDS in coalesced slabs, then each thread works on its
+// own LDS row (row stride odd in 8-byte words -> conflict-free).
+//
+// rot_mat_to_quat: the reference takes the dominant eigenvector of a symmetric 4x4 matrix
+// (numpy.linalg.eigh, ~70 % of its frame time).  For the orthonormal matrices Gram-Schmidt
+// produces that eigenvector is the rotation's unit quaternion, computed here in closed form
+// with Shepperd's pivoting (largest of trace, m00, m11, m22) and the reference's w >= 0 sign
+// rule; agreement with the eigh route is ~1e-15 (tests/test_oracle_golden.py).
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+// numpy evaluates a*b+c with two roundings; keep the device arithmetic the same
+#pragma clang fp contract(off)
+
+namespace {
+
+struct Quat { double w, x, y, z; };
+struct Vec3 { double x, y, z; };
+
+__device__ __forceinline__ Quat qmul(const Quat a, const Quat b) {   // transformations.py:140-145
+    return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+                a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+                a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+
+__device__ __forceinline__ Vec3 qrot(const Quat q, const Vec3 v) {   // q (0,v) q*
+    const Quat t = qmul(q, Quat{0.0, v.x, v.y, v.z});
+    const Quat o = qmul(t, Quat{q.w, -q.x, -q.y, -q.z});
+    return Vec3{o.x, o.y, o.z};
+}
+
+// s = [m11,m12,m21,m22,m31,m32] -> unit quaternion, w >= 0.  No zero-norm guard: NaN propagates
+// exactly like the reference.
+__device__ Quat six_drr_to_quat(const double* s) {
+    const double a1x = s[0], a1y = s[2], a1z = s[4];
+    const double a2x = s[1], a2y = s[3], a2z = s[5];
+    const double n1 = sqrt(a1x * a1x + a1y * a1y + a1z * a1z);
+    const double b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const double d = b1x * a2x + b1y * a2y + b1z * a2z;
+    const double ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+    const double n2 = sqrt(ux * ux + uy * uy + uz * uz);
+    const double b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+    const double b3x = b1y * b2z - b1z * b2y;
+    const double b3y = b1z * b2x - b1x * b2z;
+    const double b3z = b1x * b2y - b1y * b2x;
+    // R = [b1 b2 b3] as columns
+    const double m00 = b1x, m01 = b2x, m02 = b3x;
+    const double m10 = b1y, m11 = b2y, m12 = b3y;
+    const double m20 = b1z, m21 = b2z, m22 = b3z;
+    const double tr = m00 + m11 + m22;
+    Quat q;
+    if (!(tr < m00) && !(tr < m11) && !(tr < m22)) {          // trace is the pivot (also the NaN path)
+        const double s4 = 2.0 * sqrt(tr + 1.0);
+        q = Quat{0.25 * s4, (m21 - m12) / s4, (m02 - m20) / s4, (m10 - m01) / s4};
+    } else if (m00 >= m11 && m00 >= m22) {
+        const double s4 = 2.0 * sqrt(1.0 + m00 - m11 - m22);
+        q = Quat{(m21 - m12) / s4, 0.25 * s4, (m01 + m10) / s4, (m02 + m20) / s4};
+    } else if (m11 >= m22) {
+        const double s4 = 2.0 * sqrt(1.0 + m11 - m00 - m22);
+        q = Quat{(m02 - m20) / s4, (m01 + m10) / s4, 0.25 * s4, (m12 + m21) / s4};
+    } else {
+        const double s4 = 2.0 * sqrt(1.0 + m22 - m00 - m11);
+        q = Quat{(m10 - m01) / s4, (m02 + m20) / s4, (m12 + m21) / s4, 0.25 * s4};
+    }
+    if (q.w < 0.0) q = Quat{-q.w, -q.x, -q.y, -q.z};           // transformations.py:543-544
+    return q;
+}
+
+__device__ __forceinline__ Quat hips_quat(double sn, double cs) {   // transformations.py:177-179
+    const double half = 0.5 * atan2(sn, cs);
+    return Quat{cos(half), 0.0, sin(half), 0.0};
+}
+
+__device__ __forceinline__ void put_q(double* d, const Quat q) { d[0] = q.w; d[1] = q.x; d[2] = q.y; d[3] = q.z; }
+__device__ __forceinline__ void put_v(double* d, const Vec3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+__device__ __forceinline__ Vec3 vadd(const Vec3 a, const Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+
+// row -> est row, shared by the batched FK kernel and the message kernel
+__device__ void fk_row(const double* pr, const double* body, int layout, double* e) {
+    const Vec3 larm_vec{body[0], body[1], body[2]};
+    const Vec3 uarm_vec{body[3], body[4], body[5]};
+    const Vec3 uarm_orig_rh{body[6], body[7], body[8]};
+    if (layout == APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS) {             // estimate_joints.py:48-71
+        const Quat uq = six_drr_to_quat(pr + 6), lq = six_drr_to_quat(pr);
+        const Quat hq = hips_quat(pr[12], pr[13]);
+        const Vec3 uo = qrot(hq, uarm_orig_rh);
+        const Vec3 lo = vadd(qrot(uq, uarm_vec), uo);
+        const Vec3 ho = vadd(qrot(lq, larm_vec), lo);
+        put_v(e, ho); put_v(e + 3, lo); put_v(e + 6, uo); put_q(e + 9, lq); put_q(e + 13, uq); put_q(e + 17, hq);
+    } else if (layout == APE_LAYOUT_ORI_CAL_LARM_UARM) {           // estimate_joints.py:74-92
+        const Quat uq = six_drr_to_quat(pr + 6), lq = six_drr_to_quat(pr);
+        const Vec3 lo = vadd(qrot(uq, uarm_vec), uarm_orig_rh);
+        const Vec3 ho = vadd(qrot(lq, larm_vec), lo);
+        put_v(e, ho); put_v(e + 3, lo); put_q(e + 6, lq); put_q(e + 10, uq);
+    } else {                                                       // estimate_joints.py:20-45
+        const Quat uq = six_drr_to_quat(pr + 12), lq = six_drr_to_quat(pr + 3);
+        const Quat hq = hips_quat(pr[18], pr[19]);
+        const Vec3 uo = qrot(hq, uarm_orig_rh);
+        e[0] = pr[0]; e[1] = pr[1]; e[2] = pr[2];
+        e[3] = pr[9]; e[4] = pr[10]; e[5] = pr[11];
+        put_v(e + 6, uo); put_q(e + 9, lq); put_q(e + 13, uq); put_q(e + 17, hq);
+    }
+}
+
+constexpr int FK_BLOCK = 256;
+constexpr int FK_STRIDE = 23;      // >= max(O=20, W=21), odd -> per-thread rows hit distinct LDS banks
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(FK_BLOCK) void ape_fk_kernel(const FkParams p) {
+    __shared__ double slab[FK_BLOCK * FK_STRIDE];
+    const int tid = threadIdx.x;
+    const size_t row0 = (size_t)blockIdx.x * FK_BLOCK;
+    const int rows = (int)min((size_t)FK_BLOCK, (size_t)p.N - row0);
+    const TIn* src = static_cast<const TIn*>(p.preds) + row0 * p.O;
+    // coalesced slab load (+ de-normalisation in f64: estimator.py:108-109)
+    for (int idx = tid; idx < rows * p.O; idx += FK_BLOCK) {
+        const int rr = idx / p.O, c = idx - rr * p.O;
+        double v = (double)src[idx];
+        if (p.yy_m) v = v * p.yy_s[c] + p.yy_m[c];
+        slab[rr * FK_STRIDE + c] = v;
+    }
+    __syncthreads();
+    if (tid < rows) {
+        double* rowp = slab + tid * FK_STRIDE;     // this thread's row: read in place, then overwritten
+        double e[21];
+        fk_row(rowp, p.body, p.layout, e);
+#pragma unroll
+        for (int c = 0; c < 21; ++c)
+            if (c < p.W) rowp[c] = e[c];
+    }
+    __syncthreads();
+    TOut* dst = static_cast<TOut*>(p.est) + row0 * p.W;
+    for (int idx = tid; idx < rows * p.W; idx += FK_BLOCK) {
+        const int rr = idx / p.W, c = idx - rr * p.W;
+        dst[idx] = (TOut)slab[rr * FK_STRIDE + c];
+    }
+}
+
+// ---- message: N est rows -> 25 doubles ------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ __launch_bounds__(256) void ape_msg_kernel(const MsgParams p) {
+    __shared__ double scratch[4];
+    const int tid = threadIdx.x;
+    const int W = p.W, N = p.N;
+    const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+    const int qc_l = hips ? 9 : 6, qc_u = hips ? 13 : 10, qc_h = 17;
+    const int nq = hips ? 3 : 2;
+
+    double out_q[3][4];
+    double orig_mean[9];
+    if (N > 1) {
+        // sign-aligned mean: sum_i sign(q_i . q_0) q_i / N, normalised (transformations.py:40-51)
+        const double wgt = 1.0 / (double)N;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < nq) {      // uniform across the block
+                const int col = (k == 0) ? qc_l : (k == 1) ? qc_u : qc_h;
+                const double* q0 = p.est + col;
+                const double r0 = q0[0], r1 = q0[1], r2 = q0[2], r3 = q0[3];
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                for (int i = tid; i < N; i += 256) {
+                    const double* qi = p.est + (size_t)i * W + col;
+                    const double d = qi[0] * r0 + qi[1] * r1 + qi[2] * r2 + qi[3] * r3;
+                    const double sg = (i > 0 && d < 0.0) ? -wgt : wgt;
+                    a0 += qi[0] * sg; a1 += qi[1] * sg; a2 += qi[2] * sg; a3 += qi[3] * sg;
+                }
+                a0 = block_sum(a0, scratch); a1 = block_sum(a1, scratch);
+                a2 = block_sum(a2, scratch); a3 = block_sum(a3, scratch);
+                const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+                out_q[k][0] = a0 / nrm; out_q[k][1] = a1 / nrm; out_q[k][2] = a2 / nrm; out_q[k][3] = a3 / nrm;
+            }
+        }
+        if (p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS) {   // compose_msg.py:26-29: plain means
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                double a = 0;
+                for (int i = tid; i < N; i += 256) a += p.est[(size_t)i * W + c];
+                orig_mean[c] = block_sum(a, scratch) / (double)N;
+            }
+        }
+    }
+    if (tid != 0) return;
+
+    const Vec3 larm_vec{p.body[0], p.body[1], p.body[2]};
+    const Vec3 uarm_vec{p.body[3], p.body[4], p.body[5]};
+    const Vec3 uarm_orig_rh{p.body[6], p.body[7], p.body[8]};
+    Quat lq, uq, hq{1.0, 0.0, 0.0, 0.0};
+    Vec3 ho, lo, uo = uarm_orig_rh;
+    const double* e0 = p.est;
+    if (N > 1) {
+        lq = Quat{out_q[0][0], out_q[0][1], out_q[0][2], out_q[0][3]};
+        uq = Quat{out_q[1][0], out_q[1][1], out_q[1][2], out_q[1][3]};
+        if (hips) hq = Quat{out_q[2][0], out_q[2][1], out_q[2][2], out_q[2][3]};
+        if (p.layout == APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS) {        // compose_msg.py:58-61
+            uo = qrot(hq, uarm_orig_rh);
+            lo = vadd(qrot(uq, uarm_vec), uo);
+            ho = vadd(qrot(lq, larm_vec), lo);
+        } else if (p.layout == APE_LAYOUT_ORI_CAL_LARM_UARM) {      // compose_msg.py:92-94
+            lo = vadd(qrot(uq, uarm_vec), uarm_orig_rh);
+            ho = vadd(qrot(lq, larm_vec), lo);
+        } else {
+            ho = Vec3{orig_mean[0], orig_mean[1], orig_mean[2]};
+            lo = Vec3{orig_mean[3], orig_mean[4], orig_mean[5]};
+            uo = Vec3{orig_mean[6], orig_mean[7], orig_mean[8]};
+        }
+    } else {                                                        // single row: copy (compose_msg.py:63-68)
+        ho = Vec3{e0[0], e0[1], e0[2]};
+        lo = Vec3{e0[3], e0[4], e0[5]};
+        lq = Quat{e0[qc_l], e0[qc_l + 1], e0[qc_l + 2], e0[qc_l + 3]};
+        uq = Quat{e0[qc_u], e0[qc_u + 1], e0[qc_u + 2], e0[qc_u + 3]};
+        if (hips) {
+            uo = Vec3{e0[6], e0[7], e0[8]};
+            hq = Quat{e0[17], e0[18], e0[19], e0[20]};
+        }
+    }
+    // fixed joint layout, compose_msg.py:72-78 (hand rot duplicates the lower-arm quaternion)
+    double* m = p.msg;
+    put_q(m + 0, lq); put_v(m + 4, ho); put_q(m + 7, lq); put_v(m + 11, lo);
+    put_q(m + 14, uq); put_v(m + 18, uo); put_q(m + 21, hq);
+}
+
+template <typename TIn, typename TOut>
+hipError_t launch_fk(const FkParams& p, hipStream_t stream) {
+    const int grid = (p.N + FK_BLOCK - 1) / FK_BLOCK;
+    hipLaunchKernelGGL((ape_fk_kernel<TIn, TOut>), dim3(grid), dim3(FK_BLOCK), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream) {
+    if (preds_dtype == APE_F32 && est_dtype == APE_F32) return launch_fk<float, float>(p, stream);
+    if (preds_dtype == APE_F32 && est_dtype == APE_F64) return launch_fk<float, double>(p, stream);
+    if (preds_dtype == APE_F64 && est_dtype == APE_F32) return launch_fk<double, float>(p, stream);
+    if (preds_dtype == APE_F64 && est_dtype == APE_F64) return launch_fk<double, double>(p, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(ape_msg_kernel, dim3(1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}

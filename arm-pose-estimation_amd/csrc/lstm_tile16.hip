@@ -1,0 +1,293 @@
+// Batch-tile LSTM kernel for gfx950 (MI355X): one workgroup = 16 IMU windows for ALL T steps.
+//
+// Replaces torch.nn.LSTM + torch.nn.Linear as used by DropoutLSTM.forward
+// (reference estimate/nn_models.py:169-174,180-189): L stacked layers, gate order i,f,g,o,
+// gates = (x W_ih^T + b_ih) + (h W_hh^T + b_hh), c = f*c + i*g, h = o*tanh(c), zero initial
+// state per window, linear head on the last layer's output.
+//
+// Mapping onto CDNA4
+//   * 256 threads = 4 wave64, one per SIMD (1 wave/SIMD -> the whole 512-VGPR file).
+//   * wave w owns hidden units [w*H/4, (w+1)*H/4) and, for each of them, all four gates, so the
+//     gate non-linearities and the cell update are lane-local on the MFMA accumulators; the
+//     cell state c lives in registers for the whole window, h lives in LDS (double buffered)
+//     and never touches HBM.
+//   * per layer-step the stacked-gate product [16 x (in+H)] x [(in+H) x 4H] runs on
+//     v_mfma_f32_16x16x4_f32 (exact f32, one rounding per product, f32 accumulate).  The A
+//     operand (activations) is read from LDS as one ds_read_b128 per 16 k-values and reused by
+//     16 (H=256) accumulator tiles; the B operand (weights) is streamed from L2 straight into
+//     VGPRs as global_load_dwordx4 in a host-prepacked fragment order (1 KiB contiguous per
+//     wave-instruction), double-buffered one 16-deep k-block ahead, including across
+//     layer-step boundaries so the first block of the next layer-step flies under the
+//     transcendental cell update.
+//   * the only HBM traffic is x (read once, f64 z-score fused into the load) and y.
+//
+// Work per window: sum_l 2*4H*(in_l+H) FLOP per step.
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Philox4x32-10 counter-based generator (Salmon et al. 2011) for in-kernel dropout masks.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <int NT>
+__device__ __forceinline__ void load_b(f32x4 (&b)[NT], const f32x4* __restrict__ p) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = p[n * 64];
+}
+
+// 4*NT MFMAs: k-index outer so consecutive MFMAs hit different accumulators (40-cycle dependent
+// latency of v_mfma_f32_16x16x4_f32 vs its 32-cycle issue).
+template <int NT>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NT], const f32x4 a, const f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[n][j], acc[n], 0, 0, 0);
+    }
+}
+
+template <int H, int L>
+__global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
+    constexpr int UB = H / 64;        // 16-unit blocks per wave
+    constexpr int NT = 4 * UB;        // accumulator tiles per wave (4 gates x UB)
+    constexpr int SH = H + 8;         // LDS row stride of the h buffers (floats): b128 reads conflict-free
+    constexpr int QH = H / 16;        // k-blocks of the recurrent part
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15;          // A operand: batch row; C operand: unit column
+    const int g = lane >> 4;          // A/B operand: k sub-index; C operand: row group
+    const int row0 = blockIdx.x * APE_TILE_ROWS;
+    const int KX = p.KX;
+    const int SX = KX + 8;
+    const int QX = KX / 16;
+    const int T = p.T, I = p.I, O = p.O;
+    const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool all_steps = (p.flags & APE_FLAG_ALL_STEPS) != 0;
+    const bool drop_masks = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
+    const bool drop_philox = (p.flags & APE_FLAG_DROPOUT_PHILOX) != 0;
+    const bool drop = (drop_masks || drop_philox) && L > 1;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;                                  // [2][16][SX]
+    float* hbuf = xin + 2 * APE_TILE_ROWS * SX;         // [L][2][16][SH]
+    float* dbuf = hbuf + L * 2 * APE_TILE_ROWS * SH;    // [L-1][16][SH]   (carved only when dropout is on)
+    float* wout_s = dbuf + (drop ? (L - 1) : 0) * APE_TILE_ROWS * SH;    // [O][H+1]
+
+    // ---- stage the head weights once ---------------------------------------------------------
+    for (int idx = tid; idx < O * H; idx += 256) {
+        const int o = idx / H, k = idx - o * H;
+        wout_s[o * (H + 1) + k] = p.w_out[idx];
+    }
+
+    // ---- x staging: thread owns up to 4 (row,k) elements of the [16][KX] step slab -----------
+    const int n_el = KX / 16;         // 2 (KX=32) or 4 (KX=64)
+    float xr[4];
+    auto fetch_x = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xr[e] = 0.0f;
+            if (e < n_el) {
+                const int idx = tid + 256 * e;
+                const int row = idx / KX, k = idx - row * KX;
+                const int b = row0 + row;
+                if (k < I && b < p.B) {
+                    const float v = p.x[((size_t)b * T + t) * I + k];
+                    // f64 z-score then round to f32: estimator.py:103-104 + watch_phone_pocket_nn.py:100
+                    xr[e] = normalize ? (float)(((double)v - p.xx_m[k]) / p.xx_s[k]) : v;
+                }
+            }
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e < n_el) {
+                const int idx = tid + 256 * e;
+                const int row = idx / KX, k = idx - row * KX;
+                xin[(buf * APE_TILE_ROWS + row) * SX + k] = xr[e];
+            }
+        }
+    };
+    fetch_x(0);
+    store_x(0);
+
+    // ---- per-wave weight stream bases ------------------------------------------------------------
+    const f32x4* wbase[L];
+    int qtot[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        qtot[l] = (l == 0 ? QX : QH) + QH;
+        wbase[l] = p.wpack[l] + (size_t)wave * qtot[l] * NT * 64 + lane;
+    }
+
+    float cst[L][UB][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cst[l][u][i] = 0.0f;
+
+    f32x4 b0[NT], b1[NT];
+    load_b<NT>(b0, wbase[0]);     // first k-block of (layer 0, t = 0)
+    __syncthreads();              // xin[0], wout_s visible
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, prv = cur ^ 1;
+        if (t + 1 < T) fetch_x(t + 1);       // global loads fly under this step's MFMAs
+
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            // ---- accumulators start at b_ih + b_hh -------------------------------------------
+            f32x4 acc[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int gate = n / UB, u = n % UB;
+                const float bv = p.bias[l][gate * H + wave * (H / 4) + u * 16 + r];
+                acc[n] = f32x4{bv, bv, bv, bv};
+            }
+            // ---- A sources -------------------------------------------------------------------
+            const int qin = (l == 0) ? QX : QH;
+            const float* in_src;
+            if (l == 0) in_src = xin + (cur * APE_TILE_ROWS + r) * SX + 4 * g;
+            else if (drop) in_src = dbuf + ((l - 1) * APE_TILE_ROWS + r) * SH + 4 * g;
+            else in_src = hbuf + (((l - 1) * 2 + cur) * APE_TILE_ROWS + r) * SH + 4 * g;
+            const float* rec_src = hbuf + ((l * 2 + prv) * APE_TILE_ROWS + r) * SH + 4 * g;
+            // t == 0: h_{-1} = 0, the recurrent k-blocks contribute nothing and are skipped
+            const int nq = (t == 0) ? qin : qtot[l];
+            // first k-block of the NEXT layer-step, prefetched under this one's tail
+            const f32x4* wnext = wbase[(l + 1) % L];
+            const f32x4* wl = wbase[l];
+
+#pragma unroll 1
+            for (int q = 0; q < nq; q += 2) {       // nq is even by construction (KX % 32 == 0, H % 64 == 0)
+                load_b<NT>(b1, wl + (size_t)(q + 1) * NT * 64);
+                {
+                    const float* src = (q < qin) ? in_src + 16 * q : rec_src + 16 * (q - qin);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                    mfma_block<NT>(acc, a, b0);
+                }
+                load_b<NT>(b0, (q + 2 < nq) ? wl + (size_t)(q + 2) * NT * 64 : wnext);
+                {
+                    const int q1 = q + 1;
+                    const float* src = (q1 < qin) ? in_src + 16 * q1 : rec_src + 16 * (q1 - qin);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                    mfma_block<NT>(acc, a, b1);
+                }
+            }
+
+            // ---- gates + cell update, lane-local: lane holds rows 4g..4g+3 of unit column r ----
+            float* hdst = hbuf + ((l * 2 + cur) * APE_TILE_ROWS) * SH;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int unit = wave * (H / 4) + u * 16 + r;
+                uint32_t rnd[4] = {0, 0, 0, 0};
+                if (drop_philox && l < L - 1)
+                    philox4x32((uint32_t)(row0 + 4 * g), (uint32_t)t, (uint32_t)unit, (uint32_t)l,
+                               (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float iv = sigmoidf_acc(acc[0 * UB + u][i]);
+                    const float fv = sigmoidf_acc(acc[1 * UB + u][i]);
+                    const float gv = tanhf(acc[2 * UB + u][i]);
+                    const float ov = sigmoidf_acc(acc[3 * UB + u][i]);
+                    const float c = fv * cst[l][u][i] + iv * gv;
+                    cst[l][u][i] = c;
+                    const float h = ov * tanhf(c);
+                    const int row = 4 * g + i;
+                    hdst[row * SH + unit] = h;
+                    if (drop && l < L - 1) {
+                        float m;
+                        if (drop_masks) {
+                            const int b = row0 + row;
+                            m = (b < p.B) ? p.masks[(((size_t)l * p.B + b) * T + t) * H + unit] : 0.0f;
+                        } else {
+                            // uniform in [0,1) from 24 random bits; keep with probability 1-p
+                            const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                            m = (uf >= p.dropout_p) ? 1.0f / (1.0f - p.dropout_p) : 0.0f;
+                        }
+                        dbuf[(l * APE_TILE_ROWS + row) * SH + unit] = h * m;
+                    }
+                }
+            }
+            if (l == L - 1 && t + 1 < T) store_x(prv);   // x_{t+1} -> the other xin buffer
+            __syncthreads();                             // h^l_t (and x_{t+1}) visible
+        }
+
+        // ---- linear head on h^{L-1}_t: output_layer of nn_models.py:189 -----------------------------
+        if (all_steps || t == T - 1) {
+            if (tid < APE_TILE_ROWS * O) {
+                const int row = tid / O, o = tid - row * O;
+                const float* hv = hbuf + (((L - 1) * 2 + cur) * APE_TILE_ROWS + row) * SH;
+                const float* wv = wout_s + o * (H + 1);
+                float s = 0.0f;
+                for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
+                s += p.b_out[o];
+                const int b = row0 + row;
+                if (b < p.B) {
+                    if (all_steps) p.y[((size_t)b * T + t) * O + o] = s;
+                    else p.y[(size_t)b * O + o] = s;
+                }
+            }
+        }
+    }
+}
+
+template <int H, int L>
+hipError_t launch(const LstmParams& p, hipStream_t stream) {
+    const bool drop = (p.flags & (APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) != 0 && L > 1;
+    const size_t smem = ape_lstm_tile16_smem_bytes(H, L, p.KX, p.O, drop);
+    const int grid = (p.B + APE_TILE_ROWS - 1) / APE_TILE_ROWS;
+    hipLaunchKernelGGL((ape_lstm_tile16<H, L>), dim3(grid), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}
+
+template <int H, int L>
+hipError_t prepare(size_t smem) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_tile16<H, L>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+}  // namespace
+
+size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout) {
+    const size_t SX = KX + 8, SH = H + 8;
+    size_t fl = 2 * APE_TILE_ROWS * SX + (size_t)L * 2 * APE_TILE_ROWS * SH +
+                (size_t)((dropout && L > 1) ? L - 1 : 0) * APE_TILE_ROWS * SH + (size_t)O * (H + 1);
+    return fl * sizeof(float);
+}
+
+#define APE_DISPATCH(FN, ...)                                   \
+    if (H == 256) {                                             \
+        if (L == 1) return FN<256, 1>(__VA_ARGS__);             \
+        if (L == 2) return FN<256, 2>(__VA_ARGS__);             \
+        if (L == 3) return FN<256, 3>(__VA_ARGS__);             \
+    } else if (H == 128) {                                      \
+        if (L == 1) return FN<128, 1>(__VA_ARGS__);             \
+        if (L == 2) return FN<128, 2>(__VA_ARGS__);             \
+        if (L == 3) return FN<128, 3>(__VA_ARGS__);             \
+    }                                                           \
+    return hipErrorInvalidValue;
+
+// raise the dynamic-LDS limit of the instantiation once, at model creation (not in the launch
+// path, which must stay graph-capturable)
+hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes) { APE_DISPATCH(prepare, smem_bytes) }
+
+hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream) { APE_DISPATCH(launch, p, stream) }

@@ -1,0 +1,82 @@
+"""ctypes binding of libape_hip.so (C ABI: include/ape_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile`` into
+``arm-pose-estimation_amd/lib/``.  Loading failures are loud: there is no CPU fallback."""
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_PATH = Path(os.environ.get("APE_HIP_LIB", Path(__file__).resolve().parents[1] / "lib" / "libape_hip.so"))
+
+APE_OK = 0
+LAYOUT_NONE = -1
+LAYOUT_ORI_CAL_LARM_UARM_HIPS = 0
+LAYOUT_ORI_CAL_LARM_UARM = 1
+LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS = 2
+F32, F64 = 0, 1
+FLAG_NORMALIZE_INPUT = 0x1
+FLAG_ALL_STEPS = 0x2
+FLAG_DROPOUT_MASKS = 0x4
+FLAG_DROPOUT_PHILOX = 0x8
+
+EST_WIDTH = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 21, LAYOUT_ORI_CAL_LARM_UARM: 14, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 21}
+NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 20}
+
+
+class ApeDims(C.Structure):
+    _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
+                ("output_size", C.c_int32), ("target_layout", C.c_int32), ("device", C.c_int32)]
+
+
+# every symbol include/ape_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "ape_abi_version": (C.c_int, []),
+    "ape_last_error": (C.c_char_p, []),
+    "ape_device_count": (C.c_int, []),
+    "ape_model_create": (C.c_int, [C.POINTER(ApeDims), C.POINTER(C.c_void_p)]),
+    "ape_model_destroy": (C.c_int, [C.c_void_p]),
+    "ape_model_reserve": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ape_model_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ape_weight_blob_floats": (C.c_size_t, [C.POINTER(ApeDims)]),
+    "ape_model_set_norm_stats": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_double)] * 4),
+    "ape_model_set_body": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "ape_lstm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p,
+                                   C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "ape_fk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ape_msg_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ape_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
+                            C.c_int32, C.c_void_p]),
+    "ape_lstm_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ape_flops_per_window": (C.c_double, [C.POINTER(ApeDims), C.c_int32]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ``UserWarning`` (the reference's error convention) if the HIP
+    extension has not been built -- the product path never degrades to a CPU implementation."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise UserWarning(f"HIP extension missing: {LIB_PATH} (run `python -c 'import __graft_entry__ as g; "
+                              f"g.build()'` or `make -C arm-pose-estimation_amd/csrc`)")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.ape_abi_version() != 1:
+            raise UserWarning(f"{LIB_PATH}: ABI version {handle.ape_abi_version()} != 1")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = ""):
+    """non-zero status -> ``UserWarning`` raised as an exception (nn_models.py:385-400 convention)."""
+    if status != APE_OK:
+        msg = lib().ape_last_error().decode("utf-8", "replace")
+        raise UserWarning(f"[ape_hip] {what}: {msg} (status {status})")
+
+
+def dptr(array_like, dtype):
+    return array_like.ctypes.data_as(C.POINTER(dtype))

@@ -1,0 +1,230 @@
+"""``Estimator`` base class with the reference's template-method contract
+(``estimate/estimator.py:16-218``): window history with pad-by-newest cold start, z-score /
+de-normalise bookkeeping in float64, smoothing stack, FK + message, consumer-thread loop.
+
+Host side keeps only bookkeeping (list membership and order -- compared bit-exactly against the
+reference in the tests); ``msg_from_pred`` runs the FK and message kernels of libape_hip.so."""
+import logging
+import queue
+import threading
+from abc import abstractmethod
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from wear_mocap_ape_amd.data_types.bone_map import BoneMap
+from wear_mocap_ape_amd.estimate import _post
+from wear_mocap_ape_amd.utility import data_stats
+from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS, TARGET_LAYOUT
+
+
+class Estimator:
+    def __init__(self,
+                 x_inputs: NNS_INPUTS,
+                 y_targets: NNS_TARGETS,
+                 normalize: bool = True,
+                 smooth: int = 1,
+                 seq_len: int = 1,
+                 add_mc_samples: bool = True,
+                 bonemap: BoneMap = None,
+                 tag: str = "Estimator"):
+        self.__tag = tag
+        self._active = False
+        self._y_targets = y_targets
+        self._x_inputs = x_inputs
+
+        self._normalize = normalize
+        if normalize:
+            stats = data_stats.get_norm_stats(x_inputs=self._x_inputs, y_targets=self._y_targets)
+            self._xx_m, self._xx_s = stats["xx_m"], stats["xx_s"]
+            self._yy_m, self._yy_s = stats["yy_m"], stats["yy_s"]
+
+        self._smooth = max(1, smooth)
+        self._smooth_hist = []
+        self._last_msg = None
+        self._add_mc_samples = add_mc_samples
+        self._row_hist = []
+        self._sequence_len = max(1, seq_len)
+
+        if bonemap is None:
+            self._larm_vec = np.array([-BoneMap.DEFAULT_LARM_LEN, 0, 0])
+            self._uarm_vec = np.array([-BoneMap.DEFAULT_UARM_LEN, 0, 0])
+            self._uarm_orig = BoneMap.DEFAULT_UARM_ORIG_RH
+        else:
+            self._larm_vec = np.array([-bonemap.left_lower_arm_length, 0, 0])
+            self._uarm_vec = np.array([-bonemap.left_upper_arm_length, 0, 0])
+            self._uarm_orig = bonemap.left_upper_arm_origin_rh
+        # [[larm_vec, uarm_vec, uarm_orig_rh]]  (estimator.py:68)
+        self._body_measurements = np.r_[self._larm_vec, self._uarm_vec, self._uarm_orig][np.newaxis, :]
+
+        self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self._layout = TARGET_LAYOUT[y_targets]
+        self._sync_model_config()
+
+    # subclasses that own a HIP model expose it here so stats/body reach the device handle
+    def _hip_model(self):
+        return None
+
+    def _sync_model_config(self):
+        model = self._hip_model()
+        if model is None:
+            return
+        model.set_body(self._body_measurements)
+        if self._normalize:
+            model.set_norm_stats(self._xx_m, self._xx_s, self._yy_m, self._yy_s)
+
+    def set_norm_stats(self, stats: dict):
+        """overwrites the default norm stats loaded during the initialization"""
+        self._xx_m, self._xx_s = stats["xx_m"], stats["xx_s"]
+        self._yy_m, self._yy_s = stats["yy_m"], stats["yy_s"]
+        self._sync_model_config()
+        logging.info("Replaced norm stats xx m+/-s and yy m+/-s")
+
+    def get_last_msg(self):
+        return self._last_msg
+
+    def is_active(self):
+        return self._active
+
+    def terminate(self):
+        self._active = False
+
+    def reset(self):
+        self._active = False
+        self._row_hist = []
+        self._smooth_hist = []
+
+    @staticmethod
+    def _push_padded(hist: list, item, size: int):
+        """append ``item``; a history shorter than ``size`` is filled with copies of the NEWEST item
+        (cold start, estimator.py:96-97 / :114-115); the oldest entries beyond ``size`` are dropped"""
+        hist.append(item)
+        hist.extend([item] * (size - len(hist)))
+        del hist[:len(hist) - size]
+
+    def add_xx_to_row_hist_and_make_prediction(self, xx) -> np.array:
+        self._push_padded(self._row_hist, xx, self._sequence_len)
+        xx_hist = np.vstack(self._row_hist)                       # [T, I]
+        if self._normalize:                                       # float64 z-score (estimator.py:103-104)
+            xx_hist = (xx_hist - self._xx_m) / self._xx_s
+        pred = self.make_prediction_from_row_hist(xx_hist)        # [n, O]
+        if self._normalize:                                       # float64 de-normalise (:108-109)
+            pred = pred * self._yy_s + self._yy_m
+        if self._smooth > 1:                                      # stack of the last `smooth` predictions
+            self._push_padded(self._smooth_hist, pred, self._smooth)
+            pred = np.vstack(self._smooth_hist)
+        return pred
+
+    def msg_from_pred(self, pred: np.array, add_mc_samples: bool) -> np.array:
+        # arm_pose_from_nn_targets + msg_from_nn_targets_est in one device round trip
+        ctx = _post.context(self._layout)
+        with ctx.lock:
+            est, msg = _post.fk_and_msg(ctx.handle, self._layout, ctx.device, pred, self._body_measurements)
+        self._last_msg = msg.copy()
+        if add_mc_samples:
+            msg = list(msg)
+            if est.shape[0] > 1:
+                for e_row in est:
+                    msg += list(e_row[:6])
+        return msg
+
+    def process_in_thread(self, sensor_q: queue):
+        msg_q = queue.Queue()
+        t = threading.Thread(target=self.processing_loop, args=(sensor_q, msg_q))
+        t.start()
+        return msg_q
+
+    def processing_loop(self, sensor_q: queue, msg_q: queue):
+        logging.info(f"[{self.__tag}] wearable streaming loop")
+        start = datetime.now()
+        dat = 0
+        self.reset()
+        self._active = True
+        while self._active:
+            try:
+                # newest wins: skip the backlog when the consumer falls behind
+                row = sensor_q.get(timeout=2)
+                while sensor_q.qsize() > 5:
+                    row = sensor_q.get(timeout=2)
+            except queue.Empty:
+                logging.info(f"[{self.__tag}] no data")
+                continue
+
+            now = datetime.now()
+            if (now - start).seconds >= 5:
+                start = now
+                logging.info(f"[{self.__tag}] {dat / 5} Hz")
+                dat = 0
+
+            xx = self.parse_row_to_xx(row)
+            pred = self.add_xx_to_row_hist_and_make_prediction(xx)
+            msg = self.msg_from_pred(pred, self._add_mc_samples)
+            msg_q.put(msg)
+            dat += 1
+
+    @abstractmethod
+    def make_prediction_from_row_hist(self, xx_hist: np.array) -> np.array:
+        return
+
+    @abstractmethod
+    def parse_row_to_xx(self, row) -> np.array:
+        return
+
+    # ---- batched entry the reference lacks: many independent windows at once ----
+    def infer_windows(self, x, est_dtype=torch.float64, return_targets: bool = False):
+        """x: raw (un-normalised) features float32 ``[B,T,I]``, host array or CUDA tensor ->
+        est ``[B,21|14]`` (same rows ``arm_pose_from_nn_targets`` yields), on the device.
+        One ``ape_infer`` call: z-score -> LSTM -> last step -> de-normalise -> FK."""
+        import ctypes as C
+        from wear_mocap_ape_amd import _hip
+        model = self._hip_model()
+        if model is None:
+            raise UserWarning("this estimator has no HIP regressor")
+        dev = model.torch_device
+        with torch.cuda.device(dev):
+            xd = torch.as_tensor(x, dtype=torch.float32).to(dev).contiguous()
+            if xd.dim() != 3 or xd.shape[2] != model.input_size or xd.shape[0] < 1 or xd.shape[1] < 1:
+                raise UserWarning(f"expected x [B>=1,T>=1,{model.input_size}], got {tuple(xd.shape)}")
+            B, T = int(xd.shape[0]), int(xd.shape[1])
+            est = torch.empty((B, _hip.EST_WIDTH[self._layout]), dtype=est_dtype, device=dev)
+            y = torch.empty((B, model.output_size), dtype=torch.float32, device=dev) if return_targets else None
+            flags = _hip.FLAG_NORMALIZE_INPUT if self._normalize else 0
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _hip.check(_hip.lib().ape_infer(model.handle, C.c_void_p(xd.data_ptr()), B, T, flags,
+                                            C.c_void_p(y.data_ptr()) if y is not None else None,
+                                            C.c_void_p(est.data_ptr()),
+                                            _hip.F64 if est_dtype == torch.float64 else _hip.F32, stream), "ape_infer")
+        return (est, y) if return_targets else est
+
+    @property
+    def sequence_len(self):
+        return self._sequence_len
+
+    @property
+    def body_measurements(self):
+        return self._body_measurements
+
+    @property
+    def uarm_orig(self):
+        return self._uarm_orig
+
+    @property
+    def uarm_vec(self):
+        return self._uarm_vec
+
+    @property
+    def larm_vec(self):
+        return self._larm_vec
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def x_inputs(self):
+        return self._x_inputs
+
+    @property
+    def y_targets(self):
+        return self._y_targets

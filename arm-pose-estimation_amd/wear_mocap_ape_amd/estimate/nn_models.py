@@ -1,0 +1,273 @@
+"""HIP-backed pose regressor with the call surface of the reference's ``DropoutLSTM``
+(``estimate/nn_models.py:160-207``) and its checkpoint loader (``:373-415``).
+
+The module holds no arithmetic: ``forward`` hands device pointers to ``ape_lstm_forward`` of
+``libape_hip.so`` (fused L-layer LSTM + linear head, MFMA f32, state resident on chip).
+torch is used for device memory and streams only."""
+import json
+import logging
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+import wear_mocap_ape_amd.config as config
+from wear_mocap_ape_amd import _hip
+
+
+class _TrainFlag:
+    """stands in for ``self.lstm`` of the reference module: ``model.lstm.train()`` is how
+    ``monte_carlo_predictions`` switches inter-layer dropout on -- permanently (nn_models.py:204)."""
+
+    def __init__(self):
+        self.training = False
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+
+def state_dict_keys(hidden_layer_count: int):
+    keys = []
+    for k in range(hidden_layer_count):
+        keys += [f"lstm.weight_ih_l{k}", f"lstm.weight_hh_l{k}", f"lstm.bias_ih_l{k}", f"lstm.bias_hh_l{k}"]
+    return keys + ["output_layer.weight", "output_layer.bias"]
+
+
+_LAYOUT_FOR_OUTPUTS = {14: _hip.LAYOUT_ORI_CAL_LARM_UARM_HIPS, 12: _hip.LAYOUT_ORI_CAL_LARM_UARM,
+                       20: _hip.LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS}
+
+
+class DropoutLSTM:
+    """``DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size, dropout)``.
+
+    ``model(x)`` with ``x`` float32 ``[B,T,I]`` returns float32 ``[B,T,O]`` (head on every step,
+    nn_models.py:188-189); ``model.monte_carlo_predictions(n_samples, x)`` repeats a batch-1 window
+    ``n_samples`` times and runs it with inter-layer dropout (nn_models.py:191-207).  Inputs may
+    live on the host or on the model's GPU; the result is returned where the input was."""
+
+    def __init__(self, input_size, hidden_layer_size, hidden_layer_count, output_size, dropout=0.2,
+                 device: int = None, target_layout: int = None):
+        self.input_size = int(input_size)
+        self.hidden_layer_size = int(hidden_layer_size)
+        self.hidden_layer_count = int(hidden_layer_count)
+        self.output_size = int(output_size)
+        self.dropout = float(dropout)
+        self.lstm = _TrainFlag()
+        self._mc_calls = 0
+        self._seed = 0x5EED
+        self._state = None
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.device_index = int(device)
+        if target_layout is None:
+            target_layout = _LAYOUT_FOR_OUTPUTS.get(self.output_size, _hip.LAYOUT_NONE)
+        self.target_layout = target_layout
+        self._dims = _hip.ApeDims(self.input_size, self.hidden_layer_size, self.hidden_layer_count,
+                                  self.output_size, target_layout, self.device_index)
+        import ctypes as C
+        self._handle = C.c_void_p()
+        _hip.check(_hip.lib().ape_model_create(C.byref(self._dims), C.byref(self._handle)), "ape_model_create")
+
+    # ---- lifetime -----------------------------------------------------------------------------
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _hip.lib().ape_model_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    @property
+    def handle(self):
+        return self._handle
+
+    @property
+    def torch_device(self):
+        return torch.device("cuda", self.device_index)
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict):
+        """same keys and shapes as the reference module's state_dict."""
+        H, I, O = self.hidden_layer_size, self.input_size, self.output_size
+        want = OrderedDict()
+        for k in range(self.hidden_layer_count):
+            want[f"lstm.weight_ih_l{k}"] = (4 * H, I if k == 0 else H)
+            want[f"lstm.weight_hh_l{k}"] = (4 * H, H)
+            want[f"lstm.bias_ih_l{k}"] = (4 * H,)
+            want[f"lstm.bias_hh_l{k}"] = (4 * H,)
+        want["output_layer.weight"] = (O, H)
+        want["output_layer.bias"] = (O,)
+        missing = [k for k in want if k not in state_dict]
+        extra = [k for k in state_dict if k not in want]
+        if missing or extra:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {extra}")
+        parts, kept = [], OrderedDict()
+        for key, shape in want.items():
+            v = state_dict[key]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(a.shape) != shape:
+                raise RuntimeError(f"size mismatch for {key}: {tuple(a.shape)} vs {shape}")
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            kept[key] = a
+            parts.append(a.reshape(-1))
+        blob = np.concatenate(parts)
+        self.load_weight_blob(blob)
+        self._state = kept
+        return self
+
+    def load_weight_blob(self, blob):
+        """flat float32 blob in state_dict order: a host numpy array or a CUDA tensor (e.g. the
+        buffer an RCCL broadcast filled)."""
+        import ctypes as C
+        n = int(_hip.lib().ape_weight_blob_floats(C.byref(self._dims)))
+        if isinstance(blob, torch.Tensor):
+            if blob.dtype != torch.float32 or blob.numel() != n or not blob.is_contiguous():
+                raise UserWarning(f"weight blob must be contiguous float32 with {n} elements")
+            ptr = blob.data_ptr()
+        else:
+            blob = np.ascontiguousarray(blob, dtype=np.float32)
+            if blob.size != n:
+                raise UserWarning(f"weight blob must have {n} elements, got {blob.size}")
+            ptr = blob.ctypes.data
+        _hip.check(_hip.lib().ape_model_load_weights(self._handle, C.c_void_p(ptr), n), "ape_model_load_weights")
+        self._state = None
+
+    def weight_blob_floats(self) -> int:
+        import ctypes as C
+        return int(_hip.lib().ape_weight_blob_floats(C.byref(self._dims)))
+
+    def state_dict(self):
+        if self._state is None:
+            raise UserWarning("no state_dict loaded through load_state_dict")
+        return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._state.items())
+
+    def eval(self):
+        self.lstm.eval()
+        return self
+
+    def train(self, mode: bool = True):
+        self.lstm.train(mode)
+        return self
+
+    # ---- estimator configuration (host pointers, float64) --------------------------------------
+    def set_norm_stats(self, xx_m, xx_s, yy_m, yy_s):
+        import ctypes as C
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (xx_m, xx_s, yy_m, yy_s)]
+        if arrs[0].size != self.input_size or arrs[1].size != self.input_size or \
+                arrs[2].size != self.output_size or arrs[3].size != self.output_size:
+            raise UserWarning("norm stats do not match the model dimensions")
+        _hip.check(_hip.lib().ape_model_set_norm_stats(self._handle, *[_hip.dptr(a, C.c_double) for a in arrs]),
+                   "ape_model_set_norm_stats")
+
+    def set_body(self, body_measurements):
+        import ctypes as C
+        b = np.ascontiguousarray(np.asarray(body_measurements, dtype=np.float64).reshape(-1))
+        if b.size != 9:
+            raise UserWarning("body measurements must hold 9 values")
+        _hip.check(_hip.lib().ape_model_set_body(self._handle, _hip.dptr(b, C.c_double)), "ape_model_set_body")
+
+    # ---- forward --------------------------------------------------------------------------------
+    def _run(self, x, flags, masks=None, dropout_p=0.0, seed=0, last_step_only=False):
+        import ctypes as C
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
+        if x.dim() != 3 or x.shape[2] != self.input_size:
+            raise UserWarning(f"expected x of shape [B,T,{self.input_size}], got {tuple(x.shape)}")
+        if x.shape[0] < 1 or x.shape[1] < 1:
+            raise UserWarning(f"empty batch or window: {tuple(x.shape)}")
+        on_host = not x.is_cuda
+        dev = self.torch_device
+        with torch.cuda.device(dev):
+            xd = x.to(device=dev, dtype=torch.float32).contiguous()
+            B, T = int(xd.shape[0]), int(xd.shape[1])
+            if last_step_only:
+                y = torch.empty((B, 1, self.output_size), dtype=torch.float32, device=dev)
+            else:
+                y = torch.empty((B, T, self.output_size), dtype=torch.float32, device=dev)
+                flags |= _hip.FLAG_ALL_STEPS
+            mptr = None
+            if masks is not None:
+                masks = masks.to(device=dev, dtype=torch.float32).contiguous()
+                want = (self.hidden_layer_count - 1, B, T, self.hidden_layer_size)
+                if tuple(masks.shape) != want:
+                    raise UserWarning(f"masks must have shape {want}, got {tuple(masks.shape)}")
+                mptr = C.c_void_p(masks.data_ptr())
+                flags |= _hip.FLAG_DROPOUT_MASKS
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _hip.check(_hip.lib().ape_lstm_forward(self._handle, C.c_void_p(xd.data_ptr()), B, T, flags, mptr,
+                                                   float(dropout_p), int(seed), C.c_void_p(y.data_ptr()), stream),
+                       "ape_lstm_forward")
+        return y.cpu() if on_host else y
+
+    def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False):
+        """``masks`` (float32 ``[L-1,B,T,H]`` of 0 or 1/(1-p)) injects explicit dropout masks;
+        ``last_step_only`` returns ``[B,1,O]`` (only the step the estimators consume);
+        ``normalize_input`` fuses the f64 z-score of raw features into the load."""
+        if hs is not None:
+            raise UserWarning("an initial (h_0, c_0) is not supported: the path always starts from zeros")
+        flags = _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0
+        if masks is not None:
+            return self._run(x, flags, masks=masks, last_step_only=last_step_only)
+        if self.lstm.training and self.dropout > 0.0 and self.hidden_layer_count > 1:
+            self._mc_calls += 1
+            return self._run(x, flags | _hip.FLAG_DROPOUT_PHILOX, dropout_p=self.dropout,
+                             seed=(self._seed << 20) + self._mc_calls, last_step_only=last_step_only)
+        return self._run(x, flags, last_step_only=last_step_only)
+
+    __call__ = forward
+
+    def manual_seed(self, seed: int):
+        self._seed, self._mc_calls = int(seed), 0
+
+    def monte_carlo_predictions(self, n_samples: int, x, hs=None, last_step_only=False):
+        if x.shape[0] > 1:
+            raise UserWarning("MC predictions only for batch size 1")     # nn_models.py:201-202
+        self.lstm.train()                                                  # permanent, as nn_models.py:204
+        if isinstance(x, torch.Tensor):
+            rep = x.repeat((n_samples, 1, 1))
+        else:
+            rep = np.repeat(np.asarray(x), n_samples, axis=0)
+        return self.forward(rep, hs, last_step_only=last_step_only)
+
+    def kernel_name(self, B: int, T: int) -> str:
+        return _hip.lib().ape_lstm_kernel_name(self._handle, B, T).decode()
+
+    def flops_per_window(self, T: int) -> float:
+        import ctypes as C
+        return float(_hip.lib().ape_flops_per_window(C.byref(self._dims), T))
+
+
+def load_deployed_model_from_hash(hash_str: str):
+    """``hash`` -> ``(model, params)`` exactly like nn_models.py:373-415: reads
+    ``<deploy>/nn/<hash>/results.json`` and ``checkpoint.pt`` (a ``(model_state, optimizer_state)``
+    tuple), dispatches on ``params["model"]``, leaves the model in eval mode.  Missing files and
+    unknown model names raise ``UserWarning`` like the reference."""
+    save_path = Path(config.PATHS["deploy"]) / "nn" / hash_str
+    json_path = save_path / "results.json"
+    chkpt_path = save_path / "checkpoint.pt"
+    if not json_path.exists():
+        raise UserWarning(f"no json found {json_path}")
+    if not chkpt_path.exists():
+        raise UserWarning(f"no checkpoint found {chkpt_path}")
+    with open(json_path, "r") as f:
+        params = json.load(f)
+    if params["model"] == "DropoutLSTM":
+        params["model"] = DropoutLSTM
+    else:
+        # DropoutFF / ImuPoseLSTM are dispatchable upstream (nn_models.py:395-398) but no deployed
+        # checkpoint uses them; they are the next row of the hot-path scope table
+        raise UserWarning(f"{params['model']} not handled")
+    nn_model = params["model"](input_size=len(params["x_inputs_v"]), hidden_layer_size=params["hidden_layer_size"],
+                               hidden_layer_count=params["hidden_layer_count"],
+                               output_size=len(params["y_targets_v"]), dropout=params["dropout"])
+    model_state, _ = torch.load(chkpt_path, map_location="cpu")
+    nn_model.load_state_dict(model_state)
+    nn_model.eval()
+    logging.info("loaded model in eval mode from {}".format(save_path))
+    return nn_model, params

@@ -1,0 +1,61 @@
+"""``WatchOnlyNN`` -- single-device estimator (reference ``estimate/watch_only.py:13-97``):
+20 smartwatch features -> 2x256 LSTM -> 12 targets (two 6D rotations, no hips)."""
+import numpy as np
+import torch
+
+from wear_mocap_ape_amd.data_deploy.nn import deploy_models
+from wear_mocap_ape_amd.data_types import messaging
+from wear_mocap_ape_amd.data_types.bone_map import BoneMap
+from wear_mocap_ape_amd.estimate import nn_models
+from wear_mocap_ape_amd.estimate.estimator import Estimator
+from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import _SW_SENSORS, _quat
+from wear_mocap_ape_amd.utility import transformations as ts
+from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
+
+
+def features_from_row(row, slp) -> np.ndarray:
+    """28-float watch message -> float32[20] (watch_only.py:46-82)."""
+    r_pres = row[slp["sw_pres"]] - row[slp["sw_init_pres"]]
+    north = ts.north_quat_from_forward(_quat(row, slp, "sw_forward"))
+    sw_cal_g = ts.android_to_global(_quat(row, slp, "sw_rotvec"), north)
+    return np.hstack([
+        [row[slp[n]] for n in _SW_SENSORS],
+        ts.quat_to_six_drr(sw_cal_g),
+        r_pres,
+    ]).astype(np.float32)
+
+
+class WatchOnlyNN(Estimator):
+    def __init__(self,
+                 model_hash: str = deploy_models.LSTM.WATCH_ONLY.value,
+                 smooth: int = 10,
+                 add_mc_samples=True,
+                 monte_carlo_samples=25,
+                 bonemap: BoneMap = None,
+                 watch_phone: bool = False,
+                 tag: str = "PUB WATCH"):
+        self.__tag = tag
+        self.__mc_samples = monte_carlo_samples
+        self.__slp = messaging.WATCH_PHONE_IMU_LOOKUP if watch_phone else messaging.WATCH_ONLY_IMU_LOOKUP
+        self.__nn_model, params = nn_models.load_deployed_model_from_hash(hash_str=model_hash)
+        super().__init__(
+            x_inputs=NNS_INPUTS[params["x_inputs_n"]],
+            y_targets=NNS_TARGETS[params["y_targets_n"]],
+            smooth=smooth,
+            normalize=params["normalize"],
+            seq_len=params["sequence_len"],
+            add_mc_samples=add_mc_samples,
+            tag=tag,
+            bonemap=bonemap
+        )
+
+    def _hip_model(self):
+        return self.__nn_model
+
+    def parse_row_to_xx(self, row) -> np.array:
+        return features_from_row(row, self.__slp)
+
+    def make_prediction_from_row_hist(self, xx_hist: np.array) -> np.array:
+        xx = torch.tensor(xx_hist[None, :, :], dtype=torch.float32)
+        t_preds = self.__nn_model.monte_carlo_predictions(x=xx, n_samples=self.__mc_samples, last_step_only=True)
+        return t_preds.numpy()[:, -1, :]

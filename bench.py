@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the arm-pose hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the throughput configuration the metric is quoted on; configs[3]
+is the same thing on 8 GPUs): per GPU 1024 independent synthetic 50 Hz IMU windows of 64 frames x 22
+features through the watch_phone_pocket_lstm estimator's path -- f64 z-score -> 2x256 LSTM + head
+-> de-normalise -> 6D->quaternion + forward kinematics -- with the inputs already resident in HBM.
+A "step" is one pass of that path over the rank's 1024 windows (one `ape_lstm_forward` launch + one
+`ape_fk` launch).  Streams are sharded contiguously over the ranks (weak scaling, no data-path
+collective); the only collective is the start-up broadcast of the weight blob (RCCL).
+
+Prints ONE JSON line on rank 0 (see the task contract), with two extra objects:
+  roofline      dominant kernel (the LSTM) -- algorithmic FLOP per launch / its mean duration,
+                measured live with HIP events on the launch stream, vs the dense f32 MFMA peak
+  cpu_baseline  the oracle's reference-equivalent CPU path (torch nn.LSTM + per-row eigh FK) timed
+                on this host's cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+for _p in (str(REPO), str(REPO / "arm-pose-estimation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WINDOWS_PER_GPU = 1024
+T_FRAMES = 64
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+POCKET = dict(I=22, H=256, L=2, O=14, layout=0)
+
+
+def synthetic_windows(stats, lo, hi, T, I):
+    """feature f ~ N(xx_m[f], xx_s[f]) per stream; stream s always gets the same data
+    whatever the sharding (seeded per stream block), sw_dt fixed at 0.02 s = 50 Hz"""
+    out = np.empty((hi - lo, T, I), dtype=np.float32)
+    for blk in range(lo // 256, (hi + 255) // 256):
+        rng = np.random.default_rng(1_000_003 + blk)
+        x = stats["xx_m"] + stats["xx_s"] * rng.normal(size=(256, T, I))
+        a, b = max(lo, blk * 256), min(hi, (blk + 1) * 256)
+        out[a - lo:b - lo] = x[a - blk * 256:b - blk * 256]
+    out[..., 0] = 0.02
+    return out
+
+
+def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0):
+    """reference-equivalent CPU path of the oracle on this host: torch-CPU nn.LSTM + Linear (the
+    reference's third-party arithmetic) + float64 FK with one 4x4 eigh per quaternion, repeated on
+    the same 1024-window batch until ~budget_s of CPU work is done."""
+    from oracle import ape_oracle as orc
+    threads = torch.get_num_threads()
+    orc.infer_windows(sd, stats, body, layout, x[:64], route="eigh", use_torch=True)   # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc.infer_windows(sd, stats, body, layout, x, route="eigh", use_torch=True)
+        done += x.shape[0]
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 64 * x.shape[0]:
+            break
+    return {"value": done / el, "unit": "windows/s", "cores": threads, "kind": "port",
+            "sample": f"{done} windows (B={x.shape[0]}, T={x.shape[1]}) in {el:.1f} s: oracle torch-CPU nn.LSTM+Linear "
+                      f"+ per-row eigh FK, {threads} threads of {os.cpu_count()} cpus"}
+
+
+def batch1_latency(model, stats, n_frames=300):
+    """configs[1]: batch=1 streaming, T=6 window, one frame per call, HIP-event timed"""
+    from wear_mocap_ape_amd import _hip
+    x = torch.from_numpy(synthetic_windows(stats, 0, 1, 6, POCKET["I"])).cuda()
+    est = torch.empty((1, 21), dtype=torch.float64, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib = _hip.lib()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_frames)]
+    for i in range(20 + n_frames):
+        if i >= 20:
+            evs[i - 20][0].record()
+        _hip.check(lib.ape_infer(model.handle, C.c_void_p(x.data_ptr()), 1, 6, _hip.FLAG_NORMALIZE_INPUT, None,
+                                 C.c_void_p(est.data_ptr()), _hip.F64, stream), "ape_infer")
+        if i >= 20:
+            evs[i - 20][1].record()
+            evs[i - 20][1].synchronize()      # frame-by-frame, like a 50 Hz stream consumer
+    us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+    return {"workload": "configs[1]: pocket B=1 T=6 streaming, one ape_infer per frame",
+            "p50_us": float(np.percentile(us, 50)), "p99_us": float(np.percentile(us, 99)),
+            "frames_per_s": float(1e6 / np.mean(us))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from oracle import ape_oracle as orc                       # weights + CPU baseline only
+    from wear_mocap_ape_amd import _hip, streams
+    from wear_mocap_ape_amd.estimate import nn_models
+    from wear_mocap_ape_amd.utility import data_stats
+    from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
+
+    # ---- model: weights exist on rank 0 only and reach the other GPUs by ONE broadcast --------
+    model = nn_models.DropoutLSTM(POCKET["I"], POCKET["H"], POCKET["L"], POCKET["O"], device=local_rank)
+    n_w = model.weight_blob_floats()
+    sd = stats = None
+    if rank == 0:
+        sd = orc.make_state_dict(POCKET["I"], POCKET["H"], POCKET["L"], POCKET["O"], seed=0)
+        stats = data_stats.get_norm_stats(NNS_INPUTS.WATCH_PHONE_CAL_HIP, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)
+        blob = streams.flatten_state_dict(sd, nn_models.state_dict_keys(POCKET["L"]))
+    else:
+        blob = None
+    blob_dev = streams.broadcast_blob(blob, n_w, dev)
+    stats = streams.broadcast_stats(stats, POCKET["I"], POCKET["O"], dev)
+    model.load_weight_blob(blob_dev)
+    model.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
+    model.set_body(orc.DEFAULT_BODY)
+
+    # ---- this rank's shard of the streams, resident in HBM ---------------------------------------
+    lo, hi = streams.shard_range(WINDOWS_PER_GPU * world, rank, world)
+    x_host = synthetic_windows(stats, lo, hi, T_FRAMES, POCKET["I"])
+    x = torch.from_numpy(x_host).to(dev)
+    B = hi - lo
+    y = torch.empty((B, POCKET["O"]), dtype=torch.float32, device=dev)
+    est = torch.empty((B, 21), dtype=torch.float32, device=dev)
+    lib = _hip.lib()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    xp, yp, ep = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(est.data_ptr())
+
+    ev_k = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        # exactly what ape_infer enqueues, split so the LSTM launch can be bracketed by HIP events
+        if i is not None:
+            ev_k[i][0].record()
+        _hip.check(lib.ape_lstm_forward(model.handle, xp, B, T_FRAMES, _hip.FLAG_NORMALIZE_INPUT, None, 0.0, 0, yp,
+                                        stream), "ape_lstm_forward")
+        if i is not None:
+            ev_k[i][1].record()
+        _hip.check(lib.ape_fk(model.handle, yp, _hip.F32, B, 1, ep, _hip.F32, stream), "ape_fk")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k]))
+    flop_per_launch = model.flops_per_window(T_FRAMES) * B
+    achieved_tf = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        total_windows = WINDOWS_PER_GPU * world * args.steps
+        out = {
+            "metric": "IMU windows/sec", "value": total_windows / elapsed, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: watch_phone_pocket_lstm path, 1024 windows/GPU x 64 frames x 22 "
+                                   "features (I=22,H=256,L=2,O=14), z-score+LSTM+head+denorm+FK, inputs resident in HBM",
+                       "windows_per_gpu": WINDOWS_PER_GPU, "frames": T_FRAMES, "features": POCKET["I"],
+                       "sharding": f"{world} ranks x {WINDOWS_PER_GPU} contiguous streams, weights by one RCCL broadcast"},
+            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": model.kernel_name(B, T_FRAMES), "kernel_ms": kernel_ms,
+                         "flop_per_launch": flop_per_launch,
+                         "hbm_algorithmic_bytes_per_launch": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4)},
+        }
+        tfile = REPO / "profiles" / "traffic_latest.json"
+        if tfile.exists():      # HBM bytes per launch from the committed rocprofv3 --pmc pass
+            try:
+                tj = json.loads(tfile.read_text())
+                if tj.get("kernel", "") in out["roofline"]["kernel"] and tj.get("windows") == B:
+                    out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        if world == 1:
+            out["batch1"] = batch1_latency(model, stats)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(sd, stats, orc.DEFAULT_BODY, POCKET["layout"], x_host)
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

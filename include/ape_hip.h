@@ -1,0 +1,158 @@
+/*
+ * ape_hip.h -- C ABI of libape_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * arm-pose inference path of wear_mocap_ape.
+ *
+ * The reference (pure Python) has no FFI; its boundary for this path is the Python
+ * `Estimator` template-method contract.  The entry points below are
+ * exactly what a reference-side ctypes binding for that path would call; each one names the
+ * reference code it replaces (paths relative to /root/reference/src/wear_mocap_ape).  The
+ * binding a maintainer would add is shown in INTEGRATION.md; the host-side mirror of the
+ * reference classes that uses it lives in arm-pose-estimation_amd/wear_mocap_ape_amd/.
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw pointers, sizes; no torch / C++ types.
+ *   - every `*_dev` pointer is DEVICE memory on the model's GPU (e.g. tensor.data_ptr()),
+ *     row-major, contiguous.  `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream).  Calls enqueue work on `stream` and return without synchronising; they
+ *     perform no allocation once `ape_model_reserve` covers the batch (graph-capture safe).
+ *   - return value 0 = success; anything else is an APE_ERR_* code and `ape_last_error()`
+ *     (thread-local) describes it.  The Python mirror raises `UserWarning` for a non-zero
+ *     status, the reference's exception convention (nn_models.py:385-400, transformations.py:98-116).
+ *   - a handle holds no per-stream mutable state besides its workspace: use one handle per
+ *     concurrently running stream/thread (reference: one Estimator per consumer thread,
+ *     estimator.py:139-143).
+ *   - quaternions are [w,x,y,z]; all joint/column indices are fixed by the layouts below.
+ */
+#ifndef APE_HIP_H
+#define APE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APE_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------- */
+enum {
+    APE_OK = 0,
+    APE_ERR_INVALID_ARG = 1,   /* NULL pointer, non-positive size, unknown enum value           */
+    APE_ERR_UNSUPPORTED = 2,   /* dims outside what the gfx950 kernels are built for            */
+    APE_ERR_NOT_READY = 3,     /* weights / norm stats not loaded yet                           */
+    APE_ERR_HIP = 4,           /* a HIP runtime call failed (message carries hipGetErrorString) */
+    APE_ERR_NO_DEVICE = 5,     /* no usable gfx950 device: there is NO CPU fallback             */
+    APE_ERR_CAPACITY = 6       /* batch larger than ape_model_reserve()d workspace during capture */
+};
+
+/* ---- NN-target layouts: utility/names.py:4-29 (NNS_TARGETS) -------------------------------
+ * est row layouts: estimate/estimate_joints.py:48-71 / :74-92 / :20-45
+ *   APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS      O=14 -> est[21] = hand(0:3) larm_orig(3:6) uarm_orig(6:9)
+ *                                                           larm_q(9:13) uarm_q(13:17) hips_q(17:21)
+ *   APE_LAYOUT_ORI_CAL_LARM_UARM           O=12 -> est[14] = hand(0:3) larm_orig(3:6) larm_q(6:10) uarm_q(10:14)
+ *   APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS  O=20 -> est[21] (same columns as the first)
+ * message layout (all three): estimate/compose_msg.py:72-78
+ *   msg[25] = hand_rot(0:4, == larm_rot) hand_orig(4:7) larm_rot(7:11) larm_orig(11:14)
+ *             uarm_rot(14:18) uarm_orig(18:21) hips_rot(21:25)
+ */
+enum {
+    APE_LAYOUT_NONE = -1,                    /* regressor only: ape_fk / ape_msg_reduce / ape_infer refuse */
+    APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS = 0,
+    APE_LAYOUT_ORI_CAL_LARM_UARM = 1,
+    APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS = 2
+};
+
+enum { APE_F32 = 0, APE_F64 = 1 };   /* element type selector for preds / est buffers */
+
+/* ---- flags for ape_lstm_forward / ape_infer ---------------------------------------------- */
+#define APE_FLAG_NORMALIZE_INPUT 0x1u /* x is raw features: z-score in f64, cast f32 (estimator.py:103-104,
+                                         watch_phone_pocket_nn.py:100); else x is already normalised  */
+#define APE_FLAG_ALL_STEPS       0x2u /* y is [B,T,O] like DropoutLSTM.forward (nn_models.py:188-189);
+                                         else only the last step [B,O] (watch_phone_pocket_nn.py:111)   */
+#define APE_FLAG_DROPOUT_MASKS   0x4u /* inter-layer dropout with caller-supplied masks (train-mode LSTM
+                                         after monte_carlo_predictions, nn_models.py:204)               */
+#define APE_FLAG_DROPOUT_PHILOX  0x8u /* inter-layer dropout with an in-kernel counter-based generator  */
+
+typedef struct ape_model ape_model_t;
+
+/* DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size) -- nn_models.py:160-178,
+ * constructed as load_deployed_model_from_hash does (nn_models.py:402-408). */
+typedef struct ape_dims {
+    int32_t input_size;    /* I: 20 / 22 / 38 (<= 64)                      */
+    int32_t hidden_size;   /* H: 128 or 256                                */
+    int32_t num_layers;    /* L: 1..3                                      */
+    int32_t output_size;   /* O: 12 / 14 / 20 (<= 32)                      */
+    int32_t target_layout; /* APE_LAYOUT_*; O must match it (unless NONE)  */
+    int32_t device;        /* HIP device ordinal                           */
+} ape_dims_t;
+
+/* library / device --------------------------------------------------------------------------- */
+int ape_abi_version(void);
+const char* ape_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 on a CPU-only host; never fails) */
+int ape_device_count(void);
+
+/* lifetime ------------------------------------------------------------------------------------ */
+/* replaces: nn_models.DropoutLSTM.__init__ (nn_models.py:161-178) + Estimator.__init__ defaults
+ * (estimator.py:57-68: default body measurements are installed) */
+int ape_model_create(const ape_dims_t* dims, ape_model_t** out_model);
+int ape_model_destroy(ape_model_t* model);
+/* pre-allocate the [max_batch, O] intermediate so that later calls do not allocate */
+int ape_model_reserve(ape_model_t* model, int32_t max_batch);
+
+/* replaces: nn_model.load_state_dict(model_state) (nn_models.py:410-411).
+ * `blob` = float32 tensors concatenated in state_dict order:
+ *   for k in 0..L-1: lstm.weight_ih_l{k} [4H, I or H], lstm.weight_hh_l{k} [4H,H],
+ *                    lstm.bias_ih_l{k} [4H], lstm.bias_hh_l{k} [4H];
+ *   then output_layer.weight [O,H], output_layer.bias [O].
+ * `blob` may be host or device memory (e.g. the buffer an RCCL broadcast just filled);
+ * `n_floats` must equal ape_weight_blob_floats(dims).  Synchronous; init-time only. */
+int ape_model_load_weights(ape_model_t* model, const float* blob, size_t n_floats);
+size_t ape_weight_blob_floats(const ape_dims_t* dims);
+
+/* replaces: Estimator.__init__ stats load / Estimator.set_norm_stats (estimator.py:35-42,72-77).
+ * Host pointers, float64: xx_m, xx_s [I]; yy_m, yy_s [O]. */
+int ape_model_set_norm_stats(ape_model_t* model, const double* xx_m, const double* xx_s,
+                             const double* yy_m, const double* yy_s);
+/* replaces: Estimator._body_measurements (estimator.py:57-68): [larm_vec(3), uarm_vec(3), uarm_orig_rh(3)] */
+int ape_model_set_body(ape_model_t* model, const double body9[9]);
+
+/* hot path ------------------------------------------------------------------------------------ */
+/* replaces: DropoutLSTM.forward / monte_carlo_predictions (nn_models.py:180-207) as called from
+ * make_prediction_from_row_hist (watch_phone_pocket_nn.py:98-112, watch_only.py:84-97,
+ * watch_phone_uarm_nn.py:107-121).  h0 = c0 = 0 for every window (hs=None).
+ *   x_dev      f32 [B,T,I]
+ *   masks_dev  f32 [L-1,B,T,H] holding 0 or 1/(1-p)   (APE_FLAG_DROPOUT_MASKS; else NULL)
+ *   dropout_p, seed                                   (APE_FLAG_DROPOUT_PHILOX)
+ *   y_dev      f32 [B,O] or [B,T,O] (APE_FLAG_ALL_STEPS): normalised NN targets */
+int ape_lstm_forward(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+                     const float* masks_dev, float dropout_p, uint64_t seed,
+                     float* y_dev, void* stream);
+
+/* replaces: estimate_joints.arm_pose_from_nn_targets (estimate_joints.py:16-17) and, with
+ * `denormalize` != 0, the `pred * yy_s + yy_m` of estimator.py:108-109 in front of it.
+ *   preds_dev  [N,O] of preds_dtype;  est_dev [N,W] of est_dtype (W = 21 or 14).
+ * All arithmetic is float64 on the device whatever the storage types. */
+int ape_fk(ape_model_t* model, const void* preds_dev, int32_t preds_dtype, int32_t N,
+           int32_t denormalize, void* est_dev, int32_t est_dtype, void* stream);
+
+/* replaces: compose_msg.msg_from_nn_targets_est (compose_msg.py:13-14): N est rows -> msg[25].
+ * N > 1: sign-aligned quaternion means (transformations.py:32-51) and origins recomputed from
+ * them; N == 1: row 0 copied into the message layout.  est_dev f64 [N,W]; msg_dev f64 [25]. */
+int ape_msg_reduce(ape_model_t* model, const double* est_dev, int32_t N, double* msg_dev, void* stream);
+
+/* the whole batched path in one call: x -> [normalise] -> LSTM -> last step ->
+ * de-normalise -> FK.  y_dev (f32 [B,O], normalised NN targets) may be NULL. */
+int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+              float* y_dev, void* est_dev, int32_t est_dtype, void* stream);
+
+/* introspection for benchmarks: name of the dominant kernel for (B,T) and its algorithmic
+ * FLOP per window (sum_layers 2*4H*(in_l+H) per step, + 2*O*H head once). */
+const char* ape_lstm_kernel_name(const ape_model_t* model, int32_t B, int32_t T);
+double ape_flops_per_window(const ape_dims_t* dims, int32_t T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APE_HIP_H */

@@ -22,6 +22,7 @@ that the loader uses into the product package's ``data_deploy`` (model/config da
 """
 import enum
 import json
+from array import array
 import os
 import pickle
 import sys
@@ -299,7 +300,8 @@ def gen_stream_traces():
                 warnings.simplefilter("ignore")
                 est = cls(model_hash=HASHES[name], smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
             xs, preds, msgs = [], [], []
-            for row in rows:
+            for row32 in rows:
+                row = array("f", row32.tolist())     # wire type of ImuListener (stream/listener/imu.py:66-69)
                 xx = est.parse_row_to_xx(row)
                 pred = est.add_xx_to_row_hist_and_make_prediction(xx)
                 msg = est.msg_from_pred(pred, True)
@@ -308,7 +310,7 @@ def gen_stream_traces():
                 msgs.append(np.asarray(msg, dtype=np.float64))
             tag = f"s{smooth}_mc{mc}"
             blob[f"xx_{tag}"] = np.array(xs)
-            blob[f"xx_dtype_{tag}"] = np.array(str(np.asarray(est.parse_row_to_xx(rows[0])).dtype))
+            blob[f"xx_dtype_{tag}"] = np.array(str(np.asarray(est.parse_row_to_xx(array("f", rows[0].tolist()))).dtype))
             blob[f"pred_{tag}"] = np.array(preds)
             blob[f"msg_{tag}"] = np.array(msgs)
             blob[f"last_msg_{tag}"] = np.asarray(est.get_last_msg(), dtype=np.float64)
@@ -318,9 +320,28 @@ def gen_stream_traces():
     ref_nn.load_deployed_model_from_hash = real_loader
 
 
+def gen_bookkeeping():
+    """column-name enums and UDP message lookups, verbatim values from the reference (data)"""
+    from wear_mocap_ape.data_types import messaging
+    from wear_mocap_ape.data_types.bone_map import BoneMap
+    names = {
+        "NNS_INPUTS": {m.name: list(m.value) for m in NNS_INPUTS},
+        "NNS_TARGETS": {m.name: m.value for m in NNS_TARGETS if isinstance(m.value, list)},
+        "WATCH_ONLY_IMU_LOOKUP": dict(messaging.WATCH_ONLY_IMU_LOOKUP),
+        "WATCH_PHONE_IMU_LOOKUP": dict(messaging.WATCH_PHONE_IMU_LOOKUP),
+        "watch_only_imu_msg_len": messaging.watch_only_imu_msg_len,
+        "watch_phone_imu_msg_len": messaging.watch_phone_imu_msg_len,
+        "deploy_hashes": {m.name: m.value for m in ref_deploy.LSTM},
+        "bone_defaults": {"larm": BoneMap.DEFAULT_LARM_LEN, "uarm": BoneMap.DEFAULT_UARM_LEN,
+                          "uarm_orig_rh": BoneMap.DEFAULT_UARM_ORIG_RH.tolist()},
+    }
+    (OUT / "bookkeeping.json").write_text(json.dumps(names, indent=1))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     stats = export_stats_and_configs()
+    gen_bookkeeping()
     gen_lstm(stats)
     gen_quat_ops()
     gen_fk(stats)

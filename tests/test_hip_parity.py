@@ -1,0 +1,361 @@
+"""GPU parity tests: the HIP path (through the C ABI of libape_hip.so) against
+  * the golden vectors produced by the reference itself (tests/golden/),
+  * the pinned CPU oracle on seeded inputs,
+  * size-independent properties at BASELINE.json's full sizes.
+
+Stated float32 tolerances:
+  NN targets  <= 1e-5 abs at T <= 8, <= 1e-4 at T = 64
+  est rows    <= 1e-11 abs for the float64 post-filter alone; <= 5e-5 end to end
+  bookkeeping (row/column indices, lengths, duplicated/constant message fields): bit-exact
+"""
+import ctypes as C
+import json
+import shutil
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ape_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_Y_SHORT = 1e-5
+TOL_Y_T64 = 1e-4
+TOL_FK64 = 1e-11
+TOL_EST_E2E = 5e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as entry
+    entry.build()
+
+
+def make_model(name, seed, stats=None):
+    from wear_mocap_ape_amd.estimate import nn_models
+    cfg = orc.MODEL_CONFIGS[name]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed)
+    m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0)
+    m.load_state_dict(sd)
+    if stats is not None:
+        m.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
+    return m, sd, cfg
+
+
+def quat_err(a, b, amb=1e-4):
+    """strict where |w_ref| is clear of zero, sign-aware only where the reference w ~ 0"""
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    dp, dm = np.abs(a - b).max(axis=1), np.abs(a + b).max(axis=1)
+    return float(np.nanmax(np.where(np.abs(b[:, 0]) < amb, np.minimum(dp, dm), dp)))
+
+
+# ---------------- LSTM + head vs the reference's own outputs -------------------------------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_lstm_vs_reference_golden(golden, name):
+    g = golden(f"lstm_{name}.npz")
+    for seed in (0, 1):
+        model, sd, cfg = make_model(name, seed)
+        assert np.array_equal(orc.state_dict_digest(sd), g[f"digest_seed{seed}"])
+        for (B, T) in ((1, cfg["T"]), (5, cfg["T"]), (3, 64), (2, 1)):
+            x, y_ref = g[f"x_seed{seed}_B{B}_T{T}"], g[f"y_seed{seed}_B{B}_T{T}"]
+            y = model(torch.from_numpy(x))                       # host in -> host out, all steps
+            assert tuple(y.shape) == (B, T, cfg["O"]) and y.dtype == torch.float32 and not y.is_cuda
+            err = float(np.abs(y.numpy() - y_ref).max())
+            assert err < (TOL_Y_T64 if T > 8 else TOL_Y_SHORT), (name, seed, B, T, err)
+            y_last = model(torch.from_numpy(x).cuda(), last_step_only=True)   # device in -> device out
+            assert y_last.is_cuda and tuple(y_last.shape) == (B, 1, cfg["O"])
+            assert np.array_equal(y_last.cpu().numpy()[:, 0], y.numpy()[:, -1])   # same kernel arithmetic
+
+
+@pytest.mark.parametrize("name,B,T", [("pocket", 17, 6), ("pocket", 60, 6), ("watch", 33, 8), ("uarm", 16, 6),
+                                      ("uarm", 1, 3), ("pocket", 1, 1), ("watch", 130, 2)])
+def test_lstm_vs_oracle_ragged_batches(name, B, T):
+    """batch sizes that leave partial 16-row tiles, windows shorter than the deployed ones"""
+    model, sd, cfg = make_model(name, 7)
+    x = np.random.default_rng(B * 100 + T).normal(size=(B, T, cfg["I"])).astype(np.float32)
+    y = model(torch.from_numpy(x)).numpy()
+    y_ref = orc.lstm_forward(sd, x)
+    assert np.abs(y - y_ref).max() < TOL_Y_SHORT
+
+
+def test_fused_normalisation_is_bit_exact(norm_stats):
+    """APE_FLAG_NORMALIZE_INPUT == host float64 z-score followed by the float32 cast"""
+    st = norm_stats["pocket"]
+    model, sd, cfg = make_model("pocket", 2, st)
+    rng = np.random.default_rng(5)
+    x_raw = (st["xx_m"] + st["xx_s"] * rng.normal(size=(40, 6, cfg["I"]))).astype(np.float32)
+    x_norm = ((x_raw.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    y_fused = model(torch.from_numpy(x_raw), normalize_input=True).numpy()
+    y_host = model(torch.from_numpy(x_norm)).numpy()
+    assert np.array_equal(y_fused, y_host)
+
+
+@pytest.mark.parametrize("name", ["pocket", "uarm"])
+def test_dropout_with_injected_masks(name):
+    """MC-dropout parity with explicit masks: torch's internal mask stream cannot be replayed
+    (SURVEY.md 3.3), so the oracle's cell loop and the kernel get the same masks"""
+    model, sd, cfg = make_model(name, 3)
+    B, T, p = 25, cfg["T"], 0.2
+    rng = np.random.default_rng(9)
+    x = np.repeat(rng.normal(size=(1, T, cfg["I"])).astype(np.float32), B, axis=0)
+    masks = (rng.uniform(size=(cfg["L"] - 1, B, T, cfg["H"])) >= p).astype(np.float32) / (1 - p)
+    y = model(torch.from_numpy(x), masks=torch.from_numpy(masks)).numpy()
+    y_ref = orc.lstm_forward(sd, x, masks=list(masks))
+    assert np.abs(y - y_ref).max() < TOL_Y_SHORT
+    assert np.abs(y[0] - y[1]).max() > 1e-4          # masks differ per row -> rows differ
+
+
+def test_philox_dropout_statistics():
+    """in-kernel masks: deterministic per seed, different across calls, unbiased on average"""
+    model, sd, cfg = make_model("pocket", 4)
+    x = np.random.default_rng(3).normal(size=(1, 6, cfg["I"])).astype(np.float32)
+    xt = torch.from_numpy(x)
+    y_eval = model(xt).numpy()[0, -1]
+    model.manual_seed(11)
+    a = model.monte_carlo_predictions(400, xt).numpy()[:, -1]
+    b = model.monte_carlo_predictions(400, xt).numpy()[:, -1]
+    model.manual_seed(11)
+    a2 = model.monte_carlo_predictions(400, xt).numpy()[:, -1]
+    assert np.array_equal(a, a2) and not np.array_equal(a, b)
+    assert model.lstm.training                                   # permanent, like nn_models.py:204
+    assert a.std(axis=0).min() > 1e-4                            # samples really differ
+    # inverted dropout keeps the layer-1 input unbiased: the MC mean stays near the eval output
+    ref_spread = np.abs(a - y_eval).mean()
+    assert np.abs(a.mean(axis=0) - y_eval).max() < 0.35 * max(ref_spread, 1e-3) + 0.02
+    # p = 0 switches dropout off entirely
+    model.dropout = 0.0
+    assert np.array_equal(model.monte_carlo_predictions(3, xt).numpy()[0, -1], y_eval)
+    with pytest.raises(UserWarning, match="batch size 1"):
+        model.monte_carlo_predictions(3, torch.zeros(2, 6, cfg["I"]))
+
+
+# ---------------- FK + message vs the reference's own outputs ---------------------------------------
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_fk_and_msg_vs_reference_golden(golden, layout):
+    from wear_mocap_ape_amd.estimate import compose_msg, estimate_joints
+    from wear_mocap_ape_amd.utility.names import NNS_TARGETS
+    tgt = {0: NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS, 1: NNS_TARGETS.ORI_CAL_LARM_UARM,
+           2: NNS_TARGETS.ORI_POS_CAL_LARM_UARM_HIPS}[layout]
+    g = golden(f"fk_layout{layout}.npz")
+    W = orc.LAYOUT_EST_WIDTH[layout]
+    qcols = {0: (9, 13, 17), 1: (6, 10), 2: (9, 13, 17)}[layout]
+    for tag in ("bd", "bo"):
+        body = g[f"body_{tag}"]
+        for N in (1, 7, 300):
+            preds, est_ref, msg_ref = g[f"preds_{tag}_N{N}"], g[f"est_{tag}_N{N}"], g[f"msg_{tag}_N{N}"]
+            est = estimate_joints.arm_pose_from_nn_targets(preds, body, tgt)
+            assert est.shape == (N, W) and est.dtype == np.float64
+            good = ~np.isnan(est_ref).any(axis=1)
+            assert np.array_equal(good, ~np.isnan(est).any(axis=1))       # degenerate rows stay NaN
+            for c in qcols:
+                assert quat_err(est[good, c:c + 4], est_ref[good, c:c + 4]) < TOL_FK64
+            clear = good & (np.abs(est_ref[:, list(qcols)]) > 1e-4).all(axis=1)
+            assert np.abs(est[clear, :qcols[0]] - est_ref[clear, :qcols[0]]).max() < TOL_FK64
+            # message from the reference's est rows: isolates averaging + layout bookkeeping
+            rows = est_ref if (N == 1 or good.all()) else est_ref[good]
+            msg = compose_msg.msg_from_nn_targets_est(rows, body, tgt)
+            assert msg.shape == (25,) and msg.dtype == np.float64
+            if N == 1 or good.all():
+                assert np.abs(msg - msg_ref).max() < TOL_FK64
+            assert np.array_equal(msg[0:4], msg[7:11])                     # hand rot == larm rot (bit-exact)
+            if layout == 1:
+                assert np.array_equal(msg[21:25], [1.0, 0.0, 0.0, 0.0])    # constant hips
+                assert np.array_equal(msg[18:21], body[0, 6:9])            # constant upper-arm origin
+
+
+def test_fk_storage_types():
+    """f32/f64 preds and est buffers through ape_fk: same float64 arithmetic, rounded once"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import _post
+    rng = np.random.default_rng(2)
+    preds = rng.normal(size=(513, 14))
+    ctx = _post.context(0)
+    ref = _post.fk_rows(ctx.handle, 0, ctx.device, preds, orc.DEFAULT_BODY)
+    assert np.abs(ref - orc.arm_pose_from_targets(preds, orc.DEFAULT_BODY, 0, "closed")).max() < TOL_FK64
+    p32 = torch.from_numpy(preds.astype(np.float32)).cuda()
+    e32 = torch.empty((513, 21), dtype=torch.float32, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _hip.check(_hip.lib().ape_fk(ctx.handle, C.c_void_p(p32.data_ptr()), _hip.F32, 513, 0,
+                                 C.c_void_p(e32.data_ptr()), _hip.F32, stream), "ape_fk")
+    ref32 = orc.arm_pose_from_targets(preds.astype(np.float32).astype(np.float64), orc.DEFAULT_BODY, 0, "closed")
+    assert np.array_equal(e32.cpu().numpy(), ref32.astype(np.float32)) or \
+        np.abs(e32.cpu().numpy() - ref32).max() < 2e-7
+
+
+def test_error_behaviour():
+    from wear_mocap_ape_amd.estimate import estimate_joints
+    from wear_mocap_ape_amd.utility.names import NNS_TARGETS
+    model, sd, cfg = make_model("pocket", 0)
+    with pytest.raises(UserWarning):
+        model(torch.zeros(0, 6, cfg["I"]))                       # empty batch
+    with pytest.raises(UserWarning):
+        model(torch.zeros(2, 0, cfg["I"]))                       # empty window
+    with pytest.raises(UserWarning):
+        model(torch.zeros(2, 6, cfg["I"] + 1))                   # wrong feature count
+    with pytest.raises(UserWarning):
+        model(torch.zeros(2, 6, cfg["I"]), hs=(1, 2))            # carried state is not part of the path
+    with pytest.raises(UserWarning):
+        estimate_joints.arm_pose_from_nn_targets(np.zeros((3, 12)), orc.DEFAULT_BODY, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict({"lstm.weight_ih_l0": np.zeros((4, 4))})
+
+
+# ---------------- the estimator classes: streaming traces of the reference ----------------------------
+def _deploy_dir(tmp_path, name, seed, dropout):
+    """a deploy tree with a synthetic checkpoint in the reference's (model_state, optimizer_state)
+    tuple format (nn_models.py:410)"""
+    from wear_mocap_ape_amd import config
+    cfg = orc.MODEL_CONFIGS[name]
+    src = Path(config.PATHS["deploy"])
+    dst = tmp_path / "deploy"
+    shutil.copytree(src / "data_stats", dst / "data_stats", dirs_exist_ok=True)
+    hashes = {"pocket": "670b66fa7664252d1cfb3b5a8a362002ffeeba5c", "watch": "04f4ad63bfccb3668f7598c9375403e10b1fae2a",
+              "uarm": "7cb5cdf94ef4c66388c7f15f642005d5e008146a"}
+    d = dst / "nn" / hashes[name]
+    d.mkdir(parents=True, exist_ok=True)
+    p = json.loads((src / "nn" / hashes[name] / "results.json").read_text())
+    p["dropout"] = dropout
+    (d / "results.json").write_text(json.dumps(p))
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed)
+    torch.save(({k: torch.from_numpy(v) for k, v in sd.items()}, {"state": {}, "param_groups": []}), d / "checkpoint.pt")
+    return dst, hashes[name]
+
+
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_estimator_stream_trace(golden, tmp_path, monkeypatch, name):
+    from array import array
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape_amd.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+    g = golden(f"stream_trace_{name}.npz")
+    deploy, h = _deploy_dir(tmp_path, name, int(g["weights_seed"]), dropout=0.0)   # as the golden run
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    cls = {"pocket": WatchPhonePocketNN, "watch": WatchOnlyNN, "uarm": WatchPhoneUarmNN}[name]
+    cfg = orc.MODEL_CONFIGS[name]
+    for smooth, mc in ((1, 1), (5, 1), (3, 4)):
+        tag = f"s{smooth}_mc{mc}"
+        est = cls(model_hash=h, smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
+        assert est.sequence_len == cfg["T"]
+        assert np.array_equal(est.body_measurements, g["body"])
+        worst_pred = worst_msg = 0.0
+        for f, row32 in enumerate(g["rows"]):
+            xx = est.parse_row_to_xx(array("f", row32.tolist()))
+            pred = est.add_xx_to_row_hist_and_make_prediction(xx)
+            pred_ref = g[f"pred_{tag}"][f]
+            assert pred.shape == pred_ref.shape and pred.dtype == np.float64      # bookkeeping: rows = smooth*mc
+            worst_pred = max(worst_pred, float(np.abs(pred - pred_ref).max()))
+            msg = est.msg_from_pred(pred_ref, True)          # reference preds in -> isolates FK + message + MC tail
+            msg_ref = g[f"msg_{tag}"][f]
+            n_rows = pred_ref.shape[0]
+            assert isinstance(msg, list) and len(msg) == len(msg_ref) == (25 + 6 * n_rows if n_rows > 1 else 25)
+            worst_msg = max(worst_msg, float(np.abs(np.asarray(msg) - msg_ref).max()))
+        assert worst_pred < 2e-5, (tag, worst_pred)          # de-normalised targets (yy_s <= 1)
+        assert worst_msg < 1e-10, (tag, worst_msg)
+        assert np.abs(est.get_last_msg() - g[f"last_msg_{tag}"]).max() < 1e-10 and len(est.get_last_msg()) == 25
+        est.reset()
+        assert est._row_hist == [] and est._smooth_hist == [] and not est.is_active()
+
+
+def test_processing_loop_thread(tmp_path, monkeypatch, golden):
+    """the consumer thread contract: sensor_q in -> msg_q out, terminate() stops it"""
+    import queue
+    import time
+    from array import array
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    g = golden("stream_trace_pocket.npz")
+    deploy, h = _deploy_dir(tmp_path, "pocket", 3, dropout=0.2)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    est = WatchPhonePocketNN(model_hash=h, smooth=2, monte_carlo_samples=10)
+    sensor_q = queue.Queue()
+    msg_q = est.process_in_thread(sensor_q)
+    try:
+        for row32 in g["rows"][:4]:
+            sensor_q.put(array("f", row32.tolist()))
+            msg = msg_q.get(timeout=30)
+            assert len(msg) == 25 + 6 * 20
+            q = np.asarray(msg[0:4])
+            assert abs(np.linalg.norm(q) - 1.0) < 1e-9
+        assert est.is_active()
+    finally:
+        est.terminate()
+        time.sleep(0.1)
+
+
+# ---------------- the batched path at BASELINE.json's full sizes --------------------------------------
+def _synthetic_windows(st, B, T, I, seed):
+    rng = np.random.default_rng(seed)
+    x = st["xx_m"] + st["xx_s"] * rng.normal(size=(B, T, I))
+    x[..., 0] = 0.02                                    # 50 Hz
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["pocket", "watch"])
+def test_full_size_batched_path(norm_stats, name):
+    """config 3 / 5 shapes: 1024 windows x 64 frames, against the oracle and through properties"""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats[name]
+    model, sd, cfg = make_model(name, 0, st)
+    model.set_body(orc.DEFAULT_BODY)
+    B, T, W = 1024, 64, orc.LAYOUT_EST_WIDTH[cfg["layout"]]
+    x = _synthetic_windows(st, B, T, cfg["I"], 1)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+    est = torch.empty((B, W), dtype=torch.float64, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(inp, yo, eo):
+        _hip.check(_hip.lib().ape_infer(model.handle, C.c_void_p(inp.data_ptr()), inp.shape[0], T,
+                                        _hip.FLAG_NORMALIZE_INPUT, C.c_void_p(yo.data_ptr()),
+                                        C.c_void_p(eo.data_ptr()), _hip.F64, stream), "ape_infer")
+        torch.cuda.synchronize()
+
+    run(xd, y, est)
+    y_ref, est_ref = orc.infer_windows(sd, st, orc.DEFAULT_BODY, cfg["layout"], x)
+    ey = float(np.abs(y.cpu().numpy() - y_ref).max())
+    qcols = (9, 13, 17) if cfg["layout"] == 0 else (6, 10)
+    e = est.cpu().numpy()
+    eq = max(quat_err(e[:, c:c + 4], est_ref[:, c:c + 4]) for c in qcols)
+    eo = float(np.abs(e[:, :qcols[0]] - est_ref[:, :qcols[0]]).max())
+    print(f"\n[{name} B={B} T={T}] max|dy|={ey:.2e} max|dquat|={eq:.2e} max|dorig|={eo:.2e}")
+    assert ey < TOL_Y_T64 and eq < TOL_EST_E2E and eo < TOL_EST_E2E
+
+    # windows are independent: a permutation of the batch permutes the output bit-exactly
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(B)).cuda()
+    y2, est2 = torch.empty_like(y), torch.empty_like(est)
+    run(xd[perm].contiguous(), y2, est2)
+    assert torch.equal(y2, y[perm]) and torch.equal(est2, est[perm])
+    # ... and so does a ragged sub-batch (partial last tile)
+    y3, est3 = torch.empty((1001, cfg["O"]), dtype=torch.float32, device="cuda"), torch.empty((1001, W), dtype=torch.float64, device="cuda")
+    run(xd[:1001].contiguous(), y3, est3)
+    assert torch.equal(y3, y[:1001]) and torch.equal(est3, est[:1001])
+    # unit quaternions with w >= 0; bone lengths preserved by the kinematic chain
+    for c in qcols:
+        q = e[:, c:c + 4]
+        assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-12 and (q[:, 0] >= 0).all()
+    assert np.abs(np.linalg.norm(e[:, 0:3] - e[:, 3:6], axis=1) - 0.22).max() < 1e-12
+    uo = e[:, 6:9] if cfg["layout"] == 0 else orc.DEFAULT_BODY[:, 6:9]
+    assert np.abs(np.linalg.norm(e[:, 3:6] - uo, axis=1) - 0.26).max() < 1e-12
+
+
+def test_infer_windows_entry(tmp_path, monkeypatch, norm_stats):
+    """Estimator.infer_windows == per-window streaming through the same estimator"""
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    deploy, h = _deploy_dir(tmp_path, "pocket", 5, dropout=0.0)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    est = WatchPhonePocketNN(model_hash=h, smooth=1, monte_carlo_samples=1)
+    x = _synthetic_windows(norm_stats["pocket"], 9, 6, 22, 4)
+    rows = est.infer_windows(x).cpu().numpy()
+    assert rows.shape == (9, 21)
+    for b in range(9):
+        est.reset()
+        for t in range(6):
+            pred = est.add_xx_to_row_hist_and_make_prediction(x[b, t])
+        # after 6 pushes the window holds exactly x[b]; single row -> message copies the est row
+        msg = np.asarray(est.msg_from_pred(pred, False))
+        assert np.abs(msg[4:7] - rows[b, 0:3]).max() < 1e-6
+        assert quat_err(msg[7:11], rows[b, 9:13]) < 1e-6
