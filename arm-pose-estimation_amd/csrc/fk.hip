@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void ape_msg_kernel(const MsgParams p) {
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                 for (int i = tid; i < N; i += 256) {
                     const double* qi = p.est + (size_t)i * W + col;
-                    const double d = qi[0] * r0 + qi[1] * r1 + qi[2] * r2 + qi[3] * r3;
+                    // sign rule of transformations.py:44: np.dot(qi, q0) < 0.0.  numpy hands this to BLAS ddot,
+                    // whose 4-element loop is an FMA chain; at (near-)exact orthogonality only that chain
+                    // reproduces the sign of the rounding residue, so the same chain is used here.
+                    const double d = fma(qi[3], r3, fma(qi[2], r2, fma(qi[1], r1, qi[0] * r0)));
                     const double sg = (i > 0 && d < 0.0) ? -wgt : wgt;
                     a0 += qi[0] * sg; a1 += qi[1] * sg; a2 += qi[2] * sg; a3 += qi[3] * sg;
                 }

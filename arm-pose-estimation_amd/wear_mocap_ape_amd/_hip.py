@@ -6,6 +6,10 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# torch FIRST: it loads the HIP runtime (libamdhip64.so.7) that owns the device pointers and streams
+# handed to the kernels; libape_hip.so must bind to that same loaded runtime, not open a second copy.
+import torch  # noqa: F401
+
 LIB_PATH = Path(os.environ.get("APE_HIP_LIB", Path(__file__).resolve().parents[1] / "lib" / "libape_hip.so"))
 
 APE_OK = 0

@@ -3,9 +3,11 @@
   * the pinned CPU oracle on seeded inputs,
   * size-independent properties at BASELINE.json's full sizes.
 
-Stated float32 tolerances:
-  NN targets  <= 1e-5 abs at T <= 8, <= 1e-4 at T = 64
-  est rows    <= 1e-11 abs for the float64 post-filter alone; <= 5e-5 end to end
+Tolerances.  BASELINE.json / SURVEY.md 8d state float32 budgets of 1e-5 (T <= 8) and 1e-4 (T = 64)
+on the NN targets and 5e-5 on quaternions/origins.  The f32-MFMA kernel measures ~5e-8 (first GPU
+run: max|dy| 4.3e-8, max|dquat| 7.2e-8 at B=1024, T=64), so the tests assert 20x tighter bounds:
+  NN targets  <= 1e-6 abs (any T)
+  est rows    <= 1e-11 abs for the float64 post-filter alone; <= 2e-6 end to end
   bookkeeping (row/column indices, lengths, duplicated/constant message fields): bit-exact
 """
 import ctypes as C
@@ -21,10 +23,10 @@ from oracle import ape_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-TOL_Y_SHORT = 1e-5
-TOL_Y_T64 = 1e-4
+TOL_Y_SHORT = 1e-6
+TOL_Y_T64 = 1e-6
 TOL_FK64 = 1e-11
-TOL_EST_E2E = 5e-5
+TOL_EST_E2E = 2e-6
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -252,7 +254,7 @@ def test_estimator_stream_trace(golden, tmp_path, monkeypatch, name):
             n_rows = pred_ref.shape[0]
             assert isinstance(msg, list) and len(msg) == len(msg_ref) == (25 + 6 * n_rows if n_rows > 1 else 25)
             worst_msg = max(worst_msg, float(np.abs(np.asarray(msg) - msg_ref).max()))
-        assert worst_pred < 2e-5, (tag, worst_pred)          # de-normalised targets (yy_s <= 1)
+        assert worst_pred < 2e-6, (tag, worst_pred)          # de-normalised targets (yy_s <= 1)
         assert worst_msg < 1e-10, (tag, worst_msg)
         assert np.abs(est.get_last_msg() - g[f"last_msg_{tag}"]).max() < 1e-10 and len(est.get_last_msg()) == 25
         est.reset()
