@@ -59,11 +59,22 @@ def synthetic_windows(stats, lo, hi, T, I):
 
 def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0):
     """reference-equivalent CPU path of the oracle on this host: torch-CPU nn.LSTM + Linear (the
-    reference's third-party arithmetic) + float64 FK with one 4x4 eigh per quaternion, repeated on
-    the same 1024-window batch until ~budget_s of CPU work is done."""
+    reference's third-party arithmetic) + float64 FK with one 4x4 eigh per quaternion.  The thread
+    count is chosen by a short probe (torch's default of one thread per core is far from the best
+    for 2x256 LSTM GEMMs), then the 1024-window batch is repeated until ~budget_s of CPU work is done."""
     from oracle import ape_oracle as orc
-    threads = torch.get_num_threads()
-    orc.infer_windows(sd, stats, body, layout, x[:64], route="eigh", use_torch=True)   # warm-up
+    default_threads = torch.get_num_threads()
+    probe = {}
+    for n in sorted({8, 16, 32, 64, default_threads}):
+        if n > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(n)
+        orc.infer_windows(sd, stats, body, layout, x[:64], route="eigh", use_torch=True)   # warm-up
+        t0 = time.perf_counter()
+        orc.infer_windows(sd, stats, body, layout, x[:256], route="eigh", use_torch=True)
+        probe[n] = 256 / (time.perf_counter() - t0)
+    threads = max(probe, key=probe.get)
+    torch.set_num_threads(threads)
     done, t0 = 0, time.perf_counter()
     while True:
         orc.infer_windows(sd, stats, body, layout, x, route="eigh", use_torch=True)
@@ -71,9 +82,11 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or done >= 64 * x.shape[0]:
             break
+    torch.set_num_threads(default_threads)
     return {"value": done / el, "unit": "windows/s", "cores": threads, "kind": "port",
             "sample": f"{done} windows (B={x.shape[0]}, T={x.shape[1]}) in {el:.1f} s: oracle torch-CPU nn.LSTM+Linear "
-                      f"+ per-row eigh FK, {threads} threads of {os.cpu_count()} cpus"}
+                      f"+ per-row eigh FK; best of thread probe {{{', '.join(f'{k}: {v:.0f}/s' for k, v in probe.items())}}} "
+                      f"on {os.cpu_count()} cpus"}
 
 
 def batch1_latency(model, stats, n_frames=300):
