@@ -76,7 +76,15 @@ struct ape_model {
     double body[9];
     float* y_ws = nullptr;         // [cap, O] intermediate of ape_infer
     int y_cap = 0;
-    std::string kernel_name;
+    // weight-stationary cluster kernel (lstm_cluster.hip)
+    bool cluster_ok = false;
+    int kernel_choice = APE_KERNEL_AUTO;
+    float* wcl[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+    float* hx = nullptr;           // exchange slices
+    size_t hx_bytes = 0;
+    unsigned* xflags = nullptr;    // [flag words..., status word]
+    size_t xflag_bytes = 0;        // bytes of the flag block (multiple of 16), status word follows
+    std::string kernel_name, cluster_name;
 };
 
 extern "C" {
@@ -156,6 +164,24 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     char nm[64];
     snprintf(nm, sizeof(nm), "ape_lstm_tile16<%d, %d>", H, L);
     m->kernel_name = nm;
+    snprintf(nm, sizeof(nm), "ape_lstm_cluster<%d, %d, %d", H, L, m->KX);
+    m->cluster_name = nm;
+    if (ape_cluster_supported(H, L, m->KX)) {
+        const int GH = H / 16, max_clusters = 256 / GH;
+        for (int l = 0; l < L && e == hipSuccess; ++l)
+            e = hipMalloc((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
+        m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
+        m->xflag_bytes = (((size_t)max_clusters * L * GH * sizeof(unsigned)) + 15) / 16 * 16;
+        if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 16);
+        if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 16);
+        if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
+        if (e != hipSuccess) {
+            ape_model_destroy(m);
+            return fail(APE_ERR_HIP, "cluster kernel set-up failed: %s", hipGetErrorString(e));
+        }
+        m->cluster_ok = true;
+    }
     *out = m;
     return APE_OK;
 }
@@ -171,6 +197,10 @@ int ape_model_destroy(ape_model_t* m) {
     if (m->b_out) (void)hipFree(m->b_out);
     if (m->stats) (void)hipFree(m->stats);
     if (m->y_ws) (void)hipFree(m->y_ws);
+    for (int l = 0; l < APE_MAX_LAYERS; ++l)
+        if (m->wcl[l]) (void)hipFree(m->wcl[l]);
+    if (m->hx) (void)hipFree(m->hx);
+    if (m->xflags) (void)hipFree(m->xflags);
     delete m;
     return APE_OK;
 }
@@ -224,6 +254,25 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                         }
                     }
                 }
+        if (m->cluster_ok) {
+            // cluster kernel: [member GH][wave 4][i = 4q + j][lane]; lane = (g << 4) | (gate << 2) | u holds
+            // Wcat[gate*H + member*16 + wave*4 + u][16q + 4g + j] -- the register file of that wave
+            const int GH = H / 16, NW = (KXl + H) / 4;
+            std::vector<float> pc((size_t)GH * 4 * NW * 64);
+            for (int mem = 0; mem < GH; ++mem)
+                for (int w = 0; w < 4; ++w)
+                    for (int i = 0; i < NW; ++i)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int c = lane & 15, g = lane >> 4, gate = c >> 2, u = c & 3;
+                            const int row = gate * H + mem * 16 + w * 4 + u;
+                            const int k = 16 * (i / 4) + 4 * g + (i % 4);
+                            float v;
+                            if (k < KXl) v = (k < in_l) ? w_ih[(size_t)row * in_l + k] : 0.0f;
+                            else v = w_hh[(size_t)row * H + (k - KXl)];
+                            pc[(((size_t)(mem * 4 + w) * NW) + i) * 64 + lane] = v;
+                        }
+            HIP_TRY(hipMemcpy(m->wcl[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         std::vector<float> bsum(4 * H);
         for (int i = 0; i < 4 * H; ++i) bsum[i] = b_ih[i] + b_hh[i];
         HIP_TRY(hipMemcpy(m->wpack[l], packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -275,6 +324,37 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
 
+    const bool plain = (flags & (APE_FLAG_ALL_STEPS | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) == 0;
+    bool use_cluster = m->cluster_ok && plain && m->kernel_choice != APE_KERNEL_TILE16;
+    if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster)
+        return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
+    if (use_cluster) {
+        // smallest row tile count that still fits the batch on the chip: more clusters = more CUs busy
+        const int GH = H / 16, max_clusters = 256 / GH;
+        int nmt = 4;
+        for (int cand : {1, 2, 4})
+            if ((B + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
+        const int rows_per_launch = 16 * nmt * max_clusters;
+        for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
+            const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
+            ClusterParams c{};
+            c.x = x_dev + (size_t)b0 * T * m->dims.input_size;
+            c.y = y_dev + (size_t)b0 * m->dims.output_size;
+            for (int l = 0; l < L; ++l) { c.wcl[l] = m->wcl[l]; c.bias[l] = m->bias[l]; }
+            c.w_out = m->w_out; c.b_out = m->b_out;
+            c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
+            c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+            c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+            c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size; c.flags = flags;
+            const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
+            // every polled word is re-zeroed in front of EVERY launch (a memset node under graph capture)
+            hipError_t e = hipMemsetAsync(m->xflags, 0, m->xflag_bytes, (hipStream_t)stream);
+            if (e == hipSuccess) e = ape_launch_lstm_cluster(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
+        }
+        return APE_OK;
+    }
+
     LstmParams p{};
     p.x = x_dev;
     p.y = y_dev;
@@ -290,6 +370,31 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     p.seed = seed;
     hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
+    return APE_OK;
+}
+
+int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
+    if (!m) return fail(APE_ERR_INVALID_ARG, "set_kernel: NULL model");
+    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER)
+        return fail(APE_ERR_INVALID_ARG, "set_kernel: unknown choice %d", choice);
+    if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
+        return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d", m->dims.hidden_size, m->dims.num_layers);
+    m->kernel_choice = choice;
+    return APE_OK;
+}
+
+int ape_model_check(ape_model_t* m) {
+    if (!m) return fail(APE_ERR_INVALID_ARG, "check: NULL model");
+    if (!m->cluster_ok) return APE_OK;
+    HIP_TRY(hipSetDevice(m->dims.device));
+    unsigned st = 0;
+    HIP_TRY(hipMemcpy(&st, m->xflags + m->xflag_bytes / sizeof(unsigned), sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        const unsigned zero = 0;
+        HIP_TRY(hipMemcpy(m->xflags + m->xflag_bytes / sizeof(unsigned), &zero, sizeof(zero), hipMemcpyHostToDevice));
+        return fail(APE_ERR_HIP, "cluster kernel gave up waiting for a peer workgroup (status %u): not all of its "
+                    "workgroups were resident; outputs of that launch are invalid", st);
+    }
     return APE_OK;
 }
 
@@ -352,7 +457,8 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     (void)B; (void)T;
-    return m ? m->kernel_name.c_str() : "";
+    if (!m) return "";
+    return (m->cluster_ok && m->kernel_choice != APE_KERNEL_TILE16) ? m->cluster_name.c_str() : m->kernel_name.c_str();
 }
 
 }  // extern "C"

@@ -28,6 +28,24 @@ struct LstmParams {
     unsigned long long seed;
 };
 
+// Kernel arguments of the weight-stationary cluster LSTM kernel.
+struct ClusterParams {
+    const float* x;                     // [B,T,I]
+    float* y;                           // [B,O]
+    const float* wcl[APE_MAX_LAYERS];   // per layer [member GH][wave 4][NW_l][lane 64]: B-fragment registers
+    const float* bias[APE_MAX_LAYERS];  // per layer [4H] = b_ih + b_hh
+    const float* w_out;                 // [O,H]
+    const float* b_out;                 // [O]
+    const double* xx_m;
+    const double* xx_s;
+    float* hx;                          // exchange slices [cluster][L][parity 2][member GH][row MR][16]
+    size_t hx_bytes;
+    unsigned* xflags;                   // [cluster][L][GH] epoch flags, zeroed before every launch
+    unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
+    int B, T, I, O;
+    unsigned flags;
+};
+
 struct FkParams {
     const void* preds;   // [N,O] f32 or f64
     void* est;           // [N,W] f32 or f64
@@ -49,5 +67,8 @@ struct MsgParams {
 hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream);
 size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout);
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
+bool ape_cluster_supported(int H, int L, int KX);
+hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
+hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

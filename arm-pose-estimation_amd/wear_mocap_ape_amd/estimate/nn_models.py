@@ -235,6 +235,16 @@ class DropoutLSTM:
             rep = np.repeat(np.asarray(x), n_samples, axis=0)
         return self.forward(rep, hs, last_step_only=last_step_only)
 
+    def set_kernel(self, choice: str = "auto"):
+        """'auto' | 'tile16' | 'cluster': which LSTM kernel ``forward`` launches (A/B runs, tests)"""
+        code = {"auto": _hip.KERNEL_AUTO, "tile16": _hip.KERNEL_TILE16, "cluster": _hip.KERNEL_CLUSTER}[choice]
+        _hip.check(_hip.lib().ape_model_set_kernel(self._handle, code), "ape_model_set_kernel")
+        return self
+
+    def check(self):
+        """blocking health check: raises if a cluster-kernel launch gave up waiting for a peer workgroup"""
+        _hip.check(_hip.lib().ape_model_check(self._handle), "ape_model_check")
+
     def kernel_name(self, B: int, T: int) -> str:
         return _hip.lib().ape_lstm_kernel_name(self._handle, B, T).decode()
 

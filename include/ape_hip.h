@@ -74,6 +74,10 @@ enum { APE_F32 = 0, APE_F64 = 1 };   /* element type selector for preds / est bu
                                          after monte_carlo_predictions, nn_models.py:204)               */
 #define APE_FLAG_DROPOUT_PHILOX  0x8u /* inter-layer dropout with an in-kernel counter-based generator  */
 
+/* LSTM kernel selection (ape_model_set_kernel).  AUTO = the weight-stationary cluster kernel where it is
+ * built (H=256/L=2/I<=32 and H=128/L=3/32<I<=64, last-step output, no dropout), else the batch-tile kernel. */
+enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2 };
+
 typedef struct ape_model ape_model_t;
 
 /* DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size) -- nn_models.py:160-178,
@@ -146,6 +150,12 @@ int ape_msg_reduce(ape_model_t* model, const double* est_dev, int32_t N, double*
  * de-normalise -> FK.  y_dev (f32 [B,O], normalised NN targets) may be NULL. */
 int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
               float* y_dev, void* est_dev, int32_t est_dtype, void* stream);
+
+/* kernel selection for A/B runs and tests; no effect on results beyond float32 summation order */
+int ape_model_set_kernel(ape_model_t* model, int32_t choice);
+/* BLOCKING health check (synchronises the device): non-zero if a cluster-kernel launch since the last
+ * check gave up waiting for a peer workgroup (its bounded spins expired) -- its outputs are invalid. */
+int ape_model_check(ape_model_t* model);
 
 /* introspection for benchmarks: name of the dominant kernel for (B,T) and its algorithmic
  * FLOP per window (sum_layers 2*4H*(in_l+H) per step, + 2*O*H head once). */

@@ -66,9 +66,14 @@ def test_lstm_vs_reference_golden(golden, name):
             assert tuple(y.shape) == (B, T, cfg["O"]) and y.dtype == torch.float32 and not y.is_cuda
             err = float(np.abs(y.numpy() - y_ref).max())
             assert err < (TOL_Y_T64 if T > 8 else TOL_Y_SHORT), (name, seed, B, T, err)
-            y_last = model(torch.from_numpy(x).cuda(), last_step_only=True)   # device in -> device out
+            # device in -> device out, last step only: AUTO picks the cluster kernel (other summation order)
+            y_last = model(torch.from_numpy(x).cuda(), last_step_only=True)
             assert y_last.is_cuda and tuple(y_last.shape) == (B, 1, cfg["O"])
-            assert np.array_equal(y_last.cpu().numpy()[:, 0], y.numpy()[:, -1])   # same kernel arithmetic
+            assert np.abs(y_last.cpu().numpy()[:, 0] - y_ref[:, -1]).max() < TOL_Y_SHORT
+            # within ONE kernel the last-step-only and all-steps outputs are the same bits
+            y_t16 = model.set_kernel("tile16")(torch.from_numpy(x).cuda(), last_step_only=True)
+            assert np.array_equal(y_t16.cpu().numpy()[:, 0], y.numpy()[:, -1])
+            model.set_kernel("auto")
 
 
 @pytest.mark.parametrize("name,B,T", [("pocket", 17, 6), ("pocket", 60, 6), ("watch", 33, 8), ("uarm", 16, 6),
@@ -80,6 +85,27 @@ def test_lstm_vs_oracle_ragged_batches(name, B, T):
     y = model(torch.from_numpy(x)).numpy()
     y_ref = orc.lstm_forward(sd, x)
     assert np.abs(y - y_ref).max() < TOL_Y_SHORT
+
+
+@pytest.mark.parametrize("name,B,T", [("pocket", 1, 6), ("pocket", 60, 6), ("pocket", 17, 1), ("pocket", 300, 6),
+                                      ("pocket", 1024, 8), ("pocket", 1100, 3), ("watch", 1, 8), ("watch", 65, 8),
+                                      ("uarm", 1, 6), ("uarm", 50, 6), ("uarm", 700, 4), ("uarm", 2100, 2)])
+def test_cluster_kernel_vs_oracle_and_tile16(name, B, T):
+    """the weight-stationary cluster kernel (all row-tile counts, partial clusters, more than one
+    launch per call) against the oracle and against the batch-tile kernel"""
+    model, sd, cfg = make_model(name, 11)
+    x = np.random.default_rng(B * 7 + T).normal(size=(B, T, cfg["I"])).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    y_cl = model.set_kernel("cluster")(xt, last_step_only=True).cpu().numpy()[:, 0]
+    model.check()
+    y_t16 = model.set_kernel("tile16")(xt, last_step_only=True).cpu().numpy()[:, 0]
+    y_ref = orc.lstm_forward(sd, x)[:, -1]
+    assert np.abs(y_t16 - y_ref).max() < TOL_Y_SHORT
+    assert np.abs(y_cl - y_ref).max() < TOL_Y_SHORT, float(np.abs(y_cl - y_ref).max())
+    # repeatable: same launch twice gives the same bits (flags re-zeroed, no stale exchange data)
+    y_again = model.set_kernel("cluster")(xt, last_step_only=True).cpu().numpy()[:, 0]
+    assert np.array_equal(y_cl, y_again)
+    model.check()
 
 
 def test_fused_normalisation_is_bit_exact(norm_stats):
