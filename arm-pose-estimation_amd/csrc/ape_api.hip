@@ -173,8 +173,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
         m->xflag_bytes = (((size_t)max_clusters * L * GH * sizeof(unsigned)) + 15) / 16 * 16;
         if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 16);
-        if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 128);
+        if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 128);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
         if (e != hipSuccess) {
             ape_model_destroy(m);
@@ -453,6 +453,13 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
     if (int rc = ape_lstm_forward(m, x_dev, B, T, flags, nullptr, 0.0f, 0, y, stream)) return rc;
     // de-normalise exactly when the inputs were normalised (estimator.py:103-109: one switch)
     return ape_fk(m, y, APE_F32, B, (flags & APE_FLAG_NORMALIZE_INPUT) ? 1 : 0, est_dev, est_dtype, stream);
+}
+
+// internal diagnostic accessor (not part of the public header): copies the 2 stamp words
+int ape_debug_read_stamps(ape_model_t* m, unsigned long long out[9]) {
+    if (!m || !m->cluster_ok) return APE_ERR_INVALID_ARG;
+    HIP_TRY(hipMemcpy(out, m->xflags + m->xflag_bytes / sizeof(unsigned) + 4, 72, hipMemcpyDeviceToHost));
+    return APE_OK;
 }
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {

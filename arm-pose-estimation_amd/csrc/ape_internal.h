@@ -7,6 +7,10 @@
 #define APE_MAX_INPUT 64
 #define APE_MAX_OUTPUT 32
 #define APE_TILE_ROWS 16          // windows per workgroup in the batch-tile LSTM kernel
+// internal timing-only diagnostics (never set by the public API's documented flags; outputs are wrong)
+#define APE_DIAG_NO_EXCHANGE 0x40000000u
+#define APE_DIAG_NO_ACT      0x20000000u
+#define APE_DIAG_STAMP       0x10000000u
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

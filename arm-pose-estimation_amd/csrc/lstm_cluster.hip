@@ -29,6 +29,31 @@
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
 
+// Diagnostic build (make diag: -DAPE_CLUSTER_STAMPS): per-section shader-cycle sums of workgroup 0,
+// wave 0, written behind the status word (memory nothing else reads).  The shipped library has none
+// of this code.  Shares, not absolute time, are what such a build is for.
+#ifdef APE_CLUSTER_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_BEGIN()                                        \
+    do {                                                     \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        st_t0 = __builtin_amdgcn_s_memtime();                \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+#define STAMP_END(k)                                         \
+    do {                                                     \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); \
+        st_acc[k] += st_t1 - st_t0;                          \
+        st_t0 = st_t1;                                       \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN() do {} while (0)
+#define STAMP_END(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;   // bounded polls (~seconds) before giving up
@@ -36,25 +61,74 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;   // bounded polls (~seconds) before g
 __device__ __forceinline__ float gate_act(float v, bool is_tanh) {
     // sigmoid(v), or tanh(v) = 2*sigmoid(2v) - 1 on the g-gate lanes: one branch-free formula so
     // all 64 lanes (four different gates per 16-lane row) stay converged
-    const float s = 1.0f / (1.0f + expf(is_tanh ? -2.0f * v : -v));
+    // hardware v_exp_f32 (2^x) and v_rcp_f32, both ~1 ulp: absolute error of the activation ~1e-7
+    const float e = __builtin_amdgcn_exp2f((is_tanh ? -2.885390081777927f : -1.4426950408889634f) * v);
+    const float s = __builtin_amdgcn_rcpf(1.0f + e);
     return is_tanh ? 2.0f * s - 1.0f : s;
 }
 
-// acc[mt] += A[16 rows of tile mt][16 k-values of block q] * W, weights from registers
-template <int NMT, int NQ, int NW>
-__device__ __forceinline__ void mfma_span(f32x4 (&acc)[NMT], const float* __restrict__ src, int row_stride,
-                                          const float (&w)[NW], int w0) {
+// value of the lane D columns up inside the same 16-lane row (wrapping): DPP row rotate right by 16-D
+// (row_ror:n -- lane i reads lane (i - n) mod 16), no LDS round trip
+template <int D>
+__device__ __forceinline__ float row_rot_up(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (16 - D), 0xF, 0xF, false));
+}
+
+// One layer-step of MFMAs: acc[mt] += [in | rec] activations (LDS) x this wave's weight registers.
+// k-blocks 0..QIN-1 read `in_src`, QIN..QTOT-1 read `rec_src` (skipped when !do_rec: h_{-1} = 0).
+// The A fragments of block q+1 are fetched BEFORE the 4*NMT MFMAs of block q (explicit double buffer,
+// pinned with sched_barrier), so the matrix pipe never waits on a just-issued ds_read.
+template <int NMT, int QIN, int QTOT, int NW>
+__device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __restrict__ in_src, int in_stride,
+                                           const float* __restrict__ rec_src, int rec_stride,
+                                           const float (&w)[NW], bool do_rec) {
+    f32x4 a_cur[NMT], a_nxt[NMT];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        f32x4 a[NMT];
+    for (int mt = 0; mt < NMT; ++mt) {
+        a_cur[mt] = *reinterpret_cast<const f32x4*>(in_src + mt * 16 * in_stride);
+        a_nxt[mt] = a_cur[mt];
+    }
+    // input span (both spans fully unrolled: every weight-register index is a compile-time constant)
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-            a[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * row_stride + 16 * q);
+    for (int q = 0; q < QIN; ++q) {
+        if (q + 1 < QIN) {
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+                a_nxt[mt] = *reinterpret_cast<const f32x4*>(in_src + mt * 16 * in_stride + 16 * (q + 1));
+        } else if (do_rec) {
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+                a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], w[w0 + 4 * q + j], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][j], w[4 * q + j], acc[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) a_cur[mt] = a_nxt[mt];
+    }
+    if (do_rec) {                                            // recurrent span (uniform)
+#pragma unroll
+        for (int q = QIN; q < QTOT; ++q) {
+            if (q + 1 < QTOT) {
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt)
+                    a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride + 16 * (q + 1 - QIN));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][j], w[4 * q + j], acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) a_cur[mt] = a_nxt[mt];
         }
     }
 }
@@ -81,6 +155,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const int row0 = cluster * MR;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool diag_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0;    // timing only: skip polls/gathers/publishes
+    const bool diag_noact = (p.flags & APE_DIAG_NO_ACT) != 0;        // timing only: skip the transcendental math
+    // diagnostic stamps (APE_DIAG_STAMP): shader clock vs the 100 MHz real-time counter around the phase
+    // loop; written to words 4..7 behind the status word, which no other code reads
+    unsigned long long stamp_c0 = 0, stamp_r0 = 0;
+    if (p.flags & APE_DIAG_STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                           // [L][MR][SH]  gathered h of every layer
@@ -124,138 +204,206 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     if (tid == 0) ctl[0] = 0;
     __syncthreads();
 
-    // wait until every member of this cluster has published epoch `want` of layer l, then gather the
-    // GH slices (parity `par`) into hbuf[l]
-    auto gather = [&](int l, unsigned want, int par) -> bool {
-        if (wave == 0) {
-            unsigned spins = 0;
-            bool bad = false;
-            while (true) {
-                unsigned v = want;
-                if (lane < GH)
-                    v = __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((int)(v >= want))) break;
-                if (++spins > SPIN_LIMIT ||
-                    __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    bad = true;
-                    break;
+    // ---- exchange helpers ------------------------------------------------------------------------------
+    constexpr int NGV = GH / SPP;                    // 16-byte pieces each thread moves per gather
+    const int g_sl = tid / TPS, g_idx = tid - g_sl * TPS;       // slice within a pass, piece within the slice
+    const int g_row = g_idx >> 2, g_quad = g_idx & 3;
+
+    // every wave polls for itself (no barrier on the way): all members published epoch `want` of layer l?
+    // bounded; on give-up raises the sticky status word and the workgroup abort flag
+    auto peek_flags = [&](int l, unsigned want) -> unsigned {      // non-blocking: the load only
+        if (diag_noex || lane >= GH) return want;
+        return __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wait_flags = [&](int l, unsigned want, unsigned peeked) {
+        if (diag_noex) return;
+        if (__all((int)(peeked >= want))) return;                  // the prefetched look was enough
+        unsigned spins = 0;
+        while (true) {
+            unsigned v = want;
+            if (lane < GH)
+                v = __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v >= want))) return;
+            if (++spins > SPIN_LIMIT ||
+                __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __builtin_amdgcn_s_sleep(2);
+                return;
             }
-            if (bad && lane == 0) {
-                ctl[0] = 1;
-                __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            __builtin_amdgcn_s_sleep(2);
         }
-        __syncthreads();
-        if (ctl[0] != 0) return false;
+    };
+    // EVERY load of handed-off bytes is a 16-byte sc1 buffer load (bypasses this CU's L1)
+    // the NGV pieces move in two halves of NGH so that at most NGH*4 registers hold in-flight slices
+    constexpr int NGH = (NGV + 1) / 2;
+    auto issue_gather = [&](int l, int par, int half, f32x4 (&gv)[NGH]) {
+        if (diag_noex) return;
         const unsigned base = (unsigned)((((size_t)cluster * L + l) * 2 + par) * GH * MR * 16 * sizeof(float));
-        const int sl = tid / TPS, idx = tid - sl * TPS;      // slice within the pass, 16-byte piece within the slice
-        const int row = idx >> 2, quad = idx & 3;
-        f32x4 v[GH / SPP];
 #pragma unroll
-        for (int ps = 0; ps < GH / SPP; ++ps) {
-            const int m = ps * SPP + sl;
-            v[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                hx_rsrc, base + (unsigned)(((m * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */));
+        for (int k = 0; k < NGH; ++k) {
+            const int ps = half * NGH + k;
+            if (ps < NGV) {
+                const int m = ps * SPP + g_sl;
+                gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    hx_rsrc, base + (unsigned)(((m * MR + g_row) * 16 + 4 * g_quad) * sizeof(float)), 0, 16 /* sc1 */));
+            }
         }
+    };
+    auto commit_gather = [&](int l, int half, const f32x4 (&gv)[NGH]) {
+        if (diag_noex) return;
 #pragma unroll
-        for (int ps = 0; ps < GH / SPP; ++ps) {
-            const int m = ps * SPP + sl;
-            *reinterpret_cast<f32x4*>(hbuf + (l * MR + row) * SH + m * 16 + 4 * quad) = v[ps];
+        for (int k = 0; k < NGH; ++k) {
+            const int ps = half * NGH + k;
+            if (ps < NGV) {
+                const int m = ps * SPP + g_sl;
+                *reinterpret_cast<f32x4*>(hbuf + (l * MR + g_row) * SH + m * 16 + 4 * g_quad) = gv[k];
+            }
         }
+    };
+    // blocking form (pipeline fill/drain and the head): wait, load, commit, barrier
+    auto gather_now = [&](int l, unsigned want, int par) -> bool {
+        f32x4 ga[NGH], gb[NGH];
+        wait_flags(l, want, 0u);
+        issue_gather(l, par, 0, ga);
+        issue_gather(l, par, 1, gb);
+        commit_gather(l, 0, ga);
+        commit_gather(l, 1, gb);
         __syncthreads();
-        return true;
+        return ctl[0] == 0;
     };
 
+    // ---- x staging: thread owns NE (row, k) elements of the [MR][KX] step slab, all with the same k ----
+    constexpr int NE = (MR * KX) / 256;
+    const int xk = tid % KX;
+    float xr[NE];
+    auto fetch_x = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int b = row0 + (tid + 256 * e) / KX;
+            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)b * T + t) * I + xk] : 0.0f;
+        }
+    };
+    // f64 z-score, cast f32 (estimator.py:103-104, watch_phone_pocket_nn.py:100), into LDS
+    auto stage_x = [&]() {
+        // per-thread constants are re-read (L2 hits) instead of living in 6 VGPRs for the whole launch
+        const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
+        const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
+        const double x_rstd = 1.0 / x_std;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = (tid + 256 * e) / KX;
+            float v = xr[e];
+            if (normalize && xk < I && row0 + row < p.B) {
+                // (x - m) / s in f64, correctly rounded: q0 = d * (1/s), one residual step q0 + (d - q0 s)(1/s)
+                // (the tail of the hardware division sequence; a NaN residual means s = 0 or inf -> keep q0,
+                // which is then the same +-inf / NaN the division yields)
+                const double d = (double)v - x_mean;
+                const double q0 = d * x_rstd;
+                const double rr = fma(-q0, x_std, d);
+                const double q1 = fma(rr, x_rstd, q0);
+                v = (float)((rr == rr) ? q1 : q0);
+            }
+            xin[row * SX + xk] = v;
+        }
+    };
+    fetch_x(0);
+    stage_x();
+    if (T > 1) fetch_x(1);
+    __syncthreads();
+
+    STAMP_DECL
     const int P = T + L - 1;
+    bool prefetched = false;          // the gather the NEXT section needs was already committed by this one
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int t = ph - l;                      // the step layer l works on in this phase
-            // h^l_{t-1} (published one phase ago) feeds layer l at step t AND layer l+1 at step t-1, so it
-            // is gathered whenever it exists, also in the pipeline tail where layer l itself is done
+            // h^l_{t-1} (published one phase ago) feeds layer l at step t AND layer l+1 at step t-1, so it is
+            // gathered whenever it exists, also in the pipeline tail where layer l itself is done
             const bool have_prev = (t >= 1 && t <= T) && !(l == L - 1 && t == T);
             const bool active = (t >= 0 && t < T);      // both uniform over the whole grid
-            if (active && l == 0) {
-                // x_t: f64 z-score fused into the load (estimator.py:103-104, watch_phone_pocket_nn.py:100)
-#pragma unroll
-                for (int e = 0; e < (MR * KX) / 256; ++e) {
-                    const int idx = tid + 256 * e;
-                    const int row = idx / KX, k = idx - row * KX;
-                    const int b = row0 + row;
-                    float v = 0.0f;
-                    if (k < I && b < p.B) {
-                        v = p.x[((size_t)b * T + t) * I + k];
-                        if (normalize) v = (float)(((double)v - p.xx_m[k]) / p.xx_s[k]);
-                    }
-                    xin[row * SX + k] = v;
-                }
+            STAMP_BEGIN();
+            if (have_prev && !prefetched) {
+                if (!gather_now(l, (unsigned)t, (t - 1) & 1)) return;
             }
-            if (have_prev) {
-                if (!gather(l, (unsigned)t, (t - 1) & 1)) return;
-            } else if (active) {
-                __syncthreads();                        // xin (l == 0) visible
-            }
+            prefetched = false;
+            STAMP_END(1);                                // 1: blocking gathers (pipeline fill / drain only)
             if (!active) continue;
-            // ---- stacked-gate product on the matrix cores ------------------------------------------
+
+            // next section in program order: (ph, l+1) or (ph+1, 0).  Its slices were published at least one
+            // full layer-step ago and its LDS target has no reader left once barrier A below is passed, so
+            // its flag check and gather loads fly under this section's MFMAs and VALU work.
+            const int ln = (l + 1 < L) ? l + 1 : 0;
+            const int tn = (l + 1 < L) ? t - 1 : t + L;          // = ph_n - l_n
+            const bool pre = (tn >= 1 && tn <= T) && !(ln == L - 1 && tn == T) && (l + 1 < L || ph + 1 < P);
+            const unsigned peeked = pre ? peek_flags(ln, (unsigned)tn) : 0u;     // load issued, not waited for
+
+            // ---- stacked-gate product on the matrix cores ------------------------------------------------
             f32x4 acc[NMT];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{bias_r[l], bias_r[l], bias_r[l], bias_r[l]};
             const float* rec_src = hbuf + (l * MR + r) * SH + 4 * g;
             if (l == 0) {
-                mfma_span<NMT, QX, NW0>(acc, xin + r * SX + 4 * g, SX, w0, 0);
-                if (t > 0) mfma_span<NMT, QH, NW0>(acc, rec_src, SH, w0, 4 * QX);
+                layer_mfma<NMT, QX, QX + QH, NW0>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0);
             } else {
                 const float* in_src = hbuf + ((l - 1) * MR + r) * SH + 4 * g;
                 if (l == 1) {
-                    if constexpr (L > 1) {
-                        mfma_span<NMT, QH, NW1>(acc, in_src, SH, w1, 0);
-                        if (t > 0) mfma_span<NMT, QH, NW1>(acc, rec_src, SH, w1, 4 * QH);
-                    }
+                    if constexpr (L > 1) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w1, t > 0);
                 } else {
-                    if constexpr (L > 2) {
-                        mfma_span<NMT, QH, NW1>(acc, in_src, SH, w2, 0);
-                        if (t > 0) mfma_span<NMT, QH, NW1>(acc, rec_src, SH, w2, 4 * QH);
-                    }
+                    if constexpr (L > 2) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w2, t > 0);
                 }
             }
-            // ---- gate non-linearities on the accumulators (lane = one gate of one unit) ---------------
+            STAMP_END(2);                                // 2: MFMA layer-step
+
+            f32x4 gv[NGH];
+            if (pre) {
+                wait_flags(ln, (unsigned)tn, peeked);
+                issue_gather(ln, (tn - 1) & 1, 0, gv);           // first half flies under the VALU work below
+            }
+            STAMP_END(3);                                // 3: flag check + gather issue
+
+            // ---- gate non-linearities on the accumulators (lane = one gate of one unit) ------------------
             float act[NMT][4];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) act[mt][i] = gate_act(acc[mt][i], gate == 2);
-            // ---- 4x4 lane transpose: this lane collects i,f,g,o of (unit u, row tile `gate`) -----------
-            // NMT < 4: tiles beyond NMT do not exist and their lanes idle through the update
+                for (int i = 0; i < 4; ++i) act[mt][i] = diag_noact ? acc[mt][i] : gate_act(acc[mt][i], gate == 2);
+            // ---- 4x4 lane transpose by DPP row rotations: lane (gate, u) collects i,f,g,o of unit u for row
+            // tile mt == gate.  rot_d(x) = x of the lane d columns up in the same 16-lane row = gate + d/4.
             float gi[4], gf[4], gg[4], go[4];
-            const int rowbase = lane & 48;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float vi = 0.f, vf = 0.f, vg = 0.f, vo = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
-                    const float ti = __shfl(act[mt][i], rowbase + 0 + u, 64);
-                    const float tf = __shfl(act[mt][i], rowbase + 4 + u, 64);
-                    const float tg = __shfl(act[mt][i], rowbase + 8 + u, 64);
-                    const float to = __shfl(act[mt][i], rowbase + 12 + u, 64);
-                    if (gate == mt) { vi = ti; vf = tf; vg = tg; vo = to; }
+                    float v[4];
+                    v[0] = act[mt][i];
+                    v[1] = row_rot_up<4>(act[mt][i]);
+                    v[2] = row_rot_up<8>(act[mt][i]);
+                    v[3] = row_rot_up<12>(act[mt][i]);
+                    // on the lane whose own gate is mt: gate k's value sits (k - mt) mod 4 rotations up
+                    if (gate == mt) { vi = v[(0 - mt) & 3]; vf = v[(1 - mt) & 3]; vg = v[(2 - mt) & 3]; vo = v[(3 - mt) & 3]; }
                 }
                 gi[i] = vi; gf[i] = vf; gg[i] = vg; go[i] = vo;
             }
-            // ---- cell update for (unit u, rows 16*gate + 4g + i), h into the own-slice staging ---------
+            STAMP_END(4);                                // 4: activations + lane transpose
+            // ---- cell update for (unit u, rows 16*gate + 4g + i), h into the own-slice staging ------------
             if (gate < NMT) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float c = gf[i] * cst[l][i] + gi[i] * gg[i];
                     cst[l][i] = c;
-                    own[(16 * gate + 4 * g + i) * SO + wave * 4 + u] = go[i] * tanhf(c);
+                    own[(16 * gate + 4 * g + i) * SO + wave * 4 + u] = go[i] * (diag_noact ? c : gate_act(c, true));
                 }
             }
-            __syncthreads();
-            // ---- publish the slice: 16-byte write-through stores, drain, barrier, one flag -----------
-            if (tid < TPS) {
+            __syncthreads();                             // barrier A: own slice complete, all MFMAs of the section done
+            if (ctl[0] != 0) return;
+            STAMP_END(5);                                // 5: cell update + own-slice write + barrier A
+            // ---- publish: 16-byte write-through stores, (commit gather, stage x), drain, barrier, ONE flag ----
+            if (!diag_noex && tid < TPS) {
                 const int row = tid >> 2, quad = tid & 3;
                 const f32x4 hv = *reinterpret_cast<const f32x4*>(own + row * SO + 4 * quad);
                 const unsigned base = (unsigned)((((size_t)cluster * L + l) * 2 + (t & 1)) * GH * MR * 16 * sizeof(float));
@@ -263,16 +411,37 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                     __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
                     base + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave
-            __syncthreads();
-            if (tid == 0)
+            if (pre) {
+                commit_gather(ln, 0, gv);
+                issue_gather(ln, (tn - 1) & 1, 1, gv);           // second half flies under x staging / the store drain
+            }
+            if (l == 0 && t + 1 < T) {                   // x_{t+1} for the next phase (xin's readers are done)
+                stage_x();
+                if (t + 2 < T) fetch_x(t + 2);
+            }
+            if (pre) { commit_gather(ln, 1, gv); prefetched = true; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the flag
+            __syncthreads();                             // barrier B: gathered data + x visible, stores drained
+            if (!diag_noex && tid == 0)
                 __hip_atomic_store(myflags + l * GH + member, (unsigned)(t + 1), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+            STAMP_END(6);                                // 6: publish + commit + x staging + barrier B + flag
         }
     }
-
+#ifdef APE_CLUSTER_STAMPS
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 8);
+        for (int k = 0; k < 7; ++k) dbg[k] = st_acc[k];
+    }
+#endif
+    if ((p.flags & APE_DIAG_STAMP) && blockIdx.x == 0 && tid == 0) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 4);
+        dbg[0] = c1 - stamp_c0;
+        dbg[1] = r1 - stamp_r0;
+    }
     // ---- head: gather h^{L-1}_{T-1}, each member finishes MR/GH (>= 1) of the cluster's windows ------
-    if (!gather(L - 1, (unsigned)T, (T - 1) & 1)) return;
+    if (!gather_now(L - 1, (unsigned)T, (T - 1) & 1)) return;
     {
         constexpr int RPM = (MR + GH - 1) / GH;          // rows per member
         const int n_out = RPM * O;
