@@ -74,6 +74,16 @@ __device__ __forceinline__ float row_rot_up(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (16 - D), 0xF, 0xF, false));
 }
 
+// v_mfma_f32_16x16x4_f32 with the B operand (a weight that lives in an AGPR for the whole launch) and the
+// accumulator pinned to the accumulator register file: no v_accvgpr copies around the matrix pipe, and the
+// 256 architectural VGPRs stay free for activations, gathers and the cell update.  hipcc does not model an
+// asm MFMA's hazards: the accumulators are read only after `mfma_drain()` (>= 18 wait states after the
+// last 8-pass MFMA, CDNA4 ISA data-hazard table).
+__device__ __forceinline__ void mfma_aw(f32x4& acc, float a, float w) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(w));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+
 // One layer-step of MFMAs: acc[mt] += [in | rec] activations (LDS) x this wave's weight registers.
 // k-blocks 0..QIN-1 read `in_src`, QIN..QTOT-1 read `rec_src` (skipped when !do_rec: h_{-1} = 0).
 // The A fragments of block q+1 are fetched BEFORE the 4*NMT MFMAs of block q (explicit double buffer,
@@ -105,7 +115,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][j], w[4 * q + j], acc[mt], 0, 0, 0);
+                mfma_aw(acc[mt], a_cur[mt][j], w[4 * q + j]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -124,7 +134,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][j], w[4 * q + j], acc[mt], 0, 0, 0);
+                    mfma_aw(acc[mt], a_cur[mt][j], w[4 * q + j]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     };
     // EVERY load of handed-off bytes is a 16-byte sc1 buffer load (bypasses this CU's L1)
     // the NGV pieces move in two halves of NGH so that at most NGH*4 registers hold in-flight slices
-    constexpr int NGH = (NGV + 1) / 2;
+    constexpr int NGH = NGV;          // whole gather in flight at once (the weights live in AGPRs, VGPRs are free)
     auto issue_gather = [&](int l, int par, int half, f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
         const unsigned base = (unsigned)((((size_t)cluster * L + l) * 2 + par) * GH * MR * 16 * sizeof(float));
@@ -267,9 +277,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         f32x4 ga[NGH], gb[NGH];
         wait_flags(l, want, 0u);
         issue_gather(l, par, 0, ga);
-        issue_gather(l, par, 1, gb);
         commit_gather(l, 0, ga);
-        commit_gather(l, 1, gb);
+        (void)gb;
         __syncthreads();
         return ctl[0] == 0;
     };
@@ -356,12 +365,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                     if constexpr (L > 2) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w2, t > 0);
                 }
             }
+            mfma_drain();
             STAMP_END(2);                                // 2: MFMA layer-step
 
             f32x4 gv[NGH];
             if (pre) {
                 wait_flags(ln, (unsigned)tn, peeked);
-                issue_gather(ln, (tn - 1) & 1, 0, gv);           // first half flies under the VALU work below
+                issue_gather(ln, (tn - 1) & 1, 0, gv);           // flies under the VALU work below
             }
             STAMP_END(3);                                // 3: flag check + gather issue
 
@@ -411,15 +421,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                     __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
                     base + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */);
             }
-            if (pre) {
-                commit_gather(ln, 0, gv);
-                issue_gather(ln, (tn - 1) & 1, 1, gv);           // second half flies under x staging / the store drain
-            }
+            if (pre) commit_gather(ln, 0, gv);
             if (l == 0 && t + 1 < T) {                   // x_{t+1} for the next phase (xin's readers are done)
                 stage_x();
                 if (t + 2 < T) fetch_x(t + 2);
             }
-            if (pre) { commit_gather(ln, 1, gv); prefetched = true; }
+            if (pre) prefetched = true;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the flag
             __syncthreads();                             // barrier B: gathered data + x visible, stores drained
             if (!diag_noex && tid == 0)

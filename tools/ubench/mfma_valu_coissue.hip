@@ -1,0 +1,80 @@
+// Microbenchmark: one wave per SIMD issuing v_mfma_f32_16x16x4_f32 back to back (4 independent
+// accumulators, B operand resident in registers, A operand re-read from LDS per 16 MFMAs), with
+// K independent VALU instructions (exp2 / rcp / fma chain) scheduled between consecutive MFMAs.
+// Question: how many VALU instructions per MFMA gap are free?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int VPM>   // VALU ops per MFMA
+__global__ __launch_bounds__(256, 1) void k(float* out, const float* w_in, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[64 * 264];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 64 * 264; i += 256) lds[i] = 0.001f * (i % 97);
+    float w[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) w[i] = w_in[i * 64 + lane];
+    __syncthreads();
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.1f * (lane + i);
+    const float* src = lds + (lane & 15) * 264 + 4 * (lane >> 4);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            f32x4 a[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * 264 + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], w[4 * q + j], acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < VPM; ++e) {       // independent VALU stream: sigmoid-like chains
+                        const int s = (j * 4 + mt + e) & 7;
+                        if (e % 3 == 0) v[s] = __builtin_amdgcn_exp2f(v[s] * -1.4426950f);
+                        else if (e % 3 == 1) v[s] = __builtin_amdgcn_rcpf(1.0f + v[s]);
+                        else v[s] = fmaf(v[s], 0.5f, 0.25f);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+                    if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VPM VALU
+                }
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 256)[0] = t1 - t0;
+}
+
+template <int VPM>
+void run(float* out, float* w, int iters) {
+    hipLaunchKernelGGL(k<VPM>, dim3(256), dim3(256), 0, 0, out, w, iters);
+    hipDeviceSynchronize();
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<VPM>, dim3(256), dim3(256), 0, 0, out, w, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    unsigned long long cyc; hipMemcpy(&cyc, out + 256 * 256, 8, hipMemcpyDeviceToHost);
+    const double mfmas = 256.0 * iters;
+    printf("VALU/MFMA=%d : %.1f cycles per MFMA (in-kernel), %.3f ms, %.1f TFLOP/s chip\n", VPM, cyc / mfmas, ms,
+           256.0 * 4 * mfmas * 2048 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    float *out, *w;
+    hipMalloc(&out, (256 * 256 + 16) * 4); hipMalloc(&w, 64 * 64 * 4);
+    std::vector<float> hw(64 * 64); for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.01f * (i % 31) - 0.1f;
+    hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    run<0>(out, w, 200); run<1>(out, w, 200); run<2>(out, w, 200); run<3>(out, w, 200); run<4>(out, w, 200);
+    run<6>(out, w, 200); run<8>(out, w, 200);
+    return 0;
+}
