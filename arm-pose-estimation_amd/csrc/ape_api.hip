@@ -171,7 +171,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = hipMalloc((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
-        m->xflag_bytes = (((size_t)max_clusters * L * GH * sizeof(unsigned)) + 15) / 16 * 16;
+        m->xflag_bytes = (((size_t)max_clusters * L * GH * sizeof(unsigned)) + 15) / 16 * 16 + 16;   // flags + ticket word
         if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
         if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 128);
         if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 128);
@@ -345,6 +345,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
             c.hx = m->hx; c.hx_bytes = m->hx_bytes;
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+            c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
             c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size; c.flags = flags;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // every polled word is re-zeroed in front of EVERY launch (a memset node under graph capture)

@@ -45,6 +45,7 @@ struct ClusterParams {
     float* hx;                          // exchange slices [cluster][L][parity 2][member GH][row MR][16]
     size_t hx_bytes;
     unsigned* xflags;                   // [cluster][L][GH] epoch flags, zeroed before every launch
+    unsigned* ticket;                   // [1] arrival counter (inside the zeroed block)
     unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
     int B, T, I, O;
     unsigned flags;

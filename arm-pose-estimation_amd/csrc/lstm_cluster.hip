@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int gate = r >> 2, u = r & 3;           // C-operand column = gate*4 + unit
-    const int cluster = blockIdx.x / GH, member = blockIdx.x % GH;
-    const int row0 = cluster * MR;
+    // Cluster membership by ARRIVAL TICKET, not by blockIdx: the first GH workgroups to start form cluster 0,
+    // the next GH cluster 1, ...  Every member of a formed cluster is therefore resident, so formed clusters
+    // always make progress and free their CUs on exit; the launch cannot deadlock as long as one cluster fits
+    // on the chip, whatever the dispatch order or however many CUs other work occupies.
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
     const bool diag_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0;    // timing only: skip polls/gathers/publishes
@@ -176,7 +178,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     float* hbuf = smem;                           // [L][MR][SH]  gathered h of every layer
     float* xin = hbuf + L * MR * SH;              // [MR][SX]
     float* own = xin + MR * SX;                   // [MR][SO]     this member's fresh slice
-    int* ctl = reinterpret_cast<int*>(own + MR * SO);   // [0] abort flag
+    int* ctl = reinterpret_cast<int*>(own + MR * SO);   // [0] abort flag, [1] arrival ticket
+    if (threadIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
+    const int cluster = ticket / GH, member = ticket % GH;
+    const int row0 = cluster * MR;
 
     // ---- weights: registers, for the whole launch ---------------------------------------------
     float w0[NW0];
@@ -211,8 +221,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const __amdgpu_buffer_rsrc_t hx_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
     unsigned* const myflags = p.xflags + (size_t)cluster * L * GH;
-    if (tid == 0) ctl[0] = 0;
-    __syncthreads();
 
     // ---- exchange helpers ------------------------------------------------------------------------------
     constexpr int NGV = GH / SPP;                    // 16-byte pieces each thread moves per gather
