@@ -324,16 +324,21 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
 
-    const bool plain = (flags & (APE_FLAG_ALL_STEPS | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) == 0;
-    bool use_cluster = m->cluster_ok && plain && m->kernel_choice != APE_KERNEL_TILE16;
+    // the cluster kernel covers last-step output, with or without inter-layer dropout (dropout: <= 32 windows
+    // per cluster, so batches beyond 32 x clusters-per-chip go to the batch-tile kernel under AUTO)
+    const int GHc = H / 16, max_clusters_c = 256 / GHc;
+    const bool fits_drop = !drop || L == 1 || B <= 32 * max_clusters_c || m->kernel_choice == APE_KERNEL_CLUSTER;
+    bool use_cluster = m->cluster_ok && (flags & APE_FLAG_ALL_STEPS) == 0 && fits_drop &&
+                       m->kernel_choice != APE_KERNEL_TILE16;
     if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     if (use_cluster) {
         // smallest row tile count that still fits the batch on the chip: more clusters = more CUs busy
         const int GH = H / 16, max_clusters = 256 / GH;
-        int nmt = 4;
+        const bool cdrop = drop && L > 1;
+        int nmt = cdrop ? 2 : 4;
         for (int cand : {1, 2, 4})
-            if ((B + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
+            if ((!cdrop || cand <= 2) && (B + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
         const int rows_per_launch = 16 * nmt * max_clusters;
         for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
             const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
@@ -347,10 +352,16 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
             c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size; c.flags = flags;
+            // injected masks are indexed [L-1, B, T, H] over the WHOLE batch: chunks need the full B stride,
+            // so a masked call is served by one launch only (checked below)
+            c.masks = masks_dev; c.dropout_p = dropout_p; c.seed = seed;
+            if ((flags & APE_FLAG_DROPOUT_MASKS) && b0 + nb < B && cdrop)
+                return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
+            if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // every polled word is re-zeroed in front of EVERY launch (a memset node under graph capture)
             hipError_t e = hipMemsetAsync(m->xflags, 0, m->xflag_bytes, (hipStream_t)stream);
-            if (e == hipSuccess) e = ape_launch_lstm_cluster(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream);
+            if (e == hipSuccess) e = ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
         }
         return APE_OK;

@@ -47,8 +47,11 @@ struct ClusterParams {
     unsigned* xflags;                   // [cluster][L][GH] epoch flags, zeroed before every launch
     unsigned* ticket;                   // [1] arrival counter (inside the zeroed block)
     unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
+    const float* masks;                 // [L-1,B,T,H] injected dropout masks or nullptr
     int B, T, I, O;
     unsigned flags;
+    float dropout_p;
+    unsigned long long seed;
 };
 
 struct FkParams {
@@ -67,6 +70,22 @@ struct MsgParams {
     int N, W, layout;
 };
 
+#ifdef __HIPCC__
+// Philox4x32-10 counter-based generator (Salmon et al. 2011) for in-kernel dropout masks.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#endif
+
 // launchers implemented in the .hip files --------------------------------------------------
 // returns hipSuccess or the launch error; `smem_bytes` out for diagnostics
 hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream);
@@ -74,6 +93,7 @@ size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout);
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
 bool ape_cluster_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
-hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
+hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,
+                                   hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

@@ -143,7 +143,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
     }
 }
 
-template <int H, int L, int KX, int NMT>
+template <int H, int L, int KX, int NMT, bool DROP>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p) {
     constexpr int GH = H / 16;            // workgroups (CUs) per cluster
     constexpr int MR = 16 * NMT;          // windows per cluster
@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     constexpr int NW1 = (2 * H) / 4;      //                            layers >= 1
     constexpr int TPS = 4 * MR;           // threads that move one member slice (16 B each)
     constexpr int SPP = 256 / TPS;        // slices per gather pass
+    // inter-layer dropout (train-mode nn.LSTM after monte_carlo_predictions, nn_models.py:204): the slice of a
+    // layer below the top is published twice -- raw (its own recurrence) and masked (the next layer's input)
+    constexpr int NV = DROP ? 2 : 1;
+    static_assert(!DROP || 2 * TPS <= 256, "dropout variants are built for NMT <= 2");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
     const bool diag_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0;    // timing only: skip polls/gathers/publishes
     const bool diag_noact = (p.flags & APE_DIAG_NO_ACT) != 0;        // timing only: skip the transcendental math
+    const bool drop_masks = DROP && (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
     // diagnostic stamps (APE_DIAG_STAMP): shader clock vs the 100 MHz real-time counter around the phase
     // loop; written to words 4..7 behind the status word, which no other code reads
     unsigned long long stamp_c0 = 0, stamp_r0 = 0;
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                           // [L][MR][SH]  gathered h of every layer
     float* xin = hbuf + L * MR * SH;              // [MR][SX]
-    float* own = xin + MR * SX;                   // [MR][SO]     this member's fresh slice
-    int* ctl = reinterpret_cast<int*>(own + MR * SO);   // [0] abort flag, [1] arrival ticket
+    float* own = xin + MR * SX;                   // [NV][MR][SO] this member's fresh slice (raw, masked)
+    float* dbuf = own + NV * MR * SO;             // [L-1][MR][SH] gathered MASKED h (DROP only)
+    int* ctl = reinterpret_cast<int*>(dbuf + (DROP ? (L - 1) * MR * SH : 0));   // [0] abort flag, [1] arrival ticket
     if (threadIdx.x == 0) {
         ctl[0] = 0;
         ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -255,28 +261,37 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     };
     // EVERY load of handed-off bytes is a 16-byte sc1 buffer load (bypasses this CU's L1)
     // the NGV pieces move in two halves of NGH so that at most NGH*4 registers hold in-flight slices
-    constexpr int NGH = NGV;          // whole gather in flight at once (the weights live in AGPRs, VGPRs are free)
+    constexpr int NGH = NGV * NV;     // whole gather in flight at once (the weights live in AGPRs, VGPRs are free)
+    constexpr unsigned SLICE_SET = GH * MR * 16 * sizeof(float);       // bytes of one (layer, parity, variant)
+    auto hx_base = [&](int l, int par, int v) -> unsigned {
+        return (unsigned)(((((size_t)cluster * L + l) * 2 + par) * NV + v) * SLICE_SET);
+    };
     auto issue_gather = [&](int l, int par, int half, f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
-        const unsigned base = (unsigned)((((size_t)cluster * L + l) * 2 + par) * GH * MR * 16 * sizeof(float));
+        (void)half;
 #pragma unroll
-        for (int k = 0; k < NGH; ++k) {
-            const int ps = half * NGH + k;
-            if (ps < NGV) {
-                const int m = ps * SPP + g_sl;
-                gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        for (int v = 0; v < NV; ++v) {
+            if (v == 1 && l == L - 1) break;             // the top layer has no masked variant
+            const unsigned base = hx_base(l, par, v);
+#pragma unroll
+            for (int k = 0; k < NGV; ++k) {
+                const int m = k * SPP + g_sl;
+                gv[v * NGV + k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     hx_rsrc, base + (unsigned)(((m * MR + g_row) * 16 + 4 * g_quad) * sizeof(float)), 0, 16 /* sc1 */));
             }
         }
     };
     auto commit_gather = [&](int l, int half, const f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
+        (void)half;
 #pragma unroll
-        for (int k = 0; k < NGH; ++k) {
-            const int ps = half * NGH + k;
-            if (ps < NGV) {
-                const int m = ps * SPP + g_sl;
-                *reinterpret_cast<f32x4*>(hbuf + (l * MR + g_row) * SH + m * 16 + 4 * g_quad) = gv[k];
+        for (int v = 0; v < NV; ++v) {
+            if (v == 1 && l == L - 1) break;
+            float* dst = (v == 0) ? hbuf + l * MR * SH : dbuf + l * MR * SH;
+#pragma unroll
+            for (int k = 0; k < NGV; ++k) {
+                const int m = k * SPP + g_sl;
+                *reinterpret_cast<f32x4*>(dst + g_row * SH + m * 16 + 4 * g_quad) = gv[v * NGV + k];
             }
         }
     };
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             if (l == 0) {
                 layer_mfma<NMT, QX, QX + QH, NW0>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0);
             } else {
-                const float* in_src = hbuf + ((l - 1) * MR + r) * SH + 4 * g;
+                const float* in_src = (DROP ? dbuf : hbuf) + ((l - 1) * MR + r) * SH + 4 * g;
                 if (l == 1) {
                     if constexpr (L > 1) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w1, t > 0);
                 } else {
@@ -410,21 +425,40 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             STAMP_END(4);                                // 4: activations + lane transpose
             // ---- cell update for (unit u, rows 16*gate + 4g + i), h into the own-slice staging ------------
             if (gate < NMT) {
+                const int unit = member * 16 + wave * 4 + u;
+                uint32_t rnd[4] = {0, 0, 0, 0};
+                if (DROP && l < L - 1 && !drop_masks)        // same counters as the batch-tile kernel: same masks
+                    philox4x32((uint32_t)(row0 + 16 * gate + 4 * g), (uint32_t)t, (uint32_t)unit, (uint32_t)l,
+                               (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float c = gf[i] * cst[l][i] + gi[i] * gg[i];
                     cst[l][i] = c;
-                    own[(16 * gate + 4 * g + i) * SO + wave * 4 + u] = go[i] * (diag_noact ? c : gate_act(c, true));
+                    const float hval = go[i] * (diag_noact ? c : gate_act(c, true));
+                    const int row = 16 * gate + 4 * g + i;
+                    own[row * SO + wave * 4 + u] = hval;
+                    if (DROP && l < L - 1) {
+                        float m;
+                        if (drop_masks) {
+                            const int b = row0 + row;
+                            m = (b < p.B) ? p.masks[(((size_t)l * p.B + b) * T + t) * H + unit] : 0.0f;
+                        } else {
+                            const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                            m = (uf >= p.dropout_p) ? 1.0f / (1.0f - p.dropout_p) : 0.0f;
+                        }
+                        own[(MR + row) * SO + wave * 4 + u] = hval * m;
+                    }
                 }
             }
             __syncthreads();                             // barrier A: own slice complete, all MFMAs of the section done
             if (ctl[0] != 0) return;
             STAMP_END(5);                                // 5: cell update + own-slice write + barrier A
             // ---- publish: 16-byte write-through stores, (commit gather, stage x), drain, barrier, ONE flag ----
-            if (!diag_noex && tid < TPS) {
-                const int row = tid >> 2, quad = tid & 3;
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + row * SO + 4 * quad);
-                const unsigned base = (unsigned)((((size_t)cluster * L + l) * 2 + (t & 1)) * GH * MR * 16 * sizeof(float));
+            if (!diag_noex && tid < ((DROP && l < L - 1) ? 2 * TPS : TPS)) {
+                const int v = tid / TPS, idx = tid - v * TPS;        // variant 1 = masked slice
+                const int row = idx >> 2, quad = idx & 3;
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (v * MR + row) * SO + 4 * quad);
+                const unsigned base = hx_base(l, t & 1, v);
                 __builtin_amdgcn_raw_buffer_store_b128(
                     __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
                     base + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */);
@@ -475,23 +509,24 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     }
 }
 
-template <int H, int L, int KX, int NMT>
+template <int H, int L, int KX, int NMT, bool DROP>
 size_t smem_bytes() {
-    constexpr int MR = 16 * NMT;
-    return ((size_t)L * MR * (H + 8) + (size_t)MR * (KX + 8) + (size_t)MR * 20 + 4) * sizeof(float);
+    constexpr int MR = 16 * NMT, NV = DROP ? 2 : 1;
+    return ((size_t)L * MR * (H + 8) + (size_t)MR * (KX + 8) + (size_t)NV * MR * 20 +
+            (size_t)(DROP ? (L - 1) * MR * (H + 8) : 0) + 4) * sizeof(float);
 }
 
-template <int H, int L, int KX, int NMT>
+template <int H, int L, int KX, int NMT, bool DROP>
 hipError_t launch(const ClusterParams& p, int clusters, hipStream_t stream) {
-    const size_t smem = smem_bytes<H, L, KX, NMT>();
-    hipLaunchKernelGGL((ape_lstm_cluster<H, L, KX, NMT>), dim3(clusters * (H / 16)), dim3(256), smem, stream, p);
+    const size_t smem = smem_bytes<H, L, KX, NMT, DROP>();
+    hipLaunchKernelGGL((ape_lstm_cluster<H, L, KX, NMT, DROP>), dim3(clusters * (H / 16)), dim3(256), smem, stream, p);
     return hipGetLastError();
 }
 
-template <int H, int L, int KX, int NMT>
+template <int H, int L, int KX, int NMT, bool DROP>
 hipError_t prepare() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster<H, L, KX, NMT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<H, L, KX, NMT>());
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster<H, L, KX, NMT, DROP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<H, L, KX, NMT, DROP>());
 }
 
 }  // namespace
@@ -500,27 +535,29 @@ hipError_t prepare() {
 // upper-arm (H=128, L=3, 32<I<=64) regressors
 bool ape_cluster_supported(int H, int L, int KX) { return (H == 256 && L == 2 && KX == 32) || (H == 128 && L == 3 && KX == 64); }
 
-#define APE_CL_DISPATCH(FN, ...)                                             \
-    if (H == 256 && L == 2 && KX == 32) {                                    \
-        if (nmt == 1) return FN<256, 2, 32, 1>(__VA_ARGS__);                 \
-        if (nmt == 2) return FN<256, 2, 32, 2>(__VA_ARGS__);                 \
-        if (nmt == 4) return FN<256, 2, 32, 4>(__VA_ARGS__);                 \
-    } else if (H == 128 && L == 3 && KX == 64) {                             \
-        if (nmt == 1) return FN<128, 3, 64, 1>(__VA_ARGS__);                 \
-        if (nmt == 2) return FN<128, 3, 64, 2>(__VA_ARGS__);                 \
-        if (nmt == 4) return FN<128, 3, 64, 4>(__VA_ARGS__);                 \
-    }                                                                        \
+#define APE_CL_DISPATCH(FN, ...)                                                     \
+    if (H == 256 && L == 2 && KX == 32) {                                            \
+        if (nmt == 1) return dropout ? FN<256, 2, 32, 1, true>(__VA_ARGS__) : FN<256, 2, 32, 1, false>(__VA_ARGS__); \
+        if (nmt == 2) return dropout ? FN<256, 2, 32, 2, true>(__VA_ARGS__) : FN<256, 2, 32, 2, false>(__VA_ARGS__); \
+        if (nmt == 4 && !dropout) return FN<256, 2, 32, 4, false>(__VA_ARGS__);      \
+    } else if (H == 128 && L == 3 && KX == 64) {                                     \
+        if (nmt == 1) return dropout ? FN<128, 3, 64, 1, true>(__VA_ARGS__) : FN<128, 3, 64, 1, false>(__VA_ARGS__); \
+        if (nmt == 2) return dropout ? FN<128, 3, 64, 2, true>(__VA_ARGS__) : FN<128, 3, 64, 2, false>(__VA_ARGS__); \
+        if (nmt == 4 && !dropout) return FN<128, 3, 64, 4, false>(__VA_ARGS__);      \
+    }                                                                                \
     return hipErrorInvalidValue;
 
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX) {
-    for (int nmt : {1, 2, 4}) {
-        hipError_t e = [&]() -> hipError_t { APE_CL_DISPATCH(prepare) }();
-        if (e != hipSuccess) return e;
-    }
+    for (int nmt : {1, 2, 4})
+        for (bool dropout : {false, true}) {
+            if (dropout && nmt == 4) continue;
+            hipError_t e = [&]() -> hipError_t { APE_CL_DISPATCH(prepare) }();
+            if (e != hipSuccess) return e;
+        }
     return hipSuccess;
 }
 
-hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p,
+hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,
                                    hipStream_t stream) {
     APE_CL_DISPATCH(launch, p, clusters, stream)
 }

@@ -29,19 +29,6 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// Philox4x32-10 counter-based generator (Salmon et al. 2011) for in-kernel dropout masks.
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                           uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 template <int NT>
 __device__ __forceinline__ void load_b(f32x4 (&b)[NT], const f32x4* __restrict__ p) {
 #pragma unroll

@@ -123,16 +123,35 @@ def test_fused_normalisation_is_bit_exact(norm_stats):
 @pytest.mark.parametrize("name", ["pocket", "uarm"])
 def test_dropout_with_injected_masks(name):
     """MC-dropout parity with explicit masks: torch's internal mask stream cannot be replayed
-    (SURVEY.md 3.3), so the oracle's cell loop and the kernel get the same masks"""
+    (SURVEY.md 3.3), so the oracle's cell loop and the kernels get the same masks"""
     model, sd, cfg = make_model(name, 3)
     B, T, p = 25, cfg["T"], 0.2
     rng = np.random.default_rng(9)
     x = np.repeat(rng.normal(size=(1, T, cfg["I"])).astype(np.float32), B, axis=0)
     masks = (rng.uniform(size=(cfg["L"] - 1, B, T, cfg["H"])) >= p).astype(np.float32) / (1 - p)
-    y = model(torch.from_numpy(x), masks=torch.from_numpy(masks)).numpy()
     y_ref = orc.lstm_forward(sd, x, masks=list(masks))
+    y = model(torch.from_numpy(x), masks=torch.from_numpy(masks)).numpy()        # all steps: batch-tile kernel
     assert np.abs(y - y_ref).max() < TOL_Y_SHORT
     assert np.abs(y[0] - y[1]).max() > 1e-4          # masks differ per row -> rows differ
+    for kern in ("tile16", "cluster"):               # last step only: both kernels
+        yk = model.set_kernel(kern)(torch.from_numpy(x), masks=torch.from_numpy(masks), last_step_only=True).numpy()
+        assert np.abs(yk[:, 0] - y_ref[:, -1]).max() < TOL_Y_SHORT, kern
+    model.check()
+
+
+@pytest.mark.parametrize("name,n", [("pocket", 60), ("pocket", 400), ("uarm", 50), ("watch", 25)])
+def test_philox_dropout_same_masks_in_both_kernels(name, n):
+    """the cluster kernel and the batch-tile kernel draw the same Philox masks for the same seed"""
+    model, sd, cfg = make_model(name, 6)
+    xt = torch.from_numpy(np.random.default_rng(n).normal(size=(1, cfg["T"], cfg["I"])).astype(np.float32))
+    out = {}
+    for kern in ("tile16", "cluster"):
+        model.set_kernel(kern)
+        model.manual_seed(123)
+        out[kern] = model.monte_carlo_predictions(n, xt, last_step_only=True).numpy()[:, 0]
+    assert out["cluster"].std(axis=0).min() > 1e-4
+    assert np.abs(out["cluster"] - out["tile16"]).max() < TOL_Y_SHORT
+    model.check()
 
 
 def test_philox_dropout_statistics():
