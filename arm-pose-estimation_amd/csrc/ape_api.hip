@@ -351,6 +351,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             c.hx = m->hx; c.hx_bytes = m->hx_bytes;
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
+            c.done = c.ticket + 1;
             c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size; c.flags = flags;
             // injected masks are indexed [L-1, B, T, H] over the WHOLE batch: chunks need the full B stride,
             // so a masked call is served by one launch only (checked below)
@@ -359,9 +360,8 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
                 return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
-            // every polled word is re-zeroed in front of EVERY launch (a memset node under graph capture)
-            hipError_t e = hipMemsetAsync(m->xflags, 0, m->xflag_bytes, (hipStream_t)stream);
-            if (e == hipSuccess) e = ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
+            // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
+            hipError_t e = ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
         }
         return APE_OK;
@@ -402,8 +402,8 @@ int ape_model_check(ape_model_t* m) {
     unsigned st = 0;
     HIP_TRY(hipMemcpy(&st, m->xflags + m->xflag_bytes / sizeof(unsigned), sizeof(st), hipMemcpyDeviceToHost));
     if (st != 0) {
-        const unsigned zero = 0;
-        HIP_TRY(hipMemcpy(m->xflags + m->xflag_bytes / sizeof(unsigned), &zero, sizeof(zero), hipMemcpyHostToDevice));
+        // an aborted launch skipped its self-cleaning: reset flags, counters and the status word from the host
+        HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
         return fail(APE_ERR_HIP, "cluster kernel gave up waiting for a peer workgroup (status %u): not all of its "
                     "workgroups were resident; outputs of that launch are invalid", st);
     }

@@ -45,7 +45,8 @@ struct ClusterParams {
     float* hx;                          // exchange slices [cluster][L][parity 2][member GH][row MR][16]
     size_t hx_bytes;
     unsigned* xflags;                   // [cluster][L][GH] epoch flags, zeroed before every launch
-    unsigned* ticket;                   // [1] arrival counter (inside the zeroed block)
+    unsigned* ticket;                   // [1] arrival counter (re-zeroed by the last workgroup out)
+    unsigned* done;                     // [1] departure counter
     unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
     const float* masks;                 // [L-1,B,T,H] injected dropout masks or nullptr
     int B, T, I, O;

@@ -18,8 +18,9 @@
 //     storing wave drains vmcnt(0), workgroup barrier, ONE lane stores the epoch flag with an
 //     agent-scope relaxed atomic; the consumer's wave 0 polls the members' flags with agent-scope
 //     relaxed loads, workgroup barrier, then EVERY load of the payload is a 16-byte sc1 buffer
-//     load.  Exchange buffers are double-buffered by step parity; flags are zeroed by a
-//     hipMemsetAsync node in front of every launch; every spin is bounded and raises a status word.
+//     load.  Exchange buffers are double-buffered by step parity; the last workgroup to finish
+//     re-zeroes the flags and counters (self-cleaning, no memset node); every spin is bounded and raises a
+//     status word.
 //   * the layers are software-pipelined: in phase p layer l works on step t = p - l, so all the
 //     layer computations of a phase depend only on the previous phase and the exchange of one
 //     layer's slice flies under the other layers' MFMAs.
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     float* xin = hbuf + L * MR * SH;              // [MR][SX]
     float* own = xin + MR * SX;                   // [NV][MR][SO] this member's fresh slice (raw, masked)
     float* dbuf = own + NV * MR * SO;             // [L-1][MR][SH] gathered MASKED h (DROP only)
-    int* ctl = reinterpret_cast<int*>(dbuf + (DROP ? (L - 1) * MR * SH : 0));   // [0] abort flag, [1] arrival ticket
+    int* ctl = reinterpret_cast<int*>(dbuf + (DROP ? (L - 1) * MR * SH : 0));   // [0] abort flag, [1] arrival ticket, [2] last-out
     if (threadIdx.x == 0) {
         ctl[0] = 0;
         ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -505,6 +506,23 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
                 p.y[(size_t)b * O + o] = s + p.b_out[o];
             }
+        }
+    }
+    // ---- self-cleaning: the LAST workgroup to get here re-zeroes every polled word for the next launch ------
+    // (no memset node in front of the launch: graph replays and back-to-back calls find a clean state).  All
+    // the other workgroups are past their last flag read when they count themselves done.  A launch that
+    // aborted on an expired spin skips this; ape_model_check() then resets the block from the host.
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        const int n_words = (int)(gridDim.x / GH) * L * GH;
+        for (int i = tid; i < n_words; i += 256)
+            __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -37,21 +37,24 @@ def broadcast_blob(blob, n_floats: int, device: torch.device, src: int = 0) -> t
     ``device`` holding identical bytes.  One collective, init-time only."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return torch.as_tensor(blob, dtype=torch.float32).to(device)
+    # the collective runs where the backend lives: device memory for nccl (RCCL over xGMI), host for gloo
+    comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     if dist.get_rank() == src:
-        t = torch.as_tensor(blob, dtype=torch.float32).to(device).contiguous()
+        t = torch.as_tensor(blob, dtype=torch.float32).to(comm_dev).contiguous()
         if t.numel() != n_floats:
             raise UserWarning(f"blob has {t.numel()} floats, expected {n_floats}")
     else:
-        t = torch.empty((n_floats,), dtype=torch.float32, device=device)
+        t = torch.empty((n_floats,), dtype=torch.float32, device=comm_dev)
     dist.broadcast(t, src=src)
-    return t
+    return t.to(device)
 
 
 def broadcast_stats(stats: dict, I: int, O: int, device: torch.device, src: int = 0) -> dict:
     """float64 normalisation statistics travel the same way (exact bits)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return stats
-    t = torch.empty((2 * I + 2 * O,), dtype=torch.float64, device=device)
+    comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.empty((2 * I + 2 * O,), dtype=torch.float64, device=comm_dev)
     if dist.get_rank() == src:
         t.copy_(torch.from_numpy(np.concatenate([np.asarray(stats[k], dtype=np.float64).reshape(-1)
                                                  for k in ("xx_m", "xx_s", "yy_m", "yy_s")])))

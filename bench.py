@@ -126,11 +126,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal switch for a 1-GPU box: APE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (two
+    # ranks cannot form an RCCL communicator on one device); the driver's real runs never set it
+    share_gpu = os.environ.get("APE_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -144,7 +151,7 @@ def main():
     from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
 
     # ---- model: weights exist on rank 0 only and reach the other GPUs by ONE broadcast --------
-    model = nn_models.DropoutLSTM(POCKET["I"], POCKET["H"], POCKET["L"], POCKET["O"], device=local_rank)
+    model = nn_models.DropoutLSTM(POCKET["I"], POCKET["H"], POCKET["L"], POCKET["O"], device=dev_index)
     n_w = model.weight_blob_floats()
     sd = stats = None
     if rank == 0:
@@ -197,9 +204,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    model.check()           # blocking health check of the cluster kernel (bounded spins never expired)
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k]))
     flop_per_launch = model.flops_per_window(T_FRAMES) * B

@@ -388,6 +388,46 @@ def test_full_size_batched_path(norm_stats, name):
     assert np.abs(np.linalg.norm(e[:, 3:6] - uo, axis=1) - 0.26).max() < 1e-12
 
 
+def test_graph_capture_and_replay(norm_stats):
+    """ape_infer is capturable into a hipGraph (memset node + kernels, no allocation once reserved) and a
+    replay on new input data reproduces the eager result bit for bit"""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats["pocket"]
+    model, sd, cfg = make_model("pocket", 8, st)
+    model.set_body(orc.DEFAULT_BODY)
+    lib = _hip.lib()
+    for B, T in ((1, 6), (200, 6)):
+        _hip.check(lib.ape_model_reserve(model.handle, B), "reserve")
+        x = torch.from_numpy(_synthetic_windows(st, B, T, cfg["I"], 3)).cuda()
+        x2 = torch.from_numpy(_synthetic_windows(st, B, T, cfg["I"], 4)).cuda()
+        est_eager = torch.empty((B, 21), dtype=torch.float64, device="cuda")
+        est_graph = torch.zeros_like(est_eager)
+        xin = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st_ptr = C.c_void_p(side.cuda_stream)
+            call = lambda out: _hip.check(lib.ape_infer(model.handle, C.c_void_p(xin.data_ptr()), B, T,
+                                                        _hip.FLAG_NORMALIZE_INPUT, None, C.c_void_p(out.data_ptr()),
+                                                        _hip.F64, st_ptr), "ape_infer")
+            call(est_graph)                        # warm-up outside capture
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                call(est_graph)
+        torch.cuda.current_stream().wait_stream(side)
+        for data in (x, x2, x):
+            xin.copy_(data)
+            graph.replay()
+            torch.cuda.synchronize()
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _hip.check(lib.ape_infer(model.handle, C.c_void_p(data.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT, None,
+                                     C.c_void_p(est_eager.data_ptr()), _hip.F64, stream), "ape_infer")
+            torch.cuda.synchronize()
+            assert torch.equal(est_graph, est_eager)
+        model.check()
+
+
 def test_infer_windows_entry(tmp_path, monkeypatch, norm_stats):
     """Estimator.infer_windows == per-window streaming through the same estimator"""
     from wear_mocap_ape_amd import config
