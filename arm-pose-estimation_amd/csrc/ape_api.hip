@@ -80,6 +80,8 @@ struct ape_model {
     bool cluster_ok = false;
     int kernel_choice = APE_KERNEL_AUTO;
     float* wcl[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+    void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
+    int precision = APE_PRECISION_F32;
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned* xflags = nullptr;    // [flag words..., status word]
@@ -175,7 +177,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
         if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 128);
         if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 128);
+        for (int l = 0; l < L && e == hipSuccess; ++l)
+            e = hipMalloc(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
+        if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "cluster kernel set-up failed: %s", hipGetErrorString(e));
@@ -199,6 +204,8 @@ int ape_model_destroy(ape_model_t* m) {
     if (m->y_ws) (void)hipFree(m->y_ws);
     for (int l = 0; l < APE_MAX_LAYERS; ++l)
         if (m->wcl[l]) (void)hipFree(m->wcl[l]);
+    for (int l = 0; l < APE_MAX_LAYERS; ++l)
+        if (m->wcl16[l]) (void)hipFree(m->wcl16[l]);
     if (m->hx) (void)hipFree(m->hx);
     if (m->xflags) (void)hipFree(m->xflags);
     delete m;
@@ -272,6 +279,24 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                             pc[(((size_t)(mem * 4 + w) * NW) + i) * 64 + lane] = v;
                         }
             HIP_TRY(hipMemcpy(m->wcl[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
+            // fp16 variant: [member][wave][32-deep k-block q][lane][8]: lane holds Wcat[row][32q + 8g + j] as binary16
+            const int NB = (KXl + H) / 32;
+            std::vector<_Float16> ph((size_t)GH * 4 * NB * 64 * 8);
+            for (int mem = 0; mem < GH; ++mem)
+                for (int w = 0; w < 4; ++w)
+                    for (int q = 0; q < NB; ++q)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int c = lane & 15, g = lane >> 4, gate = c >> 2, u = c & 3;
+                            const int row = gate * H + mem * 16 + w * 4 + u;
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = 32 * q + 8 * g + j;
+                                float v;
+                                if (k < KXl) v = (k < in_l) ? w_ih[(size_t)row * in_l + k] : 0.0f;
+                                else v = w_hh[(size_t)row * H + (k - KXl)];
+                                ph[((((size_t)(mem * 4 + w) * NB) + q) * 64 + lane) * 8 + j] = (_Float16)v;
+                            }
+                        }
+            HIP_TRY(hipMemcpy(m->wcl16[l], ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         }
         std::vector<float> bsum(4 * H);
         for (int i = 0; i < 4 * H; ++i) bsum[i] = b_ih[i] + b_hh[i];
@@ -330,6 +355,11 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     const bool fits_drop = !drop || L == 1 || B <= 32 * max_clusters_c || m->kernel_choice == APE_KERNEL_CLUSTER;
     bool use_cluster = m->cluster_ok && (flags & APE_FLAG_ALL_STEPS) == 0 && fits_drop &&
                        m->kernel_choice != APE_KERNEL_TILE16;
+    const bool f16 = m->precision == APE_PRECISION_F16;
+    if (f16 && (!m->cluster_ok || drop || (flags & APE_FLAG_ALL_STEPS)))
+        return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant covers last-step output without dropout on "
+                    "the cluster-kernel shapes only");
+    if (f16) use_cluster = true;
     if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     if (use_cluster) {
@@ -345,7 +375,10 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             ClusterParams c{};
             c.x = x_dev + (size_t)b0 * T * m->dims.input_size;
             c.y = y_dev + (size_t)b0 * m->dims.output_size;
-            for (int l = 0; l < L; ++l) { c.wcl[l] = m->wcl[l]; c.bias[l] = m->bias[l]; }
+            for (int l = 0; l < L; ++l) {
+                c.wcl[l] = f16 ? reinterpret_cast<const float*>(m->wcl16[l]) : m->wcl[l];
+                c.bias[l] = m->bias[l];
+            }
             c.w_out = m->w_out; c.b_out = m->b_out;
             c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
             c.hx = m->hx; c.hx_bytes = m->hx_bytes;
@@ -361,7 +394,8 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
-            hipError_t e = ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
+            hipError_t e = f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
+                               : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
         }
         return APE_OK;
@@ -392,6 +426,17 @@ int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d", m->dims.hidden_size, m->dims.num_layers);
     m->kernel_choice = choice;
+    return APE_OK;
+}
+
+int ape_model_set_precision(ape_model_t* m, int32_t precision) {
+    if (!m) return fail(APE_ERR_INVALID_ARG, "set_precision: NULL model");
+    if (precision != APE_PRECISION_F32 && precision != APE_PRECISION_F16)
+        return fail(APE_ERR_INVALID_ARG, "set_precision: unknown precision %d", precision);
+    if (precision == APE_PRECISION_F16 && !m->cluster_ok)
+        return fail(APE_ERR_UNSUPPORTED, "set_precision: no fp16 kernel for H=%d L=%d", m->dims.hidden_size,
+                    m->dims.num_layers);
+    m->precision = precision;
     return APE_OK;
 }
 
@@ -477,6 +522,7 @@ int ape_debug_read_stamps(ape_model_t* m, unsigned long long out[9]) {
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     (void)B; (void)T;
     if (!m) return "";
+    if (m->precision == APE_PRECISION_F16) return "ape_lstm_cluster_f16";
     return (m->cluster_ok && m->kernel_choice != APE_KERNEL_TILE16) ? m->cluster_name.c_str() : m->kernel_name.c_str();
 }
 

@@ -96,5 +96,7 @@ bool ape_cluster_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,
                                    hipStream_t stream);
+hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
+hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

@@ -23,6 +23,7 @@ FLAG_ALL_STEPS = 0x2
 FLAG_DROPOUT_MASKS = 0x4
 FLAG_DROPOUT_PHILOX = 0x8
 KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER = 0, 1, 2
+PRECISION_F32, PRECISION_F16 = 0, 1
 
 EST_WIDTH = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 21, LAYOUT_ORI_CAL_LARM_UARM: 14, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 21}
 NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 20}
@@ -52,6 +53,7 @@ SIGNATURES = {
     "ape_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                             C.c_int32, C.c_void_p]),
     "ape_model_set_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ape_model_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "ape_model_check": (C.c_int, [C.c_void_p]),
     "ape_lstm_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "ape_flops_per_window": (C.c_double, [C.POINTER(ApeDims), C.c_int32]),

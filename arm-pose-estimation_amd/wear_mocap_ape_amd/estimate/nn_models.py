@@ -241,6 +241,13 @@ class DropoutLSTM:
         _hip.check(_hip.lib().ape_model_set_kernel(self._handle, code), "ape_model_set_kernel")
         return self
 
+    def set_precision(self, precision: str = "f32"):
+        """'f32' (exact float32 MFMA, default) | 'f16' (binary16 weights / inputs / hidden state, float32
+        accumulate and cell state: BASELINE configs[4]; last-step output without dropout)"""
+        code = {"f32": _hip.PRECISION_F32, "f16": _hip.PRECISION_F16}[precision]
+        _hip.check(_hip.lib().ape_model_set_precision(self._handle, code), "ape_model_set_precision")
+        return self
+
     def check(self):
         """blocking health check: raises if a cluster-kernel launch gave up waiting for a peer workgroup"""
         _hip.check(_hip.lib().ape_model_check(self._handle), "ape_model_check")

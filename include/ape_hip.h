@@ -78,6 +78,11 @@ enum { APE_F32 = 0, APE_F64 = 1 };   /* element type selector for preds / est bu
  * built (H=256/L=2/I<=32 and H=128/L=3/32<I<=64, last-step output, no dropout), else the batch-tile kernel. */
 enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2 };
 
+/* Storage precision of W, x and h inside the LSTM (ape_model_set_precision).  F32 (default): exact float32
+ * MFMA.  F16: binary16 weights / inputs / hidden state with float32 accumulate, cell state and head
+ * (BASELINE.json configs[4]); last-step output without dropout; parity to a stated tolerance only. */
+enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1 };
+
 typedef struct ape_model ape_model_t;
 
 /* DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size) -- nn_models.py:160-178,
@@ -153,6 +158,7 @@ int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint
 
 /* kernel selection for A/B runs and tests; no effect on results beyond float32 summation order */
 int ape_model_set_kernel(ape_model_t* model, int32_t choice);
+int ape_model_set_precision(ape_model_t* model, int32_t precision);
 /* BLOCKING health check (synchronises the device): non-zero if a cluster-kernel launch since the last
  * check gave up waiting for a peer workgroup (its bounded spins expired) -- its outputs are invalid. */
 int ape_model_check(ape_model_t* model);

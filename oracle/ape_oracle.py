@@ -104,19 +104,24 @@ def _sigmoid(v):
 
 def lstm_forward(sd: Dict[str, np.ndarray], x: np.ndarray,
                  masks: Optional[Sequence[np.ndarray]] = None,
-                 dtype=np.float32) -> np.ndarray:
+                 dtype=np.float32, storage: Optional[str] = None) -> np.ndarray:
     """x [B,T,I] -> y [B,T,O].  Zero initial state per call (nn_models.py:188 with hs=None).
 
     ``masks``: optional list of L-1 arrays [B,T,H] multiplied onto the output sequence of
     layers 0..L-2 (already holding 0 or 1/(1-p)) -- inter-layer dropout of
     ``torch.nn.LSTM(dropout=p)`` in train mode, which is what
-    ``monte_carlo_predictions`` switches on (nn_models.py:204)."""
+    ``monte_carlo_predictions`` switches on (nn_models.py:204).
+
+    ``storage="f16"`` emulates BASELINE.json configs[4] ("fp16 hidden state with fp32 accumulate"): W_ih,
+    W_hh, the inputs and every h are rounded to IEEE binary16 (round-to-nearest-even) where they are
+    stored; products, accumulation, biases, the cell state and the head stay float32."""
     L = sum(1 for k in sd if k.startswith("lstm.weight_ih_l"))
-    seq = np.asarray(x, dtype=dtype)
+    q16 = (lambda a: np.asarray(a, dtype=np.float16).astype(dtype)) if storage == "f16" else (lambda a: a)
+    seq = q16(np.asarray(x, dtype=dtype))
     B, T, _ = seq.shape
     for k in range(L):
-        w_ih = sd[f"lstm.weight_ih_l{k}"].astype(dtype)
-        w_hh = sd[f"lstm.weight_hh_l{k}"].astype(dtype)
+        w_ih = q16(sd[f"lstm.weight_ih_l{k}"].astype(dtype))
+        w_hh = q16(sd[f"lstm.weight_hh_l{k}"].astype(dtype))
         b_ih = sd[f"lstm.bias_ih_l{k}"].astype(dtype)
         b_hh = sd[f"lstm.bias_hh_l{k}"].astype(dtype)
         H = w_hh.shape[1]
@@ -130,7 +135,7 @@ def lstm_forward(sd: Dict[str, np.ndarray], x: np.ndarray,
             gg = np.tanh(pre[:, 2 * H:3 * H])
             go = _sigmoid(pre[:, 3 * H:4 * H])
             c = gf * c + gi * gg
-            h = go * np.tanh(c)
+            h = q16(go * np.tanh(c))
             out[:, t, :] = h
         if masks is not None and k < L - 1:
             out = out * np.asarray(masks[k], dtype=dtype)

@@ -31,6 +31,12 @@ for k, (kern, fl) in variants.items(): run(kern, fl, 3)
 for rnd in range(5):
     for k, (kern, fl) in variants.items():
         res[k].append(run(kern, fl, 10))
+# fp16 variant (configs[4])
+lib.ape_model_set_kernel(m.handle, 0); lib.ape_model_set_precision(m.handle, 1)
+res["cluster_f16"] = []
+run(0, 0, 3)
+for rnd in range(5): res["cluster_f16"].append(run(0, 0, 10))
+lib.ape_model_set_precision(m.handle, 0)
 flop = m.flops_per_window(T) * B
 for k, v in res.items():
     med = float(np.median(v))
