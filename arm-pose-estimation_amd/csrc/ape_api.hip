@@ -491,6 +491,23 @@ int ape_msg_reduce(ape_model_t* m, const double* est_dev, int32_t N, double* msg
     return APE_OK;
 }
 
+int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev, int32_t xx_dtype, void* stream) {
+    if (!rows_dev || !xx_dev) return fail(APE_ERR_INVALID_ARG, "parse_rows: NULL argument");
+    if (N < 1) return fail(APE_ERR_INVALID_ARG, "parse_rows: N=%d must be >= 1", N);
+    if (xx_dtype != APE_F32 && xx_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "parse_rows: unknown dtype selector");
+    int width, I;
+    switch (kind) {
+        case APE_PARSE_WATCH_PHONE_POCKET: width = 55; I = 22; break;
+        case APE_PARSE_WATCH_ONLY: width = 28; I = 20; break;
+        case APE_PARSE_WATCH_ONLY_PHONE_MSG: width = 55; I = 20; break;
+        case APE_PARSE_WATCH_PHONE_UARM: width = 55; I = 38; break;
+        default: return fail(APE_ERR_INVALID_ARG, "parse_rows: unknown kind %d", kind);
+    }
+    hipError_t e = ape_launch_parse_rows(rows_dev, N, width, kind, xx_dev, xx_dtype, I, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "parse_rows launch failed: %s", hipGetErrorString(e));
+    return APE_OK;
+}
+
 int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags, float* y_dev, void* est_dev,
               int32_t est_dtype, void* stream) {
     if (!m || !x_dev || !est_dev) return fail(APE_ERR_INVALID_ARG, "infer: NULL argument");

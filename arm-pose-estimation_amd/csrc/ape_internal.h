@@ -98,5 +98,7 @@ hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, 
                                    hipStream_t stream);
 hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
+hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
+                                 hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

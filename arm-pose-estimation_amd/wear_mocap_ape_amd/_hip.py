@@ -24,6 +24,8 @@ FLAG_DROPOUT_MASKS = 0x4
 FLAG_DROPOUT_PHILOX = 0x8
 KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER = 0, 1, 2
 PRECISION_F32, PRECISION_F16 = 0, 1
+PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3
+PARSE_SHAPES = {0: (55, 22), 1: (28, 20), 2: (55, 20), 3: (55, 38)}
 
 EST_WIDTH = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 21, LAYOUT_ORI_CAL_LARM_UARM: 14, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 21}
 NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 20}
@@ -50,6 +52,7 @@ SIGNATURES = {
                                    C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "ape_fk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "ape_msg_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ape_parse_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "ape_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                             C.c_int32, C.c_void_p]),
     "ape_model_set_kernel": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -171,6 +171,35 @@ class Estimator:
     def parse_row_to_xx(self, row) -> np.array:
         return
 
+    # ---- batched feature builder: raw messages of many streams -> features on the GPU ----
+    _parse_kind = None        # subclasses: the APE_PARSE_* selector of their message/feature layout
+
+    def parse_rows(self, rows, out_dtype=None):
+        """rows: float32 ``[N, 55|28]`` raw messages (host array or CUDA tensor) -> features ``[N, I]`` on the
+        device, the batched equivalent of ``parse_row_to_xx`` (``ape_parse_rows`` kernel, float64 arithmetic).
+        Default dtype is what the reference's ``parse_row_to_xx`` returns (float32; float64 for the
+        upper-arm estimator)."""
+        import ctypes as C
+        from wear_mocap_ape_amd import _hip
+        if self._parse_kind is None:
+            raise UserWarning("this estimator has no batched feature builder")
+        width, n_feat = _hip.PARSE_SHAPES[self._parse_kind]
+        if out_dtype is None:
+            out_dtype = torch.float64 if self._parse_kind == _hip.PARSE_WATCH_PHONE_UARM else torch.float32
+        model = self._hip_model()
+        dev = model.torch_device if model is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            rd = torch.as_tensor(rows, dtype=torch.float32).to(dev).contiguous()
+            if rd.dim() != 2 or rd.shape[1] != width or rd.shape[0] < 1:
+                raise UserWarning(f"expected rows [N>=1,{width}], got {tuple(rd.shape)}")
+            xx = torch.empty((rd.shape[0], n_feat), dtype=out_dtype, device=dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _hip.check(_hip.lib().ape_parse_rows(self._parse_kind, C.c_void_p(rd.data_ptr()), int(rd.shape[0]),
+                                                 C.c_void_p(xx.data_ptr()),
+                                                 _hip.F64 if out_dtype == torch.float64 else _hip.F32, stream),
+                       "ape_parse_rows")
+        return xx
+
     # ---- batched entry the reference lacks (SURVEY.md 3.4): many independent windows at once ----
     def infer_windows(self, x, est_dtype=torch.float64, return_targets: bool = False):
         """x: raw (un-normalised) features float32 ``[B,T,I]``, host array or CUDA tensor ->

@@ -8,6 +8,7 @@ import torch
 
 from wear_mocap_ape_amd.data_types import messaging
 from wear_mocap_ape_amd.data_types.bone_map import BoneMap
+from wear_mocap_ape_amd import _hip
 from wear_mocap_ape_amd.estimate import nn_models
 from wear_mocap_ape_amd.estimate.estimator import Estimator
 from wear_mocap_ape_amd.utility import transformations as ts
@@ -63,6 +64,8 @@ class WatchPhonePocketNN(Estimator):
 
     def _hip_model(self):
         return self.__nn_model
+
+    _parse_kind = _hip.PARSE_WATCH_PHONE_POCKET
 
     def parse_row_to_xx(self, row):
         return features_from_row(row, self.__slp)

@@ -151,6 +151,20 @@ int ape_fk(ape_model_t* model, const void* preds_dev, int32_t preds_dtype, int32
  * them; N == 1: row 0 copied into the message layout.  est_dev f64 [N,W]; msg_dev f64 [25]. */
 int ape_msg_reduce(ape_model_t* model, const double* est_dev, int32_t N, double* msg_dev, void* stream);
 
+/* feature builder, batched.  replaces: parse_row_to_xx of WatchPhonePocketNN
+ * (watch_phone_pocket_nn.py:41-96), WatchOnlyNN (watch_only.py:46-82; also with the 55-float watch+phone
+ * message, watch_only.py:29-32) and WatchPhoneUarmNN (watch_phone_uarm_nn.py:43-105).
+ *   rows_dev f32 [N,55] (or [N,28] for APE_PARSE_WATCH_ONLY): raw messages, data_types/messaging.py layouts
+ *   xx_dev   [N,22|20|20|38] of xx_dtype (the reference returns float32, float64 for the upper-arm variant)
+ * float64 arithmetic on the device.  Needs no model: runs on the current HIP device. */
+enum {
+    APE_PARSE_WATCH_PHONE_POCKET = 0,   /* 55 -> 22 */
+    APE_PARSE_WATCH_ONLY = 1,           /* 28 -> 20 */
+    APE_PARSE_WATCH_ONLY_PHONE_MSG = 2, /* 55 -> 20 */
+    APE_PARSE_WATCH_PHONE_UARM = 3      /* 55 -> 38 */
+};
+int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev, int32_t xx_dtype, void* stream);
+
 /* the whole batched path in one call: x -> [normalise] -> LSTM -> last step ->
  * de-normalise -> FK.  y_dev (f32 [B,O], normalised NN targets) may be NULL. */
 int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,

@@ -306,6 +306,43 @@ def test_estimator_stream_trace(golden, tmp_path, monkeypatch, name):
         assert est._row_hist == [] and est._smooth_hist == [] and not est.is_active()
 
 
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_batched_feature_builder(golden, tmp_path, monkeypatch, name):
+    """ape_parse_rows against the reference's own parse_row_to_xx outputs"""
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape_amd.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+    g = golden(f"stream_trace_{name}.npz")
+    deploy, h = _deploy_dir(tmp_path, name, 3, dropout=0.0)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    est = {"pocket": WatchPhonePocketNN, "watch": WatchOnlyNN, "uarm": WatchPhoneUarmNN}[name](model_hash=h)
+    ref = g["xx_s1_mc1"]
+    xx = est.parse_rows(g["rows"])
+    assert xx.is_cuda and tuple(xx.shape) == ref.shape
+    assert str(xx.dtype).endswith(str(g["xx_dtype_s1_mc1"]))          # float32 / float64 like the reference
+    # uarm: the reference's own quaternion math is partly float32 there (SURVEY appendix B.5)
+    tol = 2e-6 if name == "uarm" else 1e-6
+    assert np.abs(xx.cpu().numpy().astype(np.float64) - ref).max() < tol
+    # float64 output vs the host feature builder (same formulas in float64): tight
+    from array import array
+    xx64 = est.parse_rows(g["rows"], out_dtype=torch.float64).cpu().numpy()
+    host = np.array([np.asarray(est.parse_row_to_xx(array("f", r.tolist())), dtype=np.float64) for r in g["rows"]])
+    assert np.abs(xx64 - host).max() < (1e-12 if name == "uarm" else 1e-6)
+    # a big ragged batch: rows are independent, so tiling the trace must tile the output
+    rows = np.tile(g["rows"], (53, 1))[:1001]
+    big = est.parse_rows(rows).cpu().numpy()
+    assert np.array_equal(big, np.tile(xx.cpu().numpy(), (53, 1))[:1001])
+    if name == "watch":      # the watch-only estimator fed by the 55-float watch+phone message
+        est2 = WatchOnlyNN(model_hash=h, watch_phone=True)
+        rows55 = golden("stream_trace_pocket.npz")["rows"]
+        out = est2.parse_rows(rows55).cpu().numpy()
+        host2 = np.array([est2.parse_row_to_xx(array("f", r.tolist())) for r in rows55])
+        assert out.shape == (len(rows55), 20) and np.abs(out - host2).max() < 1e-6
+    with pytest.raises(UserWarning):
+        est.parse_rows(np.zeros((3, 7), np.float32))
+
+
 def test_processing_loop_thread(tmp_path, monkeypatch, golden):
     """the consumer thread contract: sensor_q in -> msg_q out, terminate() stops it"""
     import queue
