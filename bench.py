@@ -111,6 +111,45 @@ def batch1_latency(model, stats, n_frames=300):
             "frames_per_s": float(1e6 / np.mean(us))}
 
 
+def fp16_config4(stats_watch, n_iter=10):
+    """BASELINE configs[4]: watch-only model, 1024 windows x 64 frames x 20 features, fp16 hidden state /
+    weights with fp32 accumulate (ape_model_set_precision F16), HIP-event timed; the exact-f32 kernel on the
+    same windows beside it, and the max-abs difference of the NN targets between the two"""
+    from oracle import ape_oracle as orc
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import nn_models
+    cfg = orc.MODEL_CONFIGS["watch"]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed=0)
+    m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"])
+    m.load_state_dict(sd)
+    m.set_norm_stats(stats_watch["xx_m"], stats_watch["xx_s"], stats_watch["yy_m"], stats_watch["yy_s"])
+    x = torch.from_numpy(synthetic_windows(stats_watch, 0, WINDOWS_PER_GPU, T_FRAMES, cfg["I"])).cuda()
+    y = {p: torch.empty((WINDOWS_PER_GPU, cfg["O"]), dtype=torch.float32, device="cuda") for p in ("f32", "f16")}
+    lib = _hip.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for prec in ("f32", "f16"):
+        m.set_precision(prec)
+        run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), WINDOWS_PER_GPU, T_FRAMES,
+                                                      _hip.FLAG_NORMALIZE_INPUT, None, 0.0, 0,
+                                                      C.c_void_p(y[prec].data_ptr()), stream), "ape_lstm_forward")
+        for _ in range(3):
+            run()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n_iter):
+            run()
+        b.record()
+        b.synchronize()
+        out[prec] = a.elapsed_time(b) / n_iter
+    m.check()
+    flop = m.flops_per_window(T_FRAMES) * WINDOWS_PER_GPU
+    return {"workload": "configs[4]: watch-only (I=20,H=256,L=2,O=12), 1024 windows x 64 frames, fp16 W/x/h, fp32 accumulate",
+            "kernel_ms_f16": out["f16"], "kernel_ms_f32": out["f32"], "windows_per_s_f16": WINDOWS_PER_GPU / out["f16"] * 1e3,
+            "algorithmic_tflops_f16": flop / (out["f16"] * 1e-3) / 1e12,
+            "max_abs_diff_targets_f16_vs_f32": float((y["f16"] - y["f32"]).abs().max().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +279,8 @@ def main():
                 pass
         if world == 1:
             out["batch1"] = batch1_latency(model, stats)
+            out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
+                                                                         NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(sd, stats, orc.DEFAULT_BODY, POCKET["layout"], x_host)
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
