@@ -273,7 +273,8 @@ def main():
         if tfile.exists():      # HBM bytes per launch from the committed rocprofv3 --pmc pass
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("kernel", "") in out["roofline"]["kernel"] and tj.get("windows") == B:
+                a, b = tj.get("kernel", ""), out["roofline"]["kernel"]
+                if a and (a in b or b in a) and tj.get("windows") == B:
                     out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
             except Exception:
                 pass
