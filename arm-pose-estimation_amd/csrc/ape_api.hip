@@ -262,7 +262,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                     }
                 }
         if (m->cluster_ok) {
-            // cluster kernel: [member GH][wave 4][i = 4q + j][lane]; lane = (g << 4) | (gate << 2) | u holds
+            // cluster kernel: [member GH][wave 4][i = 4q + j][lane]; lane = (g << 4) | (u << 2) | gate holds
             // Wcat[gate*H + member*16 + wave*4 + u][16q + 4g + j] -- the register file of that wave
             const int GH = H / 16, NW = (KXl + H) / 4;
             std::vector<float> pc((size_t)GH * 4 * NW * 64);
@@ -270,7 +270,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                 for (int w = 0; w < 4; ++w)
                     for (int i = 0; i < NW; ++i)
                         for (int lane = 0; lane < 64; ++lane) {
-                            const int c = lane & 15, g = lane >> 4, gate = c >> 2, u = c & 3;
+                            const int c = lane & 15, g = lane >> 4, u = c >> 2, gate = c & 3;   // tile row = unit*4 + gate
                             const int row = gate * H + mem * 16 + w * 4 + u;
                             const int k = 16 * (i / 4) + 4 * g + (i % 4);
                             float v;
@@ -286,7 +286,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                 for (int w = 0; w < 4; ++w)
                     for (int q = 0; q < NB; ++q)
                         for (int lane = 0; lane < 64; ++lane) {
-                            const int c = lane & 15, g = lane >> 4, gate = c >> 2, u = c & 3;
+                            const int c = lane & 15, g = lane >> 4, u = c >> 2, gate = c & 3;
                             const int row = gate * H + mem * 16 + w * 4 + u;
                             for (int j = 0; j < 8; ++j) {
                                 const int k = 32 * q + 8 * g + j;

@@ -6,7 +6,7 @@
 //
 //   * GH = H/16 workgroups (one per CU) form a CLUSTER that owns MR = 16*NMT windows for all T
 //     steps.  Member m owns hidden units [16m, 16m+16) of EVERY layer with all four gates; wave w
-//     of it owns 4 of those units = one 16-column MFMA tile (column = gate*4 + unit).
+//     of it owns 4 of those units = one 16-column MFMA tile (column = unit*4 + gate).
 //   * each wave keeps its slice of [W_ih | W_hh] of every layer in REGISTERS for the whole launch,
 //     already in v_mfma_f32_16x16x4_f32 B-fragment order (200 VGPR/AGPR per lane for the pocket
 //     model): the MFMA B operand needs no load at all.  At B=1024 all 256 CUs are busy
@@ -24,9 +24,9 @@
 //   * the layers are software-pipelined: in phase p layer l works on step t = p - l, so all the
 //     layer computations of a phase depend only on the previous phase and the exchange of one
 //     layer's slice flies under the other layers' MFMAs.
-//   * gate activations are evaluated where the accumulators are (every lane: its own gate's
-//     column), then a 4x4 lane transpose (cross-lane shuffles inside 16-lane rows) gives each lane
-//     i,f,g,o of ONE (unit, row-tile), so the c/h update is spread over all 64 lanes.
+//   * the MFMA takes the weights as its A operand and the activations as B, with the wave's 16 gate
+//     columns ordered unit*4 + gate: every lane then holds i,f,g,o of ONE (unit, batch row) in its four
+//     accumulator registers, so activations and the c/h update are lane-local and spread over all 64 lanes.
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
 
@@ -80,8 +80,12 @@ __device__ __forceinline__ float row_rot_up(float x) {
 // 256 architectural VGPRs stay free for activations, gathers and the cell update.  hipcc does not model an
 // asm MFMA's hazards: the accumulators are read only after `mfma_drain()` (>= 18 wait states after the
 // last 8-pass MFMA, CDNA4 ISA data-hazard table).
+// Operand roles: A = weights (row i = lane&15 = this wave's gate column  unit*4 + gate), B = activations
+// (column j = lane&15 = batch row).  The result tile D[gate column][batch row] then puts, on every lane, the
+// four gates i,f,g,o of ONE unit (lane>>4) for ONE batch row (lane&15) into its four accumulator registers:
+// the cell update needs no cross-lane traffic at all.
 __device__ __forceinline__ void mfma_aw(f32x4& acc, float a, float w) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(w));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+a"(acc) : "v"(a), "a"(w));
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int gate = r >> 2, u = r & 3;           // C-operand column = gate*4 + unit
+    // D layout: lane (r = lane&15, g = lane>>4) holds gates i,f,g,o (register 0..3) of unit g for batch row r
     // Cluster membership by ARRIVAL TICKET, not by blockIdx: the first GH workgroups to start form cluster 0,
     // the next GH cluster 1, ...  Every member of a formed cluster is therefore resident, so formed clusters
     // always make progress and free their CUs on exit; the launch cannot deadlock as long as one cluster fits
@@ -214,15 +218,17 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             for (int i = 0; i < NW1; ++i) w2[i] = s2[i * 64];
         }
     }
-    float bias_r[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) bias_r[l] = p.bias[l][gate * H + member * 16 + wave * 4 + u];
-
-    float cst[L][4];
+    f32x4 bias_r[L];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cst[l][i] = 0.0f;
+        for (int k = 0; k < 4; ++k) bias_r[l][k] = p.bias[l][k * H + member * 16 + wave * 4 + g];
+
+    float cst[L][NMT];                // cell state of (unit g, batch row 16*mt + r)
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) cst[l][mt] = 0.0f;
 
     // exchange buffer descriptors (wave-uniform: kernel arguments only)
     const __amdgpu_buffer_rsrc_t hx_rsrc =
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             // ---- stacked-gate product on the matrix cores ------------------------------------------------
             f32x4 acc[NMT];
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{bias_r[l], bias_r[l], bias_r[l], bias_r[l]};
+            for (int mt = 0; mt < NMT; ++mt) acc[mt] = bias_r[l];
             const float* rec_src = hbuf + (l * MR + r) * SH + 4 * g;
             if (l == 0) {
                 layer_mfma<NMT, QX, QX + QH, NW0>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0);
@@ -399,61 +405,46 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             }
             STAMP_END(3);                                // 3: flag check + gather issue
 
-            // ---- gate non-linearities on the accumulators (lane = one gate of one unit) ------------------
-            float act[NMT][4];
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) act[mt][i] = diag_noact ? acc[mt][i] : gate_act(acc[mt][i], gate == 2);
-            // ---- 4x4 lane transpose by DPP row rotations: lane (gate, u) collects i,f,g,o of unit u for row
-            // tile mt == gate.  rot_d(x) = x of the lane d columns up in the same 16-lane row = gate + d/4.
-            float gi[4], gf[4], gg[4], go[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float vi = 0.f, vf = 0.f, vg = 0.f, vo = 0.f;
+            // ---- gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit g, batch row 16*mt + r) -------
+            {
+                const int unit = member * 16 + wave * 4 + g;
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
-                    float v[4];
-                    v[0] = act[mt][i];
-                    v[1] = row_rot_up<4>(act[mt][i]);
-                    v[2] = row_rot_up<8>(act[mt][i]);
-                    v[3] = row_rot_up<12>(act[mt][i]);
-                    // on the lane whose own gate is mt: gate k's value sits (k - mt) mod 4 rotations up
-                    if (gate == mt) { vi = v[(0 - mt) & 3]; vf = v[(1 - mt) & 3]; vg = v[(2 - mt) & 3]; vo = v[(3 - mt) & 3]; }
-                }
-                gi[i] = vi; gf[i] = vf; gg[i] = vg; go[i] = vo;
-            }
-            STAMP_END(4);                                // 4: activations + lane transpose
-            // ---- cell update for (unit u, rows 16*gate + 4g + i), h into the own-slice staging ------------
-            if (gate < NMT) {
-                const int unit = member * 16 + wave * 4 + u;
-                uint32_t rnd[4] = {0, 0, 0, 0};
-                if (DROP && l < L - 1 && !drop_masks)        // same counters as the batch-tile kernel: same masks
-                    philox4x32((uint32_t)(row0 + 16 * gate + 4 * g), (uint32_t)t, (uint32_t)unit, (uint32_t)l,
-                               (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float c = gf[i] * cst[l][i] + gi[i] * gg[i];
-                    cst[l][i] = c;
-                    const float hval = go[i] * (diag_noact ? c : gate_act(c, true));
-                    const int row = 16 * gate + 4 * g + i;
-                    own[row * SO + wave * 4 + u] = hval;
+                    const int row = 16 * mt + r;
+                    float hval;
+                    if (diag_noact) {
+                        const float c = acc[mt][1] * cst[l][mt] + acc[mt][0] * acc[mt][2];
+                        cst[l][mt] = c;
+                        hval = acc[mt][3] * c;
+                    } else {
+                        const float iv = gate_act(acc[mt][0], false), fv = gate_act(acc[mt][1], false);
+                        const float gv = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
+                        const float c = fv * cst[l][mt] + iv * gv;
+                        cst[l][mt] = c;
+                        hval = ov * gate_act(c, true);
+                    }
+                    own[row * SO + wave * 4 + g] = hval;
                     if (DROP && l < L - 1) {
                         float m;
+                        const int b = row0 + row;
                         if (drop_masks) {
-                            const int b = row0 + row;
                             m = (b < p.B) ? p.masks[(((size_t)l * p.B + b) * T + t) * H + unit] : 0.0f;
                         } else {
-                            const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                            // same counters as the batch-tile kernel (group of 4 rows, index row & 3): same masks
+                            uint32_t rnd[4];
+                            philox4x32((uint32_t)(b & ~3), (uint32_t)t, (uint32_t)unit, (uint32_t)l, (uint32_t)p.seed,
+                                       (uint32_t)(p.seed >> 32), rnd);
+                            const float uf = (float)(rnd[b & 3] >> 8) * (1.0f / 16777216.0f);
                             m = (uf >= p.dropout_p) ? 1.0f / (1.0f - p.dropout_p) : 0.0f;
                         }
-                        own[(MR + row) * SO + wave * 4 + u] = hval * m;
+                        own[(MR + row) * SO + wave * 4 + g] = hval * m;
                     }
                 }
             }
+            STAMP_END(4);                                // 4: activations + cell update + own-slice write
             __syncthreads();                             // barrier A: own slice complete, all MFMAs of the section done
             if (ctl[0] != 0) return;
-            STAMP_END(5);                                // 5: cell update + own-slice write + barrier A
+            STAMP_END(5);                                // 5: barrier A
             // ---- publish: 16-byte write-through stores, (commit gather, stage x), drain, barrier, ONE flag ----
             if (!diag_noex && tid < ((DROP && l < L - 1) ? 2 * TPS : TPS)) {
                 const int v = tid / TPS, idx = tid - v * TPS;        // variant 1 = masked slice

@@ -3,7 +3,8 @@
 //
 // Same decomposition, hand-off protocol and pipelining as lstm_cluster.hip (see there): GH = H/16 workgroups
 // per cluster, member m owns hidden units [16m,16m+16) of every layer, wave w one 16-column tile
-// (column = gate*4 + unit), weights resident in registers for the whole launch, h slices exchanged with sc1
+// (column = unit*4 + gate; weights are the MFMA's A operand, so each lane gets i,f,g,o of one unit and batch
+// row), weights resident in registers for the whole launch, h slices exchanged with sc1
 // write-through stores + epoch flags, layers software-pipelined, self-cleaning flags, ticketed clusters.
 // What differs:
 //   * weights, the inputs x and the hidden state h are IEEE binary16; the stacked-gate product runs on
@@ -52,7 +53,7 @@ __device__ __forceinline__ void span_f16(f32x4 (&acc)[NMT], const _Float16* __re
         }
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[mt], w[w_off + q], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[w_off + q], a_cur[mt], acc[mt], 0, 0, 0);   // A = weights, B = activations
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) a_cur[mt] = a_nxt[mt];
     }
@@ -77,7 +78,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int gate = r >> 2, u = r & 3;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
 
@@ -114,14 +114,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
             for (int i = 0; i < NB1; ++i) w2[i] = s2[i * 64];
         }
     }
-    float bias_r[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) bias_r[l] = p.bias[l][gate * H + member * 16 + wave * 4 + u];
-    float cst[L][4];
+    f32x4 bias_r[L];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cst[l][i] = 0.0f;
+        for (int k = 0; k < 4; ++k) bias_r[l][k] = p.bias[l][k * H + member * 16 + wave * 4 + g];
+    float cst[L][NMT];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) cst[l][mt] = 0.0f;
 
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
     unsigned* const myflags = p.xflags + (size_t)cluster * L * GH;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
 
             f32x4 acc[NMT];
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{bias_r[l], bias_r[l], bias_r[l], bias_r[l]};
+            for (int mt = 0; mt < NMT; ++mt) acc[mt] = bias_r[l];
             const _Float16* rec_src = hbuf + (l * MR + r) * SH + 8 * g;
             if (l == 0) {
                 span_f16<NMT, QX, NB0>(acc, xin + r * SX + 8 * g, SX, w0, 0);
@@ -252,33 +254,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
                 issue_gather(ln, (tn - 1) & 1, gv);
             }
 
-            float act[NMT][4];
+            // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit g, batch row 16*mt + r)
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) act[mt][i] = gate_act(acc[mt][i], gate == 2);
-            float gi[4], gf[4], gg[4], go[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float vi = 0.f, vf = 0.f, vg = 0.f, vo = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) {
-                    float v[4];
-                    v[0] = act[mt][i];
-                    v[1] = row_rot_up<4>(act[mt][i]);
-                    v[2] = row_rot_up<8>(act[mt][i]);
-                    v[3] = row_rot_up<12>(act[mt][i]);
-                    if (gate == mt) { vi = v[(0 - mt) & 3]; vf = v[(1 - mt) & 3]; vg = v[(2 - mt) & 3]; vo = v[(3 - mt) & 3]; }
-                }
-                gi[i] = vi; gf[i] = vf; gg[i] = vg; go[i] = vo;
-            }
-            if (gate < NMT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float c = gf[i] * cst[l][i] + gi[i] * gg[i];      // cell state stays f32
-                    cst[l][i] = c;
-                    own[(16 * gate + 4 * g + i) * SO + wave * 4 + u] = (_Float16)(go[i] * gate_act(c, true));
-                }
+            for (int mt = 0; mt < NMT; ++mt) {
+                const float iv = gate_act(acc[mt][0], false), fv = gate_act(acc[mt][1], false);
+                const float gv = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
+                const float c = fv * cst[l][mt] + iv * gv;               // cell state stays f32
+                cst[l][mt] = c;
+                own[(16 * mt + r) * SO + wave * 4 + g] = (_Float16)(ov * gate_act(c, true));
             }
             __syncthreads();                             // barrier A
             if (ctl[0] != 0) return;
