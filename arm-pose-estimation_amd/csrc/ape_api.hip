@@ -47,8 +47,12 @@ int check_dims(const ape_dims_t* d) {
         return fail(APE_ERR_UNSUPPORTED, "input_size %d outside 1..%d", d->input_size, APE_MAX_INPUT);
     if (d->hidden_size != 128 && d->hidden_size != 256)
         return fail(APE_ERR_UNSUPPORTED, "hidden_size %d: kernels are built for 128 and 256", d->hidden_size);
-    if (d->num_layers < 1 || d->num_layers > APE_MAX_LAYERS)
+    if (d->model_kind != APE_MODEL_LSTM && d->model_kind != APE_MODEL_FF)
+        return fail(APE_ERR_INVALID_ARG, "unknown model_kind %d", d->model_kind);
+    if (d->model_kind == APE_MODEL_LSTM && (d->num_layers < 1 || d->num_layers > APE_MAX_LAYERS))
         return fail(APE_ERR_UNSUPPORTED, "num_layers %d outside 1..%d", d->num_layers, APE_MAX_LAYERS);
+    if (d->model_kind == APE_MODEL_FF && (d->num_layers < 0 || d->num_layers > APE_MAX_FF_LAYERS - 1))
+        return fail(APE_ERR_UNSUPPORTED, "hidden_layer_count %d outside 0..%d", d->num_layers, APE_MAX_FF_LAYERS - 1);
     if (d->output_size < 1 || d->output_size > APE_MAX_OUTPUT)
         return fail(APE_ERR_UNSUPPORTED, "output_size %d outside 1..%d", d->output_size, APE_MAX_OUTPUT);
     if (d->target_layout == APE_LAYOUT_NONE) return APE_OK;      // regressor only, no post-filter
@@ -86,6 +90,9 @@ struct ape_model {
     size_t hx_bytes = 0;
     unsigned* xflags = nullptr;    // [flag words..., status word]
     size_t xflag_bytes = 0;        // bytes of the flag block (multiple of 16), status word follows
+    // MLP regressor (APE_MODEL_FF)
+    f32x4* ff_wpack[APE_MAX_FF_LAYERS] = {};
+    float* ff_bias[APE_MAX_FF_LAYERS] = {};
     std::string kernel_name, cluster_name;
 };
 
@@ -108,6 +115,7 @@ int ape_device_count(void) {
 size_t ape_weight_blob_floats(const ape_dims_t* d) {
     if (check_dims(d) != APE_OK) return 0;
     const size_t H = d->hidden_size, I = d->input_size, O = d->output_size;
+    if (d->model_kind == APE_MODEL_FF) return H * I + H + (size_t)d->num_layers * (H * H + H) + O * H + O;
     size_t n = 0;
     for (int l = 0; l < d->num_layers; ++l) n += 4 * H * (l == 0 ? I : H) + 4 * H * H + 8 * H;
     return n + O * H + O;
@@ -116,6 +124,7 @@ size_t ape_weight_blob_floats(const ape_dims_t* d) {
 double ape_flops_per_window(const ape_dims_t* d, int32_t T) {
     if (check_dims(d) != APE_OK || T < 1) return 0.0;
     const double H = d->hidden_size, I = d->input_size, O = d->output_size;
+    if (d->model_kind == APE_MODEL_FF) return 2.0 * (I * H + d->num_layers * H * H + O * H);   // last step only
     double step = 0;
     for (int l = 0; l < d->num_layers; ++l) step += 2.0 * 4.0 * H * ((l == 0 ? I : H) + H);
     return step * T + 2.0 * O * H;
@@ -147,6 +156,23 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, I = dims->input_size;
     const int NT = 4 * (H / 64);
     hipError_t e = hipSuccess;
+    if (dims->model_kind == APE_MODEL_FF) {
+        for (int j = 0; j <= L && e == hipSuccess; ++j) {
+            const size_t K = (j == 0) ? m->KX : H;
+            e = hipMalloc((void**)&m->ff_wpack[j], K * H * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void**)&m->ff_bias[j], H * sizeof(float));
+        }
+        if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (2 * I + 2 * O) * sizeof(double));
+        if (e != hipSuccess) {
+            ape_model_destroy(m);
+            return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
+        }
+        m->kernel_name = H == 256 ? "ape_mlp_tile16<256>" : "ape_mlp_tile16<128>";
+        *out = m;
+        return APE_OK;
+    }
     for (int l = 0; l < L && e == hipSuccess; ++l) {
         const size_t Q = ((l == 0 ? m->KX : H) + H) / 16;
         e = hipMalloc((void**)&m->wpack[l], 4 * Q * NT * 64 * sizeof(f32x4));
@@ -198,6 +224,10 @@ int ape_model_destroy(ape_model_t* m) {
         if (m->wpack[l]) (void)hipFree(m->wpack[l]);
         if (m->bias[l]) (void)hipFree(m->bias[l]);
     }
+    for (int j = 0; j < APE_MAX_FF_LAYERS; ++j) {
+        if (m->ff_wpack[j]) (void)hipFree(m->ff_wpack[j]);
+        if (m->ff_bias[j]) (void)hipFree(m->ff_bias[j]);
+    }
     if (m->w_out) (void)hipFree(m->w_out);
     if (m->b_out) (void)hipFree(m->b_out);
     if (m->stats) (void)hipFree(m->stats);
@@ -236,6 +266,34 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
     const int H = m->dims.hidden_size, L = m->dims.num_layers, O = m->dims.output_size, I = m->dims.input_size;
     const int UB = H / 64, NT = 4 * UB;
     const float* cur = host.data();
+    if (m->dims.model_kind == APE_MODEL_FF) {
+        // per layer [wave 4][k-block q][tile n][lane][4]: lane holds W[w*H/4 + n*16 + (lane&15)][16q + 4(lane>>4) + j]
+        const int NTF = H / 64;
+        for (int j = 0; j <= L; ++j) {
+            const int in_j = (j == 0) ? I : H, K = (j == 0) ? m->KX : H, Q = K / 16;
+            const float* wj = cur;  cur += (size_t)H * in_j;
+            const float* bj = cur;  cur += H;
+            std::vector<float> packed((size_t)K * H);
+            for (int w = 0; w < 4; ++w)
+                for (int q = 0; q < Q; ++q)
+                    for (int n = 0; n < NTF; ++n)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int col = w * (H / 4) + n * 16 + (lane & 15);
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int k = 16 * q + 4 * (lane >> 4) + jj;
+                                packed[((((size_t)w * Q + q) * NTF + n) * 64 + lane) * 4 + jj] =
+                                    (k < in_j) ? wj[(size_t)col * in_j + k] : 0.0f;
+                            }
+                        }
+            HIP_TRY(hipMemcpy(m->ff_wpack[j], packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(m->ff_bias[j], bj, H * sizeof(float), hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMemcpy(m->w_out, cur, (size_t)O * H * sizeof(float), hipMemcpyHostToDevice));
+        cur += (size_t)O * H;
+        HIP_TRY(hipMemcpy(m->b_out, cur, O * sizeof(float), hipMemcpyHostToDevice));
+        m->has_weights = true;
+        return APE_OK;
+    }
     for (int l = 0; l < L; ++l) {
         const int in_l = (l == 0) ? I : H;
         const int KXl = (l == 0) ? m->KX : H;
@@ -346,6 +404,25 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
         return fail(APE_ERR_INVALID_ARG, "lstm_forward: dropout_p %f outside [0,1)", dropout_p);
     const int H = m->dims.hidden_size, L = m->dims.num_layers;
     const bool drop = (flags & (APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) != 0;
+    if (m->dims.model_kind == APE_MODEL_FF) {
+        if ((flags & APE_FLAG_DROPOUT_MASKS) && !masks_dev)
+            return fail(APE_ERR_INVALID_ARG, "lstm_forward: DROPOUT_MASKS without masks");
+        MlpParams q{};
+        const bool all = (flags & APE_FLAG_ALL_STEPS) != 0;
+        q.x = x_dev; q.y = y_dev;
+        for (int j = 0; j <= L; ++j) { q.wpack[j] = m->ff_wpack[j]; q.bias[j] = m->ff_bias[j]; }
+        q.w_out = m->w_out; q.b_out = m->b_out;
+        q.xx_m = m->stats; q.xx_s = m->stats + m->dims.input_size;
+        q.mask = masks_dev;
+        q.row_stride = all ? (size_t)m->dims.input_size : (size_t)T * m->dims.input_size;
+        q.row_offset = all ? 0 : (size_t)(T - 1) * m->dims.input_size;
+        q.N = all ? B * T : B;
+        q.I = m->dims.input_size; q.O = m->dims.output_size; q.KX = m->KX; q.n_hidden = L;
+        q.flags = flags; q.dropout_p = dropout_p; q.seed = seed;
+        hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(APE_ERR_HIP, "mlp kernel launch failed: %s", hipGetErrorString(e));
+        return APE_OK;
+    }
     if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
 

@@ -55,6 +55,26 @@ struct ClusterParams {
     unsigned long long seed;
 };
 
+#define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor
+
+// Kernel arguments of the MLP (DropoutFF) kernel.
+struct MlpParams {
+    const float* x;                        // rows at x[n * row_stride + row_offset + k]
+    float* y;                              // [N,O]
+    const f32x4* wpack[APE_MAX_FF_LAYERS]; // per layer MFMA-fragment-ordered weights
+    const float* bias[APE_MAX_FF_LAYERS];  // per layer [H]
+    const float* w_out;                    // [O,H]
+    const float* b_out;                    // [O]
+    const double* xx_m;
+    const double* xx_s;
+    const float* mask;                     // [N,H] dropout mask in front of the output layer, or nullptr
+    size_t row_stride, row_offset;
+    int N, I, O, KX, n_hidden;
+    unsigned flags;
+    float dropout_p;
+    unsigned long long seed;
+};
+
 struct FkParams {
     const void* preds;   // [N,O] f32 or f64
     void* est;           // [N,W] f32 or f64
@@ -100,5 +120,6 @@ hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
                                  hipStream_t stream);
+hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

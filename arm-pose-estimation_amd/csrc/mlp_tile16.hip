@@ -1,0 +1,150 @@
+// MLP pose regressor for gfx950: the reference's DropoutFF (estimate/nn_models.py:313-370), which its
+// loader can dispatch instead of DropoutLSTM (nn_models.py:395-396):
+//     Linear(I,H) -> leaky_relu -> n x [Linear(H,H) -> leaky_relu] -> dropout -> Linear(H,O)
+// applied to the last axis of x, i.e. independently to every row (window step).
+//
+// One workgroup (4 wave64, one per SIMD) owns 16 rows and walks the layers; activations ping-pong between
+// two LDS buffers (row stride H+8 floats: conflict-free ds_read_b128), wave w owns output columns
+// [w*H/4, (w+1)*H/4).  Each layer is a [16 x K] x [K x H] product on v_mfma_f32_16x16x4_f32 (exact f32):
+// A operand from LDS (one ds_read_b128 per 16 k-values, reused by all the wave's tiles), B operand = the
+// layer's weights streamed from L2 in a host-prepacked fragment order (1 KiB per wave-instruction,
+// double-buffered one k-block ahead).  Bias is the initial accumulator, leaky_relu (slope 0.01, the torch
+// default) and the optional dropout mask of the last hidden layer are fused into the accumulator write-back;
+// the narrow output layer is a VALU dot product per (row, target).  f64 z-score of the inputs fused into the
+// load (estimator.py:103-104).  Work per row: 2*(I*H + n*H*H + H*O) FLOP; HBM bytes: I*4 in + O*4 out.
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+template <int NT>
+__device__ __forceinline__ void load_b(f32x4 (&b)[NT], const f32x4* __restrict__ p) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = p[n * 64];
+}
+
+template <int NT>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NT], const f32x4 a, const f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[n][j], acc[n], 0, 0, 0);
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void ape_mlp_tile16(const MlpParams p) {
+    constexpr int NT = H / 64;        // 16-column tiles per wave
+    constexpr int SH = H + 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * APE_TILE_ROWS;
+    const int KX = p.KX, SX = KX + 8;
+    const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool drop_masks = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
+    const bool drop_philox = (p.flags & APE_FLAG_DROPOUT_PHILOX) != 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;                              // [16][SX]
+    float* act = xin + APE_TILE_ROWS * SX;          // [2][16][SH]
+
+    // ---- inputs: row n of the batch lives at x[n * row_stride + row_offset + k] ------------------------------
+    for (int idx = tid; idx < APE_TILE_ROWS * KX; idx += 256) {
+        const int row = idx / KX, k = idx - row * KX;
+        const int n = row0 + row;
+        float v = 0.0f;
+        if (k < p.I && n < p.N) {
+            v = p.x[(size_t)n * p.row_stride + p.row_offset + k];
+            if (normalize) v = (float)(((double)v - p.xx_m[k]) / p.xx_s[k]);
+        }
+        xin[row * SX + k] = v;
+    }
+    __syncthreads();
+
+    // ---- input layer + hidden layers on the matrix cores -------------------------------------------------------
+    const int n_layers = p.n_hidden + 1;
+#pragma unroll 1
+    for (int j = 0; j < n_layers; ++j) {
+        const int K = (j == 0) ? KX : H;
+        const int nq = K / 16;                      // even (KX % 32 == 0, H % 64 == 0)
+        const float* src = (j == 0) ? xin + r * SX + 4 * g : act + (((j - 1) & 1) * APE_TILE_ROWS + r) * SH + 4 * g;
+        const f32x4* wl = p.wpack[j] + (size_t)wave * nq * NT * 64 + lane;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float bv = p.bias[j][wave * (H / 4) + n * 16 + r];
+            acc[n] = f32x4{bv, bv, bv, bv};
+        }
+        f32x4 b0[NT], b1[NT];
+        load_b<NT>(b0, wl);
+#pragma unroll 1
+        for (int q = 0; q < nq; q += 2) {
+            load_b<NT>(b1, wl + (size_t)(q + 1) * NT * 64);
+            mfma_block<NT>(acc, *reinterpret_cast<const f32x4*>(src + 16 * q), b0);
+            if (q + 2 < nq) load_b<NT>(b0, wl + (size_t)(q + 2) * NT * 64);
+            mfma_block<NT>(acc, *reinterpret_cast<const f32x4*>(src + 16 * (q + 1)), b1);
+        }
+        // leaky_relu (+ dropout on the last hidden activation, nn_models.py:351) into the other buffer
+        float* dst = act + ((j & 1) * APE_TILE_ROWS) * SH;
+        const bool last = (j == n_layers - 1);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = wave * (H / 4) + n * 16 + r;
+            uint32_t rnd[4] = {0, 0, 0, 0};
+            if (last && drop_philox)
+                philox4x32((uint32_t)(row0 + 4 * g), 0u, (uint32_t)col, 0xFFu, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * g + i;
+                float v = acc[n][i];
+                v = (v > 0.0f) ? v : 0.01f * v;
+                if (last && (drop_masks || drop_philox)) {
+                    float m;
+                    if (drop_masks) {
+                        const int nrow = row0 + row;
+                        m = (nrow < p.N) ? p.mask[(size_t)nrow * H + col] : 0.0f;
+                    } else {
+                        const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                        m = (uf >= p.dropout_p) ? 1.0f / (1.0f - p.dropout_p) : 0.0f;
+                    }
+                    v *= m;
+                }
+                dst[row * SH + col] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- output layer: one (row, target) dot product per thread ---------------------------------------------------
+    if (tid < APE_TILE_ROWS * p.O) {
+        const int row = tid / p.O, o = tid - row * p.O;
+        const int n = row0 + row;
+        if (n < p.N) {
+            const float* hv = act + (((n_layers - 1) & 1) * APE_TILE_ROWS + row) * SH;
+            const float* wv = p.w_out + (size_t)o * H;
+            float s = 0.0f;
+            for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
+            p.y[(size_t)n * p.O + o] = s + p.b_out[o];
+        }
+    }
+}
+
+template <int H>
+size_t smem_of(int KX) { return ((size_t)APE_TILE_ROWS * (KX + 8) + 2 * (size_t)APE_TILE_ROWS * (H + 8)) * sizeof(float); }
+
+}  // namespace
+
+hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream) {
+    const int grid = (p.N + APE_TILE_ROWS - 1) / APE_TILE_ROWS;
+    if (H == 256) {
+        hipLaunchKernelGGL(ape_mlp_tile16<256>, dim3(grid), dim3(256), smem_of<256>(p.KX), stream, p);
+    } else if (H == 128) {
+        hipLaunchKernelGGL(ape_mlp_tile16<128>, dim3(grid), dim3(256), smem_of<128>(p.KX), stream, p);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

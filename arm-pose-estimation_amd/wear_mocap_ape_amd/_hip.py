@@ -24,6 +24,7 @@ FLAG_DROPOUT_MASKS = 0x4
 FLAG_DROPOUT_PHILOX = 0x8
 KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER = 0, 1, 2
 PRECISION_F32, PRECISION_F16 = 0, 1
+MODEL_LSTM, MODEL_FF = 0, 1
 PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3
 PARSE_SHAPES = {0: (55, 22), 1: (28, 20), 2: (55, 20), 3: (55, 38)}
 
@@ -33,7 +34,8 @@ NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, 
 
 class ApeDims(C.Structure):
     _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
-                ("output_size", C.c_int32), ("target_layout", C.c_int32), ("device", C.c_int32)]
+                ("output_size", C.c_int32), ("target_layout", C.c_int32), ("device", C.c_int32),
+                ("model_kind", C.c_int32)]
 
 
 # every symbol include/ape_hip.h declares: name -> (restype, argtypes)

@@ -67,9 +67,12 @@ class DropoutLSTM:
         if target_layout is None:
             target_layout = _LAYOUT_FOR_OUTPUTS.get(self.output_size, _hip.LAYOUT_NONE)
         self.target_layout = target_layout
-        self._dims = _hip.ApeDims(self.input_size, self.hidden_layer_size, self.hidden_layer_count,
-                                  self.output_size, target_layout, self.device_index)
+        self._create_handle(_hip.MODEL_LSTM)
+
+    def _create_handle(self, model_kind: int):
         import ctypes as C
+        self._dims = _hip.ApeDims(self.input_size, self.hidden_layer_size, self.hidden_layer_count,
+                                  self.output_size, self.target_layout, self.device_index, model_kind)
         self._handle = C.c_void_p()
         _hip.check(_hip.lib().ape_model_create(C.byref(self._dims), C.byref(self._handle)), "ape_model_create")
 
@@ -173,6 +176,9 @@ class DropoutLSTM:
         _hip.check(_hip.lib().ape_model_set_body(self._handle, _hip.dptr(b, C.c_double)), "ape_model_set_body")
 
     # ---- forward --------------------------------------------------------------------------------
+    def _mask_shape(self, B, T, last_step_only):
+        return (self.hidden_layer_count - 1, B, T, self.hidden_layer_size)
+
     def _run(self, x, flags, masks=None, dropout_p=0.0, seed=0, last_step_only=False):
         import ctypes as C
         if not isinstance(x, torch.Tensor):
@@ -194,7 +200,7 @@ class DropoutLSTM:
             mptr = None
             if masks is not None:
                 masks = masks.to(device=dev, dtype=torch.float32).contiguous()
-                want = (self.hidden_layer_count - 1, B, T, self.hidden_layer_size)
+                want = self._mask_shape(B, T, last_step_only)
                 if tuple(masks.shape) != want:
                     raise UserWarning(f"masks must have shape {want}, got {tuple(masks.shape)}")
                 mptr = C.c_void_p(masks.data_ptr())
@@ -260,6 +266,98 @@ class DropoutLSTM:
         return float(_hip.lib().ape_flops_per_window(C.byref(self._dims), T))
 
 
+class DropoutFF(DropoutLSTM):
+    """HIP-backed MLP regressor with the call surface of the reference's ``DropoutFF``
+    (``estimate/nn_models.py:313-370``): ``Linear(I,H)``, ``hidden_layer_count`` x ``Linear(H,H)`` (all with
+    leaky_relu), dropout, ``Linear(H,O)``, applied to the last axis of ``x``.  ``model(x)`` maps ``[B,T,I]`` to
+    ``[B,T,O]`` (``[B,I]`` to ``[B,O]``); ``monte_carlo_predictions`` switches the dropout in front of the output
+    layer on -- permanently, like the reference (nn_models.py:367) -- and repeats the rows ``n_samples`` times."""
+
+    def __init__(self, output_size, hidden_layer_size, hidden_layer_count, input_size, dropout=0.2,
+                 device: int = None, target_layout: int = None):
+        self.input_size = int(input_size)
+        self.hidden_layer_size = int(hidden_layer_size)
+        self.hidden_layer_count = int(hidden_layer_count)
+        self.output_size = int(output_size)
+        self.dropout = float(dropout)
+        self._do = _TrainFlag()
+        self.lstm = self._do                     # shared plumbing looks at `.lstm.training`
+        self._mc_calls = 0
+        self._seed = 0x5EED
+        self._state = None
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.device_index = int(device)
+        if target_layout is None:
+            target_layout = _LAYOUT_FOR_OUTPUTS.get(self.output_size, _hip.LAYOUT_NONE)
+        self.target_layout = target_layout
+        self._create_handle(_hip.MODEL_FF)
+
+    def state_keys(self):
+        keys = ["_input_layer.weight", "_input_layer.bias"]
+        for k in range(self.hidden_layer_count):
+            keys += [f"_hidden_layers.{k}.weight", f"_hidden_layers.{k}.bias"]
+        return keys + ["_output_layer.weight", "_output_layer.bias"]
+
+    def load_state_dict(self, state_dict):
+        H, I, O = self.hidden_layer_size, self.input_size, self.output_size
+        want = OrderedDict()
+        want["_input_layer.weight"], want["_input_layer.bias"] = (H, I), (H,)
+        for k in range(self.hidden_layer_count):
+            want[f"_hidden_layers.{k}.weight"], want[f"_hidden_layers.{k}.bias"] = (H, H), (H,)
+        want["_output_layer.weight"], want["_output_layer.bias"] = (O, H), (O,)
+        missing = [k for k in want if k not in state_dict]
+        extra = [k for k in state_dict if k not in want]
+        if missing or extra:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {extra}")
+        parts, kept = [], OrderedDict()
+        for key, shape in want.items():
+            v = state_dict[key]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(a.shape) != shape:
+                raise RuntimeError(f"size mismatch for {key}: {tuple(a.shape)} vs {shape}")
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            kept[key] = a
+            parts.append(a.reshape(-1))
+        self.load_weight_blob(np.concatenate(parts))
+        self._state = kept
+        return self
+
+    def _mask_shape(self, B, T, last_step_only):
+        return ((B if last_step_only else B * T), self.hidden_layer_size)
+
+    def forward(self, x, masks=None, last_step_only=False, normalize_input=False):
+        """``masks``: float32 ``[rows,H]`` of 0 or 1/(1-p) for the dropout in front of the output layer"""
+        two_d = (not isinstance(x, torch.Tensor) and np.asarray(x).ndim == 2) or (isinstance(x, torch.Tensor) and x.dim() == 2)
+        if two_d:
+            x = x[:, None, :]
+        flags = _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0
+        if masks is not None:
+            y = self._run(x, flags, masks=masks, last_step_only=last_step_only)
+        elif self._do.training and self.dropout > 0.0:
+            self._mc_calls += 1
+            y = self._run(x, flags | _hip.FLAG_DROPOUT_PHILOX, dropout_p=self.dropout,
+                          seed=(self._seed << 20) + self._mc_calls, last_step_only=last_step_only)
+        else:
+            y = self._run(x, flags, last_step_only=last_step_only)
+        return y[:, 0, :] if two_d else y
+
+    __call__ = forward
+
+    def monte_carlo_predictions(self, n_samples: int, x, last_step_only=False):
+        self._do.train()                                                    # nn_models.py:367
+        rep = x.repeat((n_samples, 1, 1)) if isinstance(x, torch.Tensor) else np.tile(np.asarray(x), (n_samples, 1, 1))
+        return self.forward(rep, last_step_only=last_step_only)
+
+    def set_kernel(self, choice: str = "auto"):
+        return self                              # one kernel serves the MLP
+
+    def set_precision(self, precision: str = "f32"):
+        if precision != "f32":
+            raise UserWarning("the MLP regressor is float32 only")
+        return self
+
+
 def load_deployed_model_from_hash(hash_str: str):
     """``hash`` -> ``(model, params)`` exactly like nn_models.py:373-415: reads
     ``<deploy>/nn/<hash>/results.json`` and ``checkpoint.pt`` (a ``(model_state, optimizer_state)``
@@ -276,9 +374,11 @@ def load_deployed_model_from_hash(hash_str: str):
         params = json.load(f)
     if params["model"] == "DropoutLSTM":
         params["model"] = DropoutLSTM
+    elif params["model"] == "DropoutFF":
+        params["model"] = DropoutFF
     else:
-        # DropoutFF / ImuPoseLSTM are dispatchable upstream (nn_models.py:395-398) but no deployed
-        # checkpoint uses them; they are the next row of the hot-path scope table
+        # ImuPoseLSTM is dispatchable upstream too (nn_models.py:397-398) but no deployed checkpoint uses it;
+        # it stays on the "next" list
         raise UserWarning(f"{params['model']} not handled")
     nn_model = params["model"](input_size=len(params["x_inputs_v"]), hidden_layer_size=params["hidden_layer_size"],
                                hidden_layer_count=params["hidden_layer_count"],

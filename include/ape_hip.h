@@ -87,6 +87,12 @@ typedef struct ape_model ape_model_t;
 
 /* DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size) -- nn_models.py:160-178,
  * constructed as load_deployed_model_from_hash does (nn_models.py:402-408). */
+/* regressor architectures the reference loader dispatches (nn_models.py:393-400) */
+enum {
+    APE_MODEL_LSTM = 0,   /* DropoutLSTM  nn_models.py:160-207 */
+    APE_MODEL_FF = 1      /* DropoutFF    nn_models.py:313-370 : Linear, n x Linear (leaky_relu), dropout, Linear */
+};
+
 typedef struct ape_dims {
     int32_t input_size;    /* I: 20 / 22 / 38 (<= 64)                      */
     int32_t hidden_size;   /* H: 128 or 256                                */
@@ -94,6 +100,7 @@ typedef struct ape_dims {
     int32_t output_size;   /* O: 12 / 14 / 20 (<= 32)                      */
     int32_t target_layout; /* APE_LAYOUT_*; O must match it (unless NONE)  */
     int32_t device;        /* HIP device ordinal                           */
+    int32_t model_kind;    /* APE_MODEL_*; for APE_MODEL_FF num_layers is hidden_layer_count (0..7) */
 } ape_dims_t;
 
 /* library / device --------------------------------------------------------------------------- */
@@ -115,6 +122,8 @@ int ape_model_reserve(ape_model_t* model, int32_t max_batch);
  *   for k in 0..L-1: lstm.weight_ih_l{k} [4H, I or H], lstm.weight_hh_l{k} [4H,H],
  *                    lstm.bias_ih_l{k} [4H], lstm.bias_hh_l{k} [4H];
  *   then output_layer.weight [O,H], output_layer.bias [O].
+ * APE_MODEL_FF: _input_layer.weight [H,I], .bias [H]; _hidden_layers.{k}.weight [H,H], .bias [H] for k in
+ *   0..hidden_layer_count-1; _output_layer.weight [O,H], .bias [O]   (state_dict order of DropoutFF).
  * `blob` may be host or device memory (e.g. the buffer an RCCL broadcast just filled);
  * `n_floats` must equal ape_weight_blob_floats(dims).  Synchronous; init-time only. */
 int ape_model_load_weights(ape_model_t* model, const float* blob, size_t n_floats);
@@ -134,7 +143,10 @@ int ape_model_set_body(ape_model_t* model, const double body9[9]);
  *   x_dev      f32 [B,T,I]
  *   masks_dev  f32 [L-1,B,T,H] holding 0 or 1/(1-p)   (APE_FLAG_DROPOUT_MASKS; else NULL)
  *   dropout_p, seed                                   (APE_FLAG_DROPOUT_PHILOX)
- *   y_dev      f32 [B,O] or [B,T,O] (APE_FLAG_ALL_STEPS): normalised NN targets */
+ *   y_dev      f32 [B,O] or [B,T,O] (APE_FLAG_ALL_STEPS): normalised NN targets
+ * APE_MODEL_FF (DropoutFF.forward / monte_carlo_predictions, nn_models.py:340-370): the MLP is applied to the
+ *   last step of every window (or to all B*T rows with APE_FLAG_ALL_STEPS); masks_dev is f32 [rows,H], the
+ *   dropout in front of the output layer. */
 int ape_lstm_forward(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                      const float* masks_dev, float dropout_p, uint64_t seed,
                      float* y_dev, void* stream);

@@ -145,6 +145,42 @@ def lstm_forward(sd: Dict[str, np.ndarray], x: np.ndarray,
     return seq @ w_o.T + b_o
 
 
+# --------------------------------------------------------------------------------------
+# MLP regressor (nn_models.py:313-370, DropoutFF): Linear -> leaky_relu, n x (Linear -> leaky_relu),
+# dropout, Linear.  Applied to the last axis, so x may be [B,I] or [B,T,I].
+# --------------------------------------------------------------------------------------
+def ff_state_dict_keys(n_hidden: int) -> List[str]:
+    keys = ["_input_layer.weight", "_input_layer.bias"]
+    for k in range(n_hidden):
+        keys += [f"_hidden_layers.{k}.weight", f"_hidden_layers.{k}.bias"]
+    return keys + ["_output_layer.weight", "_output_layer.bias"]
+
+
+def make_ff_state_dict(I: int, H: int, n_hidden: int, O: int, seed: int) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    sd = {}
+    dims = [(H, I)] + [(H, H)] * n_hidden + [(O, H)]
+    for key, (fo, fi) in zip(ff_state_dict_keys(n_hidden)[0::2], dims):
+        bound = 1.0 / math.sqrt(fi)
+        sd[key] = rng.uniform(-bound, bound, size=(fo, fi)).astype(np.float32)
+        sd[key.replace("weight", "bias")] = rng.uniform(-bound, bound, size=(fo,)).astype(np.float32)
+    return {k: sd[k] for k in ff_state_dict_keys(n_hidden)}
+
+
+def ff_forward(sd: Dict[str, np.ndarray], x: np.ndarray, mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """DropoutFF.forward (nn_models.py:340-354); leaky_relu slope 0.01 (torch default); ``mask`` (0 or
+    1/(1-p), shape of the last hidden activation) is the dropout in front of the output layer."""
+    n_hidden = sum(1 for k in sd if k.startswith("_hidden_layers.") and k.endswith("weight"))
+    lrelu = lambda v: np.where(v > 0, v, np.float32(0.01) * v)
+    a = np.asarray(x, dtype=np.float32)
+    a = lrelu(a @ sd["_input_layer.weight"].T + sd["_input_layer.bias"])
+    for k in range(n_hidden):
+        a = lrelu(a @ sd[f"_hidden_layers.{k}.weight"].T + sd[f"_hidden_layers.{k}.bias"])
+    if mask is not None:
+        a = a * np.asarray(mask, dtype=np.float32)
+    return a @ sd["_output_layer.weight"].T + sd["_output_layer.bias"]
+
+
 def torch_reference_model(sd: Dict[str, np.ndarray], dropout: float = 0.2):
     """The third-party modules the reference instantiates (nn_models.py:169-174):
     ``torch.nn.LSTM(I,H,L,batch_first=True,dropout)`` + ``torch.nn.Linear(H,O)``, loaded

@@ -158,6 +158,27 @@ def gen_lstm(stats):
         np.savez_compressed(OUT / f"lstm_{name}.npz", **blob)
 
 
+def gen_ff():
+    """DropoutFF (the MLP regressor the loader can dispatch, nn_models.py:313-370,395-396) in eval mode"""
+    blob = {}
+    for tag, (I, H, n_hidden, O) in {"pocket_like": (22, 256, 2, 14), "small": (20, 128, 1, 12), "deep": (38, 256, 3, 12)}.items():
+        for seed in (0, 1):
+            sd = orc.make_ff_state_dict(I, H, n_hidden, O, seed)
+            model = ref_nn.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=n_hidden, input_size=I, dropout=0.2)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            model.eval()
+            rng = np.random.default_rng(200 + seed)
+            for shape in ((1, 6, I), (37, 6, I), (300, I)):
+                x = rng.normal(size=shape).astype(np.float32)
+                with torch.no_grad():
+                    y = model(torch.from_numpy(x)).numpy()
+                key = f"{tag}_seed{seed}_" + "x".join(map(str, shape))
+                blob["x_" + key] = x
+                blob["y_" + key] = y
+        blob["dims_" + tag] = np.array([I, H, n_hidden, O])
+    np.savez_compressed(OUT / "ff.npz", **blob)
+
+
 # ---- 3. quaternion primitive goldens ------------------------------------------------------
 def edge_six_drr(rng, n):
     """6D rows that stress the Gram-Schmidt / quaternion branches."""
@@ -343,6 +364,7 @@ def main():
     stats = export_stats_and_configs()
     gen_bookkeeping()
     gen_lstm(stats)
+    gen_ff()
     gen_quat_ops()
     gen_fk(stats)
     gen_stream_traces()

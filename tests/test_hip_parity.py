@@ -108,6 +108,56 @@ def test_cluster_kernel_vs_oracle_and_tile16(name, B, T):
     model.check()
 
 
+def test_mlp_regressor_vs_reference_golden(golden):
+    """DropoutFF (the MLP regressor of nn_models.py:313-370) against the reference module's outputs"""
+    from wear_mocap_ape_amd.estimate import nn_models
+    g = golden("ff.npz")
+    for tag in ("pocket_like", "small", "deep"):
+        I, H, n_hidden, O = (int(v) for v in g["dims_" + tag])
+        for seed in (0, 1):
+            sd = orc.make_ff_state_dict(I, H, n_hidden, O, seed)
+            m = nn_models.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=n_hidden, input_size=I, device=0)
+            m.load_state_dict(sd)
+            assert list(m.state_dict().keys()) == orc.ff_state_dict_keys(n_hidden)
+            for shape in ((1, 6, I), (37, 6, I), (300, I)):
+                key = f"{tag}_seed{seed}_" + "x".join(map(str, shape))
+                y = m(torch.from_numpy(g["x_" + key])).numpy()
+                assert y.shape == g["y_" + key].shape
+                assert np.abs(y - g["y_" + key]).max() < TOL_Y_SHORT, (key, float(np.abs(y - g["y_" + key]).max()))
+            # last step only == the last row of the all-steps output (same arithmetic)
+            x = g[f"x_{tag}_seed{seed}_37x6x{I}"]
+            assert np.array_equal(m(torch.from_numpy(x), last_step_only=True).numpy()[:, 0], m(torch.from_numpy(x)).numpy()[:, -1])
+            # injected dropout mask vs the oracle
+            rng = np.random.default_rng(1)
+            mask = (rng.uniform(size=(37, H)) >= 0.2).astype(np.float32) / 0.8
+            ym = m(torch.from_numpy(x), masks=torch.from_numpy(mask), last_step_only=True).numpy()[:, 0]
+            assert np.abs(ym - orc.ff_forward(sd, x[:, -1], mask=mask)).max() < TOL_Y_SHORT
+            # MC mode: dropout in front of the output layer, permanent, seeded, batch rows repeated
+            m.manual_seed(5)
+            a = m.monte_carlo_predictions(50, torch.from_numpy(x[:1]), last_step_only=True).numpy()[:, 0]
+            m.manual_seed(5)
+            b = m.monte_carlo_predictions(50, torch.from_numpy(x[:1]), last_step_only=True).numpy()[:, 0]
+            assert a.shape == (50, O) and np.array_equal(a, b) and a.std(axis=0).min() > 1e-5 and m._do.training
+
+
+def test_loader_dispatches_dropout_ff(tmp_path, monkeypatch):
+    """results.json with "model": "DropoutFF" + a (model_state, optimizer_state) checkpoint -> HIP MLP"""
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate import nn_models
+    I, H, n_hidden, O = 22, 256, 2, 14
+    d = tmp_path / "nn" / "ffhash"
+    d.mkdir(parents=True)
+    (d / "results.json").write_text(json.dumps({"model": "DropoutFF", "hidden_layer_size": H, "hidden_layer_count": n_hidden,
+                                                "dropout": 0.2, "x_inputs_v": ["f"] * I, "y_targets_v": ["t"] * O}))
+    sd = orc.make_ff_state_dict(I, H, n_hidden, O, 4)
+    torch.save(({k: torch.from_numpy(v) for k, v in sd.items()}, {}), d / "checkpoint.pt")
+    monkeypatch.setitem(config.PATHS, "deploy", tmp_path)
+    model, params = nn_models.load_deployed_model_from_hash("ffhash")
+    assert isinstance(model, nn_models.DropoutFF) and params["model"] is nn_models.DropoutFF
+    x = np.random.default_rng(0).normal(size=(9, 6, I)).astype(np.float32)
+    assert np.abs(model(torch.from_numpy(x)).numpy() - orc.ff_forward(sd, x)).max() < TOL_Y_SHORT
+
+
 def test_fused_normalisation_is_bit_exact(norm_stats):
     """APE_FLAG_NORMALIZE_INPUT == host float64 z-score followed by the float32 cast"""
     st = norm_stats["pocket"]

@@ -111,7 +111,7 @@ def test_loader_errors_are_userwarnings(tmp_path, monkeypatch):
     with pytest.raises(UserWarning, match="no checkpoint found"):
         nn_models.load_deployed_model_from_hash("deadbeef")
     (d / "checkpoint.pt").write_bytes(b"")
-    (d / "results.json").write_text(json.dumps({"model": "OneHotLSTM"}))
+    (d / "results.json").write_text(json.dumps({"model": "OneHotLSTM"}))       # not reachable from the loader upstream either
     with pytest.raises(UserWarning, match="not handled"):
         nn_models.load_deployed_model_from_hash("deadbeef")
 

@@ -75,6 +75,20 @@ def test_lstm_forward(golden, name):
                 assert np.abs(yt - y_ref).max() == 0.0
 
 
+def test_ff_forward(golden):
+    """MLP regressor (DropoutFF) restatement vs the reference module in eval mode"""
+    g = golden("ff.npz")
+    for tag in ("pocket_like", "small", "deep"):
+        I, H, n_hidden, O = (int(v) for v in g["dims_" + tag])
+        for seed in (0, 1):
+            sd = orc.make_ff_state_dict(I, H, n_hidden, O, seed)
+            for shape in ((1, 6, I), (37, 6, I), (300, I)):
+                key = f"{tag}_seed{seed}_" + "x".join(map(str, shape))
+                y = orc.ff_forward(sd, g["x_" + key])
+                assert y.shape == g["y_" + key].shape
+                assert np.abs(y - g["y_" + key]).max() < 2e-6
+
+
 def test_lstm_masks_are_interlayer_only():
     cfg = orc.MODEL_CONFIGS["uarm"]
     sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5)
