@@ -86,6 +86,7 @@ struct ape_model {
     float* wcl[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
     int precision = APE_PRECISION_F32;
+    bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned* xflags = nullptr;    // [flag words..., status word]
@@ -447,6 +448,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
         for (int cand : {1, 2, 4})
             if ((!cdrop || cand <= 2) && (B + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
         const int rows_per_launch = 16 * nmt * max_clusters;
+        const bool small = !f16 && !cdrop && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
         for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
             const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
             ClusterParams c{};
@@ -471,8 +473,9 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
-            hipError_t e = f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
-                               : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
+            hipError_t e = small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), c, (hipStream_t)stream)
+                           : f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
+                                 : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
         }
         return APE_OK;
@@ -503,6 +506,7 @@ int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d", m->dims.hidden_size, m->dims.num_layers);
     m->kernel_choice = choice;
+    m->small_batch_path = (choice == APE_KERNEL_AUTO);
     return APE_OK;
 }
 

@@ -1,0 +1,278 @@
+// Small-batch (1..4 windows) variant of the weight-stationary cluster LSTM kernel: the latency path
+// (BASELINE.json configs[1]: batch=1 streaming at 50 Hz).
+//
+// At 1-4 windows a 16-row MFMA tile is 75-94 % padding, so this variant keeps everything else of
+// lstm_cluster.hip (GH = H/16 workgroups per cluster, member m owns hidden units [16m,16m+16) of every layer,
+// its weights resident in registers for the whole launch in the same fragment layout, h slices exchanged with
+// sc1 write-through stores + epoch flags, self-cleaning, arrival tickets) but
+//   * the stacked-gate product is a register-resident GEMV on the VALU: lane (column c = unit*4+gate, k-group
+//     g) multiplies its 4 weights of every 16-deep k-block with the matching activations (one broadcast
+//     ds_read_b128 per block and row) and the four k-groups are summed with two wave shuffles;
+//   * lane group g then owns batch row g: one activation per lane, the four gates of a unit meet by DPP
+//     quad broadcasts, the cell update is a handful of VALU ops;
+//   * ALL layers of a phase are computed back to back and published together, so there is ONE exchange
+//     round trip per phase (layer l works on step p - l, as in the big kernel) instead of one per layer.
+// Same arithmetic as the other kernels up to float32 summation order.
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int MR = 4;                      // rows per cluster (row = lane group)
+
+__device__ __forceinline__ float gate_act(float v, bool is_tanh) {
+    const float e = __builtin_amdgcn_exp2f((is_tanh ? -2.885390081777927f : -1.4426950408889634f) * v);
+    const float s = __builtin_amdgcn_rcpf(1.0f + e);
+    return is_tanh ? 2.0f * s - 1.0f : s;
+}
+
+// value of lane (quad base + K) for every lane of the quad (DPP quad_perm broadcast)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
+                                                                 K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, false));
+}
+
+// part[m] += sum over this lane's k-slice of w * act[m]; NQ 16-deep blocks starting at weight register w0
+template <int NR, int NQ, int NW>
+__device__ __forceinline__ void gemv_span(float (&part)[NR], const float* __restrict__ src, int row_stride,
+                                          const float (&w)[NW], int w0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + m * row_stride + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[m] = fmaf(a[j], w[w0 + 4 * q + j], part[m]);
+        }
+    }
+}
+
+template <int H, int L, int KX, int NR>
+__global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterParams p) {
+    constexpr int GH = H / 16;
+    constexpr int SH = H + 8, SX = KX + 8, SO = 20;
+    constexpr int QX = KX / 16, QH = H / 16;
+    constexpr int NW0 = (KX + H) / 4, NW1 = (2 * H) / 4;
+    constexpr int PIECES = GH * MR * 4;            // 16-byte pieces of one layer's gathered slices (<= 256)
+    static_assert(PIECES <= 256 && NR <= MR, "one gather piece per thread");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;        // column = unit*4 + gate; k-group, later batch row
+    const int gate = c & 3, u = c >> 2;
+    const int T = p.T, I = p.I, O = p.O;
+    const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hbuf = smem;                            // [L][MR][SH]
+    float* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
+    float* own = xin + 2 * MR * SX;                // [L][MR][SO]
+    int* ctl = reinterpret_cast<int*>(own + L * MR * SO);
+    if (tid == 0) {
+        ctl[0] = 0;
+        ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = tid; i < L * MR * SH; i += 256) hbuf[i] = 0.0f;       // h_{-1} = 0: the first step reads zeros
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
+    const int cluster = ticket / GH, member = ticket % GH;
+    const int row0 = cluster * MR;
+
+    // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel) ----------------
+    float w0[NW0];
+    float w1[L > 1 ? NW1 : 1];
+    float w2[L > 2 ? NW1 : 1];
+    {
+        const float* s0 = p.wcl[0] + ((size_t)(member * 4 + wave) * NW0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NW0; ++i) w0[i] = s0[i * 64];
+        if constexpr (L > 1) {
+            const float* s1 = p.wcl[1] + ((size_t)(member * 4 + wave) * NW1) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NW1; ++i) w1[i] = s1[i * 64];
+        }
+        if constexpr (L > 2) {
+            const float* s2 = p.wcl[2] + ((size_t)(member * 4 + wave) * NW1) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NW1; ++i) w2[i] = s2[i * 64];
+        }
+    }
+    float bias_r[L], cst[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        bias_r[l] = p.bias[l][gate * H + member * 16 + wave * 4 + u];
+        cst[l] = 0.0f;
+    }
+
+    const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
+    unsigned* const myflag = p.xflags + (size_t)cluster * L * GH;       // one epoch word per member (all layers at once)
+    constexpr unsigned SET_BYTES = GH * MR * 16 * sizeof(float);        // one (layer, parity)
+    auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SET_BYTES); };
+
+    auto stage_x = [&](int t) {                    // x_t: f64 z-score, cast f32 (estimator.py:103-104)
+        if (tid < MR * KX) {
+            const int row = tid / KX, k = tid - row * KX;
+            const int b = row0 + row;
+            float v = 0.0f;
+            if (k < I && b < p.B) {
+                v = p.x[((size_t)b * T + t) * I + k];
+                if (normalize) v = (float)(((double)v - p.xx_m[k]) / p.xx_s[k]);
+            }
+            xin[((t & 1) * MR + row) * SX + k] = v;
+        }
+    };
+    stage_x(0);
+    __syncthreads();
+
+    const int P = T + L - 1;
+#pragma unroll 1
+    for (int ph = 0; ph < P; ++ph) {
+        // ---- every layer of this phase, back to back (layer l works on step t = ph - l) ----------------------------
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = ph - l;
+            if (t < 0 || t >= T) continue;         // uniform
+            float part[NR];
+#pragma unroll
+            for (int m = 0; m < NR; ++m) part[m] = 0.0f;
+            const float* rec_src = hbuf + l * MR * SH + 4 * g;
+            if (l == 0) {
+                gemv_span<NR, QX, NW0>(part, xin + (t & 1) * MR * SX + 4 * g, SX, w0, 0);
+                gemv_span<NR, QH, NW0>(part, rec_src, SH, w0, 4 * QX);
+            } else {
+                const float* in_src = hbuf + (l - 1) * MR * SH + 4 * g;
+                if (l == 1) {
+                    if constexpr (L > 1) {
+                        gemv_span<NR, QH, NW1>(part, in_src, SH, w1, 0);
+                        gemv_span<NR, QH, NW1>(part, rec_src, SH, w1, 4 * QH);
+                    }
+                } else {
+                    if constexpr (L > 2) {
+                        gemv_span<NR, QH, NW1>(part, in_src, SH, w2, 0);
+                        gemv_span<NR, QH, NW1>(part, rec_src, SH, w2, 4 * QH);
+                    }
+                }
+            }
+            // sum the four k-groups (lanes c, c+16, c+32, c+48): two wave shuffles per row
+            float pre = 0.0f;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                float v = part[m];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (g == m) pre = v;               // lane group g owns batch row g from here on
+            }
+            const float a = gate_act(pre + bias_r[l], gate == 2);
+            const float iv = quad_bcast<0>(a), fv = quad_bcast<1>(a), gv = quad_bcast<2>(a), ov = quad_bcast<3>(a);
+            const float cn = fv * cst[l] + iv * gv;
+            cst[l] = cn;
+            if (gate == 0 && g < NR) own[(l * MR + g) * SO + wave * 4 + u] = ov * gate_act(cn, true);
+        }
+        if (ph + 1 < T) stage_x(ph + 1);           // into the other xin buffer (its readers finished a phase ago)
+        __syncthreads();                            // own slices of every active layer complete
+        // ---- publish all active layers' slices, drain, barrier, ONE flag ----------------------------------------------
+        {
+            const int l = tid / (MR * 4), idx = tid - l * (MR * 4);      // 16 pieces per layer slice
+            const int t = ph - l;
+            if (l < L && t >= 0 && t < T) {
+                const int row = idx >> 2, quad = idx & 3;
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (l * MR + row) * SO + 4 * quad);
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
+                    hx_base(l, t & 1) + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(myflag + member, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- wait for every member's phase-ph flag, gather all layers' slices (one piece per thread and layer) -------
+        if (wave == 0) {
+            unsigned spins = 0;
+            while (true) {
+                unsigned v = (unsigned)(ph + 1);
+                if (lane < GH) v = __hip_atomic_load(myflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((int)(v >= (unsigned)(ph + 1)))) break;
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (lane == 0) {
+                        ctl[0] = 1;
+                        __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (ctl[0] != 0) return;
+        if (tid < PIECES) {
+            const int m = tid / (MR * 4), idx = tid - m * (MR * 4);
+            const int row = idx >> 2, quad = idx & 3;
+            f32x4 gv[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = ph - l;
+                if (t >= 0 && t < T)
+                    gv[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        hx_rsrc, hx_base(l, t & 1) + (unsigned)(((m * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */));
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = ph - l;
+                if (t >= 0 && t < T) *reinterpret_cast<f32x4*>(hbuf + (l * MR + row) * SH + m * 16 + 4 * quad) = gv[l];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- head: member m finishes row m (rows < NR <= 4 <= GH) ------------------------------------------------------------
+    if (member < MR && tid < O) {
+        const int b = row0 + member;
+        if (b < p.B) {
+            const float* hv = hbuf + ((L - 1) * MR + member) * SH;
+            const float* wv = p.w_out + (size_t)tid * H;
+            float s = 0.0f;
+            for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
+            p.y[(size_t)b * O + tid] = s + p.b_out[tid];
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        const int n_words = (int)(gridDim.x / GH) * L * GH;
+        for (int i = tid; i < n_words; i += 256)
+            __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int H, int L, int KX, int NR>
+hipError_t launch_small(const ClusterParams& p, hipStream_t stream) {
+    constexpr size_t smem = ((size_t)L * MR * (H + 8) + 2 * MR * (KX + 8) + (size_t)L * MR * 20 + 4) * sizeof(float);
+    hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR>), dim3(H / 16), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// one cluster, B <= 4 windows (nr = 1, 2 or 4 rows computed)
+hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, const ClusterParams& p, hipStream_t stream) {
+    if (H == 256 && L == 2 && KX == 32) {
+        if (nr == 1) return launch_small<256, 2, 32, 1>(p, stream);
+        if (nr == 2) return launch_small<256, 2, 32, 2>(p, stream);
+        if (nr == 4) return launch_small<256, 2, 32, 4>(p, stream);
+    } else if (H == 128 && L == 3 && KX == 64) {
+        if (nr == 1) return launch_small<128, 3, 64, 1>(p, stream);
+        if (nr == 2) return launch_small<128, 3, 64, 2>(p, stream);
+        if (nr == 4) return launch_small<128, 3, 64, 4>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}

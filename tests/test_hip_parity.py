@@ -158,6 +158,27 @@ def test_loader_dispatches_dropout_ff(tmp_path, monkeypatch):
     assert np.abs(model(torch.from_numpy(x)).numpy() - orc.ff_forward(sd, x)).max() < TOL_Y_SHORT
 
 
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_small_batch_latency_kernel(norm_stats, name):
+    """B <= 4: the VALU/shuffle variant of the cluster kernel (AUTO) against the oracle and the MFMA kernels"""
+    st = norm_stats[name]
+    model, sd, cfg = make_model(name, 12, st)
+    for B in (1, 2, 3, 4):
+        for T in (1, cfg["T"], 64):
+            x = _synthetic_windows(st, B, T, cfg["I"], 10 * B + T)
+            xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+            y_ref = orc.lstm_forward(sd, xn)[:, -1]
+            xt = torch.from_numpy(x).cuda()
+            y_small = model.set_kernel("auto")(xt, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+            y_mfma = model.set_kernel("cluster")(xt, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+            assert np.abs(y_small - y_ref).max() < TOL_Y_SHORT, (B, T, float(np.abs(y_small - y_ref).max()))
+            assert np.abs(y_mfma - y_ref).max() < TOL_Y_SHORT
+            again = model.set_kernel("auto")(xt, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+            assert np.array_equal(again, y_small)                  # self-cleaning state, deterministic
+    assert "cluster" in model.kernel_name(1, 6)
+    model.check()
+
+
 def test_fused_normalisation_is_bit_exact(norm_stats):
     """APE_FLAG_NORMALIZE_INPUT == host float64 z-score followed by the float32 cast"""
     st = norm_stats["pocket"]

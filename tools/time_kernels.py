@@ -31,6 +31,11 @@ for k, (kern, fl) in variants.items(): run(kern, fl, 3)
 for rnd in range(5):
     for k, (kern, fl) in variants.items():
         res[k].append(run(kern, fl, 10))
+# AUTO (B <= 4: small-batch VALU variant)
+lib.ape_model_set_kernel(m.handle, 0)
+res["auto"] = []
+run(0, 0, 3)
+for rnd in range(5): res["auto"].append(run(0, 0, 10))
 # fp16 variant (configs[4])
 lib.ape_model_set_kernel(m.handle, 0); lib.ape_model_set_precision(m.handle, 1)
 res["cluster_f16"] = []
