@@ -406,6 +406,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     const int H = m->dims.hidden_size, L = m->dims.num_layers;
     const bool drop = (flags & (APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) != 0;
     if (m->dims.model_kind == APE_MODEL_FF) {
+        if (flags & APE_FLAG_BROADCAST_X) return fail(APE_ERR_UNSUPPORTED, "lstm_forward: BROADCAST_X is an LSTM-path flag");
         if ((flags & APE_FLAG_DROPOUT_MASKS) && !masks_dev)
             return fail(APE_ERR_INVALID_ARG, "lstm_forward: DROPOUT_MASKS without masks");
         MlpParams q{};
@@ -452,7 +453,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
         for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
             const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
             ClusterParams c{};
-            c.x = x_dev + (size_t)b0 * T * m->dims.input_size;
+            c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
             c.y = y_dev + (size_t)b0 * m->dims.output_size;
             for (int l = 0; l < L; ++l) {
                 c.wcl[l] = f16 ? reinterpret_cast<const float*>(m->wcl16[l]) : m->wcl[l];

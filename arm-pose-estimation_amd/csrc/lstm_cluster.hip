@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // on the chip, whatever the dispatch order or however many CUs other work occupies.
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;   // monte_carlo_predictions: one window, B rows
     const bool diag_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0;    // timing only: skip polls/gathers/publishes
     const bool diag_noact = (p.flags & APE_DIAG_NO_ACT) != 0;        // timing only: skip the transcendental math
     const bool drop_masks = DROP && (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int b = row0 + (tid + 256 * e) / KX;
-            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)b * T + t) * I + xk] : 0.0f;
+            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + xk] : 0.0f;
         }
     };
     // f64 z-score, cast f32 (estimator.py:103-104, watch_phone_pocket_nn.py:100), into LDS

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
     const int r = lane & 15, g = lane >> 4;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;   // monte_carlo_predictions: one window, B rows
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
     _Float16* hbuf = smem16;                          // [L][MR][SH]
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int b = row0 + (tid + 256 * e) / KX;
-            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)b * T + t) * I + xk] : 0.0f;
+            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + xk] : 0.0f;
         }
     };
     auto stage_x = [&]() {

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     const int gate = c & 3, u = c >> 2;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;   // monte_carlo_predictions: one window, B rows
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                            // [L][MR][SH]
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             const int b = row0 + row;
             float v = 0.0f;
             if (k < I && b < p.B) {
-                v = p.x[((size_t)b * T + t) * I + k];
+                v = p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + k];
                 if (normalize) v = (float)(((double)v - p.xx_m[k]) / p.xx_s[k]);
             }
             xin[((t & 1) * MR + row) * SX + k] = v;

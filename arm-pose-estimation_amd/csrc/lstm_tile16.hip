@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     const int QX = KX / 16;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;   // monte_carlo_predictions: one window, B rows
     const bool all_steps = (p.flags & APE_FLAG_ALL_STEPS) != 0;
     const bool drop_masks = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
     const bool drop_philox = (p.flags & APE_FLAG_DROPOUT_PHILOX) != 0;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                 const int row = idx / KX, k = idx - row * KX;
                 const int b = row0 + row;
                 if (k < I && b < p.B) {
-                    const float v = p.x[((size_t)b * T + t) * I + k];
+                    const float v = p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + k];
                     // f64 z-score then round to f32: estimator.py:103-104 + watch_phone_pocket_nn.py:100
                     xr[e] = normalize ? (float)(((double)v - p.xx_m[k]) / p.xx_s[k]) : v;
                 }

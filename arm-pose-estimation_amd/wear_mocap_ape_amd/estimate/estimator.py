@@ -123,10 +123,10 @@ class Estimator:
             est, msg = _post.fk_and_msg(ctx.handle, self._layout, ctx.device, pred, self._body_measurements)
         self._last_msg = msg.copy()
         if add_mc_samples:
+            # list of 25 floats followed, for N > 1 rows, by every row's hand and elbow xyz (estimator.py:131-137)
             msg = list(msg)
             if est.shape[0] > 1:
-                for e_row in est:
-                    msg += list(e_row[:6])
+                msg += list(est[:, :6].reshape(-1))
         return msg
 
     def process_in_thread(self, sensor_q: queue):

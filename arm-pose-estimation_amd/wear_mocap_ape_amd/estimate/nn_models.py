@@ -179,7 +179,7 @@ class DropoutLSTM:
     def _mask_shape(self, B, T, last_step_only):
         return (self.hidden_layer_count - 1, B, T, self.hidden_layer_size)
 
-    def _run(self, x, flags, masks=None, dropout_p=0.0, seed=0, last_step_only=False):
+    def _run(self, x, flags, masks=None, dropout_p=0.0, seed=0, last_step_only=False, rows=None):
         import ctypes as C
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
@@ -192,6 +192,11 @@ class DropoutLSTM:
         with torch.cuda.device(dev):
             xd = x.to(device=dev, dtype=torch.float32).contiguous()
             B, T = int(xd.shape[0]), int(xd.shape[1])
+            if rows is not None:                 # one window shared by `rows` batch rows (MC mode)
+                if B != 1:
+                    raise UserWarning("MC predictions only for batch size 1")
+                B = int(rows)
+                flags |= _hip.FLAG_BROADCAST_X
             if last_step_only:
                 y = torch.empty((B, 1, self.output_size), dtype=torch.float32, device=dev)
             else:
@@ -211,7 +216,7 @@ class DropoutLSTM:
                        "ape_lstm_forward")
         return y.cpu() if on_host else y
 
-    def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False):
+    def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False, rows=None):
         """``masks`` (float32 ``[L-1,B,T,H]`` of 0 or 1/(1-p)) injects explicit dropout masks;
         ``last_step_only`` returns ``[B,1,O]`` (only the step the estimators consume);
         ``normalize_input`` fuses the f64 z-score of raw features into the load."""
@@ -219,12 +224,12 @@ class DropoutLSTM:
             raise UserWarning("an initial (h_0, c_0) is not supported: the path always starts from zeros")
         flags = _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0
         if masks is not None:
-            return self._run(x, flags, masks=masks, last_step_only=last_step_only)
+            return self._run(x, flags, masks=masks, last_step_only=last_step_only, rows=rows)
         if self.lstm.training and self.dropout > 0.0 and self.hidden_layer_count > 1:
             self._mc_calls += 1
             return self._run(x, flags | _hip.FLAG_DROPOUT_PHILOX, dropout_p=self.dropout,
-                             seed=(self._seed << 20) + self._mc_calls, last_step_only=last_step_only)
-        return self._run(x, flags, last_step_only=last_step_only)
+                             seed=(self._seed << 20) + self._mc_calls, last_step_only=last_step_only, rows=rows)
+        return self._run(x, flags, last_step_only=last_step_only, rows=rows)
 
     __call__ = forward
 
@@ -235,11 +240,8 @@ class DropoutLSTM:
         if x.shape[0] > 1:
             raise UserWarning("MC predictions only for batch size 1")     # nn_models.py:201-202
         self.lstm.train()                                                  # permanent, as nn_models.py:204
-        if isinstance(x, torch.Tensor):
-            rep = x.repeat((n_samples, 1, 1))
-        else:
-            rep = np.repeat(np.asarray(x), n_samples, axis=0)
-        return self.forward(rep, hs, last_step_only=last_step_only)
+        # x.repeat((n_samples, 1, 1)) of nn_models.py:206 happens inside the kernel (APE_FLAG_BROADCAST_X)
+        return self.forward(x, hs, last_step_only=last_step_only, rows=n_samples)
 
     def set_kernel(self, choice: str = "auto"):
         """'auto' | 'tile16' | 'cluster': which LSTM kernel ``forward`` launches (A/B runs, tests)"""

@@ -83,6 +83,9 @@ enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2 };
  * (BASELINE.json configs[4]); last-step output without dropout; parity to a stated tolerance only. */
 enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1 };
 
+#define APE_FLAG_BROADCAST_X     0x10u /* x_dev is ONE window [1,T,I] shared by all B rows: the x.repeat((n,1,1)) of
+                                         monte_carlo_predictions (nn_models.py:206) without materialising it    */
+
 typedef struct ape_model ape_model_t;
 
 /* DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size) -- nn_models.py:160-178,
