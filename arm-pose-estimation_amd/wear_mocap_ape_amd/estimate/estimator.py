@@ -20,47 +20,38 @@ from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS, TARGET_LAY
 
 
 class Estimator:
-    def __init__(self,
-                 x_inputs: NNS_INPUTS,
-                 y_targets: NNS_TARGETS,
-                 normalize: bool = True,
-                 smooth: int = 1,
-                 seq_len: int = 1,
-                 add_mc_samples: bool = True,
-                 bonemap: BoneMap = None,
-                 tag: str = "Estimator"):
-        self.__tag = tag
-        self._active = False
-        self._y_targets = y_targets
-        self._x_inputs = x_inputs
+    """Template-method base of the estimators.  Subclasses provide ``parse_row_to_xx`` (raw message ->
+    features) and ``make_prediction_from_row_hist`` (normalised window -> NN targets); everything else --
+    window and smoothing histories, float64 (de-)normalisation, FK + message, the consumer thread -- lives
+    here.  Constructor arguments, methods and properties are the reference's (estimator.py:16-218)."""
 
+    def __init__(self, x_inputs: NNS_INPUTS, y_targets: NNS_TARGETS, normalize: bool = True, smooth: int = 1,
+                 seq_len: int = 1, add_mc_samples: bool = True, bonemap: BoneMap = None, tag: str = "Estimator"):
+        self.__tag, self._active = tag, False
+        self._x_inputs, self._y_targets = x_inputs, y_targets
+        self._layout = TARGET_LAYOUT[y_targets]
+        self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+        # pre-computed column statistics: float64 arrays xx_m, xx_s [I] and yy_m, yy_s [O]
         self._normalize = normalize
         if normalize:
-            stats = data_stats.get_norm_stats(x_inputs=self._x_inputs, y_targets=self._y_targets)
-            self._xx_m, self._xx_s = stats["xx_m"], stats["xx_s"]
-            self._yy_m, self._yy_s = stats["yy_m"], stats["yy_s"]
+            self._take_stats(data_stats.get_norm_stats(x_inputs=x_inputs, y_targets=y_targets))
 
-        self._smooth = max(1, smooth)
-        self._smooth_hist = []
-        self._last_msg = None
-        self._add_mc_samples = add_mc_samples
-        self._row_hist = []
-        self._sequence_len = max(1, seq_len)
+        # histories: feature rows of the current window, predictions of the last `smooth` frames
+        self._sequence_len, self._smooth = max(1, seq_len), max(1, smooth)
+        self._row_hist, self._smooth_hist = [], []
+        self._add_mc_samples, self._last_msg = add_mc_samples, None
 
-        if bonemap is None:
-            self._larm_vec = np.array([-BoneMap.DEFAULT_LARM_LEN, 0, 0])
-            self._uarm_vec = np.array([-BoneMap.DEFAULT_UARM_LEN, 0, 0])
-            self._uarm_orig = BoneMap.DEFAULT_UARM_ORIG_RH
-        else:
-            self._larm_vec = np.array([-bonemap.left_lower_arm_length, 0, 0])
-            self._uarm_vec = np.array([-bonemap.left_upper_arm_length, 0, 0])
-            self._uarm_orig = bonemap.left_upper_arm_origin_rh
-        # [[larm_vec, uarm_vec, uarm_orig_rh]]  (estimator.py:68)
+        # arm geometry: both arm bones point along -x; [[larm_vec, uarm_vec, uarm_orig_rh]] as one [1,9] row
+        larm_len = BoneMap.DEFAULT_LARM_LEN if bonemap is None else bonemap.left_lower_arm_length
+        uarm_len = BoneMap.DEFAULT_UARM_LEN if bonemap is None else bonemap.left_upper_arm_length
+        self._uarm_orig = BoneMap.DEFAULT_UARM_ORIG_RH if bonemap is None else bonemap.left_upper_arm_origin_rh
+        self._larm_vec, self._uarm_vec = np.array([-larm_len, 0, 0]), np.array([-uarm_len, 0, 0])
         self._body_measurements = np.r_[self._larm_vec, self._uarm_vec, self._uarm_orig][np.newaxis, :]
-
-        self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-        self._layout = TARGET_LAYOUT[y_targets]
         self._sync_model_config()
+
+    def _take_stats(self, stats: dict):
+        self._xx_m, self._xx_s, self._yy_m, self._yy_s = (stats[k] for k in ("xx_m", "xx_s", "yy_m", "yy_s"))
 
     # subclasses that own a HIP model expose it here so stats/body reach the device handle
     def _hip_model(self):
@@ -75,9 +66,8 @@ class Estimator:
             model.set_norm_stats(self._xx_m, self._xx_s, self._yy_m, self._yy_s)
 
     def set_norm_stats(self, stats: dict):
-        """overwrites the default norm stats loaded during the initialization"""
-        self._xx_m, self._xx_s = stats["xx_m"], stats["xx_s"]
-        self._yy_m, self._yy_s = stats["yy_m"], stats["yy_s"]
+        """replace the statistics loaded at construction (also on the device handle)"""
+        self._take_stats(stats)
         self._sync_model_config()
         logging.info("Replaced norm stats xx m+/-s and yy m+/-s")
 
@@ -91,9 +81,7 @@ class Estimator:
         self._active = False
 
     def reset(self):
-        self._active = False
-        self._row_hist = []
-        self._smooth_hist = []
+        self._active, self._row_hist, self._smooth_hist = False, [], []
 
     @staticmethod
     def _push_padded(hist: list, item, size: int):
@@ -130,38 +118,37 @@ class Estimator:
         return msg
 
     def process_in_thread(self, sensor_q: queue):
+        """start the consumer thread; returns the queue the messages are put on"""
         msg_q = queue.Queue()
-        t = threading.Thread(target=self.processing_loop, args=(sensor_q, msg_q))
-        t.start()
+        threading.Thread(target=self.processing_loop, args=(sensor_q, msg_q)).start()
         return msg_q
+
+    def _newest_row(self, sensor_q: queue):
+        """latency policy of estimator.py:159-161: block up to 2 s for a row; when more than 5 rows are
+        queued behind it, skip ahead (newest wins).  Raises ``queue.Empty`` when nothing arrives."""
+        row = sensor_q.get(timeout=2)
+        while sensor_q.qsize() > 5:
+            row = sensor_q.get(timeout=2)
+        return row
 
     def processing_loop(self, sensor_q: queue, msg_q: queue):
         logging.info(f"[{self.__tag}] wearable streaming loop")
-        start = datetime.now()
-        dat = 0
         self.reset()
         self._active = True
+        tick, frames = datetime.now(), 0          # processing rate is logged every >= 5 s as frames / 5
         while self._active:
             try:
-                # newest wins: skip the backlog when the consumer falls behind
-                row = sensor_q.get(timeout=2)
-                while sensor_q.qsize() > 5:
-                    row = sensor_q.get(timeout=2)
+                row = self._newest_row(sensor_q)
             except queue.Empty:
                 logging.info(f"[{self.__tag}] no data")
                 continue
-
             now = datetime.now()
-            if (now - start).seconds >= 5:
-                start = now
-                logging.info(f"[{self.__tag}] {dat / 5} Hz")
-                dat = 0
-
-            xx = self.parse_row_to_xx(row)
-            pred = self.add_xx_to_row_hist_and_make_prediction(xx)
-            msg = self.msg_from_pred(pred, self._add_mc_samples)
-            msg_q.put(msg)
-            dat += 1
+            if (now - tick).seconds >= 5:
+                logging.info(f"[{self.__tag}] {frames / 5} Hz")
+                tick, frames = now, 0
+            pred = self.add_xx_to_row_hist_and_make_prediction(self.parse_row_to_xx(row))
+            msg_q.put(self.msg_from_pred(pred, self._add_mc_samples))
+            frames += 1
 
     @abstractmethod
     def make_prediction_from_row_hist(self, xx_hist: np.array) -> np.array:
@@ -226,34 +213,12 @@ class Estimator:
                                             _hip.F64 if est_dtype == torch.float64 else _hip.F32, stream), "ape_infer")
         return (est, y) if return_targets else est
 
-    @property
-    def sequence_len(self):
-        return self._sequence_len
-
-    @property
-    def body_measurements(self):
-        return self._body_measurements
-
-    @property
-    def uarm_orig(self):
-        return self._uarm_orig
-
-    @property
-    def uarm_vec(self):
-        return self._uarm_vec
-
-    @property
-    def larm_vec(self):
-        return self._larm_vec
-
-    @property
-    def device(self):
-        return self._device
-
-    @property
-    def x_inputs(self):
-        return self._x_inputs
-
-    @property
-    def y_targets(self):
-        return self._y_targets
+    # read-only views, same names as the reference's properties (estimator.py:188-218)
+    sequence_len = property(lambda self: self._sequence_len)
+    body_measurements = property(lambda self: self._body_measurements)
+    uarm_orig = property(lambda self: self._uarm_orig)
+    uarm_vec = property(lambda self: self._uarm_vec)
+    larm_vec = property(lambda self: self._larm_vec)
+    device = property(lambda self: self._device)
+    x_inputs = property(lambda self: self._x_inputs)
+    y_targets = property(lambda self: self._y_targets)
