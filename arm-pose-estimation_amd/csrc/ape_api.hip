@@ -75,7 +75,7 @@ struct ape_model {
     float* bias[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     float* w_out = nullptr;
     float* b_out = nullptr;
-    double* stats = nullptr;       // device: xx_m[I] xx_s[I] yy_m[O] yy_s[O]
+    double* stats = nullptr;       // device: xx_m[I] xx_s[I] yy_m[O] yy_s[O] 1/xx_s[I]
     bool has_weights = false, has_stats = false;
     double body[9];
     float* y_ws = nullptr;         // [cap, O] intermediate of ape_infer
@@ -165,7 +165,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         }
         if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (2 * I + 2 * O) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
@@ -181,7 +181,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (2 * I + 2 * O) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
     // the kernel may carve its largest LDS layout (with dropout buffers)
     const size_t smem = ape_lstm_tile16_smem_bytes(H, L, m->KX, O, true);
     if (e == hipSuccess && smem <= 160 * 1024) e = ape_prepare_lstm_tile16(H, L, smem);
@@ -200,10 +200,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = hipMalloc((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
-        m->xflag_bytes = (((size_t)max_clusters * L * GH * sizeof(unsigned)) + 15) / 16 * 16 + 16;   // flags + ticket word
+        m->xflag_bytes = (((size_t)max_clusters * L * GH * 4 * sizeof(unsigned)) + 15) / 16 * 16 + 16;   // one flag per (cluster, layer, member, wave) + ticket word
         if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 128);
-        if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 128);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 256);
+        if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 256);
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = hipMalloc(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
@@ -373,7 +373,8 @@ int ape_model_set_norm_stats(ape_model_t* m, const double* xx_m, const double* x
                              const double* yy_s) {
     if (!m || !xx_m || !xx_s || !yy_m || !yy_s) return fail(APE_ERR_INVALID_ARG, "set_norm_stats: NULL argument");
     const int I = m->dims.input_size, O = m->dims.output_size;
-    std::vector<double> h(2 * I + 2 * O);
+    std::vector<double> h(3 * I + 2 * O);
+    for (int i = 0; i < I; ++i) h[2 * I + 2 * O + i] = 1.0 / xx_s[i];     // reciprocal for the in-kernel z-score
     memcpy(&h[0], xx_m, I * sizeof(double));
     memcpy(&h[I], xx_s, I * sizeof(double));
     memcpy(&h[2 * I], yy_m, O * sizeof(double));
@@ -461,6 +462,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             }
             c.w_out = m->w_out; c.b_out = m->b_out;
             c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
+            c.xx_r = m->stats + 2 * m->dims.input_size + 2 * m->dims.output_size;
             c.hx = m->hx; c.hx_bytes = m->hx_bytes;
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
@@ -612,9 +614,9 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
 }
 
 // internal diagnostic accessor (not part of the public header): copies the 2 stamp words
-int ape_debug_read_stamps(ape_model_t* m, unsigned long long out[9]) {
+int ape_debug_read_stamps(ape_model_t* m, unsigned long long out[14]) {
     if (!m || !m->cluster_ok) return APE_ERR_INVALID_ARG;
-    HIP_TRY(hipMemcpy(out, m->xflags + m->xflag_bytes / sizeof(unsigned) + 4, 72, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, m->xflags + m->xflag_bytes / sizeof(unsigned) + 4, 112, hipMemcpyDeviceToHost));
     return APE_OK;
 }
 

@@ -42,6 +42,7 @@ struct ClusterParams {
     const float* b_out;                 // [O]
     const double* xx_m;
     const double* xx_s;
+    const double* xx_r;                 // [I] 1 / xx_s, rounded once on the host
     float* hx;                          // exchange slices [cluster][L][parity 2][member GH][row MR][16]
     size_t hx_bytes;
     unsigned* xflags;                   // [cluster][L][GH] epoch flags, zeroed before every launch

@@ -14,10 +14,11 @@
 //   * the A operand (activations of all H units of the cluster's windows) lives in LDS; every
 //     layer-step each member publishes its 16-unit slice of h to a small exchange buffer and
 //     gathers the other members' slices.  Hand-off protocol (placement-independent, MI355X guide
-//     G16 / visibility table row 1): payload by 16-byte sc1 (write-through) buffer stores, every
-//     storing wave drains vmcnt(0), workgroup barrier, ONE lane stores the epoch flag with an
-//     agent-scope relaxed atomic; the consumer's wave 0 polls the members' flags with agent-scope
-//     relaxed loads, workgroup barrier, then EVERY load of the payload is a 16-byte sc1 buffer
+//     G16 / visibility table row 1): payload by 16-byte sc1 (write-through) buffer stores, each
+//     wave stores the pieces of its own four units, drains vmcnt(0) and then raises ITS epoch flag
+//     with an agent-scope relaxed atomic (drain + flag ride a few k-blocks into the next section's
+//     MFMAs); every consumer wave polls all 4*GH wave flags of a layer with one agent-scope relaxed
+//     load per lane and only then issues loads of the payload, every one a 16-byte sc1 buffer
 //     load.  Exchange buffers are double-buffered by step parity; the last workgroup to finish
 //     re-zeroes the flags and counters (self-cleaning, no memset node); every spin is bounded and raises a
 //     status word.
@@ -34,7 +35,7 @@
 // wave 0, written behind the status word (memory nothing else reads).  The shipped library has none
 // of this code.  Shares, not absolute time, are what such a build is for.
 #ifdef APE_CLUSTER_STAMPS
-#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_DECL unsigned long long st_t0 = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP_BEGIN()                                        \
     do {                                                     \
         __builtin_amdgcn_sched_barrier(0);                   \
@@ -93,10 +94,12 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7
 // k-blocks 0..QIN-1 read `in_src`, QIN..QTOT-1 read `rec_src` (skipped when !do_rec: h_{-1} = 0).
 // The A fragments of block q+1 are fetched BEFORE the 4*NMT MFMAs of block q (explicit double buffer,
 // pinned with sched_barrier), so the matrix pipe never waits on a just-issued ds_read.
-template <int NMT, int QIN, int QTOT, int NW>
+// `hook(q)` runs in front of the MFMAs of k-block q (q is a constant after unrolling): the caller uses it to put
+// the NEXT section's gather loads into flight under this section's matrix work.
+template <int NMT, int QIN, int QTOT, int NW, typename Hook>
 __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __restrict__ in_src, int in_stride,
                                            const float* __restrict__ rec_src, int rec_stride,
-                                           const float (&w)[NW], bool do_rec) {
+                                           const float (&w)[NW], bool do_rec, Hook&& hook) {
     f32x4 a_cur[NMT], a_nxt[NMT];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
@@ -115,6 +118,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
             for (int mt = 0; mt < NMT; ++mt)
                 a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride);
         }
+        hook(q);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -134,6 +138,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
                 for (int mt = 0; mt < NMT; ++mt)
                     a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride + 16 * (q + 1 - QIN));
             }
+            hook(q);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -177,8 +182,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
     const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;   // monte_carlo_predictions: one window, B rows
+#ifdef APE_CLUSTER_STAMPS
     const bool diag_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0;    // timing only: skip polls/gathers/publishes
     const bool diag_noact = (p.flags & APE_DIAG_NO_ACT) != 0;        // timing only: skip the transcendental math
+#else
+    constexpr bool diag_noex = false, diag_noact = false;            // the shipped library has no diagnostic paths
+#endif
     const bool drop_masks = DROP && (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
     // diagnostic stamps (APE_DIAG_STAMP): shader clock vs the 100 MHz real-time counter around the phase
     // loop; written to words 4..7 behind the status word, which no other code reads
@@ -234,7 +243,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // exchange buffer descriptors (wave-uniform: kernel arguments only)
     const __amdgpu_buffer_rsrc_t hx_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
-    unsigned* const myflags = p.xflags + (size_t)cluster * L * GH;
+    constexpr int NFL = 4 * GH;                  // flags per (cluster, layer): one per member WAVE
+    unsigned* const myflags = p.xflags + (size_t)cluster * L * NFL;
 
     // ---- exchange helpers ------------------------------------------------------------------------------
     constexpr int NGV = GH / SPP;                    // 16-byte pieces each thread moves per gather
@@ -244,8 +254,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // every wave polls for itself (no barrier on the way): all members published epoch `want` of layer l?
     // bounded; on give-up raises the sticky status word and the workgroup abort flag
     auto peek_flags = [&](int l, unsigned want) -> unsigned {      // non-blocking: the load only
-        if (diag_noex || lane >= GH) return want;
-        return __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (diag_noex || lane >= NFL) return want;
+        return __hip_atomic_load(myflags + l * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto wait_flags = [&](int l, unsigned want, unsigned peeked) {
         if (diag_noex) return;
@@ -253,8 +263,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         unsigned spins = 0;
         while (true) {
             unsigned v = want;
-            if (lane < GH)
-                v = __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < NFL)
+                v = __hip_atomic_load(myflags + l * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((int)(v >= want))) return;
             if (++spins > SPIN_LIMIT ||
                 __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -274,20 +284,22 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     auto hx_base = [&](int l, int par, int v) -> unsigned {
         return (unsigned)(((((size_t)cluster * L + l) * 2 + par) * NV + v) * SLICE_SET);
     };
-    auto issue_gather = [&](int l, int par, int half, f32x4 (&gv)[NGH]) {
+    // piece kk of the gather of layer l: variant kk / NGV (0 raw, 1 masked), pass kk % NGV.  `goff` is the thread's
+    // byte offset inside a pass, or that plus 2^31 -- outside the descriptor, so the load returns zeros without
+    // touching memory -- while the flags have not been seen raised (the uniform part sits in soffset, which the
+    // range check ignores)
+    const unsigned g_thread_off = (unsigned)(((g_sl * MR + g_row) * 16 + 4 * g_quad) * sizeof(float));
+    auto issue_piece = [&](int l, int par, int kk, unsigned goff, f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
+        const int v = kk / NGV, k = kk - v * NGV;
+        if (v == 1 && l == L - 1) return;                // the top layer has no masked variant
+        gv[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            hx_rsrc, goff, hx_base(l, par, v) + (unsigned)(k * SPP * MR * 16 * sizeof(float)), 16 /* sc1 */));
+    };
+    auto issue_gather = [&](int l, int par, int half, f32x4 (&gv)[NGH]) {
         (void)half;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (v == 1 && l == L - 1) break;             // the top layer has no masked variant
-            const unsigned base = hx_base(l, par, v);
-#pragma unroll
-            for (int k = 0; k < NGV; ++k) {
-                const int m = k * SPP + g_sl;
-                gv[v * NGV + k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    hx_rsrc, base + (unsigned)(((m * MR + g_row) * 16 + 4 * g_quad) * sizeof(float)), 0, 16 /* sc1 */));
-            }
-        }
+        for (int kk = 0; kk < NGH; ++kk) issue_piece(l, par, kk, g_thread_off, gv);
     };
     auto commit_gather = [&](int l, int half, const f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
@@ -315,43 +327,61 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     };
 
     // ---- x staging: thread owns NE (row, k) elements of the [MR][KX] step slab, all with the same k ----
+    // Loads go through a buffer descriptor over this cluster's rows: rows past the batch and the padded columns
+    // k >= I fall outside it and read as 0 (no predicates, 32-bit offsets).
     constexpr int NE = (MR * KX) / 256;
-    const int xk = tid % KX;
+    constexpr int RPE = 256 / KX;                 // rows between a thread's consecutive elements
+    const int xk = tid % KX, xrow = tid / KX;
+    const int rows_here = bcast_x ? MR : min(MR, p.B - row0);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (bcast_x ? (size_t)0 : (size_t)row0 * T * I), 0,
+        (int)((size_t)(bcast_x ? 1 : rows_here) * T * I * sizeof(float)), 0x00020000);
+    const unsigned x_off0 = (xk < I) ? (unsigned)(((bcast_x ? 0 : xrow) * T * I + xk) * sizeof(float)) : 0x80000000u;
+    const unsigned x_estride = bcast_x ? 0u : (unsigned)(RPE * T * I * sizeof(float));
     float xr[NE];
-    auto fetch_x = [&](int t) {
+    auto fetch_x = [&](int t) {                    // t < T (the step offset is not range-checked)
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int b = row0 + (tid + 256 * e) / KX;
-            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + xk] : 0.0f;
-        }
+        for (int e = 0; e < NE; ++e)
+            xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        x_rsrc, x_off0 + (unsigned)e * x_estride, (unsigned)(t * I * sizeof(float)), 0));
     };
-    // f64 z-score, cast f32 (estimator.py:103-104, watch_phone_pocket_nn.py:100), into LDS
+    // f64 z-score, cast f32 (estimator.py:103-104, watch_phone_pocket_nn.py:100), into LDS.  Per-thread constants
+    // (every element a thread stages has the same k): mean, std and the host-rounded 1/std; (0, 1, 1) passes x
+    // through exactly when the caller normalised already.
+    const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
+    const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
+    const double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;
+    auto stage_elem = [&](int e) {
+        // (x - m) / s in f64, correctly rounded: q0 = d * (1/s), one residual step q0 + (d - q0 s)(1/s)
+        // (the tail of the hardware division sequence; a NaN residual means s = 0 or inf -> keep q0,
+        // which is then the same +-inf / NaN the division yields)
+        const double d = (double)xr[e] - x_mean;
+        const double q0 = d * x_rstd;
+        const double rr = fma(-q0, x_std, d);
+        const double q1 = fma(rr, x_rstd, q0);
+        xin[(xrow + e * RPE) * SX + xk] = (float)((rr == rr) ? q1 : q0);
+    };
     auto stage_x = [&]() {
-        // per-thread constants are re-read (L2 hits) instead of living in 6 VGPRs for the whole launch
-        const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
-        const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
-        const double x_rstd = 1.0 / x_std;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int row = (tid + 256 * e) / KX;
-            float v = xr[e];
-            if (normalize && xk < I && row0 + row < p.B) {
-                // (x - m) / s in f64, correctly rounded: q0 = d * (1/s), one residual step q0 + (d - q0 s)(1/s)
-                // (the tail of the hardware division sequence; a NaN residual means s = 0 or inf -> keep q0,
-                // which is then the same +-inf / NaN the division yields)
-                const double d = (double)v - x_mean;
-                const double q0 = d * x_rstd;
-                const double rr = fma(-q0, x_std, d);
-                const double q1 = fma(rr, x_rstd, q0);
-                v = (float)((rr == rr) ? q1 : q0);
-            }
-            xin[row * SX + xk] = v;
-        }
+        for (int e = 0; e < NE; ++e) stage_elem(e);
     };
     fetch_x(0);
     stage_x();
     if (T > 1) fetch_x(1);
     __syncthreads();
+
+    // The flag a wave owes for the slice it stored last: raised once those stores have drained -- a few k-blocks
+    // into the NEXT section's MFMAs (the write-through latency hides there), or at the latest before this wave
+    // blocks on anybody else's flag.
+    int pend_idx = -1;
+    unsigned pend_epoch = 0u;
+    auto raise_pending = [&]() {
+        if (pend_idx < 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's slice stores are complete
+        if (!diag_noex && lane == 0)
+            __hip_atomic_store(myflags + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_idx = -1;
+    };
 
     STAMP_DECL
     const int P = T + L - 1;
@@ -367,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             const bool active = (t >= 0 && t < T);      // both uniform over the whole grid
             STAMP_BEGIN();
             if (have_prev && !prefetched) {
+                raise_pending();
                 if (!gather_now(l, (unsigned)t, (t - 1) & 1)) return;
             }
             prefetched = false;
@@ -379,7 +410,43 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             const int ln = (l + 1 < L) ? l + 1 : 0;
             const int tn = (l + 1 < L) ? t - 1 : t + L;          // = ph_n - l_n
             const bool pre = (tn >= 1 && tn <= T) && !(ln == L - 1 && tn == T) && (l + 1 < L || ph + 1 < P);
-            const unsigned peeked = pre ? peek_flags(ln, (unsigned)tn) : 0u;     // load issued, not waited for
+            // Work that rides under this section's MFMAs (one call of `hook` per k-block, no branches in it):
+            //  * the next section's gather: the flags are looked at in block QP, judged in block Q0, and from Q0 on
+            //    PPB 16-byte pieces per block go into flight -- to real addresses if every flag was up, else outside
+            //    the descriptor (zeros, no traffic) and the blocking path below redoes them.  The 64 KB a workgroup
+            //    gathers cost ~1K cycles of the CU's vector-memory path plus the fabric latency, all hidden here;
+            //  * in section 1: the f64 z-score of x_{ph+1} into LDS and the fetch of x_{ph+2}.
+            constexpr int PPB = 4, GBLK = (NGH + PPB - 1) / PPB;
+            constexpr int EPB = (NE + QH - 1) / QH, XBLK = (NE + EPB - 1) / EPB;     // x elements per block (section 1)
+            const int nblk = (l == 0) ? QX + QH : 2 * QH;
+            // the slices wanted were stored at the end of the section before this one and their flags go up in
+            // block QF of this one: look a good 1.5K cycles later, judge 1.5K cycles after that
+            constexpr int QF = 2;                        // block in which the flag owed from the last section goes up
+            const int QP = (nblk >= 16) ? 5 : 4;
+            const int Q0 = QP + 3;
+            unsigned peeked = 0u;
+            f32x4 gv[NGH];
+            bool ready = false;
+            unsigned goff = g_thread_off + 0x80000000u;
+            auto hook = [&](int q) {
+                if (L > 1 && l == 1 && q < XBLK) {
+#pragma unroll
+                    for (int j = 0; j < EPB; ++j)
+                        if (q * EPB + j < NE) stage_elem(q * EPB + j);
+                    if (q == XBLK - 1 && ph + 2 < T) fetch_x(ph + 2);
+                }
+                if (q == QF) raise_pending();
+                if (q == QP) peeked = peek_flags(ln, (unsigned)tn);
+                if (q == Q0) {
+                    ready = pre && __all((int)(peeked >= (unsigned)tn)) != 0;
+                    goff = g_thread_off + (ready ? 0u : 0x80000000u);
+                }
+                if (q >= Q0 && q < Q0 + GBLK) {
+#pragma unroll
+                    for (int j = 0; j < PPB; ++j)
+                        if ((q - Q0) * PPB + j < NGH) issue_piece(ln, (tn - 1) & 1, (q - Q0) * PPB + j, goff, gv);
+                }
+            };
 
             // ---- stacked-gate product on the matrix cores ------------------------------------------------
             f32x4 acc[NMT];
@@ -387,22 +454,25 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = bias_r[l];
             const float* rec_src = hbuf + (l * MR + r) * SH + 4 * g;
             if (l == 0) {
-                layer_mfma<NMT, QX, QX + QH, NW0>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0);
+                layer_mfma<NMT, QX, QX + QH, NW0>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0, hook);
             } else {
                 const float* in_src = (DROP ? dbuf : hbuf) + ((l - 1) * MR + r) * SH + 4 * g;
                 if (l == 1) {
-                    if constexpr (L > 1) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w1, t > 0);
+                    if constexpr (L > 1) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w1, t > 0, hook);
                 } else {
-                    if constexpr (L > 2) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w2, t > 0);
+                    if constexpr (L > 2) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w2, t > 0, hook);
                 }
             }
             mfma_drain();
+            raise_pending();                             // (a section too short to reach block QF)
             STAMP_END(2);                                // 2: MFMA layer-step
 
-            f32x4 gv[NGH];
-            if (pre) {
+#ifdef APE_CLUSTER_STAMPS
+            if (pre && !ready) st_acc[l == 0 ? 0 : 11] += 1;    // diagnostic: how often the blocking path runs
+#endif
+            if (pre && !ready) {                         // first step of a layer, or a peer was late: blocking path
                 wait_flags(ln, (unsigned)tn, peeked);
-                issue_gather(ln, (tn - 1) & 1, 0, gv);           // flies under the VALU work below
+                issue_gather(ln, (tn - 1) & 1, 0, gv);
             }
             STAMP_END(3);                                // 3: flag check + gather issue
 
@@ -443,37 +513,39 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 }
             }
             STAMP_END(4);                                // 4: activations + cell update + own-slice write
-            __syncthreads();                             // barrier A: own slice complete, all MFMAs of the section done
+            __syncthreads();                             // barrier A: every wave's MFMAs are done, hbuf[ln] has no reader left
             if (ctl[0] != 0) return;
             STAMP_END(5);                                // 5: barrier A
-            // ---- publish: 16-byte write-through stores, (commit gather, stage x), drain, barrier, ONE flag ----
-            if (!diag_noex && tid < ((DROP && l < L - 1) ? 2 * TPS : TPS)) {
-                const int v = tid / TPS, idx = tid - v * TPS;        // variant 1 = masked slice
-                const int row = idx >> 2, quad = idx & 3;
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (v * MR + row) * SO + 4 * quad);
-                const unsigned base = hx_base(l, t & 1, v);
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
-                    base + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */);
+            if (pre) commit_gather(ln, 0, gv);           // landed during the MFMAs
+            STAMP_END(7);                                // 7: gather commit
+            // ---- publish: each wave sends the 16-byte pieces of ITS four units (row = lane) write-through, notes
+            //      the flag it owes and moves on; the drain and the flag store ride in the next section (raise_pending)
+            {
+                const int v = lane / MR, row = lane - v * MR;        // variant 1 = masked slice
+                if (!diag_noex && lane < ((DROP && l < L - 1) ? 2 * MR : MR)) {
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (v * MR + row) * SO + 4 * wave);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
+                        (unsigned)(((member * MR + row) * 16 + 4 * wave) * sizeof(float)), hx_base(l, t & 1, v), 16 /* sc1 */);
+                }
+                pend_idx = l * NFL + member * 4 + wave;
+                pend_epoch = (unsigned)(t + 1);
             }
-            if (pre) commit_gather(ln, 0, gv);
-            if (l == 0 && t + 1 < T) {                   // x_{t+1} for the next phase (xin's readers are done)
+            STAMP_END(6);                                // 6: publish store issue
+            if (l == 0 && ph == 0 && T > 1) {            // x_1 (section 1, which stages x_{ph+1}, idles in phase 0)
                 stage_x();
-                if (t + 2 < T) fetch_x(t + 2);
+                if (T > 2) fetch_x(2);
             }
             if (pre) prefetched = true;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the flag
-            __syncthreads();                             // barrier B: gathered data + x visible, stores drained
-            if (!diag_noex && tid == 0)
-                __hip_atomic_store(myflags + l * GH + member, (unsigned)(t + 1), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            STAMP_END(6);                                // 6: publish + commit + x staging + barrier B + flag
+            STAMP_END(8);                                // 8: x staging of phase 0
+            __syncthreads();                             // barrier B: gathered data (+ x) visible to every wave
+            STAMP_END(10);                               // 10: barrier B
         }
     }
 #ifdef APE_CLUSTER_STAMPS
     if (blockIdx.x == 0 && tid == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 8);
-        for (int k = 0; k < 7; ++k) dbg[k] = st_acc[k];
+        for (int k = 0; k < 12; ++k) dbg[k] = st_acc[k];
     }
 #endif
     if ((p.flags & APE_DIAG_STAMP) && blockIdx.x == 0 && tid == 0) {
@@ -482,6 +554,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         dbg[0] = c1 - stamp_c0;
         dbg[1] = r1 - stamp_r0;
     }
+    raise_pending();
     // ---- head: gather h^{L-1}_{T-1}, each member finishes MR/GH (>= 1) of the cluster's windows ------
     if (!gather_now(L - 1, (unsigned)T, (T - 1) & 1)) return;
     {
@@ -509,7 +582,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (ctl[2] != 0) {
-        const int n_words = (int)(gridDim.x / GH) * L * GH;
+        const int n_words = (int)(gridDim.x / GH) * L * NFL;
         for (int i = tid; i < n_words; i += 256)
             __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {

@@ -55,11 +55,11 @@ for fl, nm in ((0x10000000, "cluster"), (0x70000000, "cluster_noex_noact")):
     for _ in range(200):   # sustained load first
         lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, fl, None, 0.0, 0, C.c_void_p(y.data_ptr()), st)
     torch.cuda.synchronize()
-    out = (ctypes.c_ulonglong * 9)()
+    out = (ctypes.c_ulonglong * 14)()
     raw.ape_debug_read_stamps(m.handle, out)
     if out[1]:
         print(f"{nm}: phase loop {out[0]} shader cycles in {out[1] * 10} ns -> in-kernel clock {out[0] / (out[1] * 10):.3f} GHz")
-    if any(out[2:9]):
-        names = ["x-stage", "wait+gather", "mfma", "activations", "transpose", "cell+own+barrier", "publish"]
-        tot = sum(out[2:9]); P = T + cfg["L"] - 1
-        print(f"{nm}: section cycles per phase (wave 0 of workgroup 0): " + ", ".join(f"{n} {v / P:.0f}" for n, v in zip(names, out[2:9])) + f"  | sum {tot / P:.0f}")
+    if any(out[2:14]):
+        names = ["fallbacks-l0", "blocking-gather", "mfma", "flags+gather-issue", "act+cell", "barrier-A", "store-issue", "gather-commit", "x-stage", "drain", "barrier-B+flag", "fallbacks-l>0"]
+        tot = sum(out[2:14]); P = T + cfg["L"] - 1
+        print(f"{nm}: section cycles per phase (wave 0 of workgroup 0): " + ", ".join(f"{n} {v / P:.2f}" if n.startswith("fallb") else f"{n} {v / P:.0f}" for n, v in zip(names, out[2:14])) + f"  | sum {tot / P:.0f}")
