@@ -56,6 +56,23 @@
 #define STAMP_END(k) do {} while (0)
 #endif
 
+// k-block schedule of the exchange work under the MFMAs (see the phase loop); tunable at build time
+#ifndef APE_QF
+#define APE_QF 1      // block in which the flag owed from the last section goes up
+#endif
+#ifndef APE_QP
+#define APE_QP 6      // block in which the next layer's flags are looked at
+#endif
+#ifndef APE_QJ
+#define APE_QJ 3      // blocks between the look and the verdict (= first gather block)
+#endif
+#ifndef APE_PPB
+#define APE_PPB 8     // gather pieces put into flight per block
+#endif
+#ifndef APE_CPB
+#define APE_CPB 4     // gathered pieces committed to LDS per block
+#endif
+
 namespace {
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;   // bounded polls (~seconds) before giving up
@@ -94,8 +111,9 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7
 // k-blocks 0..QIN-1 read `in_src`, QIN..QTOT-1 read `rec_src` (skipped when !do_rec: h_{-1} = 0).
 // The A fragments of block q+1 are fetched BEFORE the 4*NMT MFMAs of block q (explicit double buffer,
 // pinned with sched_barrier), so the matrix pipe never waits on a just-issued ds_read.
-// `hook(q)` runs in front of the MFMAs of k-block q (q is a constant after unrolling): the caller uses it to put
-// the NEXT section's gather loads into flight under this section's matrix work.
+// `hook(q)` runs in front of k-block q -- before the A fragments of block q+1 are fetched, so a barrier placed in
+// hook(QIN-1) precedes every read of `rec_src` -- and q is a constant after unrolling: the caller uses it to put
+// exchange traffic, LDS commits and x staging under this section's matrix work.
 template <int NMT, int QIN, int QTOT, int NW, typename Hook>
 __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __restrict__ in_src, int in_stride,
                                            const float* __restrict__ rec_src, int rec_stride,
@@ -109,6 +127,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
     // input span (both spans fully unrolled: every weight-register index is a compile-time constant)
 #pragma unroll
     for (int q = 0; q < QIN; ++q) {
+        hook(q);
         if (q + 1 < QIN) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
@@ -118,7 +137,6 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
             for (int mt = 0; mt < NMT; ++mt)
                 a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride);
         }
-        hook(q);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -133,12 +151,12 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
     if (do_rec) {                                            // recurrent span (uniform)
 #pragma unroll
         for (int q = QIN; q < QTOT; ++q) {
+            hook(q);
             if (q + 1 < QTOT) {
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt)
                     a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride + 16 * (q + 1 - QIN));
             }
-            hook(q);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -315,14 +333,24 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             }
         }
     };
-    // blocking form (pipeline fill/drain and the head): wait, load, commit, barrier
+    auto commit_piece = [&](int l, int kk, const f32x4 (&gv)[NGH]) {
+        if (diag_noex) return;
+        const int v = kk / NGV, k = kk - v * NGV;
+        if (v == 1 && l == L - 1) return;
+        float* dst = (v == 0) ? hbuf + l * MR * SH : dbuf + l * MR * SH;
+        *reinterpret_cast<f32x4*>(dst + g_row * SH + (k * SPP + g_sl) * 16 + 4 * g_quad) = gv[kk];
+    };
+    // workgroup barrier that waits for this wave's LDS traffic only (not for loads/stores in flight to memory)
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // blocking form (pipeline fill/drain and the head): wait, load, barrier (no reader of the target left), commit,
+    // barrier
     auto gather_now = [&](int l, unsigned want, int par) -> bool {
-        f32x4 ga[NGH], gb[NGH];
+        f32x4 ga[NGH];
         wait_flags(l, want, 0u);
         issue_gather(l, par, 0, ga);
+        bar();
         commit_gather(l, 0, ga);
-        (void)gb;
-        __syncthreads();
+        bar();
         return ctl[0] == 0;
     };
 
@@ -385,7 +413,17 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 
     STAMP_DECL
     const int P = T + L - 1;
-    bool prefetched = false;          // the gather the NEXT section needs was already committed by this one
+    // Section (ph, l) = layer l on step t = ph - l.  What it gathers is what the NEXT section in program order
+    // needs: the freshly published slices of layer ln.  Where the gathered registers go:
+    //   * ln >= 1: they are CARRIED into section ln and committed to hbuf[ln] during its input span (which reads
+    //     hbuf[ln-1] only); the mid-section barrier in front of the recurrent span makes them visible;
+    //   * ln == 0 (gathered by the top layer's section): committed to hbuf[0] in the last k-blocks of that same
+    //     section, after its mid-section barrier (no reader of hbuf[0] is left), visible by its end barrier.
+    // So a phase has one barrier per layer above 0 plus one at its end, none of them waiting on memory, and every
+    // LDS commit, flag and gather instruction sits between MFMAs.
+    bool prefetched = false;          // the slices the NEXT section reads are in hbuf or on their way there in gv
+    bool carry = false;               // gv holds slices the next section has to commit to its recurrent buffer
+    f32x4 gv[NGH];
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
 #pragma unroll
@@ -396,44 +434,59 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             const bool have_prev = (t >= 1 && t <= T) && !(l == L - 1 && t == T);
             const bool active = (t >= 0 && t < T);      // both uniform over the whole grid
             STAMP_BEGIN();
-            if (have_prev && !prefetched) {
+            if (have_prev && !prefetched) {             // pipeline fill / drain only
                 raise_pending();
                 if (!gather_now(l, (unsigned)t, (t - 1) & 1)) return;
             }
             prefetched = false;
+            if (!active) {
+                if (carry) {                            // (tail) nobody will run the input span that commits them
+                    raise_pending();
+                    bar();
+                    commit_gather(l, 0, gv);
+                    bar();
+                    carry = false;
+                }
+                continue;
+            }
             STAMP_END(1);                                // 1: blocking gathers (pipeline fill / drain only)
-            if (!active) continue;
 
-            // next section in program order: (ph, l+1) or (ph+1, 0).  Its slices were published at least one
-            // full layer-step ago and its LDS target has no reader left once barrier A below is passed, so
-            // its flag check and gather loads fly under this section's MFMAs and VALU work.
+            // next section in program order: (ph, l+1) or (ph+1, 0)
             const int ln = (l + 1 < L) ? l + 1 : 0;
             const int tn = (l + 1 < L) ? t - 1 : t + L;          // = ph_n - l_n
             const bool pre = (tn >= 1 && tn <= T) && !(ln == L - 1 && tn == T) && (l + 1 < L || ph + 1 < P);
-            // Work that rides under this section's MFMAs (one call of `hook` per k-block, no branches in it):
-            //  * the next section's gather: the flags are looked at in block QP, judged in block Q0, and from Q0 on
-            //    PPB 16-byte pieces per block go into flight -- to real addresses if every flag was up, else outside
-            //    the descriptor (zeros, no traffic) and the blocking path below redoes them.  The 64 KB a workgroup
-            //    gathers cost ~1K cycles of the CU's vector-memory path plus the fabric latency, all hidden here;
-            //  * in section 1: the f64 z-score of x_{ph+1} into LDS and the fetch of x_{ph+2}.
-            constexpr int PPB = 4, GBLK = (NGH + PPB - 1) / PPB;
-            constexpr int EPB = (NE + QH - 1) / QH, XBLK = (NE + EPB - 1) / EPB;     // x elements per block (section 1)
+            const bool last = (l == L - 1);
+            const bool carry_in = carry;
+            carry = false;
+            // k-block schedule of the work under the MFMAs (one call of `hook` per k-block):
+            //   0 .. CBLK-1   (l >= 1) commit the carried slices, CPB pieces per block
+            //   QF            raise the flag owed for the slice stored at the end of the last section
+            //   QP / Q0       look at / judge the flags of layer ln; from Q0 on PPB gather pieces per block -- to real
+            //                 addresses if every flag was up, else outside the descriptor (zeros, no traffic) and the
+            //                 blocking path behind the MFMAs redoes them
+            //   QM = QIN-1    (l >= 1) mid-section barrier, in front of the first read of the recurrent buffer
+            //   QIN ..        (l == 1) f64 z-score of x_{ph+1} into LDS, then the fetch of x_{ph+2}
+            //   QC ..         (top layer) commit the slices just gathered to hbuf[0]
+            constexpr int PPB = APE_PPB, GBLK = (NGH + PPB - 1) / PPB;
+            constexpr int CPB = APE_CPB, CBLK = (NGH + CPB - 1) / CPB;
+            constexpr int EPB = (NE + QH - 1) / QH, XBLK = (NE + EPB - 1) / EPB;
+            constexpr int QF = APE_QF;
             const int nblk = (l == 0) ? QX + QH : 2 * QH;
-            // the slices wanted were stored at the end of the section before this one and their flags go up in
-            // block QF of this one: look a good 1.5K cycles later, judge 1.5K cycles after that
-            constexpr int QF = 2;                        // block in which the flag owed from the last section goes up
-            const int QP = (nblk >= 16) ? 5 : 4;
-            const int Q0 = QP + 3;
+            const int QIN = (l == 0) ? QX : QH;
+            const int QP = (nblk >= 16) ? APE_QP : APE_QP - 1;
+            const int Q0 = QP + APE_QJ;
+            const int QM = QIN - 1;
+            const int QC = nblk - CBLK;
+            static_assert(CBLK <= QH - 1 && APE_QP + APE_QJ + GBLK <= 2 * QH - CBLK && CBLK <= APE_QP + APE_QJ - 1 + 1,
+                          "k-block schedule does not fit");
             unsigned peeked = 0u;
-            f32x4 gv[NGH];
-            bool ready = false;
+            bool ready = false, new_done = false;
             unsigned goff = g_thread_off + 0x80000000u;
             auto hook = [&](int q) {
-                if (L > 1 && l == 1 && q < XBLK) {
+                if (l >= 1 && q < CBLK && carry_in) {
 #pragma unroll
-                    for (int j = 0; j < EPB; ++j)
-                        if (q * EPB + j < NE) stage_elem(q * EPB + j);
-                    if (q == XBLK - 1 && ph + 2 < T) fetch_x(ph + 2);
+                    for (int j = 0; j < CPB; ++j)
+                        if (q * CPB + j < NGH) commit_piece(l, q * CPB + j, gv);
                 }
                 if (q == QF) raise_pending();
                 if (q == QP) peeked = peek_flags(ln, (unsigned)tn);
@@ -445,6 +498,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 #pragma unroll
                     for (int j = 0; j < PPB; ++j)
                         if ((q - Q0) * PPB + j < NGH) issue_piece(ln, (tn - 1) & 1, (q - Q0) * PPB + j, goff, gv);
+                }
+                if (l >= 1 && q == QM) bar();
+                if (L > 1 && l == 1 && q >= QIN && q < QIN + XBLK) {
+#pragma unroll
+                    for (int j = 0; j < EPB; ++j)
+                        if ((q - QIN) * EPB + j < NE) stage_elem((q - QIN) * EPB + j);
+                    if (q == QIN + XBLK - 1 && ph + 2 < T) fetch_x(ph + 2);
+                }
+                if (last && q >= QC && ready) {
+#pragma unroll
+                    for (int j = 0; j < CPB; ++j)
+                        if ((q - QC) * CPB + j < NGH) commit_piece(ln, (q - QC) * CPB + j, gv);
+                    if (q == nblk - 1) new_done = true;
                 }
             };
 
@@ -467,6 +533,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             raise_pending();                             // (a section too short to reach block QF)
             STAMP_END(2);                                // 2: MFMA layer-step
 
+            // first step of a layer above 0: there was no recurrent span, hence none of the work scheduled in it
+            // (the mid-section barrier, in the input span, did run: no reader of xin or hbuf[0] is left)
+            bool odd_path = false;
+            if (l >= 1 && t == 0) {
+                if (l == 1) {
+                    stage_x();
+                    if (ph + 2 < T) fetch_x(ph + 2);
+                }
+                odd_path = true;
+            }
 #ifdef APE_CLUSTER_STAMPS
             if (pre && !ready) st_acc[l == 0 ? 0 : 11] += 1;    // diagnostic: how often the blocking path runs
 #endif
@@ -474,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 wait_flags(ln, (unsigned)tn, peeked);
                 issue_gather(ln, (tn - 1) & 1, 0, gv);
             }
-            STAMP_END(3);                                // 3: flag check + gather issue
+            STAMP_END(3);                                // 3: flag wait + gather issue of the blocking path
 
             // ---- gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit g, batch row 16*mt + r) -------
             {
@@ -489,8 +565,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                         hval = acc[mt][3] * c;
                     } else {
                         const float iv = gate_act(acc[mt][0], false), fv = gate_act(acc[mt][1], false);
-                        const float gv = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
-                        const float c = fv * cst[l][mt] + iv * gv;
+                        const float gv_ = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
+                        const float c = fv * cst[l][mt] + iv * gv_;
                         cst[l][mt] = c;
                         hval = ov * gate_act(c, true);
                     }
@@ -513,13 +589,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 }
             }
             STAMP_END(4);                                // 4: activations + cell update + own-slice write
-            __syncthreads();                             // barrier A: every wave's MFMAs are done, hbuf[ln] has no reader left
-            if (ctl[0] != 0) return;
-            STAMP_END(5);                                // 5: barrier A
-            if (pre) commit_gather(ln, 0, gv);           // landed during the MFMAs
-            STAMP_END(7);                                // 7: gather commit
-            // ---- publish: each wave sends the 16-byte pieces of ITS four units (row = lane) write-through, notes
-            //      the flag it owes and moves on; the drain and the flag store ride in the next section (raise_pending)
+            // ---- publish: each wave sends the 16-byte pieces of ITS four units (row = lane; its own LDS staging
+            //      columns, no barrier) write-through, notes the flag it owes and moves on
             {
                 const int v = lane / MR, row = lane - v * MR;        // variant 1 = masked slice
                 if (!diag_noex && lane < ((DROP && l < L - 1) ? 2 * MR : MR)) {
@@ -532,14 +603,23 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 pend_epoch = (unsigned)(t + 1);
             }
             STAMP_END(6);                                // 6: publish store issue
-            if (l == 0 && ph == 0 && T > 1) {            // x_1 (section 1, which stages x_{ph+1}, idles in phase 0)
-                stage_x();
-                if (T > 2) fetch_x(2);
+            if (last) {
+                if (pre && !new_done) commit_gather(ln, 0, gv);      // blocking path / first step: every wave is past
+                STAMP_END(7);                                        // the input span (mid or odd-path barrier)
+                bar();                                   // end of phase: hbuf[0] and x of the next phase visible
+                if (ctl[0] != 0) return;
+                STAMP_END(10);                           // 10: end-of-phase barrier
+            } else {
+                carry = pre;
+                if (odd_path) bar();                     // x staged on the odd path must be visible to the next phase
             }
             if (pre) prefetched = true;
-            STAMP_END(8);                                // 8: x staging of phase 0
-            __syncthreads();                             // barrier B: gathered data (+ x) visible to every wave
-            STAMP_END(10);                               // 10: barrier B
+            if (l == 0 && ph == 0 && T > 1) {            // x_1 (section 1, which stages x_{ph+1}, idles in phase 0)
+                bar();
+                stage_x();
+                if (T > 2) fetch_x(2);
+                bar();
+            }
         }
     }
 #ifdef APE_CLUSTER_STAMPS
