@@ -89,6 +89,7 @@ struct ape_model {
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
+    unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
     unsigned* xflags = nullptr;    // [flag words..., status word]
     size_t xflag_bytes = 0;        // bytes of the flag block (multiple of 16), status word follows
     // MLP regressor (APE_MODEL_FF)
@@ -202,6 +203,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
         m->xflag_bytes = (((size_t)max_clusters * L * GH * 4 * sizeof(unsigned)) + 15) / 16 * 16 + 16;   // one flag per (cluster, layer, member, wave) + ticket word
         if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(m->dbg_wg, 0, 256 * 8 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 256);
         if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 256);
         for (int l = 0; l < L && e == hipSuccess; ++l)
@@ -238,6 +241,7 @@ int ape_model_destroy(ape_model_t* m) {
     for (int l = 0; l < APE_MAX_LAYERS; ++l)
         if (m->wcl16[l]) (void)hipFree(m->wcl16[l]);
     if (m->hx) (void)hipFree(m->hx);
+    if (m->dbg_wg) (void)hipFree(m->dbg_wg);
     if (m->xflags) (void)hipFree(m->xflags);
     delete m;
     return APE_OK;
@@ -471,6 +475,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             // injected masks are indexed [L-1, B, T, H] over the WHOLE batch: chunks need the full B stride,
             // so a masked call is served by one launch only (checked below)
             c.masks = masks_dev; c.dropout_p = dropout_p; c.seed = seed;
+            c.dbg_wg = m->dbg_wg;
             if ((flags & APE_FLAG_DROPOUT_MASKS) && b0 + nb < B && cdrop)
                 return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
@@ -617,6 +622,12 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
 int ape_debug_read_stamps(ape_model_t* m, unsigned long long out[14]) {
     if (!m || !m->cluster_ok) return APE_ERR_INVALID_ARG;
     HIP_TRY(hipMemcpy(out, m->xflags + m->xflag_bytes / sizeof(unsigned) + 4, 112, hipMemcpyDeviceToHost));
+    return APE_OK;
+}
+
+int ape_debug_read_wg(ape_model_t* m, unsigned long long out[256 * 8]) {
+    if (!m || !m->dbg_wg) return APE_ERR_INVALID_ARG;
+    HIP_TRY(hipMemcpy(out, m->dbg_wg, 256 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return APE_OK;
 }
 

@@ -54,6 +54,7 @@ struct ClusterParams {
     unsigned flags;
     float dropout_p;
     unsigned long long seed;
+    unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
 };
 
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor

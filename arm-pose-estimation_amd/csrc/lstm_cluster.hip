@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // loop; written to words 4..7 behind the status word, which no other code reads
     unsigned long long stamp_c0 = 0, stamp_r0 = 0;
     if (p.flags & APE_DIAG_STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
+#ifdef APE_CLUSTER_STAMPS
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wg_t1 = 0, wg_t2 = 0;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                           // [L][MR][SH]  gathered h of every layer
@@ -411,6 +415,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         pend_idx = -1;
     };
 
+#ifdef APE_CLUSTER_STAMPS
+    wg_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     STAMP_DECL
     const int P = T + L - 1;
     // Section (ph, l) = layer l on step t = ph - l.  What it gathers is what the NEXT section in program order
@@ -634,6 +641,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         dbg[0] = c1 - stamp_c0;
         dbg[1] = r1 - stamp_r0;
     }
+#ifdef APE_CLUSTER_STAMPS
+    wg_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     raise_pending();
     // ---- head: gather h^{L-1}_{T-1}, each member finishes MR/GH (>= 1) of the cluster's windows ------
     if (!gather_now(L - 1, (unsigned)T, (T - 1) & 1)) return;
@@ -653,6 +663,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             }
         }
     }
+#ifdef APE_CLUSTER_STAMPS
+    if (tid == 0 && p.dbg_wg != nullptr && blockIdx.x < 256) {
+        unsigned long long* d = p.dbg_wg + blockIdx.x * 8;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[0] = (unsigned long long)ticket; d[1] = xcc & 0xF; d[2] = wg_t0; d[3] = wg_t1; d[4] = wg_t2;
+        d[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // ---- self-cleaning: the LAST workgroup to get here re-zeroes every polled word for the next launch ------
     // (no memset node in front of the launch: graph replays and back-to-back calls find a clean state).  All
     // the other workgroups are past their last flag read when they count themselves done.  A launch that

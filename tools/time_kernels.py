@@ -51,7 +51,7 @@ for k, v in res.items():
 import ctypes
 raw = ctypes.CDLL(str(_hip.LIB_PATH))
 lib.ape_model_set_kernel(m.handle, 2)
-for fl, nm in ((0x10000000, "cluster"), (0x70000000, "cluster_noex_noact")):
+for fl, nm in ((0x70000000, "cluster_noex_noact"), (0x10000000, "cluster")):
     for _ in range(200):   # sustained load first
         lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, fl, None, 0.0, 0, C.c_void_p(y.data_ptr()), st)
     torch.cuda.synchronize()
@@ -63,3 +63,19 @@ for fl, nm in ((0x10000000, "cluster"), (0x70000000, "cluster_noex_noact")):
         names = ["fallbacks-l0", "blocking-gather", "mfma", "flags+gather-issue", "act+cell", "barrier-A", "store-issue", "gather-commit", "x-stage", "drain", "barrier-B+flag", "fallbacks-l>0"]
         tot = sum(out[2:14]); P = T + cfg["L"] - 1
         print(f"{nm}: section cycles per phase (wave 0 of workgroup 0): " + ", ".join(f"{n} {v / P:.2f}" if n.startswith("fallb") else f"{n} {v / P:.0f}" for n, v in zip(names, out[2:14])) + f"  | sum {tot / P:.0f}")
+
+# per-workgroup timeline of the last stamped launch (diagnostic library only): cluster = ticket // GH
+try:
+    buf = (ctypes.c_ulonglong * (256 * 8))()
+    if raw.ape_debug_read_wg(m.handle, buf) == 0 and any(buf):
+        a = np.array(buf[:], dtype=np.float64).reshape(256, 8)
+        GH = cfg["H"] // 16
+        t0 = a[:, 2].min()
+        cl = (a[:, 0] // GH).astype(int)
+        print("cluster: members' XCDs | start spread, prologue end, loop end, kernel end (us after first start)")
+        for c in sorted(set(cl)):
+            r = a[cl == c]
+            print(f"  {c:2d}: xcd {''.join(str(int(v)) for v in r[:, 1])} | start {((r[:, 2].max() - t0) / 100):6.1f} prologue {((r[:, 3].max() - t0) / 100):6.1f}"
+                  f" loop {((r[:, 4].min() - t0) / 100):7.1f}..{((r[:, 4].max() - t0) / 100):7.1f} end {((r[:, 5].max() - t0) / 100):7.1f}")
+except AttributeError:
+    pass
