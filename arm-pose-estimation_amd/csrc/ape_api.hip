@@ -66,6 +66,16 @@ int check_dims(const ape_dims_t* d) {
 
 int padded_input(int I) { return ((I + 31) / 32) * 32; }
 
+bool parse_kind_dims(int kind, int* width, int* I) {
+    switch (kind) {
+        case APE_PARSE_WATCH_PHONE_POCKET: *width = 55; *I = 22; return true;
+        case APE_PARSE_WATCH_ONLY: *width = 28; *I = 20; return true;
+        case APE_PARSE_WATCH_ONLY_PHONE_MSG: *width = 55; *I = 20; return true;
+        case APE_PARSE_WATCH_PHONE_UARM: *width = 55; *I = 38; return true;
+    }
+    return false;
+}
+
 }  // namespace
 
 struct ape_model {
@@ -395,8 +405,10 @@ int ape_model_set_body(ape_model_t* m, const double body9[9]) {
     return APE_OK;
 }
 
-int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
-                     const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream) {
+// x_ring: time step t of every window lives in slot (t + x_ring) mod T (0 = the linear layout of the public entry)
+static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+                             const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream,
+                             int x_ring) {
     if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
     if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
@@ -472,6 +484,7 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
             c.done = c.ticket + 1;
             c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size; c.flags = flags;
+            c.x_ring = x_ring;
             // injected masks are indexed [L-1, B, T, H] over the WHOLE batch: chunks need the full B stride,
             // so a masked call is served by one launch only (checked below)
             c.masks = masks_dev; c.dropout_p = dropout_p; c.seed = seed;
@@ -499,12 +512,18 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     p.xx_s = m->stats + m->dims.input_size;
     p.masks = masks_dev;
     p.B = B; p.T = T; p.I = m->dims.input_size; p.O = m->dims.output_size; p.KX = m->KX;
+    p.x_ring = x_ring;
     p.flags = flags;
     p.dropout_p = dropout_p;
     p.seed = seed;
     hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
     return APE_OK;
+}
+
+int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+                     const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream) {
+    return lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0);
 }
 
 int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
@@ -585,14 +604,11 @@ int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev,
     if (N < 1) return fail(APE_ERR_INVALID_ARG, "parse_rows: N=%d must be >= 1", N);
     if (xx_dtype != APE_F32 && xx_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "parse_rows: unknown dtype selector");
     int width, I;
-    switch (kind) {
-        case APE_PARSE_WATCH_PHONE_POCKET: width = 55; I = 22; break;
-        case APE_PARSE_WATCH_ONLY: width = 28; I = 20; break;
-        case APE_PARSE_WATCH_ONLY_PHONE_MSG: width = 55; I = 20; break;
-        case APE_PARSE_WATCH_PHONE_UARM: width = 55; I = 38; break;
-        default: return fail(APE_ERR_INVALID_ARG, "parse_rows: unknown kind %d", kind);
-    }
-    hipError_t e = ape_launch_parse_rows(rows_dev, N, width, kind, xx_dev, xx_dtype, I, (hipStream_t)stream);
+    const int big_endian = (kind & APE_PARSE_BIG_ENDIAN) ? 1 : 0;
+    kind &= ~APE_PARSE_BIG_ENDIAN;
+    if (!parse_kind_dims(kind, &width, &I)) return fail(APE_ERR_INVALID_ARG, "parse_rows: unknown kind %d", kind);
+    hipError_t e = ape_launch_parse_rows(rows_dev, N, width, kind, xx_dev, xx_dtype, I, (size_t)I, 1, 0, big_endian,
+                                         (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "parse_rows launch failed: %s", hipGetErrorString(e));
     return APE_OK;
 }
@@ -616,6 +632,120 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
     if (int rc = ape_lstm_forward(m, x_dev, B, T, flags, nullptr, 0.0f, 0, y, stream)) return rc;
     // de-normalise exactly when the inputs were normalised (estimator.py:103-109: one switch)
     return ape_fk(m, y, APE_F32, B, (flags & APE_FLAG_NORMALIZE_INPUT) ? 1 : 0, est_dev, est_dtype, stream);
+}
+
+
+// ---- stream bank ------------------------------------------------------------------------------------------
+struct ape_streams {
+    ape_model* model = nullptr;
+    int S = 0, T = 0, smooth = 0;
+    float* xring = nullptr;      // [S,T,I] feature rows, slot = frame mod T
+    float* yring = nullptr;      // [S,smooth,O] model outputs, slot = step mod smooth
+    float* y_new = nullptr;      // [S,O]
+    long long frames = 0;        // rows pushed since the last reset
+    long long steps = 0;         // predictions made since the last reset
+};
+
+int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32_t smooth, ape_streams_t** out) {
+    if (!out) return fail(APE_ERR_INVALID_ARG, "streams_create: out is NULL");
+    *out = nullptr;
+    if (!m) return fail(APE_ERR_INVALID_ARG, "streams_create: NULL model");
+    if (m->dims.model_kind != APE_MODEL_LSTM) return fail(APE_ERR_UNSUPPORTED, "streams_create: LSTM models only");
+    if (m->dims.target_layout == APE_LAYOUT_NONE) return fail(APE_ERR_INVALID_ARG, "streams_create: model has no target layout");
+    if (n_streams < 1 || seq_len < 1) return fail(APE_ERR_INVALID_ARG, "streams_create: n_streams=%d seq_len=%d", n_streams, seq_len);
+    if (smooth < 1 || smooth > 64) return fail(APE_ERR_UNSUPPORTED, "streams_create: smooth %d outside 1..64", smooth);
+    ape_streams* b = new (std::nothrow) ape_streams();
+    if (!b) return fail(APE_ERR_HIP, "out of host memory");
+    b->model = m; b->S = n_streams; b->T = seq_len; b->smooth = smooth;
+    const size_t I = m->dims.input_size, O = m->dims.output_size;
+    HIP_TRY(hipSetDevice(m->dims.device));
+    hipError_t e = hipMalloc((void**)&b->xring, (size_t)n_streams * seq_len * I * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->yring, (size_t)n_streams * smooth * O * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->y_new, (size_t)n_streams * O * sizeof(float));
+    if (e != hipSuccess) {
+        ape_streams_destroy(b);
+        return fail(APE_ERR_HIP, "streams_create: allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return APE_OK;
+}
+
+int ape_streams_destroy(ape_streams_t* b) {
+    if (!b) return APE_OK;
+    if (b->xring) (void)hipFree(b->xring);
+    if (b->yring) (void)hipFree(b->yring);
+    if (b->y_new) (void)hipFree(b->y_new);
+    delete b;
+    return APE_OK;
+}
+
+int ape_streams_reset(ape_streams_t* b) {
+    if (!b) return fail(APE_ERR_INVALID_ARG, "streams_reset: NULL bank");
+    b->frames = 0; b->steps = 0;
+    return APE_OK;
+}
+
+// where the next row goes: one slot of every window, or -- first row after a reset -- all T of them
+static void next_slot(const ape_streams* b, size_t I, float** out, int* rep) {
+    const bool cold = b->frames == 0;
+    *out = b->xring + (cold ? 0 : (size_t)(b->frames % b->T) * I);
+    *rep = cold ? b->T : 1;
+}
+
+int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev, void* stream) {
+    if (!b || !rows_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_rows: NULL argument");
+    int width, I;
+    const int big_endian = (kind & APE_PARSE_BIG_ENDIAN) ? 1 : 0;
+    kind &= ~APE_PARSE_BIG_ENDIAN;
+    if (!parse_kind_dims(kind, &width, &I)) return fail(APE_ERR_INVALID_ARG, "streams_push_rows: unknown kind %d", kind);
+    if (I != b->model->dims.input_size)
+        return fail(APE_ERR_INVALID_ARG, "streams_push_rows: kind %d builds %d features, the model takes %d", kind, I,
+                    b->model->dims.input_size);
+    float* out; int rep;
+    next_slot(b, (size_t)I, &out, &rep);
+    hipError_t e = ape_launch_parse_rows(rows_dev, b->S, width, kind, out, APE_F32, I, (size_t)b->T * I, rep, (size_t)I,
+                                         big_endian, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_push_rows launch failed: %s", hipGetErrorString(e));
+    ++b->frames;
+    return APE_OK;
+}
+
+int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* stream) {
+    if (!b || !xx_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_features: NULL argument");
+    const int I = b->model->dims.input_size;
+    float* out; int rep;
+    next_slot(b, (size_t)I, &out, &rep);
+    hipError_t e = ape_launch_ring_write(xx_dev, b->S, I, out, (size_t)b->T * I, rep, (size_t)I, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_push_features launch failed: %s", hipGetErrorString(e));
+    ++b->frames;
+    return APE_OK;
+}
+
+int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream) {
+    if (!b || !msg_dev) return fail(APE_ERR_INVALID_ARG, "streams_step: NULL argument");
+    if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
+    if (flags & ~(uint32_t)APE_FLAG_NORMALIZE_INPUT) return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT is accepted");
+    if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_step: unknown dtype selector");
+    ape_model* m = b->model;
+    const bool norm = (flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    if (norm && !m->has_stats) return fail(APE_ERR_NOT_READY, "streams_step: NORMALIZE_INPUT without norm stats");
+    // oldest row of every window: the slot after the newest one
+    const int x_ring = (int)(b->frames % b->T);
+    if (int rc = lstm_forward_impl(m, b->xring, b->S, b->T, flags, nullptr, 0.0f, 0, b->y_new, stream, x_ring)) return rc;
+    StreamPostParams q{};
+    q.y_new = b->y_new; q.yring = b->yring; q.msg = msg_dev; q.tail = tail_dev;
+    q.yy_m = norm ? m->stats + 2 * m->dims.input_size : nullptr;      // one switch (estimator.py:103-109)
+    q.yy_s = norm ? m->stats + 2 * m->dims.input_size + m->dims.output_size : nullptr;
+    memcpy(q.body, m->body, sizeof(q.body));
+    q.S = b->S; q.O = m->dims.output_size; q.W = layout_est_width(m->dims.target_layout); q.layout = m->dims.target_layout;
+    q.smooth = b->smooth;
+    q.pos = (int)(b->steps % b->smooth);
+    q.cold = b->steps == 0 ? 1 : 0;
+    q.msg_dtype = out_dtype;
+    hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
+    ++b->steps;
+    return APE_OK;
 }
 
 // internal diagnostic accessor (not part of the public header): copies the 2 stamp words

@@ -27,6 +27,7 @@ struct LstmParams {
     const float* masks;                 // [L-1,B,T,H] or nullptr
     int B, T, I, O;
     int KX;                             // input width padded to a multiple of 32
+    int x_ring;                         // time step t lives in slot (t + x_ring) mod T of a window (0: linear)
     unsigned flags;
     float dropout_p;
     unsigned long long seed;
@@ -51,6 +52,7 @@ struct ClusterParams {
     unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
     const float* masks;                 // [L-1,B,T,H] injected dropout masks or nullptr
     int B, T, I, O;
+    int x_ring;                         // time step t lives in slot (t + x_ring) mod T of a window (0: linear)
     unsigned flags;
     float dropout_p;
     unsigned long long seed;
@@ -84,6 +86,21 @@ struct FkParams {
     const double* yy_s;
     double body[9];      // larm_vec, uarm_vec, uarm_orig_rh
     int N, O, W, layout;
+};
+
+// Kernel arguments of the per-stream smoothing + message kernel (stream bank).
+struct StreamPostParams {
+    const float* y_new;  // [S,O] NN targets of this step (model output, still normalised)
+    float* yring;        // [S,smooth,O] the last `smooth` predictions of every stream
+    void* msg;           // [S,25] of msg_dtype
+    void* tail;          // [S,smooth,6] of msg_dtype (hand xyz, elbow xyz of every smoothing row) or nullptr
+    const double* yy_m;  // [O] or nullptr (no de-normalisation)
+    const double* yy_s;
+    double body[9];
+    int S, O, W, layout, smooth;
+    int pos;             // ring slot of this step's prediction
+    int cold;            // 1: first step after a reset -- every slot takes this prediction (estimator.py:114-115)
+    int msg_dtype;
 };
 
 struct MsgParams {
@@ -122,7 +139,10 @@ hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, const Clu
 hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
-                                 hipStream_t stream);
+                                 size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream);
+hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size_t out_stride, int rep,
+                                 size_t rep_stride, hipStream_t stream);
+hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream);
 hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

@@ -150,6 +150,49 @@ __global__ __launch_bounds__(FK_BLOCK) void ape_fk_kernel(const FkParams p) {
     }
 }
 
+// The message from its parts (compose_msg.py:48-108): for N > 1 the sign-aligned mean quaternions `out_q`
+// (lower arm, upper arm, hips) with the origins recomputed from them (or plain origin means for the position
+// layout), for N == 1 a copy of est row `e0`.  Fixed joint layout, compose_msg.py:72-78.
+__device__ void finish_msg(int layout, int N, const double (&out_q)[3][4], const double (&orig_mean)[9],
+                           const double* e0, const double* body, double* m) {
+    const bool hips = layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+    const int qc_l = hips ? 9 : 6, qc_u = hips ? 13 : 10;
+    const Vec3 larm_vec{body[0], body[1], body[2]};
+    const Vec3 uarm_vec{body[3], body[4], body[5]};
+    const Vec3 uarm_orig_rh{body[6], body[7], body[8]};
+    Quat lq, uq, hq{1.0, 0.0, 0.0, 0.0};
+    Vec3 ho, lo, uo = uarm_orig_rh;
+    if (N > 1) {
+        lq = Quat{out_q[0][0], out_q[0][1], out_q[0][2], out_q[0][3]};
+        uq = Quat{out_q[1][0], out_q[1][1], out_q[1][2], out_q[1][3]};
+        if (hips) hq = Quat{out_q[2][0], out_q[2][1], out_q[2][2], out_q[2][3]};
+        if (layout == APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS) {        // compose_msg.py:58-61
+            uo = qrot(hq, uarm_orig_rh);
+            lo = vadd(qrot(uq, uarm_vec), uo);
+            ho = vadd(qrot(lq, larm_vec), lo);
+        } else if (layout == APE_LAYOUT_ORI_CAL_LARM_UARM) {      // compose_msg.py:92-94
+            lo = vadd(qrot(uq, uarm_vec), uarm_orig_rh);
+            ho = vadd(qrot(lq, larm_vec), lo);
+        } else {
+            ho = Vec3{orig_mean[0], orig_mean[1], orig_mean[2]};
+            lo = Vec3{orig_mean[3], orig_mean[4], orig_mean[5]};
+            uo = Vec3{orig_mean[6], orig_mean[7], orig_mean[8]};
+        }
+    } else {                                                        // single row: copy (compose_msg.py:63-68)
+        ho = Vec3{e0[0], e0[1], e0[2]};
+        lo = Vec3{e0[3], e0[4], e0[5]};
+        lq = Quat{e0[qc_l], e0[qc_l + 1], e0[qc_l + 2], e0[qc_l + 3]};
+        uq = Quat{e0[qc_u], e0[qc_u + 1], e0[qc_u + 2], e0[qc_u + 3]};
+        if (hips) {
+            uo = Vec3{e0[6], e0[7], e0[8]};
+            hq = Quat{e0[17], e0[18], e0[19], e0[20]};
+        }
+    }
+    // (hand rot duplicates the lower-arm quaternion)
+    put_q(m + 0, lq); put_v(m + 4, ho); put_q(m + 7, lq); put_v(m + 11, lo);
+    put_q(m + 14, uq); put_v(m + 18, uo); put_q(m + 21, hq);
+}
+
 // ---- message: N est rows -> 25 doubles ------------------------------------------------------
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
 #pragma unroll
@@ -206,43 +249,88 @@ __global__ __launch_bounds__(256) void ape_msg_kernel(const MsgParams p) {
         }
     }
     if (tid != 0) return;
+    finish_msg(p.layout, N, out_q, orig_mean, p.est, p.body, p.msg);
+}
 
-    const Vec3 larm_vec{p.body[0], p.body[1], p.body[2]};
-    const Vec3 uarm_vec{p.body[3], p.body[4], p.body[5]};
-    const Vec3 uarm_orig_rh{p.body[6], p.body[7], p.body[8]};
-    Quat lq, uq, hq{1.0, 0.0, 0.0, 0.0};
-    Vec3 ho, lo, uo = uarm_orig_rh;
-    const double* e0 = p.est;
-    if (N > 1) {
-        lq = Quat{out_q[0][0], out_q[0][1], out_q[0][2], out_q[0][3]};
-        uq = Quat{out_q[1][0], out_q[1][1], out_q[1][2], out_q[1][3]};
-        if (hips) hq = Quat{out_q[2][0], out_q[2][1], out_q[2][2], out_q[2][3]};
-        if (p.layout == APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS) {        // compose_msg.py:58-61
-            uo = qrot(hq, uarm_orig_rh);
-            lo = vadd(qrot(uq, uarm_vec), uo);
-            ho = vadd(qrot(lq, larm_vec), lo);
-        } else if (p.layout == APE_LAYOUT_ORI_CAL_LARM_UARM) {      // compose_msg.py:92-94
-            lo = vadd(qrot(uq, uarm_vec), uarm_orig_rh);
-            ho = vadd(qrot(lq, larm_vec), lo);
-        } else {
-            ho = Vec3{orig_mean[0], orig_mean[1], orig_mean[2]};
-            lo = Vec3{orig_mean[3], orig_mean[4], orig_mean[5]};
-            uo = Vec3{orig_mean[6], orig_mean[7], orig_mean[8]};
+// ---- stream bank: per stream, the smoothing stack + FK + message of one frame ---------------------
+// Replaces, for S streams at once, the tail of Estimator.add_xx_to_row_hist_and_make_prediction
+// (estimator.py:108-118: de-normalise, push onto the smoothing history -- padded with the newest prediction on a
+// cold start --, stack oldest..newest) and Estimator.msg_from_pred (:122-137: FK per row, message, the
+// 6-float hand/elbow tail of every row).  One wave per stream, lane i = smoothing row i (oldest first,
+// smooth <= 64); sums over rows by wave shuffles.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return __shfl(v, 0, 64);
+}
+
+template <typename TMsg>
+__global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostParams p) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= p.S) return;                                   // whole wave
+    const int N = p.smooth, O = p.O, W = p.W;
+    const bool act = lane < N;
+    const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+    double pr[20], e[21];
+#pragma unroll
+    for (int c = 0; c < 21; ++c) e[c] = 0.0;
+    if (act) {
+        // row i of the stack: the newest prediction sits in ring slot `pos`, the oldest one slot further
+        const bool fresh = p.cold || lane == N - 1;
+        const int slot = (p.pos + 1 + lane) % N;
+        const float* src = fresh ? p.y_new + (size_t)s * O : p.yring + ((size_t)s * N + slot) * O;
+        float raw[20];
+#pragma unroll
+        for (int c = 0; c < 20; ++c) raw[c] = (c < O) ? src[c] : 0.0f;
+        if (fresh) {                                        // keep it for the next frames
+            float* dst = p.yring + ((size_t)s * N + (p.cold ? lane : p.pos)) * O;
+#pragma unroll
+            for (int c = 0; c < 20; ++c)
+                if (c < O) dst[c] = raw[c];
         }
-    } else {                                                        // single row: copy (compose_msg.py:63-68)
-        ho = Vec3{e0[0], e0[1], e0[2]};
-        lo = Vec3{e0[3], e0[4], e0[5]};
-        lq = Quat{e0[qc_l], e0[qc_l + 1], e0[qc_l + 2], e0[qc_l + 3]};
-        uq = Quat{e0[qc_u], e0[qc_u + 1], e0[qc_u + 2], e0[qc_u + 3]};
-        if (hips) {
-            uo = Vec3{e0[6], e0[7], e0[8]};
-            hq = Quat{e0[17], e0[18], e0[19], e0[20]};
+#pragma unroll
+        for (int c = 0; c < 20; ++c) {
+            double v = (double)raw[c];
+            if (p.yy_m && c < O) v = v * p.yy_s[c] + p.yy_m[c];      // estimator.py:108-109
+            pr[c] = v;
+        }
+        fk_row(pr, p.body, p.layout, e);
+        if (p.tail) {                                       // estimator.py:131-137: est[i, :6] of every row
+            TMsg* t = static_cast<TMsg*>(p.tail) + ((size_t)s * N + lane) * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) t[c] = (TMsg)e[c];
         }
     }
-    // fixed joint layout, compose_msg.py:72-78 (hand rot duplicates the lower-arm quaternion)
-    double* m = p.msg;
-    put_q(m + 0, lq); put_v(m + 4, ho); put_q(m + 7, lq); put_v(m + 11, lo);
-    put_q(m + 14, uq); put_v(m + 18, uo); put_q(m + 21, hq);
+    double out_q[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    double orig_mean[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (N > 1) {
+        const double wgt = 1.0 / (double)N;
+        const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < (hips ? 3 : 2)) {
+                const double q0 = e[qc[k]], q1 = e[qc[k] + 1], q2 = e[qc[k] + 2], q3 = e[qc[k] + 3];
+                const double r0 = __shfl(q0, 0, 64), r1 = __shfl(q1, 0, 64), r2 = __shfl(q2, 0, 64), r3 = __shfl(q3, 0, 64);
+                const double d = fma(q3, r3, fma(q2, r2, fma(q1, r1, q0 * r0)));      // the sign rule of ape_msg_kernel
+                const double sg = !act ? 0.0 : ((lane > 0 && d < 0.0) ? -wgt : wgt);
+                const double a0 = wave_sum(q0 * sg), a1 = wave_sum(q1 * sg), a2 = wave_sum(q2 * sg), a3 = wave_sum(q3 * sg);
+                const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+                out_q[k][0] = a0 / nrm; out_q[k][1] = a1 / nrm; out_q[k][2] = a2 / nrm; out_q[k][3] = a3 / nrm;
+            }
+        }
+        if (p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) orig_mean[c] = wave_sum(act ? e[c] : 0.0) / (double)N;
+        }
+    }
+    if (lane != 0) return;
+    double m[25];
+    finish_msg(p.layout, N, out_q, orig_mean, e, p.body, m);
+    TMsg* dst = static_cast<TMsg*>(p.msg) + (size_t)s * 25;
+#pragma unroll
+    for (int c = 0; c < 25; ++c) dst[c] = (TMsg)m[c];
+    (void)W;
 }
 
 template <typename TIn, typename TOut>
@@ -264,5 +352,12 @@ hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipS
 
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(ape_msg_kernel, dim3(1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream) {
+    const int grid = (p.S + 3) / 4;
+    if (p.msg_dtype == APE_F32) hipLaunchKernelGGL(ape_stream_post_kernel<float>, dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ape_stream_post_kernel<double>, dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

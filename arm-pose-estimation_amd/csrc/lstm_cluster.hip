@@ -372,10 +372,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const unsigned x_estride = bcast_x ? 0u : (unsigned)(RPE * T * I * sizeof(float));
     float xr[NE];
     auto fetch_x = [&](int t) {                    // t < T (the step offset is not range-checked)
+        const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;      // windows kept as rings
 #pragma unroll
         for (int e = 0; e < NE; ++e)
             xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        x_rsrc, x_off0 + (unsigned)e * x_estride, (unsigned)(t * I * sizeof(float)), 0));
+                        x_rsrc, x_off0 + (unsigned)e * x_estride, (unsigned)(slot * I * sizeof(float)), 0));
     };
     // f64 z-score, cast f32 (estimator.py:103-104, watch_phone_pocket_nn.py:100), into LDS.  Per-thread constants
     // (every element a thread stages has the same k): mean, std and the host-rounded 1/std; (0, 1, 1) passes x

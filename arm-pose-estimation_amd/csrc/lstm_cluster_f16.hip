@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int b = row0 + (tid + 256 * e) / KX;
-            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + xk] : 0.0f;
+            xr[e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + (t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring)) * I + xk] : 0.0f;
         }
     };
     auto stage_x = [&]() {

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             const int b = row0 + row;
             float v = 0.0f;
             if (k < I && b < p.B) {
-                v = p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + k];
+                v = p.x[((size_t)(bcast_x ? 0 : b) * T + (t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring)) * I + k];
                 if (normalize) v = (float)(((double)v - p.xx_m[k]) / p.xx_s[k]);
             }
             xin[((t & 1) * MR + row) * SX + k] = v;

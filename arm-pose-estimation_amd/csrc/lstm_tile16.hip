@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                 const int row = idx / KX, k = idx - row * KX;
                 const int b = row0 + row;
                 if (k < I && b < p.B) {
-                    const float v = p.x[((size_t)(bcast_x ? 0 : b) * T + t) * I + k];
+                    const float v = p.x[((size_t)(bcast_x ? 0 : b) * T + (t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring)) * I + k];
                     // f64 z-score then round to f32: estimator.py:103-104 + watch_phone_pocket_nn.py:100
                     xr[e] = normalize ? (float)(((double)v - p.xx_m[k]) / p.xx_s[k]) : v;
                 }

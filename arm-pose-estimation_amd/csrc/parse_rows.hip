@@ -63,16 +63,24 @@ __device__ __forceinline__ int ph_sensor_col(int i) { return i < 9 ? 33 + i : 34
 
 constexpr int PR_BLOCK = 128;
 
+// Output row n goes to out[n * out_stride + j * rep_stride + 0..I) for j < rep: rep = 1 and out_stride = I is the
+// plain [N,I] matrix; the stream bank (ape_streams_push_rows) points it at one slot of every stream's window ring
+// (out_stride = T*I) or, on a cold start, at all T of them (rep = T, rep_stride = I: estimator.py:96-97).
+// big_endian: the rows are the UDP payload as received (55 or 28 big-endian float32, stream_listener/imu.py:53).
 template <typename TOut>
 __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* __restrict__ rows, int N, int width,
-                                                                  int kind, TOut* __restrict__ out, int I) {
+                                                                  int kind, TOut* __restrict__ out, int I,
+                                                                  size_t out_stride, int rep, size_t rep_stride,
+                                                                  int big_endian) {
     __shared__ float slab[PR_BLOCK * 57];       // row stride 57: odd -> conflict-free per-thread rows
     const int tid = threadIdx.x;
     const size_t r0 = (size_t)blockIdx.x * PR_BLOCK;
     const int n = (int)min((size_t)PR_BLOCK, (size_t)N - r0);
     for (int idx = tid; idx < n * width; idx += PR_BLOCK) {
         const int rr = idx / width, c = idx - rr * width;
-        slab[rr * 57 + c] = rows[r0 * width + idx];
+        float v = rows[r0 * width + idx];
+        if (big_endian) v = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, v)));
+        slab[rr * 57 + c] = v;
     }
     __syncthreads();
     if (tid >= n) return;
@@ -108,20 +116,41 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
             xx[o++] = cos(hy);
         }
     }
-    TOut* dst = out + (r0 + tid) * I;
-    for (int i = 0; i < I; ++i) dst[i] = (TOut)xx[i];
+    for (int j = 0; j < rep; ++j) {
+        TOut* dst = out + (r0 + tid) * out_stride + j * rep_stride;
+        for (int i = 0; i < I; ++i) dst[i] = (TOut)xx[i];
+    }
 }
 
 }  // namespace
 
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
-                                 hipStream_t stream) {
+                                 size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream) {
     const int grid = (N + PR_BLOCK - 1) / PR_BLOCK;
     if (out_dtype == APE_F32)
         hipLaunchKernelGGL(ape_parse_rows_kernel<float>, dim3(grid), dim3(PR_BLOCK), 0, stream, rows, N, width, kind,
-                           static_cast<float*>(out), I);
+                           static_cast<float*>(out), I, out_stride, rep, rep_stride, big_endian);
     else
         hipLaunchKernelGGL(ape_parse_rows_kernel<double>, dim3(grid), dim3(PR_BLOCK), 0, stream, rows, N, width, kind,
-                           static_cast<double*>(out), I);
+                           static_cast<double*>(out), I, out_stride, rep, rep_stride, big_endian);
+    return hipGetLastError();
+}
+
+// features computed by the caller -> window rings (same addressing as above)
+__global__ void ape_ring_write_kernel(const float* __restrict__ xx, int N, int I, float* __restrict__ out,
+                                      size_t out_stride, int rep, size_t rep_stride) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * I) return;
+    const size_t n = idx / I;
+    const int i = (int)(idx - n * I);
+    const float v = xx[idx];
+    for (int j = 0; j < rep; ++j) out[n * out_stride + j * rep_stride + i] = v;
+}
+
+hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size_t out_stride, int rep,
+                                 size_t rep_stride, hipStream_t stream) {
+    const size_t total = (size_t)N * I;
+    hipLaunchKernelGGL(ape_ring_write_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xx, N, I, out,
+                       out_stride, rep, rep_stride);
     return hipGetLastError();
 }

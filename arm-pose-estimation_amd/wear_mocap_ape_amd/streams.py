@@ -61,3 +61,65 @@ def broadcast_stats(stats: dict, I: int, O: int, device: torch.device, src: int 
     dist.broadcast(t, src=src)
     h = t.cpu().numpy()
     return {"xx_m": h[:I], "xx_s": h[I:2 * I], "yy_m": h[2 * I:2 * I + O], "yy_s": h[2 * I + O:]}
+
+
+class StreamBank:
+    """The per-frame step of many independent wearable streams with all state on the device: window rings,
+    smoothing stacks, regressor, FK and messages (C ABI ``ape_streams_*``).  For every stream it does what one
+    ``Estimator`` does per frame with one Monte-Carlo sample (estimator.py:93-137), so S estimator threads of the
+    reference become three kernel launches per frame.  Rank-local: give each rank its ``shard_range`` of streams.
+
+    ``model`` is a HIP-backed ``DropoutLSTM`` (nn_models.py) with weights, norm stats and body set."""
+
+    def __init__(self, model, n_streams: int, seq_len: int, smooth: int = 1, normalize: bool = True,
+                 dtype: torch.dtype = torch.float32):
+        from . import _hip
+        import ctypes as C
+        self._hip, self._C = _hip, C
+        if dtype not in (torch.float32, torch.float64):
+            raise UserWarning(f"StreamBank messages are float32 or float64, not {dtype}")
+        self._model, self._n, self._smooth = model, n_streams, smooth
+        self._flags = _hip.FLAG_NORMALIZE_INPUT if normalize else 0
+        self._dtype, self._sel = dtype, (_hip.F32 if dtype == torch.float32 else _hip.F64)
+        self._device = torch.device("cuda", model.device_index)
+        handle = C.c_void_p()
+        _hip.check(_hip.lib().ape_streams_create(model.handle, n_streams, seq_len, smooth, C.byref(handle)),
+                   "ape_streams_create")
+        self._handle = handle
+        self._msg = torch.empty((n_streams, 25), dtype=dtype, device=self._device)
+        self._tail = torch.empty((n_streams, smooth, 6), dtype=dtype, device=self._device)
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._hip.lib().ape_streams_destroy(h)
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def reset(self):
+        self._hip.check(self._hip.lib().ape_streams_reset(self._handle), "ape_streams_reset")
+
+    def push_rows(self, rows: torch.Tensor, kind: int, big_endian: bool = False):
+        """rows: float32 [S, 55|28] on the device -- one raw message per stream (data_types/messaging.py layouts)"""
+        width = self._hip.PARSE_SHAPES[kind][0]
+        if rows.dtype != torch.float32 or tuple(rows.shape) != (self._n, width) or not rows.is_cuda or not rows.is_contiguous():
+            raise UserWarning(f"push_rows wants a contiguous float32 [{self._n},{width}] device tensor")
+        k = kind | (self._hip.PARSE_BIG_ENDIAN if big_endian else 0)
+        self._hip.check(self._hip.lib().ape_streams_push_rows(self._handle, k, self._C.c_void_p(rows.data_ptr()),
+                                                              self._stream()), "ape_streams_push_rows")
+
+    def push_features(self, xx: torch.Tensor):
+        """xx: float32 [S, I] on the device -- what ``parse_row_to_xx`` returns, one row per stream"""
+        if xx.dtype != torch.float32 or xx.shape[0] != self._n or not xx.is_cuda or not xx.is_contiguous():
+            raise UserWarning(f"push_features wants a contiguous float32 [{self._n},I] device tensor")
+        self._hip.check(self._hip.lib().ape_streams_push_features(self._handle, self._C.c_void_p(xx.data_ptr()),
+                                                                  self._stream()), "ape_streams_push_features")
+
+    def step(self, with_tail: bool = False):
+        """-> msg [S,25] (and, with_tail, the hand/elbow xyz of every smoothing row [S,smooth,6]); the returned
+        tensors are the bank's own buffers, overwritten by the next step"""
+        tail = self._C.c_void_p(self._tail.data_ptr()) if with_tail else None
+        self._hip.check(self._hip.lib().ape_streams_step(self._handle, self._flags, self._C.c_void_p(self._msg.data_ptr()),
+                                                         tail, self._sel, self._stream()), "ape_streams_step")
+        return (self._msg, self._tail) if with_tail else self._msg

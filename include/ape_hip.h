@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 1
+#define APE_ABI_VERSION 2
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -176,12 +176,38 @@ enum {
     APE_PARSE_WATCH_PHONE_POCKET = 0,   /* 55 -> 22 */
     APE_PARSE_WATCH_ONLY = 1,           /* 28 -> 20 */
     APE_PARSE_WATCH_ONLY_PHONE_MSG = 2, /* 55 -> 20 */
-    APE_PARSE_WATCH_PHONE_UARM = 3      /* 55 -> 38 */
+    APE_PARSE_WATCH_PHONE_UARM = 3,     /* 55 -> 38 */
+    /* OR-ed into a kind: the rows are UDP payloads as received -- big-endian float32
+     * (stream_listener/imu.py:53,68-69 unpacks them with '>f'); default is native float32 */
+    APE_PARSE_BIG_ENDIAN = 0x100
 };
 int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev, int32_t xx_dtype, void* stream);
 
 /* the whole batched path in one call: x -> [normalise] -> LSTM -> last step ->
  * de-normalise -> FK.  y_dev (f32 [B,O], normalised NN targets) may be NULL. */
+/* stream bank: the per-frame step of S independent wearable streams, state resident on the device (SURVEY.md 8a-1,
+ * 8a-15, 8f-2).  replaces, for all streams at once, Estimator.add_xx_to_row_hist_and_make_prediction
+ * (estimator.py:93-120: window of the last seq_len feature rows, padded with the newest row on a cold start :96-97;
+ * z-score; model; de-normalise; smoothing stack of the last `smooth` predictions, padded the same way :112-118) and
+ * Estimator.msg_from_pred (:122-137) with one Monte-Carlo sample per stream (deterministic weights).
+ *   ape_streams_push_rows      rows_dev f32 [S,55|28] raw messages of `kind` (ape_parse_rows kinds, may carry
+ *                              APE_PARSE_BIG_ENDIAN) -> features -> next slot of every stream's window ring
+ *   ape_streams_push_features  xx_dev f32 [S,I]: the same for callers that build features themselves
+ *   ape_streams_step           one prediction per stream from the current windows:
+ *                              msg_dev  [S,25] of out_dtype, layout of compose_msg.py:72-78
+ *                              tail_dev [S,smooth,6] of out_dtype or NULL: hand and elbow xyz of every smoothing row
+ *                              (what msg_from_pred appends to the message when add_mc_samples is set and smooth > 1)
+ *                              flags: APE_FLAG_NORMALIZE_INPUT or 0
+ *   ape_streams_reset          cold start: the next row fills the whole window, the next prediction the whole stack
+ * One bank = one model handle = one HIP stream at a time.  smooth <= 64. */
+typedef struct ape_streams ape_streams_t;
+int ape_streams_create(ape_model_t* model, int32_t n_streams, int32_t seq_len, int32_t smooth, ape_streams_t** out_bank);
+int ape_streams_destroy(ape_streams_t* bank);
+int ape_streams_reset(ape_streams_t* bank);
+int ape_streams_push_rows(ape_streams_t* bank, int32_t kind, const float* rows_dev, void* stream);
+int ape_streams_push_features(ape_streams_t* bank, const float* xx_dev, void* stream);
+int ape_streams_step(ape_streams_t* bank, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream);
+
 int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
               float* y_dev, void* est_dev, int32_t est_dtype, void* stream);
 

@@ -581,3 +581,69 @@ def test_infer_windows_entry(tmp_path, monkeypatch, norm_stats):
         msg = np.asarray(est.msg_from_pred(pred, False))
         assert np.abs(msg[4:7] - rows[b, 0:3]).max() < 1e-6
         assert quat_err(msg[7:11], rows[b, 9:13]) < 1e-6
+
+
+# ---------------- stream bank: window rings + smoothing stacks + messages on the device ---------------------
+@pytest.mark.parametrize("name,S,kernel", [("pocket", 7, "auto"), ("pocket", 3, "auto"), ("pocket", 21, "tile16"),
+                                           ("watch", 9, "auto"), ("uarm", 6, "auto")])
+def test_stream_bank(golden, norm_stats, name, S, kernel):
+    """ape_streams_* (SURVEY 8a-1, 8a-15, 8f-2): S streams stepped together against (i) the reference's own
+    end-to-end trace on stream 0 and (ii) the oracle's window/smoothing bookkeeping + FK + message on all of them"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    g = golden(f"stream_trace_{name}.npz")
+    stats, body = norm_stats[name], g["body"]
+    m, sd, cfg = make_model(name, int(g["weights_seed"]), stats)
+    m.set_body(body)
+    if kernel == "tile16":
+        m.set_kernel("tile16")
+    kind = {"pocket": _hip.PARSE_WATCH_PHONE_POCKET, "watch": _hip.PARSE_WATCH_ONLY, "uarm": _hip.PARSE_WATCH_PHONE_UARM}[name]
+    rows = g["rows"].astype(np.float32)
+    F, T = len(rows), cfg["T"]
+    rng = np.random.default_rng(5)
+    order = [np.arange(F)] + [rng.permutation(F) for _ in range(S - 1)]       # stream 0 replays the golden trace
+    # features per raw row, float32 like the reference's parse_row_to_xx (the builder has its own test)
+    xx_all = torch.empty((F, cfg["I"]), dtype=torch.float32, device="cuda")
+    _hip.check(_hip.lib().ape_parse_rows(kind, C.c_void_p(torch.from_numpy(rows).cuda().data_ptr()), F,
+                                         C.c_void_p(xx_all.data_ptr()), _hip.F32, None), "ape_parse_rows")
+    torch.cuda.synchronize()
+    xx_all = xx_all.cpu().numpy()
+    for smooth in (1, 5):
+        bank = StreamBank(m, S, T, smooth=smooth, normalize=True, dtype=torch.float64)
+        predict = lambda hist: orc.lstm_forward(sd, np.asarray(hist, dtype=np.float32)[None])[:, -1, :]
+        wins = [orc.WindowOracle(T, smooth, stats, predict) for _ in range(S)]
+        worst_ref = worst_orc = worst_tail = 0.0
+        for rnd in range(2):                                  # second round after reset(): cold start again
+            for f in range(F):
+                batch = np.stack([rows[order[s][f]] for s in range(S)])
+                if f % 2:       # every other frame arrives as the UDP payload: big-endian float32
+                    dev = torch.from_numpy(batch.astype(">f4").view(np.float32)).cuda()
+                    bank.push_rows(dev, kind, big_endian=True)
+                else:
+                    bank.push_rows(torch.from_numpy(batch).cuda(), kind)
+                msg, tail = bank.step(with_tail=True)
+                msg, tail = msg.cpu().numpy(), tail.cpu().numpy()
+                assert msg.shape == (S, 25) and tail.shape == (S, smooth, 6)
+                for s in range(S):
+                    pred = wins[s].push(xx_all[order[s][f]])
+                    assert pred.shape == (smooth, cfg["O"])
+                    est = orc.arm_pose_from_targets(pred, body, cfg["layout"], "eigh")
+                    ref = orc.msg_from_est(est, body, cfg["layout"])
+                    worst_orc = max(worst_orc, float(np.abs(msg[s] - ref).max()))
+                    worst_tail = max(worst_tail, float(np.abs(tail[s] - est[:, :6]).max()))
+                    assert np.array_equal(msg[s, 0:4], msg[s, 7:11])          # hand rot duplicates larm rot
+                    if cfg["layout"] == 1:
+                        assert np.array_equal(msg[s, 21:25], [1.0, 0.0, 0.0, 0.0]) and np.array_equal(msg[s, 18:21], body[0, 6:9])
+                ref0 = g[f"msg_s{smooth}_mc1"][f]                     # the reference itself, end to end
+                worst_ref = max(worst_ref, float(np.abs(msg[0] - ref0[:25]).max()))
+                if smooth > 1:
+                    assert len(ref0) == 25 + 6 * smooth
+                    worst_ref = max(worst_ref, float(np.abs(tail[0].reshape(-1) - ref0[25:]).max()))
+            bank.reset()
+            wins = [orc.WindowOracle(T, smooth, stats, predict) for _ in range(S)]
+        m.check()
+        assert worst_orc < 5e-6 and worst_tail < 5e-6 and worst_ref < 5e-6, (smooth, worst_orc, worst_tail, worst_ref)
+    with pytest.raises(UserWarning):
+        StreamBank(m, S, T, smooth=65)
+    with pytest.raises(UserWarning):
+        StreamBank(m, S, T).step()                            # nothing pushed yet
