@@ -91,8 +91,11 @@ class StreamBank:
 
     def __del__(self):
         h, self._handle = getattr(self, "_handle", None), None
-        if h:
-            self._hip.lib().ape_streams_destroy(h)
+        try:
+            if h:
+                self._hip.lib().ape_streams_destroy(h)
+        except Exception:          # interpreter shutdown: the binding module may already be torn down
+            pass
 
     def _stream(self):
         return self._C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)

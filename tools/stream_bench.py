@@ -38,3 +38,26 @@ for mc, smooth in ((1, 1), (25, 1), (60, 5)):
         d = time.perf_counter(); tp += b - a; tm += c - b; tf += d - c
     el = time.perf_counter() - t0
     print(f"mc={mc} smooth={smooth}: {n / el:.0f} frames/s  ({el / n * 1e6:.0f} us/frame: parse {tp / n * 1e6:.0f}, window+model {tm / n * 1e6:.0f}, fk+msg {tf / n * 1e6:.0f}), msg len {len(msg)}")
+
+# ---- stream bank: S streams stepped together, all state on the device (ape_streams_*) ----------------------
+from wear_mocap_ape_amd import _hip
+from wear_mocap_ape_amd.estimate import nn_models
+from wear_mocap_ape_amd.streams import StreamBank
+from wear_mocap_ape_amd.utility import data_stats
+from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
+stats = data_stats.get_norm_stats(NNS_INPUTS.WATCH_PHONE_CAL_HIP, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)
+m = nn_models.DropoutLSTM(22, 256, 2, 14, device=0); m.load_state_dict(sd)
+m.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
+raw = torch.from_numpy(g["rows"].astype(np.float32)).cuda()
+for S, smooth in ((1, 1), (64, 5), (1024, 1), (1024, 5), (4096, 5)):
+    bank = StreamBank(m, S, 6, smooth=smooth, normalize=True, dtype=torch.float32)
+    batch = [raw[(torch.arange(S, device="cuda") + f) % len(raw)].contiguous() for f in range(8)]
+    for f in range(20):
+        bank.push_rows(batch[f % 8], _hip.PARSE_WATCH_PHONE_POCKET); bank.step(with_tail=True)
+    torch.cuda.synchronize(); n = 200; t0 = time.perf_counter()
+    for f in range(n):
+        bank.push_rows(batch[f % 8], _hip.PARSE_WATCH_PHONE_POCKET); bank.step(with_tail=True)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    m.check()
+    print(f"stream bank S={S} smooth={smooth}: {el / n * 1e6:.0f} us per frame of all streams = {S * n / el:.0f} stream-frames/s "
+          f"({S * n / el / 50:.0f} streams at 50 Hz)")
