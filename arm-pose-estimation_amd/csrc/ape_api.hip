@@ -47,9 +47,12 @@ int check_dims(const ape_dims_t* d) {
         return fail(APE_ERR_UNSUPPORTED, "input_size %d outside 1..%d", d->input_size, APE_MAX_INPUT);
     if (d->hidden_size != 128 && d->hidden_size != 256)
         return fail(APE_ERR_UNSUPPORTED, "hidden_size %d: kernels are built for 128 and 256", d->hidden_size);
-    if (d->model_kind != APE_MODEL_LSTM && d->model_kind != APE_MODEL_FF)
+    if (d->model_kind != APE_MODEL_LSTM && d->model_kind != APE_MODEL_FF && d->model_kind != APE_MODEL_IMUPOSE)
         return fail(APE_ERR_INVALID_ARG, "unknown model_kind %d", d->model_kind);
-    if (d->model_kind == APE_MODEL_LSTM && (d->num_layers < 1 || d->num_layers > APE_MAX_LAYERS))
+    if (d->model_kind == APE_MODEL_IMUPOSE && (d->hidden_size != 256 || d->num_layers != 2))
+        return fail(APE_ERR_INVALID_ARG, "ImuPoseLSTM is a fixed 2 x 256 LSTM behind a 256-wide input layer "
+                    "(nn_models.py:222-229), got hidden_size %d num_layers %d", d->hidden_size, d->num_layers);
+    if (d->model_kind != APE_MODEL_FF && (d->num_layers < 1 || d->num_layers > APE_MAX_LAYERS))
         return fail(APE_ERR_UNSUPPORTED, "num_layers %d outside 1..%d", d->num_layers, APE_MAX_LAYERS);
     if (d->model_kind == APE_MODEL_FF && (d->num_layers < 0 || d->num_layers > APE_MAX_FF_LAYERS - 1))
         return fail(APE_ERR_UNSUPPORTED, "hidden_layer_count %d outside 0..%d", d->num_layers, APE_MAX_FF_LAYERS - 1);
@@ -80,7 +83,11 @@ bool parse_kind_dims(int kind, int* width, int* I) {
 
 struct ape_model {
     ape_dims_t dims{};
-    int KX = 0;
+    int KX = 0;                    // LSTM layer-0 input width, padded to the kernels' k-blocking
+    int lstm_in = 0;               // LSTM layer-0 input width (input_size; 256 behind ImuPoseLSTM's input layer)
+    int KXpre = 0;                 // ImuPoseLSTM: padded width of the input layer's input
+    float* z_ws = nullptr;         // ImuPoseLSTM: [cap rows, 256] activations of the input layer
+    size_t z_cap = 0;
     f32x4* wpack[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     float* bias[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     float* w_out = nullptr;
@@ -129,7 +136,9 @@ size_t ape_weight_blob_floats(const ape_dims_t* d) {
     const size_t H = d->hidden_size, I = d->input_size, O = d->output_size;
     if (d->model_kind == APE_MODEL_FF) return H * I + H + (size_t)d->num_layers * (H * H + H) + O * H + O;
     size_t n = 0;
-    for (int l = 0; l < d->num_layers; ++l) n += 4 * H * (l == 0 ? I : H) + 4 * H * H + 8 * H;
+    const size_t in0 = (d->model_kind == APE_MODEL_IMUPOSE) ? H : I;          // LSTM layer 0 reads the input layer's output
+    if (d->model_kind == APE_MODEL_IMUPOSE) n += H * I + H;
+    for (int l = 0; l < d->num_layers; ++l) n += 4 * H * (l == 0 ? in0 : H) + 4 * H * H + 8 * H;
     return n + O * H + O;
 }
 
@@ -138,7 +147,9 @@ double ape_flops_per_window(const ape_dims_t* d, int32_t T) {
     const double H = d->hidden_size, I = d->input_size, O = d->output_size;
     if (d->model_kind == APE_MODEL_FF) return 2.0 * (I * H + d->num_layers * H * H + O * H);   // last step only
     double step = 0;
-    for (int l = 0; l < d->num_layers; ++l) step += 2.0 * 4.0 * H * ((l == 0 ? I : H) + H);
+    const double in0 = (d->model_kind == APE_MODEL_IMUPOSE) ? H : I;
+    if (d->model_kind == APE_MODEL_IMUPOSE) step += 2.0 * I * H;
+    for (int l = 0; l < d->num_layers; ++l) step += 2.0 * 4.0 * H * ((l == 0 ? in0 : H) + H);
     return step * T + 2.0 * O * H;
 }
 
@@ -162,7 +173,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     ape_model* m = new (std::nothrow) ape_model();
     if (!m) return fail(APE_ERR_HIP, "out of host memory");
     m->dims = *dims;
-    m->KX = padded_input(dims->input_size);
+    const bool imupose = dims->model_kind == APE_MODEL_IMUPOSE;
+    m->lstm_in = imupose ? dims->hidden_size : dims->input_size;
+    m->KX = padded_input(m->lstm_in);
+    m->KXpre = padded_input(dims->input_size);
     const double def_body[9] = {-0.22, 0, 0, -0.26, 0, 0, -0.1704612, 0.4309841, -0.00670862};  // bone_map.py:42-45
     memcpy(m->body, def_body, sizeof(def_body));
     const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, I = dims->input_size;
@@ -193,16 +207,22 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
+    if (imupose) {       // input layer: the MLP kernel's packing and launch, with the activation as its result
+        if (e == hipSuccess) e = hipMalloc((void**)&m->ff_wpack[0], (size_t)m->KXpre * H * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->ff_bias[0], H * sizeof(float));
+        if (e == hipSuccess) e = ape_prepare_lstm_tile16_wide(ape_lstm_tile16_smem_bytes(H, L, m->KX, O, false));
+    }
     // the kernel may carve its largest LDS layout (with dropout buffers)
     const size_t smem = ape_lstm_tile16_smem_bytes(H, L, m->KX, O, true);
-    if (e == hipSuccess && smem <= 160 * 1024) e = ape_prepare_lstm_tile16(H, L, smem);
+    if (imupose) {}
+    else if (e == hipSuccess && smem <= 160 * 1024) e = ape_prepare_lstm_tile16(H, L, smem);
     else if (e == hipSuccess) e = ape_prepare_lstm_tile16(H, L, ape_lstm_tile16_smem_bytes(H, L, m->KX, O, false));
     if (e != hipSuccess) {
         ape_model_destroy(m);
         return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
     char nm[64];
-    snprintf(nm, sizeof(nm), "ape_lstm_tile16<%d, %d>", H, L);
+    snprintf(nm, sizeof(nm), "ape_lstm_tile16<%d, %d, %d>", H, L, imupose ? 16 : 4);
     m->kernel_name = nm;
     snprintf(nm, sizeof(nm), "ape_lstm_cluster<%d, %d, %d", H, L, m->KX);
     m->cluster_name = nm;
@@ -246,6 +266,7 @@ int ape_model_destroy(ape_model_t* m) {
     if (m->b_out) (void)hipFree(m->b_out);
     if (m->stats) (void)hipFree(m->stats);
     if (m->y_ws) (void)hipFree(m->y_ws);
+    if (m->z_ws) (void)hipFree(m->z_ws);
     for (int l = 0; l < APE_MAX_LAYERS; ++l)
         if (m->wcl[l]) (void)hipFree(m->wcl[l]);
     for (int l = 0; l < APE_MAX_LAYERS; ++l)
@@ -281,11 +302,12 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
     const int H = m->dims.hidden_size, L = m->dims.num_layers, O = m->dims.output_size, I = m->dims.input_size;
     const int UB = H / 64, NT = 4 * UB;
     const float* cur = host.data();
-    if (m->dims.model_kind == APE_MODEL_FF) {
+    if (m->dims.model_kind == APE_MODEL_FF || m->dims.model_kind == APE_MODEL_IMUPOSE) {
         // per layer [wave 4][k-block q][tile n][lane][4]: lane holds W[w*H/4 + n*16 + (lane&15)][16q + 4(lane>>4) + j]
         const int NTF = H / 64;
-        for (int j = 0; j <= L; ++j) {
-            const int in_j = (j == 0) ? I : H, K = (j == 0) ? m->KX : H, Q = K / 16;
+        const bool pre_only = m->dims.model_kind == APE_MODEL_IMUPOSE;      // just the input layer, then the LSTM below
+        for (int j = 0; j <= (pre_only ? 0 : L); ++j) {
+            const int in_j = (j == 0) ? I : H, K = (j == 0) ? (pre_only ? m->KXpre : m->KX) : H, Q = K / 16;
             const float* wj = cur;  cur += (size_t)H * in_j;
             const float* bj = cur;  cur += H;
             std::vector<float> packed((size_t)K * H);
@@ -303,14 +325,16 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
             HIP_TRY(hipMemcpy(m->ff_wpack[j], packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(m->ff_bias[j], bj, H * sizeof(float), hipMemcpyHostToDevice));
         }
-        HIP_TRY(hipMemcpy(m->w_out, cur, (size_t)O * H * sizeof(float), hipMemcpyHostToDevice));
-        cur += (size_t)O * H;
-        HIP_TRY(hipMemcpy(m->b_out, cur, O * sizeof(float), hipMemcpyHostToDevice));
-        m->has_weights = true;
-        return APE_OK;
+        if (!pre_only) {
+            HIP_TRY(hipMemcpy(m->w_out, cur, (size_t)O * H * sizeof(float), hipMemcpyHostToDevice));
+            cur += (size_t)O * H;
+            HIP_TRY(hipMemcpy(m->b_out, cur, O * sizeof(float), hipMemcpyHostToDevice));
+            m->has_weights = true;
+            return APE_OK;
+        }
     }
     for (int l = 0; l < L; ++l) {
-        const int in_l = (l == 0) ? I : H;
+        const int in_l = (l == 0) ? m->lstm_in : H;
         const int KXl = (l == 0) ? m->KX : H;
         const int Q = (KXl + H) / 16;
         const float* w_ih = cur;  cur += (size_t)4 * H * in_l;
@@ -438,9 +462,37 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         q.N = all ? B * T : B;
         q.I = m->dims.input_size; q.O = m->dims.output_size; q.KX = m->KX; q.n_hidden = L;
         q.flags = flags; q.dropout_p = dropout_p; q.seed = seed;
+        q.neg_slope = 0.01f;                      // torch's leaky_relu default (nn_models.py:347,349)
         hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "mlp kernel launch failed: %s", hipGetErrorString(e));
         return APE_OK;
+    }
+    const float* lstm_x = x_dev;
+    if (m->dims.model_kind == APE_MODEL_IMUPOSE) {
+        // relu(input_layer(x)) for every row of every window (nn_models.py:242), then the LSTM reads those 256 columns
+        if (drop) return fail(APE_ERR_UNSUPPORTED, "lstm_forward: ImuPoseLSTM has no Monte-Carlo dropout mode "
+                              "(its monte_carlo_predictions is the plain forward, nn_models.py:246-251)");
+        const size_t rows = (size_t)((flags & APE_FLAG_BROADCAST_X) ? 1 : B) * T;
+        if (rows > m->z_cap) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing((hipStream_t)stream, &st);
+            if (st != hipStreamCaptureStatusNone)
+                return fail(APE_ERR_CAPACITY, "lstm_forward: %zu input-layer rows exceed the workspace during stream capture", rows);
+            if (m->z_ws) { HIP_TRY(hipFree(m->z_ws)); m->z_ws = nullptr; m->z_cap = 0; }
+            HIP_TRY(hipMalloc((void**)&m->z_ws, rows * H * sizeof(float)));
+            m->z_cap = rows;
+        }
+        MlpParams q{};
+        q.x = x_dev; q.y = nullptr; q.hidden_out = m->z_ws;
+        q.wpack[0] = m->ff_wpack[0]; q.bias[0] = m->ff_bias[0];
+        q.xx_m = m->stats; q.xx_s = m->stats + m->dims.input_size;
+        q.row_stride = (size_t)m->dims.input_size; q.row_offset = 0;
+        q.N = (int)rows; q.I = m->dims.input_size; q.O = m->dims.output_size; q.KX = m->KXpre; q.n_hidden = 0;
+        q.flags = flags & APE_FLAG_NORMALIZE_INPUT; q.neg_slope = 0.0f;
+        hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(APE_ERR_HIP, "input-layer kernel launch failed: %s", hipGetErrorString(e));
+        lstm_x = m->z_ws;
+        flags &= ~(uint32_t)APE_FLAG_NORMALIZE_INPUT;        // done in front of the input layer
     }
     if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
@@ -503,7 +555,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     }
 
     LstmParams p{};
-    p.x = x_dev;
+    p.x = lstm_x;
     p.y = y_dev;
     for (int l = 0; l < L; ++l) { p.wpack[l] = m->wpack[l]; p.bias[l] = m->bias[l]; }
     p.w_out = m->w_out;
@@ -511,7 +563,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     p.xx_m = m->stats;
     p.xx_s = m->stats + m->dims.input_size;
     p.masks = masks_dev;
-    p.B = B; p.T = T; p.I = m->dims.input_size; p.O = m->dims.output_size; p.KX = m->KX;
+    p.B = B; p.T = T; p.I = m->lstm_in; p.O = m->dims.output_size; p.KX = m->KX;
     p.x_ring = x_ring;
     p.flags = flags;
     p.dropout_p = dropout_p;

@@ -72,6 +72,8 @@ struct MlpParams {
     const double* xx_m;
     const double* xx_s;
     const float* mask;                     // [N,H] dropout mask in front of the output layer, or nullptr
+    float* hidden_out;                     // [N,H]: write the last hidden activation here INSTEAD of the output layer
+    float neg_slope;                       // 0.01 leaky_relu (DropoutFF), 0 relu (ImuPoseLSTM's input layer)
     size_t row_stride, row_offset;
     int N, I, O, KX, n_hidden;
     unsigned flags;
@@ -131,6 +133,7 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream);
 size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout);
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
+hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes);
 bool ape_cluster_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,

@@ -47,7 +47,7 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[NT], const f32x4 a, cons
     }
 }
 
-template <int H, int L>
+template <int H, int L, int XE>
 __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     constexpr int UB = H / 64;        // 16-unit blocks per wave
     constexpr int NT = 4 * UB;        // accumulator tiles per wave (4 gates x UB)
@@ -84,11 +84,17 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     }
 
     // ---- x staging: thread owns up to 4 (row,k) elements of the [16][KX] step slab -----------
-    const int n_el = KX / 16;         // 2 (KX=32) or 4 (KX=64)
-    float xr[4];
+    const int n_el = KX / 16;         // 2 (KX=32), 4 (KX=64) or 16 (KX=256: XE=16 instantiation, ImuPoseLSTM)
+    // (the wide instantiation copies its 16 elements per thread straight to LDS in store_x -- one exposed
+    //  round trip per step, ~4 % of a step -- instead of holding 16 more registers across the MFMAs)
+    constexpr int XR = (XE > 4) ? 1 : XE;
+    float xr[XR];
+    int x_step = 0;
     auto fetch_x = [&](int t) {
+        x_step = t;
+        if (XE > 4) return;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < XR; ++e) {
             xr[e] = 0.0f;
             if (e < n_el) {
                 const int idx = tid + 256 * e;
@@ -103,8 +109,21 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
         }
     };
     auto store_x = [&](int buf) {
+        if (XE > 4) {                 // wide: rows are full (I == KX), already normalised by the layer in front
+            const int slot = (x_step + p.x_ring >= T) ? x_step + p.x_ring - T : x_step + p.x_ring;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < XE / 4; ++e) {
+                const int idx = (tid + 256 * e) * 4;
+                const int row = idx / KX, k = idx - row * KX;
+                const int b = row0 + row;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (b < p.B) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(bcast_x ? 0 : b) * T + slot) * I + k);
+                *reinterpret_cast<f32x4*>(xin + (buf * APE_TILE_ROWS + row) * SX + k) = v;
+            }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < XR; ++e) {
             if (e < n_el) {
                 const int idx = tid + 256 * e;
                 const int row = idx / KX, k = idx - row * KX;
@@ -238,18 +257,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     }
 }
 
-template <int H, int L>
+template <int H, int L, int XE = 4>
 hipError_t launch(const LstmParams& p, hipStream_t stream) {
     const bool drop = (p.flags & (APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) != 0 && L > 1;
     const size_t smem = ape_lstm_tile16_smem_bytes(H, L, p.KX, p.O, drop);
     const int grid = (p.B + APE_TILE_ROWS - 1) / APE_TILE_ROWS;
-    hipLaunchKernelGGL((ape_lstm_tile16<H, L>), dim3(grid), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((ape_lstm_tile16<H, L, XE>), dim3(grid), dim3(256), smem, stream, p);
     return hipGetLastError();
 }
 
-template <int H, int L>
+template <int H, int L, int XE = 4>
 hipError_t prepare(size_t smem) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_tile16<H, L>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_tile16<H, L, XE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
@@ -278,4 +297,12 @@ size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout) {
 // path, which must stay graph-capturable)
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes) { APE_DISPATCH(prepare, smem_bytes) }
 
-hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream) { APE_DISPATCH(launch, p, stream) }
+hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream) {
+    if (p.KX > 64) {      // wide layer-0 input (ImuPoseLSTM: the 256 activations of its input layer), H=256 L=2 only
+        if (H == 256 && L == 2 && p.KX == 256) return launch<256, 2, 16>(p, stream);
+        return hipErrorInvalidValue;
+    }
+    APE_DISPATCH(launch, p, stream)
+}
+
+hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes) { return prepare<256, 2, 16>(smem_bytes); }

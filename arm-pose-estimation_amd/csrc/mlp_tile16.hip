@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_tile16(const MlpParams p) {
             for (int i = 0; i < 4; ++i) {
                 const int row = 4 * g + i;
                 float v = acc[n][i];
-                v = (v > 0.0f) ? v : 0.01f * v;
+                v = (v > 0.0f) ? v : p.neg_slope * v;
                 if (last && (drop_masks || drop_philox)) {
                     float m;
                     if (drop_masks) {
@@ -113,13 +113,15 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_tile16(const MlpParams p) {
                     v *= m;
                 }
                 dst[row * SH + col] = v;
+                // ImuPoseLSTM's input layer (nn_models.py:242): the activation itself is the result
+                if (last && p.hidden_out != nullptr && row0 + row < p.N) p.hidden_out[(size_t)(row0 + row) * H + col] = v;
             }
         }
         __syncthreads();
     }
 
     // ---- output layer: one (row, target) dot product per thread ---------------------------------------------------
-    if (tid < APE_TILE_ROWS * p.O) {
+    if (p.hidden_out == nullptr && tid < APE_TILE_ROWS * p.O) {
         const int row = tid / p.O, o = tid - row * p.O;
         const int n = row0 + row;
         if (n < p.N) {

@@ -50,6 +50,8 @@ class DropoutLSTM:
     ``n_samples`` times and runs it with inter-layer dropout (nn_models.py:191-207).  Inputs may
     live on the host or on the model's GPU; the result is returned where the input was."""
 
+    _MODEL_KIND = _hip.MODEL_LSTM
+
     def __init__(self, input_size, hidden_layer_size, hidden_layer_count, output_size, dropout=0.2,
                  device: int = None, target_layout: int = None):
         self.input_size = int(input_size)
@@ -67,7 +69,7 @@ class DropoutLSTM:
         if target_layout is None:
             target_layout = _LAYOUT_FOR_OUTPUTS.get(self.output_size, _hip.LAYOUT_NONE)
         self.target_layout = target_layout
-        self._create_handle(_hip.MODEL_LSTM)
+        self._create_handle(self._MODEL_KIND)
 
     def _create_handle(self, model_kind: int):
         import ctypes as C
@@ -97,15 +99,7 @@ class DropoutLSTM:
     # ---- weights ------------------------------------------------------------------------------
     def load_state_dict(self, state_dict):
         """same keys and shapes as the reference module's state_dict."""
-        H, I, O = self.hidden_layer_size, self.input_size, self.output_size
-        want = OrderedDict()
-        for k in range(self.hidden_layer_count):
-            want[f"lstm.weight_ih_l{k}"] = (4 * H, I if k == 0 else H)
-            want[f"lstm.weight_hh_l{k}"] = (4 * H, H)
-            want[f"lstm.bias_ih_l{k}"] = (4 * H,)
-            want[f"lstm.bias_hh_l{k}"] = (4 * H,)
-        want["output_layer.weight"] = (O, H)
-        want["output_layer.bias"] = (O,)
+        want = self._wanted_shapes()
         missing = [k for k in want if k not in state_dict]
         extra = [k for k in state_dict if k not in want]
         if missing or extra:
@@ -123,6 +117,19 @@ class DropoutLSTM:
         self.load_weight_blob(blob)
         self._state = kept
         return self
+
+    def _wanted_shapes(self, lstm_in: int = None) -> OrderedDict:
+        H, O = self.hidden_layer_size, self.output_size
+        I = self.input_size if lstm_in is None else lstm_in
+        want = OrderedDict()
+        for k in range(self.hidden_layer_count):
+            want[f"lstm.weight_ih_l{k}"] = (4 * H, I if k == 0 else H)
+            want[f"lstm.weight_hh_l{k}"] = (4 * H, H)
+            want[f"lstm.bias_ih_l{k}"] = (4 * H,)
+            want[f"lstm.bias_hh_l{k}"] = (4 * H,)
+        want["output_layer.weight"] = (O, H)
+        want["output_layer.bias"] = (O,)
+        return want
 
     def load_weight_blob(self, blob):
         """flat float32 blob in state_dict order: a host numpy array or a CUDA tensor (e.g. the
@@ -360,6 +367,41 @@ class DropoutFF(DropoutLSTM):
         return self
 
 
+class ImuPoseLSTM(DropoutLSTM):
+    """HIP-backed ``ImuPoseLSTM`` (``estimate/nn_models.py:210-249``): ``Linear(I,256)`` + ReLU in front of a 2 x 256
+    LSTM and ``Linear(256,O)``.  Like the reference it keeps, and ignores, ``hidden_layer_size`` /
+    ``hidden_layer_count`` (:217-229); its ``monte_carlo_predictions`` is the plain forward of the window it is
+    given -- no repeat, no dropout (:246-251)."""
+    _MODEL_KIND = _hip.MODEL_IMUPOSE
+
+    def __init__(self, input_size, hidden_layer_size, hidden_layer_count, output_size, dropout=0.2,
+                 device: int = None, target_layout: int = None):
+        super().__init__(input_size, 256, 2, output_size, dropout, device, target_layout)
+
+    def _wanted_shapes(self, lstm_in: int = None) -> OrderedDict:
+        want = OrderedDict()
+        want["input_layer.weight"], want["input_layer.bias"] = (256, self.input_size), (256,)
+        want.update(super()._wanted_shapes(lstm_in=256))
+        return want
+
+    def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False, rows=None):
+        if hs is not None:
+            raise UserWarning("an initial (h_0, c_0) is not supported: the path always starts from zeros")
+        if masks is not None:
+            raise UserWarning("ImuPoseLSTM has no dropout mode")
+        return self._run(x, _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0, last_step_only=last_step_only, rows=rows)
+
+    __call__ = forward
+
+    def monte_carlo_predictions(self, n_samples: int, x, hs=None, last_step_only=False):
+        return self.forward(x, None, last_step_only=last_step_only)
+
+    def set_precision(self, precision: str = "f32"):
+        if precision != "f32":
+            raise UserWarning("ImuPoseLSTM is float32 only")
+        return self
+
+
 def load_deployed_model_from_hash(hash_str: str):
     """``hash`` -> ``(model, params)`` exactly like nn_models.py:373-415: reads
     ``<deploy>/nn/<hash>/results.json`` and ``checkpoint.pt`` (a ``(model_state, optimizer_state)``
@@ -378,9 +420,9 @@ def load_deployed_model_from_hash(hash_str: str):
         params["model"] = DropoutLSTM
     elif params["model"] == "DropoutFF":
         params["model"] = DropoutFF
+    elif params["model"] == "ImuPoseLSTM":
+        params["model"] = ImuPoseLSTM
     else:
-        # ImuPoseLSTM is dispatchable upstream too (nn_models.py:397-398) but no deployed checkpoint uses it;
-        # it stays on the "next" list
         raise UserWarning(f"{params['model']} not handled")
     nn_model = params["model"](input_size=len(params["x_inputs_v"]), hidden_layer_size=params["hidden_layer_size"],
                                hidden_layer_count=params["hidden_layer_count"],

@@ -57,7 +57,7 @@ def synthetic_windows(stats, lo, hi, T, I):
     return out
 
 
-def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0):
+def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0, gpu_y=None, gpu_est=None):
     """reference-equivalent CPU path of the oracle on this host: torch-CPU nn.LSTM + Linear (the
     reference's third-party arithmetic) + float64 FK with one 4x4 eigh per quaternion.  The thread
     count is chosen by a short probe (torch's default of one thread per core is far from the best
@@ -77,13 +77,26 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0):
     torch.set_num_threads(threads)
     done, t0 = 0, time.perf_counter()
     while True:
-        orc.infer_windows(sd, stats, body, layout, x, route="eigh", use_torch=True)
+        y_ref, est_ref = orc.infer_windows(sd, stats, body, layout, x, route="eigh", use_torch=True)
         done += x.shape[0]
         el = time.perf_counter() - t0
         if el >= budget_s or done >= 64 * x.shape[0]:
             break
     torch.set_num_threads(default_threads)
-    return {"value": done / el, "unit": "windows/s", "cores": threads, "kind": "port",
+    # the same windows went through the HIP path in the timed region: report the error of what was timed
+    parity = None
+    if gpu_y is not None:
+        dy = float(np.abs(gpu_y - y_ref).max())
+        e = gpu_est.astype(np.float64)
+        worst_q = 0.0
+        for c in (9, 13, 17):              # quaternions: strict, sign-aware only where the reference w ~ 0
+            a, b = e[:, c:c + 4], est_ref[:, c:c + 4]
+            dp, dm = np.abs(a - b).max(axis=1), np.abs(a + b).max(axis=1)
+            worst_q = max(worst_q, float(np.where(np.abs(b[:, 0]) < 1e-4, np.minimum(dp, dm), dp).max()))
+        parity = {"windows": int(x.shape[0]), "max_abs_nn_targets": dy, "max_abs_quaternions": worst_q,
+                  "max_abs_origins": float(np.abs(e[:, :9] - est_ref[:, :9]).max()),
+                  "budget": "1e-4 targets / 5e-5 quaternions and origins at T=64 (SURVEY 8d); est rows stored as f32"}
+    return {"parity": parity, "value": done / el, "unit": "windows/s", "cores": threads, "kind": "port",
             "sample": f"{done} windows (B={x.shape[0]}, T={x.shape[1]}) in {el:.1f} s: oracle torch-CPU nn.LSTM+Linear "
                       f"+ per-row eigh FK; best of thread probe {{{', '.join(f'{k}: {v:.0f}/s' for k, v in probe.items())}}} "
                       f"on {os.cpu_count()} cpus"}
@@ -290,7 +303,10 @@ def main():
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
                                                                          NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(sd, stats, orc.DEFAULT_BODY, POCKET["layout"], x_host)
+                cb = cpu_baseline(sd, stats, orc.DEFAULT_BODY, POCKET["layout"], x_host, gpu_y=y.cpu().numpy(),
+                                  gpu_est=est.cpu().numpy())
+                out["parity_vs_cpu_reference"] = cb.pop("parity")
+                out["cpu_baseline"] = cb
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -93,7 +93,9 @@ typedef struct ape_model ape_model_t;
 /* regressor architectures the reference loader dispatches (nn_models.py:393-400) */
 enum {
     APE_MODEL_LSTM = 0,   /* DropoutLSTM  nn_models.py:160-207 */
-    APE_MODEL_FF = 1      /* DropoutFF    nn_models.py:313-370 : Linear, n x Linear (leaky_relu), dropout, Linear */
+    APE_MODEL_FF = 1,     /* DropoutFF    nn_models.py:313-370 : Linear, n x Linear (leaky_relu), dropout, Linear */
+    APE_MODEL_IMUPOSE = 2 /* ImuPoseLSTM  nn_models.py:210-249 : Linear(I,256)+ReLU, fixed 2 x 256 LSTM, Linear(256,O);
+                             hidden_size must be 256 and num_layers 2 (the reference ignores its ctor arguments) */
 };
 
 typedef struct ape_dims {
@@ -127,6 +129,8 @@ int ape_model_reserve(ape_model_t* model, int32_t max_batch);
  *   then output_layer.weight [O,H], output_layer.bias [O].
  * APE_MODEL_FF: _input_layer.weight [H,I], .bias [H]; _hidden_layers.{k}.weight [H,H], .bias [H] for k in
  *   0..hidden_layer_count-1; _output_layer.weight [O,H], .bias [O]   (state_dict order of DropoutFF).
+ * APE_MODEL_IMUPOSE: input_layer.weight [256,I], .bias [256]; then the APE_MODEL_LSTM tensors with a 256-wide
+ *   layer-0 input (state_dict order of ImuPoseLSTM).
  * `blob` may be host or device memory (e.g. the buffer an RCCL broadcast just filled);
  * `n_floats` must equal ape_weight_blob_floats(dims).  Synchronous; init-time only. */
 int ape_model_load_weights(ape_model_t* model, const float* blob, size_t n_floats);
@@ -149,7 +153,9 @@ int ape_model_set_body(ape_model_t* model, const double body9[9]);
  *   y_dev      f32 [B,O] or [B,T,O] (APE_FLAG_ALL_STEPS): normalised NN targets
  * APE_MODEL_FF (DropoutFF.forward / monte_carlo_predictions, nn_models.py:340-370): the MLP is applied to the
  *   last step of every window (or to all B*T rows with APE_FLAG_ALL_STEPS); masks_dev is f32 [rows,H], the
- *   dropout in front of the output layer. */
+ *   dropout in front of the output layer.
+ * APE_MODEL_IMUPOSE (ImuPoseLSTM.forward, nn_models.py:236-244): as APE_MODEL_LSTM, no dropout modes (its
+ *   monte_carlo_predictions is the plain forward, :246-251). */
 int ape_lstm_forward(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                      const float* masks_dev, float dropout_p, uint64_t seed,
                      float* y_dev, void* stream);

@@ -181,6 +181,33 @@ def ff_forward(sd: Dict[str, np.ndarray], x: np.ndarray, mask: Optional[np.ndarr
     return a @ sd["_output_layer.weight"].T + sd["_output_layer.bias"]
 
 
+# --------------------------------------------------------------------------------------
+# ImuPoseLSTM (nn_models.py:210-249): Linear(I,256) + ReLU in front of a fixed 2 x 256 LSTM + Linear(256,O)
+# --------------------------------------------------------------------------------------
+IMUPOSE_HIDDEN, IMUPOSE_LAYERS = 256, 2        # hard-wired by the reference whatever the ctor is given (:222-229)
+
+
+def imupose_state_dict_keys() -> List[str]:
+    return ["input_layer.weight", "input_layer.bias"] + state_dict_keys(IMUPOSE_LAYERS)
+
+
+def make_imupose_state_dict(I: int, O: int, seed: int) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    b_in = 1.0 / math.sqrt(I)
+    sd = {"input_layer.weight": rng.uniform(-b_in, b_in, size=(IMUPOSE_HIDDEN, I)).astype(np.float32),
+          "input_layer.bias": rng.uniform(-b_in, b_in, size=(IMUPOSE_HIDDEN,)).astype(np.float32)}
+    sd.update(make_state_dict(IMUPOSE_HIDDEN, IMUPOSE_HIDDEN, IMUPOSE_LAYERS, O, seed + 1000))
+    return {k: sd[k] for k in imupose_state_dict_keys()}
+
+
+def imupose_forward(sd: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray:
+    """ImuPoseLSTM.forward (nn_models.py:236-244): x [B,T,I] -> [B,T,O]; its monte_carlo_predictions (:246-251) is
+    the same forward, without the repeat of DropoutLSTM"""
+    a = np.asarray(x, dtype=np.float32)
+    z = np.maximum(a @ sd["input_layer.weight"].T + sd["input_layer.bias"], np.float32(0.0)).astype(np.float32)
+    return lstm_forward({k: v for k, v in sd.items() if not k.startswith("input_layer.")}, z)
+
+
 def torch_reference_model(sd: Dict[str, np.ndarray], dropout: float = 0.2):
     """The third-party modules the reference instantiates (nn_models.py:169-174):
     ``torch.nn.LSTM(I,H,L,batch_first=True,dropout)`` + ``torch.nn.Linear(H,O)``, loaded

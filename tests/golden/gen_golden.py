@@ -180,6 +180,29 @@ def gen_ff():
 
 
 # ---- 3. quaternion primitive goldens ------------------------------------------------------
+def gen_imupose():
+    """ImuPoseLSTM (nn_models.py:210-249), the third architecture the loader dispatches (:397-398), eval mode"""
+    blob = {}
+    for tag, (I, O) in {"pocket_like": (22, 14), "uarm_like": (38, 12)}.items():
+        for seed in (0, 1):
+            sd = orc.make_imupose_state_dict(I, O, seed)
+            model = ref_nn.ImuPoseLSTM(input_size=I, hidden_layer_size=128, hidden_layer_count=3, output_size=O, dropout=0.2)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            model.eval()
+            blob[f"digest_{tag}_seed{seed}"] = orc.state_dict_digest(sd)
+            rng = np.random.default_rng(300 + seed)
+            for (B, T) in ((1, 6), (21, 6), (3, 64), (2, 1)):
+                x = rng.normal(size=(B, T, I)).astype(np.float32)
+                with torch.no_grad():
+                    y = model(torch.from_numpy(x)).numpy()
+                    ymc = model.monte_carlo_predictions(5, torch.from_numpy(x[:1])).numpy()
+                blob[f"x_{tag}_seed{seed}_B{B}_T{T}"] = x
+                blob[f"y_{tag}_seed{seed}_B{B}_T{T}"] = y
+                blob[f"ymc_{tag}_seed{seed}_B{B}_T{T}"] = ymc       # [1,T,O]: no repeat, no dropout (:246-251)
+        blob["dims_" + tag] = np.array([I, O])
+    np.savez_compressed(OUT / "imupose.npz", **blob)
+
+
 def edge_six_drr(rng, n):
     """6D rows that stress the Gram-Schmidt / quaternion branches."""
     rows = []
@@ -361,10 +384,15 @@ def gen_bookkeeping():
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if sys.argv[1:] == ["imupose"]:          # add this one fixture without rewriting the others
+        gen_imupose()
+        print("wrote", OUT / "imupose.npz")
+        return
     stats = export_stats_and_configs()
     gen_bookkeeping()
     gen_lstm(stats)
     gen_ff()
+    gen_imupose()
     gen_quat_ops()
     gen_fk(stats)
     gen_stream_traces()

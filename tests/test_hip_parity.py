@@ -140,6 +140,53 @@ def test_mlp_regressor_vs_reference_golden(golden):
             assert a.shape == (50, O) and np.array_equal(a, b) and a.std(axis=0).min() > 1e-5 and m._do.training
 
 
+def test_imupose_lstm_vs_reference_golden(golden, norm_stats, tmp_path, monkeypatch):
+    """ImuPoseLSTM (nn_models.py:210-249: Linear+ReLU, fixed 2 x 256 LSTM, Linear) against the reference module's
+    outputs; loader dispatch; fused normalisation; stream bank on top of it"""
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate import nn_models
+    g = golden("imupose.npz")
+    for tag in ("pocket_like", "uarm_like"):
+        I, O = (int(v) for v in g["dims_" + tag])
+        for seed in (0, 1):
+            sd = orc.make_imupose_state_dict(I, O, seed)
+            m = nn_models.ImuPoseLSTM(I, 128, 3, O, device=0)             # size arguments kept but ignored (:217-229)
+            m.load_state_dict(sd)
+            assert list(m.state_dict().keys()) == orc.imupose_state_dict_keys()
+            for (B, T) in ((1, 6), (21, 6), (3, 64), (2, 1)):
+                key = f"{tag}_seed{seed}_B{B}_T{T}"
+                x = torch.from_numpy(g["x_" + key])
+                y = m(x).numpy()
+                assert y.shape == g["y_" + key].shape == (B, T, O)
+                assert np.abs(y - g["y_" + key]).max() < TOL_Y_SHORT, (key, float(np.abs(y - g["y_" + key]).max()))
+                assert np.array_equal(m(x, last_step_only=True).numpy()[:, 0], y[:, -1])
+                ymc = m.monte_carlo_predictions(5, x[:1]).numpy()          # plain forward: no repeat, no dropout
+                assert ymc.shape == (1, T, O) and np.abs(ymc - g["ymc_" + key]).max() < TOL_Y_SHORT
+            m.check()
+    # a ragged bigger batch vs the oracle, raw features with the z-score fused in front of the input layer
+    stats = norm_stats["pocket"]
+    sd = orc.make_imupose_state_dict(22, 14, 7)
+    m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0)
+    m.load_state_dict(sd)
+    m.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
+    raw = _synthetic_windows(stats, 77, 6, 22, 3)
+    xn = ((raw.astype(np.float64) - stats["xx_m"]) / stats["xx_s"]).astype(np.float32)
+    y = m(torch.from_numpy(raw), normalize_input=True, last_step_only=True).numpy()[:, 0]
+    assert np.abs(y - orc.imupose_forward(sd, xn)[:, -1]).max() < TOL_Y_SHORT
+    with pytest.raises(UserWarning):
+        m(torch.from_numpy(raw), masks=torch.zeros((1, 77, 6, 256)))
+    # loader dispatch (nn_models.py:397-398)
+    d = tmp_path / "nn" / "imuhash"
+    d.mkdir(parents=True)
+    (d / "results.json").write_text(json.dumps({"model": "ImuPoseLSTM", "hidden_layer_size": 128, "hidden_layer_count": 3,
+                                                "dropout": 0.2, "x_inputs_v": ["f"] * 22, "y_targets_v": ["t"] * 14}))
+    torch.save(({k: torch.from_numpy(v) for k, v in sd.items()}, {}), d / "checkpoint.pt")
+    monkeypatch.setitem(config.PATHS, "deploy", tmp_path)
+    model, params = nn_models.load_deployed_model_from_hash("imuhash")
+    assert isinstance(model, nn_models.ImuPoseLSTM) and params["model"] is nn_models.ImuPoseLSTM
+    assert np.abs(model(torch.from_numpy(xn)).numpy() - orc.imupose_forward(sd, xn)).max() < TOL_Y_SHORT
+
+
 def test_loader_dispatches_dropout_ff(tmp_path, monkeypatch):
     """results.json with "model": "DropoutFF" + a (model_state, optimizer_state) checkpoint -> HIP MLP"""
     from wear_mocap_ape_amd import config

@@ -89,6 +89,23 @@ def test_ff_forward(golden):
                 assert np.abs(y - g["y_" + key]).max() < 2e-6
 
 
+def test_imupose_forward(golden):
+    """ImuPoseLSTM restatement (Linear+ReLU in front of a fixed 2 x 256 LSTM) vs the reference module"""
+    g = golden("imupose.npz")
+    for tag in ("pocket_like", "uarm_like"):
+        I, O = (int(v) for v in g["dims_" + tag])
+        for seed in (0, 1):
+            sd = orc.make_imupose_state_dict(I, O, seed)
+            assert np.array_equal(orc.state_dict_digest(sd), g[f"digest_{tag}_seed{seed}"])
+            for (B, T) in ((1, 6), (21, 6), (3, 64), (2, 1)):
+                key = f"{tag}_seed{seed}_B{B}_T{T}"
+                y = orc.imupose_forward(sd, g["x_" + key])
+                assert y.shape == g["y_" + key].shape == (B, T, O)
+                assert np.abs(y - g["y_" + key]).max() < LSTM_TOL
+                # its "Monte-Carlo" predictions are the plain forward of the one window, not n repeats
+                assert g["ymc_" + key].shape == (1, T, O) and np.abs(g["ymc_" + key] - g["y_" + key][:1]).max() < 1e-6
+
+
 def test_lstm_masks_are_interlayer_only():
     cfg = orc.MODEL_CONFIGS["uarm"]
     sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5)
