@@ -359,7 +359,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                     }
                 }
         if (m->cluster_ok) {
-            // cluster kernel: [member GH][wave 4][i = 4q + j][lane]; lane = (g << 4) | (u << 2) | gate holds
+            // cluster kernel: [member GH][wave 4][i/4][lane][i%4] with i = 4q + j; lane = (g << 4) | (u << 2) | gate holds
             // Wcat[gate*H + member*16 + wave*4 + u][16q + 4g + j] -- the register file of that wave
             const int GH = H / 16, NW = (KXl + H) / 4;
             std::vector<float> pc((size_t)GH * 4 * NW * 64);
@@ -373,7 +373,8 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                             float v;
                             if (k < KXl) v = (k < in_l) ? w_ih[(size_t)row * in_l + k] : 0.0f;
                             else v = w_hh[(size_t)row * H + (k - KXl)];
-                            pc[(((size_t)(mem * 4 + w) * NW) + i) * 64 + lane] = v;
+                            // register i of that lane; stored [k-quad i/4][lane][i%4] so a lane fetches 4 registers per load
+                            pc[((((size_t)(mem * 4 + w) * (NW / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] = v;
                         }
             HIP_TRY(hipMemcpy(m->wcl[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
             // fp16 variant: [member][wave][32-deep k-block q][lane][8]: lane holds Wcat[row][32q + 8g + j] as binary16

@@ -232,22 +232,33 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const int row0 = cluster * MR;
 
     // ---- weights: registers, for the whole launch ---------------------------------------------
+    static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
     float w0[NW0];
     float w1[L > 1 ? NW1 : 1];
     float w2[L > 2 ? NW1 : 1];
     {
-        const float* s0 = p.wcl[0] + ((size_t)(member * 4 + wave) * NW0) * 64 + lane;
+        // 16 bytes per lane and load (host order [k-quad][lane][4]): a quarter of the instructions of a dword walk
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < NW0; ++i) w0[i] = s0[i * 64];
+        for (int i = 0; i < NW0 / 4; ++i) {
+            const f32x4 v = s0[i * 64];
+            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
+        }
         if constexpr (L > 1) {
-            const float* s1 = p.wcl[1] + ((size_t)(member * 4 + wave) * NW1) * 64 + lane;
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NW1; ++i) w1[i] = s1[i * 64];
+            for (int i = 0; i < NW1 / 4; ++i) {
+                const f32x4 v = s1[i * 64];
+                w1[4 * i] = v[0]; w1[4 * i + 1] = v[1]; w1[4 * i + 2] = v[2]; w1[4 * i + 3] = v[3];
+            }
         }
         if constexpr (L > 2) {
-            const float* s2 = p.wcl[2] + ((size_t)(member * 4 + wave) * NW1) * 64 + lane;
+            const f32x4* s2 = reinterpret_cast<const f32x4*>(p.wcl[2]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NW1; ++i) w2[i] = s2[i * 64];
+            for (int i = 0; i < NW1 / 4; ++i) {
+                const f32x4 v = s2[i * 64];
+                w2[4 * i] = v[0]; w2[4 * i + 1] = v[1]; w2[4 * i + 2] = v[2]; w2[4 * i + 3] = v[3];
+            }
         }
     }
     f32x4 bias_r[L];
@@ -646,23 +657,44 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     wg_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
     raise_pending();
-    // ---- head: gather h^{L-1}_{T-1}, each member finishes MR/GH (>= 1) of the cluster's windows ------
-    if (!gather_now(L - 1, (unsigned)T, (T - 1) & 1)) return;
+    // ---- head: each member finishes RPM = MR/GH (>= 1) of the cluster's windows and gathers only THOSE rows of
+    //      h^{L-1}_{T-1} (GH x RPM x 4 sixteen-byte pieces = at most one per thread, not the whole 64 KB slice set)
     {
         constexpr int RPM = (MR + GH - 1) / GH;          // rows per member
+        static_assert(GH * RPM * 4 <= 256, "one head piece per thread");
+        wait_flags(L - 1, (unsigned)T, 0u);
+        const int h_m = tid / (RPM * 4), h_rr = (tid / 4) % RPM, h_quad = tid & 3;
+        const int h_row = member * RPM + h_rr;
+        if (!diag_noex && tid < GH * RPM * 4 && h_row < MR) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                hx_rsrc, (unsigned)(((h_m * MR + h_row) * 16 + 4 * h_quad) * sizeof(float)), hx_base(L - 1, (T - 1) & 1, 0),
+                16 /* sc1 */));
+            *reinterpret_cast<f32x4*>(hbuf + ((L - 1) * MR + h_row) * SH + h_m * 16 + 4 * h_quad) = v;
+        }
+        bar();
+        if (ctl[0] != 0) return;
+        // (row, target) dot products over H, PL lanes each (k interleaved by 4), combined by lane shuffles
         const int n_out = RPM * O;
-        if (tid < n_out) {
-            const int rr = tid / O, o = tid - rr * O;
-            const int row = member * RPM + rr;
-            const int b = row0 + row;
-            if (row < MR && b < p.B) {
-                const float* hv = hbuf + ((L - 1) * MR + row) * SH;
-                const float* wv = p.w_out + (size_t)o * H;
-                float s = 0.0f;
-                for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
-                p.y[(size_t)b * O + o] = s + p.b_out[o];
+        constexpr int PL = (RPM * APE_MAX_OUTPUT * 4 <= 256) ? 4 : ((RPM * APE_MAX_OUTPUT * 2 <= 256) ? 2 : 1);
+        const int oi = tid / PL, part = tid % PL;
+        float s_acc = 0.0f;
+        const bool live = oi < n_out;
+        const int rr = live ? oi / O : 0, o = live ? oi - rr * O : 0;
+        const int row = member * RPM + rr;
+        if (live && row < MR) {
+            const float* hv = hbuf + ((L - 1) * MR + row) * SH;
+            const float* wv = p.w_out + (size_t)o * H;
+            for (int k = 4 * part; k < H; k += 4 * PL) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(hv + k);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wv + k);
+                s_acc = fmaf(a[0], w[0], s_acc); s_acc = fmaf(a[1], w[1], s_acc);
+                s_acc = fmaf(a[2], w[2], s_acc); s_acc = fmaf(a[3], w[3], s_acc);
             }
         }
+        if (PL >= 2) s_acc += __shfl_xor(s_acc, 1, 64);
+        if (PL >= 4) s_acc += __shfl_xor(s_acc, 2, 64);
+        const int b = row0 + row;
+        if (live && part == 0 && row < MR && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
     }
 #ifdef APE_CLUSTER_STAMPS
     if (tid == 0 && p.dbg_wg != nullptr && blockIdx.x < 256) {

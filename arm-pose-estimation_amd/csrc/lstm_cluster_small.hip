@@ -83,22 +83,33 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     const int row0 = cluster * MR;
 
     // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel) ----------------
+    static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
     float w0[NW0];
     float w1[L > 1 ? NW1 : 1];
     float w2[L > 2 ? NW1 : 1];
     {
-        const float* s0 = p.wcl[0] + ((size_t)(member * 4 + wave) * NW0) * 64 + lane;
+        // 16 bytes per lane and load (host order [k-quad][lane][4]): a quarter of the instructions of a dword walk
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < NW0; ++i) w0[i] = s0[i * 64];
+        for (int i = 0; i < NW0 / 4; ++i) {
+            const f32x4 v = s0[i * 64];
+            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
+        }
         if constexpr (L > 1) {
-            const float* s1 = p.wcl[1] + ((size_t)(member * 4 + wave) * NW1) * 64 + lane;
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NW1; ++i) w1[i] = s1[i * 64];
+            for (int i = 0; i < NW1 / 4; ++i) {
+                const f32x4 v = s1[i * 64];
+                w1[4 * i] = v[0]; w1[4 * i + 1] = v[1]; w1[4 * i + 2] = v[2]; w1[4 * i + 3] = v[3];
+            }
         }
         if constexpr (L > 2) {
-            const float* s2 = p.wcl[2] + ((size_t)(member * 4 + wave) * NW1) * 64 + lane;
+            const f32x4* s2 = reinterpret_cast<const f32x4*>(p.wcl[2]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NW1; ++i) w2[i] = s2[i * 64];
+            for (int i = 0; i < NW1 / 4; ++i) {
+                const f32x4 v = s2[i * 64];
+                w2[4 * i] = v[0]; w2[4 * i + 1] = v[1]; w2[4 * i + 2] = v[2]; w2[4 * i + 3] = v[3];
+            }
         }
     }
     float bias_r[L], cst[L];
