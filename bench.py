@@ -44,6 +44,26 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 POCKET = dict(I=22, H=256, L=2, O=14, layout=0)
 
 
+WATCH = dict(I=20, H=256, L=2, O=12, layout=1)
+DEFAULT_BODY = np.array([[-0.22, 0.0, 0.0, -0.26, 0.0, 0.0, -0.1704612, 0.4309841, -0.00670862]])   # bone_map.py:42-45
+
+
+def synthetic_state_dict(I, H, L, O, seed):
+    """random-init weights of the architecture (there are no trained checkpoints offline): uniform +-1/sqrt(H) like
+    torch's default LSTM / Linear init, numpy PCG64 stream, reference state_dict key order"""
+    rng = np.random.default_rng(seed)
+    bound = 1.0 / np.sqrt(H)
+    sd = {}
+    for k in range(L):
+        sd[f"lstm.weight_ih_l{k}"] = rng.uniform(-bound, bound, size=(4 * H, I if k == 0 else H)).astype(np.float32)
+        sd[f"lstm.weight_hh_l{k}"] = rng.uniform(-bound, bound, size=(4 * H, H)).astype(np.float32)
+        sd[f"lstm.bias_ih_l{k}"] = rng.uniform(-bound, bound, size=(4 * H,)).astype(np.float32)
+        sd[f"lstm.bias_hh_l{k}"] = rng.uniform(-bound, bound, size=(4 * H,)).astype(np.float32)
+    sd["output_layer.weight"] = rng.uniform(-bound, bound, size=(O, H)).astype(np.float32)
+    sd["output_layer.bias"] = rng.uniform(-bound, bound, size=(O,)).astype(np.float32)
+    return sd
+
+
 def synthetic_windows(stats, lo, hi, T, I):
     """feature f ~ N(xx_m[f], xx_s[f]) per stream; stream s always gets the same data
     whatever the sharding (seeded per stream block), sw_dt fixed at 0.02 s = 50 Hz"""
@@ -62,7 +82,7 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0, gpu_y=None, gpu_est=
     reference's third-party arithmetic) + float64 FK with one 4x4 eigh per quaternion.  The thread
     count is chosen by a short probe (torch's default of one thread per core is far from the best
     for 2x256 LSTM GEMMs), then the 1024-window batch is repeated until ~budget_s of CPU work is done."""
-    from oracle import ape_oracle as orc
+    from oracle import ape_oracle as orc          # the checker: imported by this leg only
     default_threads = torch.get_num_threads()
     probe = {}
     for n in sorted({8, 16, 32, 64, default_threads}):
@@ -153,11 +173,10 @@ def fp16_config4(stats_watch, n_iter=10):
     """BASELINE configs[4]: watch-only model, 1024 windows x 64 frames x 20 features, fp16 hidden state /
     weights with fp32 accumulate (ape_model_set_precision F16), HIP-event timed; the exact-f32 kernel on the
     same windows beside it, and the max-abs difference of the NN targets between the two"""
-    from oracle import ape_oracle as orc
     from wear_mocap_ape_amd import _hip
     from wear_mocap_ape_amd.estimate import nn_models
-    cfg = orc.MODEL_CONFIGS["watch"]
-    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed=0)
+    cfg = WATCH
+    sd = synthetic_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed=0)
     m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"])
     m.load_state_dict(sd)
     m.set_norm_stats(stats_watch["xx_m"], stats_watch["xx_s"], stats_watch["yy_m"], stats_watch["yy_s"])
@@ -224,7 +243,6 @@ def main():
         entry.build()
     if world > 1:
         dist.barrier()
-    from oracle import ape_oracle as orc                       # weights + CPU baseline only
     from wear_mocap_ape_amd import _hip, streams
     from wear_mocap_ape_amd.estimate import nn_models
     from wear_mocap_ape_amd.utility import data_stats
@@ -235,7 +253,7 @@ def main():
     n_w = model.weight_blob_floats()
     sd = stats = None
     if rank == 0:
-        sd = orc.make_state_dict(POCKET["I"], POCKET["H"], POCKET["L"], POCKET["O"], seed=0)
+        sd = synthetic_state_dict(POCKET["I"], POCKET["H"], POCKET["L"], POCKET["O"], seed=0)
         stats = data_stats.get_norm_stats(NNS_INPUTS.WATCH_PHONE_CAL_HIP, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)
         blob = streams.flatten_state_dict(sd, nn_models.state_dict_keys(POCKET["L"]))
     else:
@@ -244,7 +262,7 @@ def main():
     stats = streams.broadcast_stats(stats, POCKET["I"], POCKET["O"], dev)
     model.load_weight_blob(blob_dev)
     model.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
-    model.set_body(orc.DEFAULT_BODY)
+    model.set_body(DEFAULT_BODY)
 
     # ---- this rank's shard of the streams, resident in HBM ---------------------------------------
     lo, hi = streams.shard_range(WINDOWS_PER_GPU * world, rank, world)
@@ -328,7 +346,7 @@ def main():
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
                                                                          NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:
-                cb = cpu_baseline(sd, stats, orc.DEFAULT_BODY, POCKET["layout"], x_host, gpu_y=y.cpu().numpy(),
+                cb = cpu_baseline(sd, stats, DEFAULT_BODY, POCKET["layout"], x_host, gpu_y=y.cpu().numpy(),
                                   gpu_est=est.cpu().numpy())
                 out["parity_vs_cpu_reference"] = cb.pop("parity")
                 out["cpu_baseline"] = cb
