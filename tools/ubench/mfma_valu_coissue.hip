@@ -54,6 +54,69 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const float* w_in, int i
     if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 256)[0] = t1 - t0;
 }
 
+// Two waves per SIMD: waves 0-3 (one per SIMD) run the bare MFMA loop, waves 4-7 (the second wave of each SIMD) a
+// bare transcendental loop of `vops` exp2/rcp pairs per trip.  Question: does ANOTHER wave's VALU work slow the
+// MFMA wave down the way the same wave's does?
+__global__ __launch_bounds__(512, 1) void k2(float* out, const float* w_in, int iters, int valu_trips) {
+    __shared__ __attribute__((aligned(16))) float lds[64 * 264];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 264; i += 512) lds[i] = 0.001f * (i % 97);
+    __syncthreads();
+    if (wave < 4) {
+        float w[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) w[i] = w_in[i * 64 + lane];
+        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        const float* src = lds + (lane & 15) * 264 + 4 * (lane >> 4);
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                f32x4 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * 264 + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], w[4 * q + j], acc[mt], 0, 0, 0);
+            }
+        }
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        out[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+        if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 512)[0] = t1 - t0;
+    } else {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.1f * (lane + i);
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < valu_trips; ++it) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = __builtin_amdgcn_exp2f(v[e] * -1.4426950f);
+                v[e] = __builtin_amdgcn_rcpf(1.0f + v[e]);
+            }
+        }
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        float s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
+        if (threadIdx.x == 256 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 512)[1] = t1 - t0;
+    }
+}
+
+void run2(float* out, float* w, int iters, int valu_trips) {
+    hipLaunchKernelGGL(k2, dim3(256), dim3(512), 0, 0, out, w, iters, valu_trips);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(k2, dim3(256), dim3(512), 0, 0, out, w, iters, valu_trips);
+    hipDeviceSynchronize();
+    unsigned long long cyc[2]; hipMemcpy(cyc, out + 256 * 512, 16, hipMemcpyDeviceToHost);
+    printf("2 waves/SIMD, helper wave runs %d x 16 transcendentals: MFMA wave %.1f cycles per MFMA (%llu cycles), "
+           "helper wave %llu cycles = %.1f per transcendental\n", valu_trips, cyc[0] / (256.0 * iters), cyc[0], cyc[1],
+           valu_trips ? cyc[1] / (16.0 * valu_trips) : 0.0);
+}
+
 template <int VPM>
 void run(float* out, float* w, int iters) {
     hipLaunchKernelGGL(k<VPM>, dim3(256), dim3(256), 0, 0, out, w, iters);
@@ -71,10 +134,12 @@ void run(float* out, float* w, int iters) {
 
 int main() {
     float *out, *w;
-    hipMalloc(&out, (256 * 256 + 16) * 4); hipMalloc(&w, 64 * 64 * 4);
+    hipMalloc(&out, (256 * 512 + 16) * 4); hipMalloc(&w, 64 * 64 * 4);
     std::vector<float> hw(64 * 64); for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.01f * (i % 31) - 0.1f;
     hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     run<0>(out, w, 200); run<1>(out, w, 200); run<2>(out, w, 200); run<3>(out, w, 200); run<4>(out, w, 200);
     run<6>(out, w, 200); run<8>(out, w, 200);
+    // 200 iterations x 256 MFMAs x 32 cycles = 1.64M cycles of MFMA work per wave
+    run2(out, w, 200, 0); run2(out, w, 200, 1000); run2(out, w, 200, 3000); run2(out, w, 200, 6000); run2(out, w, 200, 12000);
     return 0;
 }
