@@ -57,12 +57,17 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const float* w_in, int i
 // Two waves per SIMD: waves 0-3 (one per SIMD) run the bare MFMA loop, waves 4-7 (the second wave of each SIMD) a
 // bare transcendental loop of `vops` exp2/rcp pairs per trip.  Question: does ANOTHER wave's VALU work slow the
 // MFMA wave down the way the same wave's does?
-__global__ __launch_bounds__(512, 1) void k2(float* out, const float* w_in, int iters, int valu_trips) {
+__global__ __launch_bounds__(512, 1) void k2(float* out, const float* w_in, int iters, int valu_trips, unsigned mfma_mask) {
     __shared__ __attribute__((aligned(16))) float lds[64 * 264];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 64 * 264; i += 512) lds[i] = 0.001f * (i % 97);
+    if (blockIdx.x == 0 && lane == 0) {          // which SIMD did this wave land on (HW_ID bits 5:4)?
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        reinterpret_cast<unsigned*>(out + 256 * 512 + 8)[wave] = (hw >> 4) & 3;
+    }
     __syncthreads();
-    if (wave < 4) {
+    if ((mfma_mask >> wave) & 1) {
         float w[64];
 #pragma unroll
         for (int i = 0; i < 64; ++i) w[i] = w_in[i * 64 + lane];
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, const float* w_in, int 
         }
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         out[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
-        if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 512)[0] = t1 - t0;
+        if (lane == 0 && blockIdx.x == 0 && wave == __builtin_ctz(mfma_mask)) reinterpret_cast<unsigned long long*>(out + 256 * 512)[0] = t1 - t0;
     } else {
         float v[8];
 #pragma unroll
@@ -102,16 +107,20 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, const float* w_in, int 
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += v[i];
         out[blockIdx.x * 512 + threadIdx.x] = s;
-        if (threadIdx.x == 256 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 512)[1] = t1 - t0;
+        if (lane == 0 && blockIdx.x == 0 && wave == __builtin_ctz(~mfma_mask & 0xFF)) reinterpret_cast<unsigned long long*>(out + 256 * 512)[1] = t1 - t0;
     }
 }
 
-void run2(float* out, float* w, int iters, int valu_trips) {
-    hipLaunchKernelGGL(k2, dim3(256), dim3(512), 0, 0, out, w, iters, valu_trips);
-    hipDeviceSynchronize();
-    hipLaunchKernelGGL(k2, dim3(256), dim3(512), 0, 0, out, w, iters, valu_trips);
-    hipDeviceSynchronize();
-    unsigned long long cyc[2]; hipMemcpy(cyc, out + 256 * 512, 16, hipMemcpyDeviceToHost);
+void run2(float* out, float* w, int iters, int valu_trips, unsigned mfma_mask = 0x0F) {
+    (void)hipMemset(out + 256 * 512, 0, 64);
+    hipLaunchKernelGGL(k2, dim3(256), dim3(512), 0, 0, out, w, iters, valu_trips, mfma_mask);
+    (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(k2, dim3(256), dim3(512), 0, 0, out, w, iters, valu_trips, mfma_mask);
+    (void)hipDeviceSynchronize();
+    unsigned long long cyc[2]; (void)hipMemcpy(cyc, out + 256 * 512, 16, hipMemcpyDeviceToHost);
+    unsigned simd[8]; (void)hipMemcpy(simd, out + 256 * 512 + 8, 32, hipMemcpyDeviceToHost);
+    printf("MFMA waves mask 0x%02x, SIMD of waves 0..7: %u%u%u%u%u%u%u%u | ", mfma_mask, simd[0], simd[1], simd[2], simd[3], simd[4],
+           simd[5], simd[6], simd[7]);
     printf("2 waves/SIMD, helper wave runs %d x 16 transcendentals: MFMA wave %.1f cycles per MFMA (%llu cycles), "
            "helper wave %llu cycles = %.1f per transcendental\n", valu_trips, cyc[0] / (256.0 * iters), cyc[0], cyc[1],
            valu_trips ? cyc[1] / (16.0 * valu_trips) : 0.0);
@@ -134,12 +143,15 @@ void run(float* out, float* w, int iters) {
 
 int main() {
     float *out, *w;
-    hipMalloc(&out, (256 * 512 + 16) * 4); hipMalloc(&w, 64 * 64 * 4);
+    hipMalloc(&out, (256 * 512 + 64) * 4); hipMalloc(&w, 64 * 64 * 4);
     std::vector<float> hw(64 * 64); for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.01f * (i % 31) - 0.1f;
     hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     run<0>(out, w, 200); run<1>(out, w, 200); run<2>(out, w, 200); run<3>(out, w, 200); run<4>(out, w, 200);
     run<6>(out, w, 200); run<8>(out, w, 200);
     // 200 iterations x 256 MFMAs x 32 cycles = 1.64M cycles of MFMA work per wave
-    run2(out, w, 200, 0); run2(out, w, 200, 1000); run2(out, w, 200, 3000); run2(out, w, 200, 6000); run2(out, w, 200, 12000);
+    run2(out, w, 200, 0); run2(out, w, 200, 3000); run2(out, w, 200, 12000);
+    run2(out, w, 200, 0, 0x55); run2(out, w, 200, 3000, 0x55);      // MFMA on waves 0,2,4,6
+    run2(out, w, 200, 0, 0x01); run2(out, w, 200, 3000, 0x01);      // ONE MFMA wave, seven helpers
+    run2(out, w, 200, 0, 0x33); run2(out, w, 200, 3000, 0x33);
     return 0;
 }
