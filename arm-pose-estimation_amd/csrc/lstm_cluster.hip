@@ -7,24 +7,27 @@
 //   * GH = H/16 workgroups (one per CU) form a CLUSTER that owns MR = 16*NMT windows for all T
 //     steps.  Member m owns hidden units [16m, 16m+16) of EVERY layer with all four gates; wave w
 //     of it owns 4 of those units = one 16-column MFMA tile (column = unit*4 + gate).
-//   * each wave keeps its slice of [W_ih | W_hh] of every layer in REGISTERS for the whole launch,
-//     already in v_mfma_f32_16x16x4_f32 B-fragment order (200 VGPR/AGPR per lane for the pocket
-//     model): the MFMA B operand needs no load at all.  At B=1024 all 256 CUs are busy
+//   * each wave keeps its slice of [W_ih | W_hh] of every layer in REGISTERS for the whole launch
+//     (AGPRs, already in v_mfma_f32_16x16x4_f32 fragment order: 200 per lane for the pocket model), so
+//     the weight operand of the MFMA needs no load at all.  At B=1024 all 256 CUs are busy
 //     (16 clusters x 16 CUs) instead of 64, and no CU re-streams weights every step.
-//   * the A operand (activations of all H units of the cluster's windows) lives in LDS; every
+//   * the activation operand (h of all H units of the cluster's windows, and x_t) lives in LDS; every
 //     layer-step each member publishes its 16-unit slice of h to a small exchange buffer and
 //     gathers the other members' slices.  Hand-off protocol (placement-independent, MI355X guide
 //     G16 / visibility table row 1): payload by 16-byte sc1 (write-through) buffer stores, each
 //     wave stores the pieces of its own four units, drains vmcnt(0) and then raises ITS epoch flag
-//     with an agent-scope relaxed atomic (drain + flag ride a few k-blocks into the next section's
-//     MFMAs); every consumer wave polls all 4*GH wave flags of a layer with one agent-scope relaxed
-//     load per lane and only then issues loads of the payload, every one a 16-byte sc1 buffer
-//     load.  Exchange buffers are double-buffered by step parity; the last workgroup to finish
-//     re-zeroes the flags and counters (self-cleaning, no memset node); every spin is bounded and raises a
-//     status word.
+//     with an agent-scope relaxed atomic; every consumer wave polls all 4*GH wave flags of a layer with
+//     one agent-scope relaxed load per lane and only then issues loads of the payload, every one a
+//     16-byte sc1 buffer load.  Exchange buffers are double-buffered by step parity; the last
+//     workgroup to finish re-zeroes the flags and counters (self-cleaning, no memset node); every spin
+//     is bounded and raises a status word.
+//   * everything but the gate math rides BETWEEN MFMAs (hook() in layer_mfma, one call per 16-MFMA
+//     k-block): the flag owed for the previous section's slice, the look at the next layer's flags, the
+//     gather loads, the LDS commits of gathered slices, the f64 z-score of the next x row.  A phase has one
+//     barrier per layer above 0 (in front of the first read of its recurrent buffer) and one at its end.
 //   * the layers are software-pipelined: in phase p layer l works on step t = p - l, so all the
 //     layer computations of a phase depend only on the previous phase and the exchange of one
-//     layer's slice flies under the other layers' MFMAs.
+//     layer's slice flies under the other layers' MFMAs (see the k-block schedule at the phase loop).
 //   * the MFMA takes the weights as its A operand and the activations as B, with the wave's 16 gate
 //     columns ordered unit*4 + gate: every lane then holds i,f,g,o of ONE (unit, batch row) in its four
 //     accumulator registers, so activations and the c/h update are lane-local and spread over all 64 lanes.
@@ -329,14 +332,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         gv[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             hx_rsrc, goff, hx_base(l, par, v) + (unsigned)(k * SPP * MR * 16 * sizeof(float)), 16 /* sc1 */));
     };
-    auto issue_gather = [&](int l, int par, int half, f32x4 (&gv)[NGH]) {
-        (void)half;
+    auto issue_gather = [&](int l, int par, f32x4 (&gv)[NGH]) {
 #pragma unroll
         for (int kk = 0; kk < NGH; ++kk) issue_piece(l, par, kk, g_thread_off, gv);
     };
-    auto commit_gather = [&](int l, int half, const f32x4 (&gv)[NGH]) {
+    auto commit_gather = [&](int l, const f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
-        (void)half;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (v == 1 && l == L - 1) break;
@@ -362,9 +363,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     auto gather_now = [&](int l, unsigned want, int par) -> bool {
         f32x4 ga[NGH];
         wait_flags(l, want, 0u);
-        issue_gather(l, par, 0, ga);
+        issue_gather(l, par, ga);
         bar();
-        commit_gather(l, 0, ga);
+        commit_gather(l, ga);
         bar();
         return ctl[0] == 0;
     };
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 if (carry) {                            // (tail) nobody will run the input span that commits them
                     raise_pending();
                     bar();
-                    commit_gather(l, 0, gv);
+                    commit_gather(l, gv);
                     bar();
                     carry = false;
                 }
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 #endif
             if (pre && !ready) {                         // first step of a layer, or a peer was late: blocking path
                 wait_flags(ln, (unsigned)tn, peeked);
-                issue_gather(ln, (tn - 1) & 1, 0, gv);
+                issue_gather(ln, (tn - 1) & 1, gv);
             }
             STAMP_END(3);                                // 3: flag wait + gather issue of the blocking path
 
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             }
             STAMP_END(6);                                // 6: publish store issue
             if (last) {
-                if (pre && !new_done) commit_gather(ln, 0, gv);      // blocking path / first step: every wave is past
+                if (pre && !new_done) commit_gather(ln, gv);      // blocking path / first step: every wave is past
                 STAMP_END(7);                                        // the input span (mid or odd-path barrier)
                 bar();                                   // end of phase: hbuf[0] and x of the next phase visible
                 if (ctl[0] != 0) return;
