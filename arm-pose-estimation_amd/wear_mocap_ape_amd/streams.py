@@ -32,10 +32,10 @@ def flatten_state_dict(state_dict, keys) -> np.ndarray:
     return np.concatenate(parts)
 
 
-def broadcast_blob(blob, n_floats: int, device: torch.device, src: int = 0) -> torch.Tensor:
+def broadcast_blob(blob, n_floats: int, device: torch.device, src: int = 0, always: bool = False) -> torch.Tensor:
     """rank ``src`` passes the float32 blob, the others pass None; every rank returns a tensor on
     ``device`` holding identical bytes.  One collective, init-time only."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):     # `always`: 1-rank rehearsals
         return torch.as_tensor(blob, dtype=torch.float32).to(device)
     # the collective runs where the backend lives: device memory for nccl (RCCL over xGMI), host for gloo
     comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -49,9 +49,9 @@ def broadcast_blob(blob, n_floats: int, device: torch.device, src: int = 0) -> t
     return t.to(device)
 
 
-def broadcast_stats(stats: dict, I: int, O: int, device: torch.device, src: int = 0) -> dict:
+def broadcast_stats(stats: dict, I: int, O: int, device: torch.device, src: int = 0, always: bool = False) -> dict:
     """float64 normalisation statistics travel the same way (exact bits)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return stats
     comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.empty((2 * I + 2 * O,), dtype=torch.float64, device=comm_dev)

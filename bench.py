@@ -228,11 +228,17 @@ def main():
     # rehearsal switch for a 1-GPU box: APE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (two
     # ranks cannot form an RCCL communicator on one device); the driver's real runs never set it
     share_gpu = os.environ.get("APE_BENCH_SHARE_GPU") == "1"
+    # APE_BENCH_FORCE_DIST=1: run the process-group code path (RCCL init, broadcast, barrier, all-reduce) with ONE
+    # rank too -- the rehearsal of the N > 1 plumbing that a 1-GPU box allows
+    use_dist = world > 1 or os.environ.get("APE_BENCH_FORCE_DIST") == "1"
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if share_gpu:
             dist.init_process_group(backend="gloo")
         else:
@@ -241,7 +247,7 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from wear_mocap_ape_amd import _hip, streams
     from wear_mocap_ape_amd.estimate import nn_models
@@ -258,8 +264,8 @@ def main():
         blob = streams.flatten_state_dict(sd, nn_models.state_dict_keys(POCKET["L"]))
     else:
         blob = None
-    blob_dev = streams.broadcast_blob(blob, n_w, dev)
-    stats = streams.broadcast_stats(stats, POCKET["I"], POCKET["O"], dev)
+    blob_dev = streams.broadcast_blob(blob, n_w, dev, always=use_dist)
+    stats = streams.broadcast_stats(stats, POCKET["I"], POCKET["O"], dev, always=use_dist)
     model.load_weight_blob(blob_dev)
     model.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
     model.set_body(DEFAULT_BODY)
@@ -293,18 +299,18 @@ def main():
     for _ in range(PREROLL + args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -352,7 +358,7 @@ def main():
                 out["cpu_baseline"] = cb
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
