@@ -1,12 +1,17 @@
 // fp16 variant of the weight-stationary cluster LSTM kernel (BASELINE.json configs[4]: "fp16 hidden state
 // with fp32 accumulate").
 //
-// Same decomposition, hand-off protocol and pipelining as lstm_cluster.hip (see there): GH = H/16 workgroups
+// Same decomposition and hand-off protocol as lstm_cluster.hip (see there): GH = H/16 workgroups
 // per cluster, member m owns hidden units [16m,16m+16) of every layer, wave w one 16-column tile
 // (column = unit*4 + gate; weights are the MFMA's A operand, so each lane gets i,f,g,o of one unit and batch
 // row), weights resident in registers for the whole launch, h slices exchanged with sc1
-// write-through stores + epoch flags, layers software-pipelined, self-cleaning flags, ticketed clusters.
+// write-through stores + epoch flags, layers software-pipelined (phase p: layer l on step p - l), self-cleaning
+// flags, ticketed clusters.
 // What differs:
+//   * the f16 MFMAs of a phase take ~1.6K cycles (the f32 kernel's: 25.6K), far too little to hide an exchange
+//     behind, so the phase is SYNCHRONOUS like the small-batch kernel's: all active layers are computed back to
+//     back from the LDS state, their slices published together under ONE flag per member, and one gather brings
+//     in every layer's slices -- one fabric round trip per phase instead of one per layer-step;
 //   * weights, the inputs x and the hidden state h are IEEE binary16; the stacked-gate product runs on
 //     v_mfma_f32_16x16x32_f16 (K = 32 per instruction, 16 cycles: 16x the f32 MFMA rate) with f32
 //     accumulators; gate pre-activations, the cell state c, the cell update and the linear head stay f32;
@@ -84,9 +89,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
     _Float16* hbuf = smem16;                          // [L][MR][SH]
-    _Float16* xin = hbuf + L * MR * SH;               // [MR][SX]
-    _Float16* own = xin + MR * SX;                    // [MR][SO]
-    int* ctl = reinterpret_cast<int*>(own + MR * SO); // [0] abort, [1] ticket, [2] last-out
+    _Float16* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
+    _Float16* own = xin + 2 * MR * SX;                // [L][MR][SO]
+    int* ctl = reinterpret_cast<int*>(own + L * MR * SO); // [0] abort, [1] ticket, [2] last-out
     if (threadIdx.x == 0) {
         ctl[0] = 0;
         ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -127,22 +132,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
         for (int mt = 0; mt < NMT; ++mt) cst[l][mt] = 0.0f;
 
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
-    unsigned* const myflags = p.xflags + (size_t)cluster * L * GH;
+    unsigned* const myflags = p.xflags + (size_t)cluster * L * GH;      // word [member]: phases published (all layers at once)
     constexpr unsigned SLICE_SET = GH * MR * 16 * sizeof(_Float16);
     auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SLICE_SET); };
 
     const int g_sl = tid / TPS, g_idx = tid - g_sl * TPS;
     const int g_row = g_idx >> 1, g_hq = g_idx & 1;
-    auto peek_flags = [&](int l, unsigned want) -> unsigned {
-        if (lane >= GH) return want;
-        return __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto wait_flags = [&](int l, unsigned want, unsigned peeked) {
-        if (__all((int)(peeked >= want))) return;
+    // every wave polls for itself: have all members published phase `want`?  bounded; on give-up raises the
+    // sticky status word and the workgroup abort flag
+    auto wait_flags = [&](unsigned want) {
         unsigned spins = 0;
         while (true) {
             unsigned v = want;
-            if (lane < GH) v = __hip_atomic_load(myflags + l * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < GH) v = __hip_atomic_load(myflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((int)(v >= want))) return;
             if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 if (lane == 0) {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
                 }
                 return;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
     };
     auto issue_gather = [&](int l, int par, f32x4 (&gv)[NGV]) {
@@ -171,15 +173,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
             if (m < GH) *reinterpret_cast<f32x4*>(hbuf + (l * MR + g_row) * SH + m * 16 + 8 * g_hq) = gv[k];
         }
     };
-    auto gather_now = [&](int l, unsigned want, int par) -> bool {
-        f32x4 gv[NGV];
-        wait_flags(l, want, 0u);
-        issue_gather(l, par, gv);
-        commit_gather(l, gv);
-        __syncthreads();
-        return ctl[0] == 0;
-    };
-
     // ---- x staging (f64 z-score, then binary16) -----------------------------------------------------------
     constexpr int NE = (MR * KX) / 256;
     const int xk = tid % KX;
@@ -191,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
             xr[e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + (t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring)) * I + xk] : 0.0f;
         }
     };
-    auto stage_x = [&]() {
+    auto stage_x = [&](int t) {
         const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
         const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
 #pragma unroll
@@ -199,40 +192,34 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
             const int row = (tid + 256 * e) / KX;
             float v = xr[e];
             if (normalize && xk < I && row0 + row < p.B) v = (float)(((double)v - x_mean) / x_std);
-            xin[row * SX + xk] = (_Float16)v;
+            xin[((t & 1) * MR + row) * SX + xk] = (_Float16)v;
         }
     };
     fetch_x(0);
-    stage_x();
+    stage_x(0);
     if (T > 1) fetch_x(1);
     __syncthreads();
 
     const int P = T + L - 1;
-    bool prefetched = false;
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
+        // x_{ph+1} into the other xin buffer (its readers finished a phase ago), x_{ph+2} into flight under the MFMAs and
+        // the gate math, so that the store drain below does not wait on it
+        if (ph + 1 < T) {
+            stage_x(ph + 1);
+            if (ph + 2 < T) fetch_x(ph + 2);
+        }
+        // ---- every active layer of this phase from the LDS state of the last one (layer l works on step ph - l) ----
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int t = ph - l;
-            const bool have_prev = (t >= 1 && t <= T) && !(l == L - 1 && t == T);
-            const bool active = (t >= 0 && t < T);
-            if (have_prev && !prefetched) {
-                if (!gather_now(l, (unsigned)t, (t - 1) & 1)) return;
-            }
-            prefetched = false;
-            if (!active) continue;
-
-            const int ln = (l + 1 < L) ? l + 1 : 0;
-            const int tn = (l + 1 < L) ? t - 1 : t + L;
-            const bool pre = (tn >= 1 && tn <= T) && !(ln == L - 1 && tn == T) && (l + 1 < L || ph + 1 < P);
-            const unsigned peeked = pre ? peek_flags(ln, (unsigned)tn) : 0u;
-
+            if (t < 0 || t >= T) continue;              // uniform over the grid
             f32x4 acc[NMT];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = bias_r[l];
             const _Float16* rec_src = hbuf + (l * MR + r) * SH + 8 * g;
             if (l == 0) {
-                span_f16<NMT, QX, NB0>(acc, xin + r * SX + 8 * g, SX, w0, 0);
+                span_f16<NMT, QX, NB0>(acc, xin + ((t & 1) * MR + r) * SX + 8 * g, SX, w0, 0);
                 if (t > 0) span_f16<NMT, QH, NB0>(acc, rec_src, SH, w0, QX);
             } else {
                 const _Float16* in_src = hbuf + ((l - 1) * MR + r) * SH + 8 * g;
@@ -248,45 +235,52 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
                     }
                 }
             }
-
-            f32x4 gv[NGV];
-            if (pre) {
-                wait_flags(ln, (unsigned)tn, peeked);
-                issue_gather(ln, (tn - 1) & 1, gv);
-            }
-
             // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit g, batch row 16*mt + r)
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
                 const float iv = gate_act(acc[mt][0], false), fv = gate_act(acc[mt][1], false);
-                const float gv = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
-                const float c = fv * cst[l][mt] + iv * gv;               // cell state stays f32
+                const float gg = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
+                const float c = fv * cst[l][mt] + iv * gg;               // cell state stays f32
                 cst[l][mt] = c;
-                own[(16 * mt + r) * SO + wave * 4 + g] = (_Float16)(ov * gate_act(c, true));
+                own[(l * MR + 16 * mt + r) * SO + wave * 4 + g] = (_Float16)(ov * gate_act(c, true));
             }
-            __syncthreads();                             // barrier A
-            if (ctl[0] != 0) return;
-            if (tid < TPS) {
-                const int row = tid >> 1, hq = tid & 1;
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + row * SO + 8 * hq);
+        }
+        __syncthreads();                                // own slices of every active layer complete
+        // ---- publish all active layers' slices (16-byte write-through stores), drain, barrier, ONE flag --------------
+        for (int idx = tid; idx < L * TPS; idx += 256) {
+            const int l = idx / TPS, pc = idx - l * TPS;
+            const int t = ph - l;
+            if (t >= 0 && t < T) {
+                const int row = pc >> 1, hq = pc & 1;
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (l * MR + row) * SO + 8 * hq);
                 __builtin_amdgcn_raw_buffer_store_b128(
                     __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
-                    hx_base(l, t & 1) + (unsigned)(((member * MR + row) * 16 + 8 * hq) * sizeof(_Float16)), 0, 16 /* sc1 */);
+                    hx_base(l, ph & 1) + (unsigned)(((member * MR + row) * 16 + 8 * hq) * sizeof(_Float16)), 0, 16 /* sc1 */);
             }
-            if (pre) { commit_gather(ln, gv); prefetched = true; }
-            if (l == 0 && t + 1 < T) {
-                stage_x();
-                if (t + 2 < T) fetch_x(t + 2);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                             // barrier B
-            if (tid == 0)
-                __hip_atomic_store(myflags + l * GH + member, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains before the flag (incl. the x fetch)
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(myflags + member, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- wait for every member's flag of this phase, gather every active layer's slices ------------------------------
+        wait_flags((unsigned)(ph + 1));
+        f32x4 gv[L][NGV];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = ph - l;
+            if (t >= 0 && t < T) issue_gather(l, ph & 1, gv[l]);
+        }
+        // (no wave reads hbuf between the barrier above and the one below: the commit cannot race a reader)
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = ph - l;
+            if (t >= 0 && t < T) commit_gather(l, gv[l]);
+        }
+        __syncthreads();                                // gathered h and x_{ph+1} visible
+        if (ctl[0] != 0) return;
     }
 
     // ---- head (f32 weights, f16 h) --------------------------------------------------------------------------
-    if (!gather_now(L - 1, (unsigned)T, (T - 1) & 1)) return;
     {
         constexpr int RPM = (MR + GH - 1) / GH;
         if (tid < RPM * O) {
@@ -320,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
 template <int H, int L, int KX, int NMT>
 size_t smem_bytes() {
     constexpr int MR = 16 * NMT;
-    return ((size_t)L * MR * (H + 16) + (size_t)MR * (KX + 16) + (size_t)MR * 24) * sizeof(_Float16) + 16;
+    return ((size_t)L * MR * (H + 16) + (size_t)2 * MR * (KX + 16) + (size_t)L * MR * 24) * sizeof(_Float16) + 16;
 }
 
 template <int H, int L, int KX, int NMT>
