@@ -694,3 +694,21 @@ def test_stream_bank(golden, norm_stats, name, S, kernel):
         StreamBank(m, S, T, smooth=65)
     with pytest.raises(UserWarning):
         StreamBank(m, S, T).step()                            # nothing pushed yet
+
+
+@pytest.mark.parametrize("name,B", [("pocket", 2500), ("uarm", 4100)])
+def test_batches_beyond_one_cluster_launch(norm_stats, name, B):
+    """more windows than one cluster launch covers (1024 / 2048 rows): the entry point chunks the batch; every chunk
+    must read its own inputs and write its own outputs (spot-checked against the oracle, all rows against tile16)"""
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 11, st)
+    raw = _synthetic_windows(st, B, cfg["T"], cfg["I"], 9)
+    x = torch.from_numpy(raw).cuda()
+    y = m(x, last_step_only=True, normalize_input=True)[:, 0].cpu().numpy()
+    m.check()
+    y16 = m.set_kernel("tile16")(x, last_step_only=True, normalize_input=True)[:, 0].cpu().numpy()
+    m.set_kernel("auto")
+    assert np.abs(y - y16).max() < TOL_Y_SHORT
+    pick = np.r_[0:3, 1022:1027, 2046:2051, B - 3:B]
+    xn = ((raw[pick].astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    assert np.abs(y[pick] - orc.lstm_forward(sd, xn)[:, -1]).max() < TOL_Y_SHORT
