@@ -336,7 +336,11 @@ def main():
                          "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "kernel": model.kernel_name(B, T_FRAMES), "kernel_ms": kernel_ms,
                          "flop_per_launch": flop_per_launch,
-                         "hbm_algorithmic_bytes_per_launch": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4)},
+                         "hbm_algorithmic_bytes_per_launch": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4),
+                         # the other roofline, stated plainly: ~1.8e4 FLOP per algorithmic byte, so HBM is idle by construction
+                         "hbm_algorithmic_GBps": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4) / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_peak_GBps": 8000.0,
+                         "hbm_frac": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4) / (kernel_ms * 1e-3) / 8e12},
         }
         tfile = REPO / "profiles" / "traffic_latest.json"
         if tfile.exists():      # HBM bytes per launch from the committed rocprofv3 --pmc pass
