@@ -241,7 +241,6 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
             e = hipMalloc(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
-        if (e == hipSuccess) e = ape_prepare_lstm_cluster_duo(H, L, m->KX);
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "cluster kernel set-up failed: %s", hipGetErrorString(e));
@@ -502,8 +501,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     // the cluster kernel covers last-step output, with or without inter-layer dropout (dropout: <= 32 windows
     // per cluster, so batches beyond 32 x clusters-per-chip go to the batch-tile kernel under AUTO)
     const int GHc = H / 16, max_clusters_c = 256 / GHc;
-    const bool fits_drop = !drop || L == 1 || B <= 32 * max_clusters_c || m->kernel_choice == APE_KERNEL_CLUSTER ||
-                           m->kernel_choice == APE_KERNEL_DUO;
+    const bool fits_drop = !drop || L == 1 || B <= 32 * max_clusters_c || m->kernel_choice == APE_KERNEL_CLUSTER;
     bool use_cluster = m->cluster_ok && (flags & APE_FLAG_ALL_STEPS) == 0 && fits_drop &&
                        m->kernel_choice != APE_KERNEL_TILE16;
     const bool f16 = m->precision == APE_PRECISION_F16;
@@ -511,7 +509,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant covers last-step output without dropout on "
                     "the cluster-kernel shapes only");
     if (f16) use_cluster = true;
-    if ((m->kernel_choice == APE_KERNEL_CLUSTER || m->kernel_choice == APE_KERNEL_DUO) && !use_cluster)
+    if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     if (use_cluster) {
         // smallest row tile count that still fits the batch on the chip: more clusters = more CUs busy
@@ -549,9 +547,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
-            const bool duo = !small && !f16 && !cdrop && nmt == 4 && m->kernel_choice == APE_KERNEL_DUO;
-            hipError_t e = duo ? ape_launch_lstm_cluster_duo(H, L, m->KX, clusters, c, (hipStream_t)stream)
-                           : small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), c, (hipStream_t)stream)
+            hipError_t e = small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), c, (hipStream_t)stream)
                            : f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
                                  : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
@@ -585,9 +581,9 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
 
 int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "set_kernel: NULL model");
-    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER && choice != APE_KERNEL_DUO)
+    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER)
         return fail(APE_ERR_INVALID_ARG, "set_kernel: unknown choice %d", choice);
-    if ((choice == APE_KERNEL_CLUSTER || choice == APE_KERNEL_DUO) && !m->cluster_ok)
+    if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d", m->dims.hidden_size, m->dims.num_layers);
     m->kernel_choice = choice;
     m->small_batch_path = (choice == APE_KERNEL_AUTO);

@@ -712,3 +712,4 @@ def test_batches_beyond_one_cluster_launch(norm_stats, name, B):
     pick = np.r_[0:3, 1022:1027, 2046:2051, B - 3:B]
     xn = ((raw[pick].astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
     assert np.abs(y[pick] - orc.lstm_forward(sd, xn)[:, -1]).max() < TOL_Y_SHORT
+

@@ -5,13 +5,15 @@
 // exchanged with sc1 write-through stores + per-wave epoch flags, layers software-pipelined, ticketed clusters,
 // self-cleaning flags -- but the workgroup has EIGHT waves, two per SIMD, with different jobs:
 //
-//   * waves 0-3, the MATRIX waves (one per SIMD, wave w owns units 4w..4w+3 as before), do nothing but the MFMAs:
-//     wait until the LDS holds the section's inputs, run the input and recurrent spans, hand the 16 accumulator
-//     registers to their partner through LDS, go on with the next section;
-//   * waves 4-7, the HELPER waves (wave 4+w shares a SIMD with matrix wave w), do everything else for the same
-//     units: gate non-linearities and cell update, publishing the slice, draining and raising the flag, polling
-//     the peers' flags, gathering their slices, committing them to LDS once the last reader is through, the f64
-//     z-score of the next input row.
+//   * waves 0-3, the MATRIX waves (one per SIMD, wave w owns units 4w..4w+3 as before), do the arithmetic: wait
+//     until the LDS holds the section's inputs, run the input and recurrent spans, apply the gate non-linearities
+//     and the cell update (lane-local, full VALU rate), leave their 4 x 64 fresh h values in a wave-private LDS
+//     staging area, go on with the next section;
+//   * waves 4-7, the HELPER waves (wave 4+w shares a SIMD with matrix wave w), do the exchange for the same units:
+//     publishing the slice, draining and raising the flag, polling the peers' flags, gathering their slices,
+//     committing them to LDS once the last reader is through, and the f64 z-score of the next input row -- few
+//     instructions and long waits, which is what a wave beside a saturated matrix pipe is good for (it gets about
+//     one VALU issue per MFMA: a first version that also gave it the gate math was helper-bound at 1.37 ms).
 //
 // Why: a measurement (tools/ubench/mfma_valu_coissue.hip) shows that VALU work of ANOTHER wave on the SIMD does not
 // slow an MFMA wave down at all (32.4 cycles per v_mfma_f32_16x16x4_f32 with or without a co-resident wave running
@@ -21,8 +23,6 @@
 //
 // Synchronisation inside the workgroup is by monotonic counters in LDS (no s_barrier in the loop -- a barrier would
 // couple the two roles):
-//   acc_seq[w]    matrix wave w has put the accumulators of its n-th section into accb[w]
-//   acc_free[w]   its helper has taken them (accb[w] is single-buffered; the helper also stages its slice there)
 //   m_in[w]       matrix wave w has finished the INPUT span of its n-th section (last read of the layer below)
 //   m_done[w]     ... the whole n-th section (last read of its own recurrent buffer and of xin)
 //   commit[l]     helper waves that have committed layer l's slices, summed over steps (4 per step)
@@ -58,66 +58,75 @@ __device__ __forceinline__ void mfma_va(f32x4& acc, float a, float w) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+v"(acc) : "v"(a), "a"(w));
 }
 
-// layer_mfma of lstm_cluster_common.h with the accumulators in VGPRs and the weights in VGPRs (WA = false) or AGPRs
+// One layer-step of MFMAs with the accumulators in VGPRs and the weights in VGPRs (WA = false) or AGPRs.  Only ONE set
+// of activation fragments (16 registers) is kept: a k-block is worked off in two halves of 8 MFMAs, row tiles 0-1 then
+// row tiles 2-3 (two accumulator chains 64 cycles apart: no dependent-issue stall), and the fragments of the finished
+// pair are refilled IN PLACE for block q+1 (ds_read_b128, conflict-free as before) while the other pair computes -- the
+// LDS latency hides behind 8 MFMAs (256 cycles) and the matrix wave fits 128 VGPRs next to 72 weight registers, 16
+// accumulators and the cell state.
 template <int NMT, int QIN, int QTOT, int NW, bool WA, typename Hook>
 __device__ __forceinline__ void layer_mfma_duo(f32x4 (&acc)[NMT], const float* __restrict__ in_src, int in_stride,
                                                const float* __restrict__ rec_src, int rec_stride,
                                                const float (&w)[NW], bool do_rec, Hook&& hook) {
-    f32x4 a_cur[NMT], a_nxt[NMT];
+    static_assert(NMT == 4, "tile pairs");
+    f32x4 a[NMT];
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) {
-        a_cur[mt] = *reinterpret_cast<const f32x4*>(in_src + mt * 16 * in_stride);
-        a_nxt[mt] = a_cur[mt];
-    }
-    auto block = [&](int q) {
-        __builtin_amdgcn_sched_barrier(0);
+    for (int mt = 0; mt < NMT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(in_src + mt * 16 * in_stride);
+    auto half = [&](int q, int h2) {                      // the 8 MFMAs of block q on row tiles 2*h2, 2*h2+1
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) {
-                if constexpr (WA) mfma_va(acc[mt], a_cur[mt][j], w[4 * q + j]);
-                else mfma_vv(acc[mt], a_cur[mt][j], w[4 * q + j]);
+            for (int mt = 2 * h2; mt < 2 * h2 + 2; ++mt) {
+                if constexpr (WA) mfma_va(acc[mt], a[mt][j], w[4 * q + j]);
+                else mfma_vv(acc[mt], a[mt][j], w[4 * q + j]);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto refill = [&](const float* src, int stride, int qs, int h2) {      // fragments of block qs for tiles 2*h2, 2*h2+1
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) a_cur[mt] = a_nxt[mt];
+        for (int mt = 2 * h2; mt < 2 * h2 + 2; ++mt)
+            a[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * stride + 16 * qs);
     };
     // both spans fully unrolled: every weight-register index is a compile-time constant
 #pragma unroll
     for (int q = 0; q < QIN; ++q) {
         hook(q);
-        if (q + 1 < QIN) {
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-                a_nxt[mt] = *reinterpret_cast<const f32x4*>(in_src + mt * 16 * in_stride + 16 * (q + 1));
-        } else if (do_rec) {
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-                a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride);
+        for (int h2 = 0; h2 < 2; ++h2) {
+            __builtin_amdgcn_sched_barrier(0);
+            half(q, h2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < QIN) refill(in_src, in_stride, q + 1, h2);
+            else if (do_rec) refill(rec_src, rec_stride, 0, h2);
         }
-        block(q);
     }
     if (do_rec) {
 #pragma unroll
         for (int q = QIN; q < QTOT; ++q) {
             hook(q);
-            if (q + 1 < QTOT) {
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt)
-                    a_nxt[mt] = *reinterpret_cast<const f32x4*>(rec_src + mt * 16 * rec_stride + 16 * (q + 1 - QIN));
+            for (int h2 = 0; h2 < 2; ++h2) {
+                __builtin_amdgcn_sched_barrier(0);
+                half(q, h2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < QTOT) refill(rec_src, rec_stride, q + 1 - QIN, h2);
             }
-            block(q);
         }
     }
 }
+
+#ifdef APE_CLUSTER_STAMPS
+#define EV(cond, slot) do { if ((cond) && blockIdx.x == 0 && lane == 0 && p.dbg_wg) p.dbg_wg[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EV(cond, slot) do {} while (0)
+#endif
 
 template <int H, int L, int KX>
 __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterParams p) {
     constexpr int NMT = 4;
     constexpr int GH = H / 16;
     constexpr int MR = 16 * NMT;
-    constexpr int SH = H + 8, SX = KX + 8, SO = 16;    // SO: slice staging row stride inside accb[w] (64 rows x 16 floats)
+    constexpr int SH = H + 8, SX = KX + 8, SO = 16;    // SO: row stride of a matrix wave's slice staging area (64 rows x 16 floats, 4 used)
     constexpr int QX = KX / 16, QH = H / 16;
     constexpr int NW0 = (KX + H) / 4, NW1 = (2 * H) / 4;
     constexpr int NFL = 4 * GH;                   // flags per (cluster, layer): one per member helper wave
@@ -139,9 +148,10 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                           // [L][MR][SH]  gathered h of every layer
     float* xin = hbuf + L * MR * SH;              // [MR][SX]
-    float* accb = xin + MR * SX;                  // [4][MR*16]   accumulators matrix wave -> helper; then slice staging
-    int* sync = reinterpret_cast<int*>(accb + 4 * MR * 16);
-    int* acc_seq = sync, *acc_free = sync + 4, *m_in = sync + 8, *m_done = sync + 12;
+    float* stage = xin + MR * SX;                 // [4][MR][SO]  fresh slice of each matrix wave (wave-private columns)
+    float* bias_s = stage + 4 * MR * SO;          // [L][16 units][4 gates] of this member
+    int* sync = reinterpret_cast<int*>(bias_s + APE_MAX_LAYERS * 64);
+    int* m_in = sync + 8, *m_done = sync + 12;
     int* commit = sync + 16;                      // [L]
     int* x_cnt = sync + 16 + APE_MAX_LAYERS;
     int* ctl = x_cnt + 1;                         // [0] abort flag, [1] arrival ticket, [2] last-out
@@ -151,6 +161,11 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
     const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
     const int cluster = ticket / GH, member = ticket % GH;
     const int row0 = cluster * MR;
+    if (tid < L * 64) {                           // bias: [l][unit][gate], a lane reads its four gates with one ds_read_b128
+        const int l = tid / 64, u = (tid % 64) / 4, gt = tid % 4;
+        bias_s[tid] = p.bias[l][gt * H + member * 16 + u];
+    }
+    __syncthreads();
 
     // bounded wait for an LDS counter; false on abort (a helper's poll of the peers expired, or this one did)
     auto wait_ge = [&](const int* ptr, int want) -> bool {
@@ -169,6 +184,10 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
         return true;
     };
     const int P = T + L - 1;
+    const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
+    unsigned* const myflags = p.xflags + (size_t)cluster * L * NFL;
+    constexpr unsigned SLICE_SET = GH * MR * 16 * sizeof(float);
+    auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SLICE_SET); };
 
     if (!helper) {
         // =========================== matrix waves =========================================================================
@@ -199,8 +218,23 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                 }
             }
         }
-        float* const my_acc = accb + w * (MR * 16);
+        float* const my_stage = stage + w * (MR * SO);
+        float cst[L][NMT];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) cst[l][mt] = 0.0f;
         int sidx = 0;
+        // the flag owed for the slice stored at the end of the last section: raised, once those stores have drained, one
+        // k-block into the next section (or at the very end)
+        int pend_idx = -1;
+        unsigned pend_epoch = 0u;
+        auto raise_pending = [&]() {
+            if (pend_idx < 0) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(myflags + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend_idx = -1;
+        };
         STAMP_DECL
 #pragma unroll 1
         for (int ph = 0; ph < P; ++ph) {
@@ -209,19 +243,36 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                 const int t = ph - l;
                 if (t < 0 || t >= T) continue;
                 STAMP_BEGIN();
-                // inputs of this section in LDS?  x_t (layer 0), h^l_{t-1}, h^{l-1}_t
+                // inputs of the INPUT span in LDS?  x_t (layer 0) or h^{l-1}_t.  The recurrent input h^l_{t-1} is waited for
+                // only in front of the recurrent span (hook below): its exchange, which started at the end of this
+                // layer's previous section, then has that section's successor PLUS this input span to finish in
+                // (a wave never blocks on the peers while it owes them a flag: with T = 1 the layer below finished in the
+                //  section right before this one and its flag would otherwise go up only inside this section)
+                if (l > 0 && lds_load(commit + l - 1) < 4 * (t + 1)) raise_pending();
                 bool ok = true;
                 if (l == 0) ok = wait_ge(x_cnt, 4 * (t + 1));
-                if (ok && t > 0) ok = wait_ge(commit + l, 4 * t);
                 if (ok && l > 0) ok = wait_ge(commit + l - 1, 4 * (t + 1));
                 if (!ok) goto done;
+                EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 0);      // section started (inputs of the input span there)
                 STAMP_END(1);                            // 1: matrix wave waits for its inputs
                 f32x4 acc[NMT];
+                {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (l * 16 + w * 4 + g) * 4);
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // the helper adds the bias
+                    for (int mt = 0; mt < NMT; ++mt) acc[mt] = bv;       // bias = initial accumulator, as everywhere
+                }
                 const float* rec_src = hbuf + (l * MR + r) * SH + 4 * g;
                 const int QIN = (l == 0) ? QX : QH;
                 auto hook = [&](int q) {
+                    if (q == ((QIN - 1 < 6) ? QIN - 1 : 6)) {           // store acknowledged by now (~1.5 us): no stall in the drain;
+                        raise_pending();                                  // and BEFORE the wait that depends on the peers
+                        EV(w == 0 && sidx >= 41 && sidx < 45, (sidx - 41) * 10 + 3);   // flag of the previous section raised
+                    }
+                    if (q == QIN - 1 && t > 0) {
+                        EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 8);   // reached the recurrent-input wait
+                        (void)wait_ge(commit + l, 4 * t);                 // (an abort surfaces at the next checked wait)
+                        EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 9);   // ... passed it
+                    }
                     if (q == QIN) lds_store(m_in + w, sidx + 1);          // the layer below has no reader left in this wave
                 };
                 if (l == 0) {
@@ -235,17 +286,35 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                     }
                 }
                 mfma_drain();
+                EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 1);      // MFMAs of the section done
                 STAMP_END(2);                            // 2: MFMAs
                 if (t == 0) lds_store(m_in + w, sidx + 1);
-                if (!wait_ge(acc_free + w, sidx)) goto done;               // the helper took the last section's accumulators
+                lds_store(m_done + w, sidx + 1);                           // last LDS read of this section is behind us
+                raise_pending();                                           // (a section too short to reach block 1)
+                // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit g, batch row 16*mt + r)
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) *reinterpret_cast<f32x4*>(my_acc + (mt * 64 + lane) * 4) = acc[mt];
-                lds_store(m_done + w, sidx + 1);
-                lds_store(acc_seq + w, sidx + 1);
-                STAMP_END(3);                            // 3: accumulator hand-off
+                for (int mt = 0; mt < NMT; ++mt) {
+                    const float iv = gate_act(acc[mt][0], false), fv = gate_act(acc[mt][1], false);
+                    const float gg = gate_act(acc[mt][2], true), ov = gate_act(acc[mt][3], false);
+                    const float c = fv * cst[l][mt] + iv * gg;
+                    cst[l][mt] = c;
+                    my_stage[(16 * mt + r) * SO + g] = ov * gate_act(c, true);
+                }
+                {   // publish: lane = row, one 16-byte piece (this wave's four units) per row, write-through; the staging
+                    // area is this wave's own, LDS operations of one wave are ordered
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(my_stage + lane * SO);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
+                        (unsigned)(((member * MR + lane) * 16 + 4 * w) * sizeof(float)), hx_base(l, t & 1), 16 /* sc1 */);
+                    pend_idx = l * NFL + member * 4 + w;
+                    pend_epoch = (unsigned)(t + 1);
+                }
+                EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 2);      // slice stored
+                STAMP_END(3);                            // 3: gate math + publish
                 ++sidx;
             }
         }
+        raise_pending();
 #ifdef APE_CLUSTER_STAMPS
         if (blockIdx.x == 0 && tid == 0) {
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 8);
@@ -254,21 +323,9 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
 #endif
     } else {
         // =========================== helper waves =========================================================================
-        f32x4 bias_r[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bias_r[l][k] = p.bias[l][k * H + member * 16 + w * 4 + g];
-        float cst[L][NMT];
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) cst[l][mt] = 0.0f;
-
-        const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
-        unsigned* const myflags = p.xflags + (size_t)cluster * L * NFL;
-        constexpr unsigned SLICE_SET = GH * MR * 16 * sizeof(float);
-        auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SLICE_SET); };
+        // few instructions, all of them on somebody's critical path: let them win the issue arbitration against the
+        // matrix wave of their SIMD (measured: without this a helper instruction waits ~90 cycles for a slot)
+        __builtin_amdgcn_s_setprio(3);
         const int g_row = ht >> 2, g_quad = ht & 3;                          // gather: piece (row, quad) of every member
         const unsigned g_thread_off = (unsigned)((g_row * 16 + 4 * g_quad) * sizeof(float));
 
@@ -287,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                     }
                     return false;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(4);
             }
         };
 
@@ -325,7 +382,6 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
         if (T > 1) fetch_x(1);
         lds_count_wave(x_cnt);
 
-        float* const my_acc = accb + w * (MR * 16);
         int sidx = 0;
         STAMP_DECL
 #pragma unroll 1
@@ -335,34 +391,6 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                 const int t = ph - l;
                 if (t < 0 || t >= T) continue;
                 STAMP_BEGIN();
-                // ---- this quad's accumulators -> gates, cell update, slice ---------------------------------------------------
-                if (!wait_ge(acc_seq + w, sidx + 1)) goto done;
-                STAMP_END(4);                            // 4: helper waits for the accumulators
-                f32x4 acc[NMT];
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) acc[mt] = *reinterpret_cast<const f32x4*>(my_acc + (mt * 64 + lane) * 4);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) {
-                    const float iv = gate_act(acc[mt][0] + bias_r[l][0], false), fv = gate_act(acc[mt][1] + bias_r[l][1], false);
-                    const float gg = gate_act(acc[mt][2] + bias_r[l][2], true), ov = gate_act(acc[mt][3] + bias_r[l][3], false);
-                    const float c = fv * cst[l][mt] + iv * gg;
-                    cst[l][mt] = c;
-                    my_acc[(16 * mt + r) * SO + g] = ov * gate_act(c, true);      // staging: row-major, this wave's 4 units
-                }
-                {   // publish: lane = row, one 16-byte piece (this quad's units) per row, write-through
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(my_acc + lane * SO);
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
-                        (unsigned)(((member * MR + lane) * 16 + 4 * w) * sizeof(float)), hx_base(l, t & 1), 16 /* sc1 */);
-                }
-                lds_store(acc_free + w, sidx + 1);                       // accb[w] may take the next section's accumulators
-                STAMP_END(5);                            // 5: gates + cell + staging + store issue
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slice stores complete (and the x fetch, issued long ago)
-                if (lane == 0)
-                    __hip_atomic_store(myflags + l * NFL + member * 4 + w, (unsigned)(t + 1), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                STAMP_END(6);                            // 6: drain + flag
                 // ---- x_{t+1}: xin has no reader left once every matrix wave is through this layer-0 section ----------------------
                 if (l == 0 && t + 1 < T) {
                     bool ok = true;
@@ -374,14 +402,15 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                     if (t + 2 < T) fetch_x(t + 2);
                 }
                 // ---- the peers' slices of this layer-step: gather, wait for the last reader of the old ones, commit ------------------
-                STAMP_END(7);                            // 7: x staging (incl. waiting for the matrix waves)
                 if (!wait_flags(l, (unsigned)(t + 1))) goto done;
+                EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 4);      // helper saw every flag of the section
                 STAMP_END(8);                            // 8: waiting for the peers' flags
                 f32x4 gv[NGV];
 #pragma unroll
                 for (int m = 0; m < NGV; ++m)
                     gv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                         hx_rsrc, g_thread_off, hx_base(l, t & 1) + (unsigned)(m * MR * 16 * sizeof(float)), 16 /* sc1 */));
+                STAMP_END(7);                            // 7: gather issue + x staging
                 {
                     // readers of hbuf[l] = h^l_{t-1}: this section (recurrent span) and, one section later in program order,
                     // layer l+1 on step t-1 (input span)
@@ -394,11 +423,13 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster_duo(const ClusterPara
                     }
                     if (!ok) goto done;
                 }
+                EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 5);      // gather issued, last reader through
                 STAMP_END(9);                            // 9: gather issue + waiting for the last reader
 #pragma unroll
                 for (int m = 0; m < NGV; ++m)
                     *reinterpret_cast<f32x4*>(hbuf + (l * MR + g_row) * SH + m * 16 + 4 * g_quad) = gv[m];
                 lds_count_wave(commit + l);
+                EV(w == 0 && sidx >= 40 && sidx < 44, (sidx - 40) * 10 + 6);      // committed
                 STAMP_END(10);                           // 10: commit
                 ++sidx;
             }
@@ -456,7 +487,7 @@ done:
 
 template <int H, int L, int KX>
 size_t smem_bytes() {
-    return ((size_t)L * 64 * (H + 8) + (size_t)64 * (KX + 8) + (size_t)4 * 64 * 16) * sizeof(float) + 32 * sizeof(int);
+    return ((size_t)L * 64 * (H + 8) + (size_t)64 * (KX + 8) + (size_t)4 * 64 * 16 + APE_MAX_LAYERS * 64) * sizeof(float) + 32 * sizeof(int);
 }
 
 template <int H, int L, int KX>

@@ -64,19 +64,6 @@ for fl, nm in ((0x70000000, "cluster_noex_noact"), (0x10000000, "cluster")):
         tot = sum(out[2:14]); P = T + cfg["L"] - 1
         print(f"{nm}: section cycles per phase (wave 0 of workgroup 0): " + ", ".join(f"{n} {v / P:.2f}" if n.startswith("fallb") else f"{n} {v / P:.0f}" for n, v in zip(names, out[2:14])) + f"  | sum {tot / P:.0f}")
 
-# two-role kernel: matrix-wave and helper-wave shares
-lib.ape_model_set_kernel(m.handle, 3)
-for _ in range(100):
-    lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0x10000000, None, 0.0, 0, C.c_void_p(y.data_ptr()), st)
-torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 14)()
-raw.ape_debug_read_stamps(m.handle, out)
-if any(out[2:14]):
-    names = ["-", "M:wait-inputs", "M:mfma", "M:hand-off", "H:wait-acc", "H:act+publish", "H:drain+flag", "H:x-stage", "H:wait-flags", "H:gather+wait-readers", "H:commit", "-"]
-    P = T + cfg["L"] - 1
-    print("duo: cycles per phase: " + ", ".join(f"{n} {v / P:.0f}" for n, v in zip(names, out[2:14])))
-lib.ape_model_set_kernel(m.handle, 2)
-
 # per-workgroup timeline of the last stamped launch (diagnostic library only): cluster = ticket // GH
 try:
     buf = (ctypes.c_ulonglong * (256 * 8))()
