@@ -26,8 +26,9 @@ def run(n):
     return a.elapsed_time(b) / n * 1e3
 run(20)
 v = [run(20) for _ in range(9)]
-ref = orc.lstm_forward(sd, x[:8].cpu().numpy())[:, -1]
-err = float(np.abs(y[:8].cpu().numpy() - ref).max())
+pick = np.unique(np.r_[0:4, np.linspace(0, B - 1, 24).astype(int), max(0, B - 4):B])      # rows from every part of the batch
+ref = orc.lstm_forward(sd, x.cpu().numpy()[pick])[:, -1]
+err = float(np.abs(y.cpu().numpy()[pick] - ref).max())
 m.check()
 flop = m.flops_per_window(T) * B
 print(f"{os.environ.get('APE_HIP_LIB', 'default'):60s} {name} B={B} T={T}: median {np.median(v):8.1f} us  min {min(v):8.1f}  {flop / np.median(v) / 1e6:6.1f} TFLOP/s  max|dy| {err:.1e}")
