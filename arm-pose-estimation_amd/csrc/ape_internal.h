@@ -44,7 +44,7 @@ struct ClusterParams {
     const double* xx_m;
     const double* xx_s;
     const double* xx_r;                 // [I] 1 / xx_s, rounded once on the host
-    float* hx;                          // exchange slices [cluster][L][parity 2][member GH][row MR][16]
+    float* hx;                          // exchange slices [cluster][L][parity 2][member GH][wave 4][row MR][4 units] (f32 cluster kernel)
     size_t hx_bytes;
     unsigned* xflags;                   // [cluster][L][GH] epoch flags, zeroed before every launch
     unsigned* ticket;                   // [1] arrival counter (re-zeroed by the last workgroup out)

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // ---- exchange helpers ------------------------------------------------------------------------------
     constexpr int NGV = GH / SPP;                    // 16-byte pieces each thread moves per gather
     const int g_sl = tid / TPS, g_idx = tid - g_sl * TPS;       // slice within a pass, piece within the slice
-    const int g_row = g_idx >> 2, g_quad = g_idx & 3;
+    const int g_row = g_idx % MR, g_quad = g_idx / MR;           // row fastest: a wave's 64 pieces are 1 KiB contiguous
 
     // every wave polls for itself (no barrier on the way): all members published epoch `want` of layer l?
     // bounded; on give-up raises the sticky status word and the workgroup abort flag
@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // byte offset inside a pass, or that plus 2^31 -- outside the descriptor, so the load returns zeros without
     // touching memory -- while the flags have not been seen raised (the uniform part sits in soffset, which the
     // range check ignores)
-    const unsigned g_thread_off = (unsigned)(((g_sl * MR + g_row) * 16 + 4 * g_quad) * sizeof(float));
+    // exchange layout [member][wave quad][row][4 units]: what ONE wave stores per layer-step (64 rows x 16 B) is one
+    // contiguous KiB -- whole 64-byte lines, not a quarter of each row's line
+    const unsigned g_thread_off = (unsigned)((((g_sl * 4 + g_quad) * MR + g_row) * 4) * sizeof(float));
     auto issue_piece = [&](int l, int par, int kk, unsigned goff, f32x4 (&gv)[NGH]) {
         if (diag_noex) return;
         const int v = kk / NGV, k = kk - v * NGV;
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                     const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (v * MR + row) * SO + 4 * wave);
                     __builtin_amdgcn_raw_buffer_store_b128(
                         __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
-                        (unsigned)(((member * MR + row) * 16 + 4 * wave) * sizeof(float)), hx_base(l, t & 1, v), 16 /* sc1 */);
+                        (unsigned)((((member * 4 + wave) * MR + row) * 4) * sizeof(float)), hx_base(l, t & 1, v), 16 /* sc1 */);
                 }
                 pend_idx = l * NFL + member * 4 + wave;
                 pend_epoch = (unsigned)(t + 1);
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         const int h_row = member * RPM + h_rr;
         if (!diag_noex && tid < GH * RPM * 4 && h_row < MR) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                hx_rsrc, (unsigned)(((h_m * MR + h_row) * 16 + 4 * h_quad) * sizeof(float)), hx_base(L - 1, (T - 1) & 1, 0),
+                hx_rsrc, (unsigned)((((h_m * 4 + h_quad) * MR + h_row) * 4) * sizeof(float)), hx_base(L - 1, (T - 1) & 1, 0),
                 16 /* sc1 */));
             *reinterpret_cast<f32x4*>(hbuf + ((L - 1) * MR + h_row) * SH + h_m * 16 + 4 * h_quad) = v;
         }
