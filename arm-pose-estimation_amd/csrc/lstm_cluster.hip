@@ -546,6 +546,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     {
         constexpr int RPM = (MR + GH - 1) / GH;          // rows per member
         static_assert(GH * RPM * 4 <= 256, "one head piece per thread");
+        // this thread's share of the head weights first: the loads fly while the last flags and slices arrive
+        const int n_out = RPM * O;
+        constexpr int PL = (RPM * APE_MAX_OUTPUT * 4 <= 256) ? 4 : ((RPM * APE_MAX_OUTPUT * 2 <= 256) ? 2 : 1);
+        constexpr int NHW = H / (4 * PL);                 // 16-byte weight pieces per thread
+        const int oi = tid / PL, part = tid % PL;
+        const bool live = oi < n_out;
+        const int rr = live ? oi / O : 0, o = live ? oi - rr * O : 0;
+        const int row = member * RPM + rr;
+        f32x4 hw[NHW];
+#pragma unroll
+        for (int i = 0; i < NHW; ++i)
+            hw[i] = (live && row < MR) ? *reinterpret_cast<const f32x4*>(p.w_out + (size_t)o * H + 4 * part + 4 * PL * i)
+                                       : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         wait_flags(L - 1, (unsigned)T, 0u);
         const int h_m = tid / (RPM * 4), h_rr = (tid / 4) % RPM, h_quad = tid & 3;
         const int h_row = member * RPM + h_rr;
@@ -558,21 +571,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         bar();
         if (ctl[0] != 0) return;
         // (row, target) dot products over H, PL lanes each (k interleaved by 4), combined by lane shuffles
-        const int n_out = RPM * O;
-        constexpr int PL = (RPM * APE_MAX_OUTPUT * 4 <= 256) ? 4 : ((RPM * APE_MAX_OUTPUT * 2 <= 256) ? 2 : 1);
-        const int oi = tid / PL, part = tid % PL;
         float s_acc = 0.0f;
-        const bool live = oi < n_out;
-        const int rr = live ? oi / O : 0, o = live ? oi - rr * O : 0;
-        const int row = member * RPM + rr;
         if (live && row < MR) {
-            const float* hv = hbuf + ((L - 1) * MR + row) * SH;
-            const float* wv = p.w_out + (size_t)o * H;
-            for (int k = 4 * part; k < H; k += 4 * PL) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(hv + k);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wv + k);
-                s_acc = fmaf(a[0], w[0], s_acc); s_acc = fmaf(a[1], w[1], s_acc);
-                s_acc = fmaf(a[2], w[2], s_acc); s_acc = fmaf(a[3], w[3], s_acc);
+            const float* hv = hbuf + ((L - 1) * MR + row) * SH + 4 * part;
+#pragma unroll
+            for (int i = 0; i < NHW; ++i) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(hv + 4 * PL * i);
+                s_acc = fmaf(a[0], hw[i][0], s_acc); s_acc = fmaf(a[1], hw[i][1], s_acc);
+                s_acc = fmaf(a[2], hw[i][2], s_acc); s_acc = fmaf(a[3], hw[i][3], s_acc);
             }
         }
         if (PL >= 2) s_acc += __shfl_xor(s_acc, 1, 64);
