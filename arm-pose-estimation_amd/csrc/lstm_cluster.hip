@@ -115,36 +115,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const int cluster = ticket / GH, member = ticket % GH;
     const int row0 = cluster * MR;
 
-    // ---- weights: registers, for the whole launch ---------------------------------------------
-    static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
-    float w0[NW0];
-    float w1[L > 1 ? NW1 : 1];
-    float w2[L > 2 ? NW1 : 1];
-    {
-        // 16 bytes per lane and load (host order [k-quad][lane][4]): a quarter of the instructions of a dword walk
-        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NW0 / 4; ++i) {
-            const f32x4 v = s0[i * 64];
-            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
-        }
-        if constexpr (L > 1) {
-            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < NW1 / 4; ++i) {
-                const f32x4 v = s1[i * 64];
-                w1[4 * i] = v[0]; w1[4 * i + 1] = v[1]; w1[4 * i + 2] = v[2]; w1[4 * i + 3] = v[3];
-            }
-        }
-        if constexpr (L > 2) {
-            const f32x4* s2 = reinterpret_cast<const f32x4*>(p.wcl[2]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < NW1 / 4; ++i) {
-                const f32x4 v = s2[i * 64];
-                w2[4 * i] = v[0]; w2[4 * i + 1] = v[1]; w2[4 * i + 2] = v[2]; w2[4 * i + 3] = v[3];
-            }
-        }
-    }
     f32x4 bias_r[L];
 #pragma unroll
     for (int l = 0; l < L; ++l)
@@ -294,9 +264,41 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         for (int e = 0; e < NE; ++e) stage_elem(e);
     };
     fetch_x(0);
+    // ---- weights: registers, for the whole launch.  Issued AFTER the bias and x_0 loads (loads return in order): the
+    //      first phase needs x_0, the bias and only the 8 x-span registers of layer 0, so the other ~190 loads per lane
+    //      land under phase 0 and the pipeline-fill exchange instead of in front of them
+    static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
+    float w0[NW0];
+    float w1[L > 1 ? NW1 : 1];
+    float w2[L > 2 ? NW1 : 1];
+    {
+        // 16 bytes per lane and load (host order [k-quad][lane][4]): a quarter of the instructions of a dword walk
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NW0 / 4; ++i) {
+            const f32x4 v = s0[i * 64];
+            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
+        }
+        if constexpr (L > 1) {
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NW1 / 4; ++i) {
+                const f32x4 v = s1[i * 64];
+                w1[4 * i] = v[0]; w1[4 * i + 1] = v[1]; w1[4 * i + 2] = v[2]; w1[4 * i + 3] = v[3];
+            }
+        }
+        if constexpr (L > 2) {
+            const f32x4* s2 = reinterpret_cast<const f32x4*>(p.wcl[2]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NW1 / 4; ++i) {
+                const f32x4 v = s2[i * 64];
+                w2[4 * i] = v[0]; w2[4 * i + 1] = v[1]; w2[4 * i + 2] = v[2]; w2[4 * i + 3] = v[3];
+            }
+        }
+    }
     stage_x();
     if (T > 1) fetch_x(1);
-    __syncthreads();
+    bar();
 
     // The flag a wave owes for the slice it stored last: raised once those stores have drained -- a few k-blocks
     // into the NEXT section's MFMAs (the write-through latency hides there), or at the latest before this wave
