@@ -571,7 +571,7 @@ def test_fp16_hidden_state_variant(norm_stats, name, B, T):
 
 
 def test_graph_capture_and_replay(norm_stats):
-    """ape_infer is capturable into a hipGraph (memset node + kernels, no allocation once reserved) and a
+    """ape_infer is capturable into a hipGraph (kernels only -- the cluster kernel cleans its own flags --, no allocation once reserved) and a
     replay on new input data reproduces the eager result bit for bit"""
     from wear_mocap_ape_amd import _hip
     st = norm_stats["pocket"]
