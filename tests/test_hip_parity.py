@@ -713,3 +713,55 @@ def test_batches_beyond_one_cluster_launch(norm_stats, name, B):
     xn = ((raw[pick].astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
     assert np.abs(y[pick] - orc.lstm_forward(sd, xn)[:, -1]).max() < TOL_Y_SHORT
 
+
+
+def test_c_caller(tmp_path):
+    """tests/c_abi/demo.c -- plain C on the C ABI, no Python or torch in the process -- against the oracle on the same
+    LCG-seeded weights, statistics and windows: ape_infer rows and the stream bank's messages"""
+    import subprocess
+    from test_host_bookkeeping import build_c_caller
+    exe = build_c_caller(tmp_path)
+    out = tmp_path / "demo.bin"
+    run = subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr + run.stdout
+    I, H, L, O, B, T, S, SMOOTH = 22, 256, 2, 14, 37, 6, 5, 3
+
+    def lcg(seed, n):                              # the generator of demo.c
+        state, vals = np.uint32(seed), np.empty(n, np.float32)
+        s = int(state)
+        for i in range(n):
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            vals[i] = np.float32(s >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+        return vals
+
+    from wear_mocap_ape_amd.estimate import nn_models
+    n_w = 4 * H * (I + H) + 8 * H + 4 * H * (H + H) + 8 * H + O * H + O
+    blob = (np.float32(0.0625) * lcg(12345, n_w)).astype(np.float32)
+    sd, cur = {}, 0
+    for key in nn_models.state_dict_keys(L):
+        shape = {"weight_ih_l0": (4 * H, I), "weight_ih_l1": (4 * H, H), "weight_hh_l0": (4 * H, H), "weight_hh_l1": (4 * H, H),
+                 "bias_ih_l0": (4 * H,), "bias_hh_l0": (4 * H,), "bias_ih_l1": (4 * H,), "bias_hh_l1": (4 * H,),
+                 "weight": (O, H), "bias": (O,)}[key.split(".")[-1]]
+        n = int(np.prod(shape))
+        sd[key] = blob[cur:cur + n].reshape(shape)
+        cur += n
+    assert cur == n_w
+    stats = {"xx_m": 0.1 * np.arange(I) - 1.0, "xx_s": 0.5 + 0.05 * np.arange(I),
+             "yy_m": 0.02 * np.arange(O), "yy_s": 0.3 + 0.01 * np.arange(O)}
+    u = lcg(777, B * T * I).reshape(B, T, I)
+    x = (stats["xx_m"] + stats["xx_s"] * u.astype(np.float64)).astype(np.float32)      # (float)(m + s * u) in double, as in C
+    raw = np.fromfile(out, dtype=np.uint8)
+    y = raw[:B * O * 4].view(np.float32).reshape(B, O)
+    est = raw[B * O * 4:B * O * 4 + B * 21 * 8].view(np.float64).reshape(B, 21)
+    msg = raw[B * O * 4 + B * 21 * 8:].view(np.float64).reshape(S, 25)
+    y_ref, est_ref = orc.infer_windows(sd, stats, orc.DEFAULT_BODY, 0, x, route="eigh")
+    assert np.abs(y - y_ref).max() < TOL_Y_SHORT
+    assert np.abs(est - est_ref).max() < TOL_EST_E2E
+    # stream bank: T frames pushed, smoothing stack of the last 3 predictions; frame f sees the window padded with x_0
+    predict = lambda hist: orc.lstm_forward(sd, np.asarray(hist, dtype=np.float32)[None])[:, -1, :]
+    for s in range(S):
+        win = orc.WindowOracle(T, SMOOTH, stats, predict)
+        for t in range(T):
+            pred = win.push(x[s, t])
+        ref = orc.msg_from_est(orc.arm_pose_from_targets(pred, orc.DEFAULT_BODY, 0, "eigh"), orc.DEFAULT_BODY, 0)
+        assert np.abs(msg[s] - ref).max() < 5e-6

@@ -171,3 +171,23 @@ def test_features_from_row(golden, name):
         xx = fn(array("f", row32.tolist()), lookup)
         assert str(xx.dtype) == dtype and xx.shape == ref[f].shape
         assert np.abs(xx.astype(np.float64) - ref[f]).max() < tol, (f, np.abs(xx - ref[f]).max())
+
+
+def build_c_caller(tmp_path):
+    """gcc-compile tests/c_abi/demo.c (plain C, no Python, no torch) against include/ape_hip.h and libape_hip.so"""
+    import subprocess
+    import __graft_entry__ as entry
+    entry.build()
+    exe = tmp_path / "c_abi_demo"
+    lib_dir = REPO / "arm-pose-estimation_amd" / "lib"
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{REPO / 'include'}",
+           str(REPO / "tests" / "c_abi" / "demo.c"), f"-L{lib_dir}", "-lape_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_c_caller_compiles_and_links(tmp_path):
+    """the header is valid C (not only C++) and every entry point the C caller uses resolves at link time"""
+    exe = build_c_caller(tmp_path)
+    assert exe.exists() and exe.stat().st_size > 0
