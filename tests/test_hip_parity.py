@@ -765,3 +765,26 @@ def test_c_caller(tmp_path):
             pred = win.push(x[s, t])
         ref = orc.msg_from_est(orc.arm_pose_from_targets(pred, orc.DEFAULT_BODY, 0, "eigh"), orc.DEFAULT_BODY, 0)
         assert np.abs(msg[s] - ref).max() < 5e-6
+
+
+def test_two_models_on_two_streams_concurrently(norm_stats):
+    """two cluster-kernel launches (different models, own exchange buffers and tickets) in flight on the same GPU at
+    once: their workgroups compete for the CUs, clusters form by arrival ticket, nothing deadlocks, results are the
+    ones each model produces alone"""
+    a, _, cfg_a = make_model("pocket", 31, norm_stats["pocket"])
+    b, _, cfg_b = make_model("uarm", 32, norm_stats["uarm"])
+    xa = torch.from_numpy(_synthetic_windows(norm_stats["pocket"], 1024, 16, cfg_a["I"], 1)).cuda()
+    xb = torch.from_numpy(_synthetic_windows(norm_stats["uarm"], 2048, 16, cfg_b["I"], 2)).cuda()
+    ya_alone = a(xa, last_step_only=True, normalize_input=True).clone()
+    yb_alone = b(xb, last_step_only=True, normalize_input=True).clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(25):
+        with torch.cuda.stream(sa):
+            ya = a(xa, last_step_only=True, normalize_input=True)
+        with torch.cuda.stream(sb):
+            yb = b(xb, last_step_only=True, normalize_input=True)
+    torch.cuda.synchronize()
+    a.check()
+    b.check()
+    assert torch.equal(ya, ya_alone) and torch.equal(yb, yb_alone)
