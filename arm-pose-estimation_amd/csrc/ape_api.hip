@@ -87,6 +87,8 @@ struct ape_model {
     int lstm_in = 0;               // LSTM layer-0 input width (input_size; 256 behind ImuPoseLSTM's input layer)
     int KXpre = 0;                 // ImuPoseLSTM: padded width of the input layer's input
     float* z_ws = nullptr;         // ImuPoseLSTM: [cap rows, 256] activations of the input layer
+    float* hseq_ws = nullptr;      // all-steps mode of the cluster kernel: [cap rows = B*T, H] top-layer outputs
+    size_t hseq_cap = 0;
     size_t z_cap = 0;
     f32x4* wpack[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     float* bias[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
@@ -267,6 +269,7 @@ int ape_model_destroy(ape_model_t* m) {
     if (m->stats) (void)hipFree(m->stats);
     if (m->y_ws) (void)hipFree(m->y_ws);
     if (m->z_ws) (void)hipFree(m->z_ws);
+    if (m->hseq_ws) (void)hipFree(m->hseq_ws);
     for (int l = 0; l < APE_MAX_LAYERS; ++l)
         if (m->wcl[l]) (void)hipFree(m->wcl[l]);
     for (int l = 0; l < APE_MAX_LAYERS; ++l)
@@ -502,9 +505,11 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     // per cluster, so batches beyond 32 x clusters-per-chip go to the batch-tile kernel under AUTO)
     const int GHc = H / 16, max_clusters_c = 256 / GHc;
     const bool fits_drop = !drop || L == 1 || B <= 32 * max_clusters_c || m->kernel_choice == APE_KERNEL_CLUSTER;
-    bool use_cluster = m->cluster_ok && (flags & APE_FLAG_ALL_STEPS) == 0 && fits_drop &&
-                       m->kernel_choice != APE_KERNEL_TILE16;
     const bool f16 = m->precision == APE_PRECISION_F16;
+    // all-steps output: the cluster kernel also writes every step's top-layer output to a [B,T,H] workspace and the
+    // head runs over those rows in a second, HBM-bound launch
+    const bool all_steps = (flags & APE_FLAG_ALL_STEPS) != 0;
+    bool use_cluster = m->cluster_ok && fits_drop && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16);
     if (f16 && (!m->cluster_ok || drop || (flags & APE_FLAG_ALL_STEPS)))
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant covers last-step output without dropout on "
                     "the cluster-kernel shapes only");
@@ -519,12 +524,25 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         for (int cand : {1, 2, 4})
             if ((!cdrop || cand <= 2) && (B + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
         const int rows_per_launch = 16 * nmt * max_clusters;
-        const bool small = !f16 && !cdrop && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        if (all_steps) {
+            const size_t rows = (size_t)B * T;
+            if (rows > m->hseq_cap) {
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing((hipStream_t)stream, &st);
+                if (st != hipStreamCaptureStatusNone)
+                    return fail(APE_ERR_CAPACITY, "lstm_forward: the all-steps workspace (%zu rows) cannot grow during stream capture", rows);
+                if (m->hseq_ws) { HIP_TRY(hipFree(m->hseq_ws)); m->hseq_ws = nullptr; m->hseq_cap = 0; }
+                HIP_TRY(hipMalloc((void**)&m->hseq_ws, rows * H * sizeof(float)));
+                m->hseq_cap = rows;
+            }
+        }
         for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
             const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
             ClusterParams c{};
             c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
-            c.y = y_dev + (size_t)b0 * m->dims.output_size;
+            c.y = all_steps ? nullptr : y_dev + (size_t)b0 * m->dims.output_size;
+            c.hseq = all_steps ? m->hseq_ws + (size_t)b0 * T * H : nullptr;
             for (int l = 0; l < L; ++l) {
                 c.wcl[l] = f16 ? reinterpret_cast<const float*>(m->wcl16[l]) : m->wcl[l];
                 c.bias[l] = m->bias[l];
@@ -536,7 +554,8 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
             c.done = c.ticket + 1;
-            c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size; c.flags = flags;
+            c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
+            c.flags = flags & ~(uint32_t)APE_FLAG_ALL_STEPS;
             c.x_ring = x_ring;
             // injected masks are indexed [L-1, B, T, H] over the WHOLE batch: chunks need the full B stride,
             // so a masked call is served by one launch only (checked below)
@@ -551,6 +570,11 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                            : f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
                                  : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));
+        }
+        if (all_steps) {
+            hipError_t e = ape_launch_head_rows(m->hseq_ws, B * T, H, m->dims.output_size, m->w_out, m->b_out, y_dev,
+                                                (hipStream_t)stream);
+            if (e != hipSuccess) return fail(APE_ERR_HIP, "head kernel launch failed: %s", hipGetErrorString(e));
         }
         return APE_OK;
     }

@@ -56,6 +56,7 @@ struct ClusterParams {
     unsigned flags;
     float dropout_p;
     unsigned long long seed;
+    float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
 };
 
@@ -147,5 +148,7 @@ hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size
                                  size_t rep_stride, hipStream_t stream);
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream);
 hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream);
+hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const float* w_out, const float* b_out, float* y,
+                                hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);
 hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream);

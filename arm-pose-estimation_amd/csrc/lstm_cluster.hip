@@ -503,6 +503,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                     __builtin_amdgcn_raw_buffer_store_b128(
                         __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
                         (unsigned)((((member * 4 + wave) * MR + row) * 4) * sizeof(float)), hx_base(l, t & 1, v), 16 /* sc1 */);
+                    // all-steps mode (DropoutLSTM.forward returns every step, nn_models.py:188-189): the top layer's raw
+                    // output of this step also goes to [B,T,H]; the head runs over those rows afterwards (ape_head_rows)
+                    if (p.hseq != nullptr && l == L - 1 && v == 0 && row0 + row < p.B)
+                        *reinterpret_cast<f32x4*>(p.hseq + ((size_t)(row0 + row) * T + t) * H + member * 16 + 4 * wave) = hv;
                 }
                 pend_idx = l * NFL + member * 4 + wave;
                 pend_epoch = (unsigned)(t + 1);
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         if (PL >= 2) s_acc += __shfl_xor(s_acc, 1, 64);
         if (PL >= 4) s_acc += __shfl_xor(s_acc, 2, 64);
         const int b = row0 + row;
-        if (live && part == 0 && row < MR && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
+        if (p.y != nullptr && live && part == 0 && row < MR && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
     }
 #ifdef APE_CLUSTER_STAMPS
     if (tid == 0 && p.dbg_wg != nullptr && blockIdx.x < 256) {

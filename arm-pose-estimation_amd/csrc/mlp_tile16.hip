@@ -139,6 +139,52 @@ size_t smem_of(int KX) { return ((size_t)APE_TILE_ROWS * (KX + 8) + 2 * (size_t)
 
 }  // namespace
 
+// Linear head over rows: y[n][o] = b_out[o] + sum_k hseq[n][k] * w_out[o][k] (k ascending, one fma per term: the same
+// order as the heads inside the LSTM kernels).  64 rows per workgroup, rows and weights staged in LDS; HBM-bound
+// (H*4 bytes in, O*4 out per row).  Used for the all-steps output of the cluster kernel.
+namespace {
+constexpr int HR_ROWS = 64;
+__global__ __launch_bounds__(256) void ape_head_rows_kernel(const float* __restrict__ hseq, int N, int H, int O,
+                                                            const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                            float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float hr_smem[];
+    float* rows = hr_smem;                          // [64][H+4]
+    float* ws = rows + HR_ROWS * (H + 4);           // [O][H+1]
+    const int tid = threadIdx.x;
+    const size_t n0 = (size_t)blockIdx.x * HR_ROWS;
+    const int nr = (int)min((size_t)HR_ROWS, (size_t)N - n0);
+    for (int idx = tid; idx < O * H; idx += 256) ws[(idx / H) * (H + 1) + idx % H] = w_out[idx];
+    for (int idx = tid; idx < nr * (H / 4); idx += 256) {
+        const int rr = idx / (H / 4), c4 = idx - rr * (H / 4);
+        *reinterpret_cast<f32x4*>(rows + rr * (H + 4) + 4 * c4) = *reinterpret_cast<const f32x4*>(hseq + (n0 + rr) * H + 4 * c4);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nr * O; idx += 256) {
+        const int rr = idx / O, o = idx - rr * O;
+        const float* hv = rows + rr * (H + 4);
+        const float* wv = ws + o * (H + 1);
+        float s = 0.0f;
+        for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
+        y[(n0 + rr) * O + o] = s + b_out[o];
+    }
+}
+}  // namespace
+
+hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const float* w_out, const float* b_out, float* y,
+                                hipStream_t stream) {
+    const size_t smem = ((size_t)HR_ROWS * (H + 4) + (size_t)O * (H + 1)) * sizeof(float);      // <= 64 KB + 33 KB
+    static bool prepared = false;
+    if (!prepared) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_head_rows_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+        if (e != hipSuccess) return e;
+        prepared = true;
+    }
+    hipLaunchKernelGGL(ape_head_rows_kernel, dim3((N + HR_ROWS - 1) / HR_ROWS), dim3(256), smem, stream, hseq, N, H, O, w_out,
+                       b_out, y);
+    return hipGetLastError();
+}
+
 hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream) {
     const int grid = (p.N + APE_TILE_ROWS - 1) / APE_TILE_ROWS;
     if (H == 256) {

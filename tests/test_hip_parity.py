@@ -70,9 +70,13 @@ def test_lstm_vs_reference_golden(golden, name):
             y_last = model(torch.from_numpy(x).cuda(), last_step_only=True)
             assert y_last.is_cuda and tuple(y_last.shape) == (B, 1, cfg["O"])
             assert np.abs(y_last.cpu().numpy()[:, 0] - y_ref[:, -1]).max() < TOL_Y_SHORT
-            # within ONE kernel the last-step-only and all-steps outputs are the same bits
-            y_t16 = model.set_kernel("tile16")(torch.from_numpy(x).cuda(), last_step_only=True)
-            assert np.array_equal(y_t16.cpu().numpy()[:, 0], y.numpy()[:, -1])
+            # within the batch-tile kernel the last-step-only and all-steps outputs are the same bits
+            model.set_kernel("tile16")
+            y16_all = model(torch.from_numpy(x).cuda())
+            y_t16 = model(torch.from_numpy(x).cuda(), last_step_only=True)
+            assert np.array_equal(y_t16.cpu().numpy()[:, 0], y16_all.cpu().numpy()[:, -1])
+            # AUTO's all-steps route (cluster kernel + head over the [B,T,H] rows) against it, every step
+            assert np.abs(y.numpy() - y16_all.cpu().numpy()).max() < TOL_Y_SHORT
             model.set_kernel("auto")
 
 
@@ -248,8 +252,11 @@ def test_dropout_with_injected_masks(name):
     x = np.repeat(rng.normal(size=(1, T, cfg["I"])).astype(np.float32), B, axis=0)
     masks = (rng.uniform(size=(cfg["L"] - 1, B, T, cfg["H"])) >= p).astype(np.float32) / (1 - p)
     y_ref = orc.lstm_forward(sd, x, masks=list(masks))
-    y = model(torch.from_numpy(x), masks=torch.from_numpy(masks)).numpy()        # all steps: batch-tile kernel
+    y = model(torch.from_numpy(x), masks=torch.from_numpy(masks)).numpy()        # all steps: cluster kernel + head rows
     assert np.abs(y - y_ref).max() < TOL_Y_SHORT
+    y16 = model.set_kernel("tile16")(torch.from_numpy(x), masks=torch.from_numpy(masks)).numpy()   # all steps, batch-tile kernel
+    model.set_kernel("auto")
+    assert np.abs(y16 - y_ref).max() < TOL_Y_SHORT
     assert np.abs(y[0] - y[1]).max() > 1e-4          # masks differ per row -> rows differ
     for kern in ("tile16", "cluster"):               # last step only: both kernels
         yk = model.set_kernel(kern)(torch.from_numpy(x), masks=torch.from_numpy(masks), last_step_only=True).numpy()
@@ -788,3 +795,25 @@ def test_two_models_on_two_streams_concurrently(norm_stats):
     a.check()
     b.check()
     assert torch.equal(ya, ya_alone) and torch.equal(yb, yb_alone)
+
+
+@pytest.mark.parametrize("name,B,T", [("pocket", 1024, 64), ("pocket", 3, 2), ("uarm", 300, 6), ("watch", 70, 8)])
+def test_all_steps_output_on_the_cluster_kernel(norm_stats, name, B, T):
+    """DropoutLSTM.forward returns every step (nn_models.py:188-189): under AUTO that is the cluster kernel writing each
+    step's top-layer output to [B,T,H] plus one head launch over those rows -- against the batch-tile kernel (every
+    step) and the oracle (sampled windows), with the z-score fused; the last step equals the last-step-only call"""
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 41, st)
+    raw = _synthetic_windows(st, B, T, cfg["I"], 17)
+    x = torch.from_numpy(raw).cuda()
+    y_all = m(x, normalize_input=True)
+    assert tuple(y_all.shape) == (B, T, cfg["O"])
+    m.check()
+    y_last = m(x, last_step_only=True, normalize_input=True)
+    assert np.abs(y_all[:, -1].cpu().numpy() - y_last[:, 0].cpu().numpy()).max() < TOL_Y_SHORT
+    y16 = m.set_kernel("tile16")(x, normalize_input=True)
+    m.set_kernel("auto")
+    assert np.abs(y_all.cpu().numpy() - y16.cpu().numpy()).max() < TOL_Y_SHORT
+    pick = np.unique(np.r_[0:2, B // 2, B - 2:B])
+    xn = ((raw[pick].astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    assert np.abs(y_all.cpu().numpy()[pick] - orc.lstm_forward(sd, xn)).max() < TOL_Y_SHORT
