@@ -75,7 +75,7 @@ enum { APE_F32 = 0, APE_F64 = 1 };   /* element type selector for preds / est bu
 #define APE_FLAG_DROPOUT_PHILOX  0x8u /* inter-layer dropout with an in-kernel counter-based generator  */
 
 /* LSTM kernel selection (ape_model_set_kernel).  AUTO = the weight-stationary cluster kernel where it is
- * built (H=256/L=2/I<=32 and H=128/L=3/32<I<=64, last-step output, no dropout), else the batch-tile kernel. */
+ * built (H=256/L=2/I<=32 and H=128/L=3/32<I<=64; dropout up to 32 windows per cluster), else the batch-tile kernel. */
 enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2 };
 
 /* Storage precision of W, x and h inside the LSTM (ape_model_set_precision).  F32 (default): exact float32
