@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ape_hip.h"
@@ -83,6 +84,8 @@ bool parse_kind_dims(int kind, int* width, int* I) {
 
 struct ape_model {
     ape_dims_t dims{};
+    void* slab = nullptr;          // the one device allocation every fixed-size buffer below points into
+    size_t slab_bytes = 0;
     int KX = 0;                    // LSTM layer-0 input width, padded to the kernels' k-blocking
     int lstm_in = 0;               // LSTM layer-0 input width (input_size; 256 behind ImuPoseLSTM's input layer)
     int KXpre = 0;                 // ImuPoseLSTM: padded width of the input layer's input
@@ -184,15 +187,33 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, I = dims->input_size;
     const int NT = 4 * (H / 64);
     hipError_t e = hipSuccess;
+    // every fixed-size device buffer of the model comes out of ONE allocation (planned first, carved after): a few MB in
+    // one piece land on large pages next to each other, a dozen small hipMallocs need not (a second model created
+    // while another was alive ran its latency path 2.3x slower until this was one slab)
+    std::vector<std::pair<void**, size_t>> plan_list;
+    auto plan = [&](void** ptr, size_t bytes) { plan_list.emplace_back(ptr, bytes); return hipSuccess; };
+    auto commit_plan = [&]() -> hipError_t {
+        size_t total = 0;
+        for (auto& it : plan_list) total += (it.second + 255) / 256 * 256;
+        hipError_t ee = hipMalloc(&m->slab, total);
+        if (ee != hipSuccess) return ee;
+        m->slab_bytes = total;
+        ee = hipMemset(m->slab, 0, total);
+        if (ee != hipSuccess) return ee;
+        size_t off = 0;
+        for (auto& it : plan_list) { *it.first = static_cast<char*>(m->slab) + off; off += (it.second + 255) / 256 * 256; }
+        return hipSuccess;
+    };
     if (dims->model_kind == APE_MODEL_FF) {
         for (int j = 0; j <= L && e == hipSuccess; ++j) {
             const size_t K = (j == 0) ? m->KX : H;
-            e = hipMalloc((void**)&m->ff_wpack[j], K * H * sizeof(float));
-            if (e == hipSuccess) e = hipMalloc((void**)&m->ff_bias[j], H * sizeof(float));
+            e = plan((void**)&m->ff_wpack[j], K * H * sizeof(float));
+            if (e == hipSuccess) e = plan((void**)&m->ff_bias[j], H * sizeof(float));
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
+        if (e == hipSuccess) e = plan((void**)&m->w_out, (size_t)O * H * sizeof(float));
+        if (e == hipSuccess) e = plan((void**)&m->b_out, O * sizeof(float));
+        if (e == hipSuccess) e = plan((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
+        if (e == hipSuccess) e = commit_plan();
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
@@ -203,15 +224,15 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     }
     for (int l = 0; l < L && e == hipSuccess; ++l) {
         const size_t Q = ((l == 0 ? m->KX : H) + H) / 16;
-        e = hipMalloc((void**)&m->wpack[l], 4 * Q * NT * 64 * sizeof(f32x4));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->bias[l], 4 * H * sizeof(float));
+        e = plan((void**)&m->wpack[l], 4 * Q * NT * 64 * sizeof(f32x4));
+        if (e == hipSuccess) e = plan((void**)&m->bias[l], 4 * H * sizeof(float));
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&m->w_out, (size_t)O * H * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->b_out, O * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
+    if (e == hipSuccess) e = plan((void**)&m->w_out, (size_t)O * H * sizeof(float));
+    if (e == hipSuccess) e = plan((void**)&m->b_out, O * sizeof(float));
+    if (e == hipSuccess) e = plan((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
     if (imupose) {       // input layer: the MLP kernel's packing and launch, with the activation as its result
-        if (e == hipSuccess) e = hipMalloc((void**)&m->ff_wpack[0], (size_t)m->KXpre * H * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->ff_bias[0], H * sizeof(float));
+        if (e == hipSuccess) e = plan((void**)&m->ff_wpack[0], (size_t)m->KXpre * H * sizeof(float));
+        if (e == hipSuccess) e = plan((void**)&m->ff_bias[0], H * sizeof(float));
         if (e == hipSuccess) e = ape_prepare_lstm_tile16_wide(ape_lstm_tile16_smem_bytes(H, L, m->KX, O, false));
     }
     // the kernel may carve its largest LDS layout (with dropout buffers)
@@ -231,16 +252,14 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     if (ape_cluster_supported(H, L, m->KX)) {
         const int GH = H / 16, max_clusters = 256 / GH;
         for (int l = 0; l < L && e == hipSuccess; ++l)
-            e = hipMalloc((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
+            e = plan((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
         m->xflag_bytes = (((size_t)max_clusters * L * GH * 4 * sizeof(unsigned)) + 15) / 16 * 16 + 16;   // one flag per (cluster, layer, member, wave) + ticket word
-        if (e == hipSuccess) e = hipMalloc((void**)&m->hx, m->hx_bytes);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(m->dbg_wg, 0, 256 * 8 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->xflags, m->xflag_bytes + 256);
-        if (e == hipSuccess) e = hipMemset(m->xflags, 0, m->xflag_bytes + 256);
+        if (e == hipSuccess) e = plan((void**)&m->hx, m->hx_bytes);
+        if (e == hipSuccess) e = plan((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = plan((void**)&m->xflags, m->xflag_bytes + 256);
         for (int l = 0; l < L && e == hipSuccess; ++l)
-            e = hipMalloc(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
+            e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
         if (e != hipSuccess) {
@@ -249,6 +268,11 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         }
         m->cluster_ok = true;
     }
+    e = commit_plan();
+    if (e != hipSuccess) {
+        ape_model_destroy(m);
+        return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
+    }
     *out = m;
     return APE_OK;
 }
@@ -256,27 +280,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
 int ape_model_destroy(ape_model_t* m) {
     if (!m) return APE_OK;
     (void)hipSetDevice(m->dims.device);
-    for (int l = 0; l < APE_MAX_LAYERS; ++l) {
-        if (m->wpack[l]) (void)hipFree(m->wpack[l]);
-        if (m->bias[l]) (void)hipFree(m->bias[l]);
-    }
-    for (int j = 0; j < APE_MAX_FF_LAYERS; ++j) {
-        if (m->ff_wpack[j]) (void)hipFree(m->ff_wpack[j]);
-        if (m->ff_bias[j]) (void)hipFree(m->ff_bias[j]);
-    }
-    if (m->w_out) (void)hipFree(m->w_out);
-    if (m->b_out) (void)hipFree(m->b_out);
-    if (m->stats) (void)hipFree(m->stats);
-    if (m->y_ws) (void)hipFree(m->y_ws);
+    if (m->slab) (void)hipFree(m->slab);             // weights, packs, statistics, exchange buffers, flags: one allocation
+    if (m->y_ws) (void)hipFree(m->y_ws);             // workspaces grow on demand and are their own allocations
     if (m->z_ws) (void)hipFree(m->z_ws);
     if (m->hseq_ws) (void)hipFree(m->hseq_ws);
-    for (int l = 0; l < APE_MAX_LAYERS; ++l)
-        if (m->wcl[l]) (void)hipFree(m->wcl[l]);
-    for (int l = 0; l < APE_MAX_LAYERS; ++l)
-        if (m->wcl16[l]) (void)hipFree(m->wcl16[l]);
-    if (m->hx) (void)hipFree(m->hx);
-    if (m->dbg_wg) (void)hipFree(m->dbg_wg);
-    if (m->xflags) (void)hipFree(m->xflags);
     delete m;
     return APE_OK;
 }

@@ -22,22 +22,25 @@ torch.save(({k: torch.from_numpy(v) for k, v in sd.items()}, {}), tmp / "nn" / h
 config.PATHS["deploy"] = tmp
 g = np.load("/root/repo/tests/golden/stream_trace_pocket.npz")
 rows = [array("f", r.tolist()) for r in g["rows"]]
-for mc, smooth in ((1, 1), (25, 1), (60, 5)):
+for mc, smooth in ((1, 1), (25, 1), (60, 5), (1, 1), (25, 1)):
     est = WatchPhonePocketNN(model_hash=h, smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
     def frame(i):
         xx = est.parse_row_to_xx(rows[i % len(rows)])
         pred = est.add_xx_to_row_hist_and_make_prediction(xx)
         return est.msg_from_pred(pred, True)
     for i in range(30): frame(i)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
-    tp = tm = tf = 0.0
+    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 2000
+    tt = np.zeros((n, 4))
     for i in range(n):
         a = time.perf_counter(); xx = est.parse_row_to_xx(rows[i % len(rows)])
         b = time.perf_counter(); pred = est.add_xx_to_row_hist_and_make_prediction(xx)
         c = time.perf_counter(); msg = est.msg_from_pred(pred, True)
-        d = time.perf_counter(); tp += b - a; tm += c - b; tf += d - c
+        d = time.perf_counter(); tt[i] = (b - a, c - b, d - c, d - a)
     el = time.perf_counter() - t0
-    print(f"mc={mc} smooth={smooth}: {n / el:.0f} frames/s  ({el / n * 1e6:.0f} us/frame: parse {tp / n * 1e6:.0f}, window+model {tm / n * 1e6:.0f}, fk+msg {tf / n * 1e6:.0f}), msg len {len(msg)}")
+    q = lambda c, f: np.quantile(tt[:, c], f) * 1e6
+    print(f"mc={mc} smooth={smooth}: {n / el:.0f} frames/s mean; per frame p50 {q(3, .5):.0f} us (parse {q(0, .5):.0f}, window+model "
+          f"{q(1, .5):.0f}, fk+msg {q(2, .5):.0f}), p90 {q(3, .9):.0f} us, p99 {q(3, .99):.0f} us; slow stretches: "
+          f"{[int(x) for x in (tt[:, 3].reshape(20, -1).mean(1) * 1e6)]}; msg len {len(msg)}")
 
 # ---- stream bank: S streams stepped together, all state on the device (ape_streams_*) ----------------------
 from wear_mocap_ape_amd import _hip
