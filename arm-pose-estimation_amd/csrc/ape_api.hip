@@ -723,12 +723,29 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
 struct ape_streams {
     ape_model* model = nullptr;
     int S = 0, T = 0, smooth = 0;
-    float* xring = nullptr;      // [S,T,I] feature rows, slot = frame mod T
-    float* yring = nullptr;      // [S,smooth,O] model outputs, slot = step mod smooth
-    float* y_new = nullptr;      // [S,O]
+    int n_mc = 1;                // Monte-Carlo samples per stream and step
+    bool mc = false;             // dropout on (ape_streams_set_mc was called)
+    float dropout_p = 0.0f;
+    unsigned long long seed = 0, mc_calls = 0;
+    float* xring = nullptr;      // [S,n_mc,T,I] feature rows, slot = frame mod T (a stream's n_mc windows are copies)
+    float* yring = nullptr;      // [S,smooth,n_mc,O] model outputs, slot = step mod smooth
+    float* y_new = nullptr;      // [S,n_mc,O]
     long long frames = 0;        // rows pushed since the last reset
     long long steps = 0;         // predictions made since the last reset
 };
+
+// (re)allocates the three rings for the bank's current S, T, smooth, n_mc
+static hipError_t bank_alloc(ape_streams* b) {
+    const size_t I = b->model->dims.input_size, O = b->model->dims.output_size, R = (size_t)b->S * b->n_mc;
+    if (b->xring) (void)hipFree(b->xring);
+    if (b->yring) (void)hipFree(b->yring);
+    if (b->y_new) (void)hipFree(b->y_new);
+    b->xring = b->yring = b->y_new = nullptr;
+    hipError_t e = hipMalloc((void**)&b->xring, R * b->T * I * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->yring, R * b->smooth * O * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->y_new, R * O * sizeof(float));
+    return e;
+}
 
 int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32_t smooth, ape_streams_t** out) {
     if (!out) return fail(APE_ERR_INVALID_ARG, "streams_create: out is NULL");
@@ -741,16 +758,27 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
     ape_streams* b = new (std::nothrow) ape_streams();
     if (!b) return fail(APE_ERR_HIP, "out of host memory");
     b->model = m; b->S = n_streams; b->T = seq_len; b->smooth = smooth;
-    const size_t I = m->dims.input_size, O = m->dims.output_size;
     HIP_TRY(hipSetDevice(m->dims.device));
-    hipError_t e = hipMalloc((void**)&b->xring, (size_t)n_streams * seq_len * I * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&b->yring, (size_t)n_streams * smooth * O * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&b->y_new, (size_t)n_streams * O * sizeof(float));
+    hipError_t e = bank_alloc(b);
     if (e != hipSuccess) {
         ape_streams_destroy(b);
         return fail(APE_ERR_HIP, "streams_create: allocation failed: %s", hipGetErrorString(e));
     }
     *out = b;
+    return APE_OK;
+}
+
+int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t seed) {
+    if (!b) return fail(APE_ERR_INVALID_ARG, "streams_set_mc: NULL bank");
+    if (n_mc < 1 || (long long)n_mc * b->smooth > 4096)
+        return fail(APE_ERR_INVALID_ARG, "streams_set_mc: n_mc=%d with smooth=%d (1 <= smooth*n_mc <= 4096)", n_mc, b->smooth);
+    if (!(dropout_p >= 0.0f && dropout_p < 1.0f)) return fail(APE_ERR_INVALID_ARG, "streams_set_mc: dropout_p %g outside [0,1)", (double)dropout_p);
+    HIP_TRY(hipSetDevice(b->model->dims.device));
+    HIP_TRY(hipDeviceSynchronize());             // the rings may still be read by an earlier step
+    b->n_mc = n_mc; b->mc = true; b->dropout_p = dropout_p; b->seed = seed; b->mc_calls = 0;
+    b->frames = 0; b->steps = 0;
+    hipError_t e = bank_alloc(b);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_set_mc: allocation failed: %s", hipGetErrorString(e));
     return APE_OK;
 }
 
@@ -769,11 +797,13 @@ int ape_streams_reset(ape_streams_t* b) {
     return APE_OK;
 }
 
-// where the next row goes: one slot of every window, or -- first row after a reset -- all T of them
-static void next_slot(const ape_streams* b, size_t I, float** out, int* rep) {
+// where the next row goes: one slot of each of the stream's n_mc windows (stride T*I apart), or -- first row after
+// a reset -- all n_mc*T slots, which are contiguous
+static void next_slot(const ape_streams* b, size_t I, float** out, int* rep, size_t* rep_stride) {
     const bool cold = b->frames == 0;
     *out = b->xring + (cold ? 0 : (size_t)(b->frames % b->T) * I);
-    *rep = cold ? b->T : 1;
+    *rep = cold ? b->T * b->n_mc : b->n_mc;
+    *rep_stride = cold ? I : (size_t)b->T * I;
 }
 
 int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev, void* stream) {
@@ -785,10 +815,10 @@ int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev,
     if (I != b->model->dims.input_size)
         return fail(APE_ERR_INVALID_ARG, "streams_push_rows: kind %d builds %d features, the model takes %d", kind, I,
                     b->model->dims.input_size);
-    float* out; int rep;
-    next_slot(b, (size_t)I, &out, &rep);
-    hipError_t e = ape_launch_parse_rows(rows_dev, b->S, width, kind, out, APE_F32, I, (size_t)b->T * I, rep, (size_t)I,
-                                         big_endian, (hipStream_t)stream);
+    float* out; int rep; size_t rep_stride;
+    next_slot(b, (size_t)I, &out, &rep, &rep_stride);
+    hipError_t e = ape_launch_parse_rows(rows_dev, b->S, width, kind, out, APE_F32, I, (size_t)b->n_mc * b->T * I, rep,
+                                         rep_stride, big_endian, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_push_rows launch failed: %s", hipGetErrorString(e));
     ++b->frames;
     return APE_OK;
@@ -797,9 +827,9 @@ int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev,
 int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* stream) {
     if (!b || !xx_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_features: NULL argument");
     const int I = b->model->dims.input_size;
-    float* out; int rep;
-    next_slot(b, (size_t)I, &out, &rep);
-    hipError_t e = ape_launch_ring_write(xx_dev, b->S, I, out, (size_t)b->T * I, rep, (size_t)I, (hipStream_t)stream);
+    float* out; int rep; size_t rep_stride;
+    next_slot(b, (size_t)I, &out, &rep, &rep_stride);
+    hipError_t e = ape_launch_ring_write(xx_dev, b->S, I, out, (size_t)b->n_mc * b->T * I, rep, rep_stride, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_push_features launch failed: %s", hipGetErrorString(e));
     ++b->frames;
     return APE_OK;
@@ -815,14 +845,17 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     if (norm && !m->has_stats) return fail(APE_ERR_NOT_READY, "streams_step: NORMALIZE_INPUT without norm stats");
     // oldest row of every window: the slot after the newest one
     const int x_ring = (int)(b->frames % b->T);
-    if (int rc = lstm_forward_impl(m, b->xring, b->S, b->T, flags, nullptr, 0.0f, 0, b->y_new, stream, x_ring)) return rc;
+    const bool drop = b->mc && b->dropout_p > 0.0f && m->dims.num_layers > 1;
+    if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
+                                   drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring)) return rc;
+    ++b->mc_calls;
     StreamPostParams q{};
     q.y_new = b->y_new; q.yring = b->yring; q.msg = msg_dev; q.tail = tail_dev;
     q.yy_m = norm ? m->stats + 2 * m->dims.input_size : nullptr;      // one switch (estimator.py:103-109)
     q.yy_s = norm ? m->stats + 2 * m->dims.input_size + m->dims.output_size : nullptr;
     memcpy(q.body, m->body, sizeof(q.body));
     q.S = b->S; q.O = m->dims.output_size; q.W = layout_est_width(m->dims.target_layout); q.layout = m->dims.target_layout;
-    q.smooth = b->smooth;
+    q.smooth = b->smooth; q.n_mc = b->n_mc;
     q.pos = (int)(b->steps % b->smooth);
     q.cold = b->steps == 0 ? 1 : 0;
     q.msg_dtype = out_dtype;

@@ -93,14 +93,15 @@ struct FkParams {
 
 // Kernel arguments of the per-stream smoothing + message kernel (stream bank).
 struct StreamPostParams {
-    const float* y_new;  // [S,O] NN targets of this step (model output, still normalised)
-    float* yring;        // [S,smooth,O] the last `smooth` predictions of every stream
+    const float* y_new;  // [S,n_mc,O] NN targets of this step (model output, still normalised)
+    float* yring;        // [S,smooth,n_mc,O] the last `smooth` predictions (n_mc samples each) of every stream
     void* msg;           // [S,25] of msg_dtype
-    void* tail;          // [S,smooth,6] of msg_dtype (hand xyz, elbow xyz of every smoothing row) or nullptr
+    void* tail;          // [S,smooth*n_mc,6] of msg_dtype (hand xyz, elbow xyz of every stacked row) or nullptr
     const double* yy_m;  // [O] or nullptr (no de-normalisation)
     const double* yy_s;
     double body[9];
     int S, O, W, layout, smooth;
+    int n_mc;            // Monte-Carlo samples per stream and step (1: deterministic bank)
     int pos;             // ring slot of this step's prediction
     int cold;            // 1: first step after a reset -- every slot takes this prediction (estimator.py:114-115)
     int msg_dtype;

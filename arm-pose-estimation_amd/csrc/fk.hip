@@ -269,68 +269,98 @@ __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostPa
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= p.S) return;                                   // whole wave
-    const int N = p.smooth, O = p.O, W = p.W;
-    const bool act = lane < N;
+    const int M = p.n_mc, N = p.smooth * M, O = p.O;
     const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
-    double pr[20], e[21];
+    const int nq = hips ? 3 : 2;
+    const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
+    const double wgt = 1.0 / (double)N;
+    double e0[21];                                          // lane 0: row 0 of the stack (the N == 1 message)
+    double ref[3][4];                                       // row 0's quaternions: the sign reference of the mean
+    double acc[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    double osum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // stacked row i = (prediction j of the last `smooth`, oldest first; Monte-Carlo sample k of it): lanes take
+    // rows lane, lane + 64, ... (trip count uniform over the wave)
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const bool act = i < N;
+        double pr[20], e[21];
 #pragma unroll
-    for (int c = 0; c < 21; ++c) e[c] = 0.0;
-    if (act) {
-        // row i of the stack: the newest prediction sits in ring slot `pos`, the oldest one slot further
-        const bool fresh = p.cold || lane == N - 1;
-        const int slot = (p.pos + 1 + lane) % N;
-        const float* src = fresh ? p.y_new + (size_t)s * O : p.yring + ((size_t)s * N + slot) * O;
-        float raw[20];
+        for (int c = 0; c < 21; ++c) e[c] = 0.0;
+        if (act) {
+            const int j = i / M, k = i - j * M;
+            // the newest prediction sits in ring slot `pos`, the oldest one slot further
+            const bool fresh = p.cold || j == p.smooth - 1;
+            const int slot = (p.pos + 1 + j) % p.smooth;
+            const float* src = fresh ? p.y_new + ((size_t)s * M + k) * O
+                                     : p.yring + (((size_t)s * p.smooth + slot) * M + k) * O;
+            float raw[20];
 #pragma unroll
-        for (int c = 0; c < 20; ++c) raw[c] = (c < O) ? src[c] : 0.0f;
-        if (fresh) {                                        // keep it for the next frames
-            float* dst = p.yring + ((size_t)s * N + (p.cold ? lane : p.pos)) * O;
+            for (int c = 0; c < 20; ++c) raw[c] = (c < O) ? src[c] : 0.0f;
+            if (fresh) {                                    // keep it for the next frames
+                float* dst = p.yring + (((size_t)s * p.smooth + (p.cold ? j : p.pos)) * M + k) * O;
 #pragma unroll
-            for (int c = 0; c < 20; ++c)
-                if (c < O) dst[c] = raw[c];
+                for (int c = 0; c < 20; ++c)
+                    if (c < O) dst[c] = raw[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 20; ++c) {
+                double v = (double)raw[c];
+                if (p.yy_m && c < O) v = v * p.yy_s[c] + p.yy_m[c];      // estimator.py:108-109
+                pr[c] = v;
+            }
+            fk_row(pr, p.body, p.layout, e);
+            if (p.tail) {                                   // estimator.py:131-137: est[i, :6] of every row
+                TMsg* t = static_cast<TMsg*>(p.tail) + ((size_t)s * N + i) * 6;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) t[c] = (TMsg)e[c];
+            }
         }
+        if (base == 0) {
 #pragma unroll
-        for (int c = 0; c < 20; ++c) {
-            double v = (double)raw[c];
-            if (p.yy_m && c < O) v = v * p.yy_s[c] + p.yy_m[c];      // estimator.py:108-109
-            pr[c] = v;
+            for (int c = 0; c < 21; ++c) e0[c] = e[c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ref[k][c] = (k < nq) ? __shfl(e[qc[k] + c], 0, 64) : 0.0;
         }
-        fk_row(pr, p.body, p.layout, e);
-        if (p.tail) {                                       // estimator.py:131-137: est[i, :6] of every row
-            TMsg* t = static_cast<TMsg*>(p.tail) + ((size_t)s * N + lane) * 6;
+        if (N > 1) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) t[c] = (TMsg)e[c];
+            for (int k = 0; k < 3; ++k) {
+                if (k < nq) {
+                    const double q0 = e[qc[k]], q1 = e[qc[k] + 1], q2 = e[qc[k] + 2], q3 = e[qc[k] + 3];
+                    const double d = fma(q3, ref[k][3], fma(q2, ref[k][2], fma(q1, ref[k][1], q0 * ref[k][0])));   // the sign rule of ape_msg_kernel
+                    const double sg = !act ? 0.0 : ((i > 0 && d < 0.0) ? -wgt : wgt);
+                    acc[k][0] += q0 * sg; acc[k][1] += q1 * sg; acc[k][2] += q2 * sg; acc[k][3] += q3 * sg;
+                }
+            }
+            if (p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) osum[c] += act ? e[c] : 0.0;
+            }
         }
     }
     double out_q[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     double orig_mean[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (N > 1) {
-        const double wgt = 1.0 / (double)N;
-        const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (k < (hips ? 3 : 2)) {
-                const double q0 = e[qc[k]], q1 = e[qc[k] + 1], q2 = e[qc[k] + 2], q3 = e[qc[k] + 3];
-                const double r0 = __shfl(q0, 0, 64), r1 = __shfl(q1, 0, 64), r2 = __shfl(q2, 0, 64), r3 = __shfl(q3, 0, 64);
-                const double d = fma(q3, r3, fma(q2, r2, fma(q1, r1, q0 * r0)));      // the sign rule of ape_msg_kernel
-                const double sg = !act ? 0.0 : ((lane > 0 && d < 0.0) ? -wgt : wgt);
-                const double a0 = wave_sum(q0 * sg), a1 = wave_sum(q1 * sg), a2 = wave_sum(q2 * sg), a3 = wave_sum(q3 * sg);
+            if (k < nq) {
+                const double a0 = wave_sum(acc[k][0]), a1 = wave_sum(acc[k][1]), a2 = wave_sum(acc[k][2]), a3 = wave_sum(acc[k][3]);
                 const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
                 out_q[k][0] = a0 / nrm; out_q[k][1] = a1 / nrm; out_q[k][2] = a2 / nrm; out_q[k][3] = a3 / nrm;
             }
         }
         if (p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) orig_mean[c] = wave_sum(act ? e[c] : 0.0) / (double)N;
+            for (int c = 0; c < 9; ++c) orig_mean[c] = wave_sum(osum[c]) / (double)N;
         }
     }
     if (lane != 0) return;
     double m[25];
-    finish_msg(p.layout, N, out_q, orig_mean, e, p.body, m);
+    finish_msg(p.layout, N, out_q, orig_mean, e0, p.body, m);
     TMsg* dst = static_cast<TMsg*>(p.msg) + (size_t)s * 25;
 #pragma unroll
     for (int c = 0; c < 25; ++c) dst[c] = (TMsg)m[c];
-    (void)W;
 }
 
 template <typename TIn, typename TOut>

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ape_streams_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "ape_streams_destroy": (C.c_int, [C.c_void_p]),
     "ape_streams_reset": (C.c_int, [C.c_void_p]),
+    "ape_streams_set_mc": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_uint64]),
     "ape_streams_push_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ape_streams_push_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ape_streams_step": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

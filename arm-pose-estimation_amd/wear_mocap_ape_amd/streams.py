@@ -66,13 +66,16 @@ def broadcast_stats(stats: dict, I: int, O: int, device: torch.device, src: int 
 class StreamBank:
     """The per-frame step of many independent wearable streams with all state on the device: window rings,
     smoothing stacks, regressor, FK and messages (C ABI ``ape_streams_*``).  For every stream it does what one
-    ``Estimator`` does per frame with one Monte-Carlo sample (estimator.py:93-137), so S estimator threads of the
-    reference become three kernel launches per frame.  Rank-local: give each rank its ``shard_range`` of streams.
+    ``Estimator`` does per frame (estimator.py:93-137), so S estimator threads of the reference become three kernel
+    launches per frame.  Rank-local: give each rank its ``shard_range`` of streams.
 
-    ``model`` is a HIP-backed ``DropoutLSTM`` (nn_models.py) with weights, norm stats and body set."""
+    ``model`` is a HIP-backed ``DropoutLSTM`` (nn_models.py) with weights, norm stats and body set.
+    ``monte_carlo_samples=None`` runs the regressor once per stream with deterministic weights; an integer n runs
+    it n times per stream and frame with inter-layer dropout ``dropout`` (default: the model's) like
+    ``monte_carlo_predictions`` (nn_models.py:191-207), and the stack / tail hold ``smooth * n`` rows per stream."""
 
     def __init__(self, model, n_streams: int, seq_len: int, smooth: int = 1, normalize: bool = True,
-                 dtype: torch.dtype = torch.float32):
+                 dtype: torch.dtype = torch.float32, monte_carlo_samples=None, dropout=None, seed: int = 0x5EED):
         from . import _hip
         import ctypes as C
         self._hip, self._C = _hip, C
@@ -86,8 +89,13 @@ class StreamBank:
         _hip.check(_hip.lib().ape_streams_create(model.handle, n_streams, seq_len, smooth, C.byref(handle)),
                    "ape_streams_create")
         self._handle = handle
+        self._n_mc = 1
+        if monte_carlo_samples is not None:
+            self._n_mc = int(monte_carlo_samples)
+            p = float(model.dropout if dropout is None else dropout)
+            _hip.check(_hip.lib().ape_streams_set_mc(handle, self._n_mc, p, int(seed) & (2 ** 64 - 1)), "ape_streams_set_mc")
         self._msg = torch.empty((n_streams, 25), dtype=dtype, device=self._device)
-        self._tail = torch.empty((n_streams, smooth, 6), dtype=dtype, device=self._device)
+        self._tail = torch.empty((n_streams, smooth * self._n_mc, 6), dtype=dtype, device=self._device)
 
     def __del__(self):
         h, self._handle = getattr(self, "_handle", None), None
@@ -120,7 +128,7 @@ class StreamBank:
                                                                   self._stream()), "ape_streams_push_features")
 
     def step(self, with_tail: bool = False):
-        """-> msg [S,25] (and, with_tail, the hand/elbow xyz of every smoothing row [S,smooth,6]); the returned
+        """-> msg [S,25] (and, with_tail, the hand/elbow xyz of every stacked row [S,smooth*n_mc,6]); the returned
         tensors are the bank's own buffers, overwritten by the next step"""
         tail = self._C.c_void_p(self._tail.data_ptr()) if with_tail else None
         self._hip.check(self._hip.lib().ape_streams_step(self._handle, self._flags, self._C.c_void_p(self._msg.data_ptr()),

@@ -205,11 +205,21 @@ int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev,
  *                              (what msg_from_pred appends to the message when add_mc_samples is set and smooth > 1)
  *                              flags: APE_FLAG_NORMALIZE_INPUT or 0
  *   ape_streams_reset          cold start: the next row fills the whole window, the next prediction the whole stack
+ *   ape_streams_set_mc         Monte-Carlo dropout per stream, as every reference estimator runs it
+ *                              (monte_carlo_samples, watch_phone_pocket_nn.py:105-110 -> nn_models.py:191-207): each
+ *                              frame runs every stream's window n_mc times with independent inter-layer dropout
+ *                              masks (in-kernel Philox, keyed by `seed` + a per-step counter), the smoothing stack
+ *                              holds smooth x n_mc rows per stream in the reference's order (estimator.py:112-118:
+ *                              oldest prediction first, its n_mc samples in order), tail_dev becomes
+ *                              [S, smooth*n_mc, 6].  dropout_p = 0 gives n_mc identical samples.  Call it before the
+ *                              first row is pushed or right after ape_streams_reset (it re-allocates the rings and
+ *                              implies a reset); smooth*n_mc <= 4096.
  * One bank = one model handle = one HIP stream at a time.  smooth <= 64. */
 typedef struct ape_streams ape_streams_t;
 int ape_streams_create(ape_model_t* model, int32_t n_streams, int32_t seq_len, int32_t smooth, ape_streams_t** out_bank);
 int ape_streams_destroy(ape_streams_t* bank);
 int ape_streams_reset(ape_streams_t* bank);
+int ape_streams_set_mc(ape_streams_t* bank, int32_t n_mc, float dropout_p, uint64_t seed);
 int ape_streams_push_rows(ape_streams_t* bank, int32_t kind, const float* rows_dev, void* stream);
 int ape_streams_push_features(ape_streams_t* bank, const float* xx_dev, void* stream);
 int ape_streams_step(ape_streams_t* bank, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream);

@@ -703,6 +703,72 @@ def test_stream_bank(golden, norm_stats, name, S, kernel):
         StreamBank(m, S, T).step()                            # nothing pushed yet
 
 
+@pytest.mark.parametrize("name,S,n_mc,smooth,p_drop", [("pocket", 5, 3, 1, 0.0), ("pocket", 3, 25, 5, 0.2),
+                                                        ("watch", 2, 70, 1, 0.2), ("uarm", 4, 4, 3, 0.2)])
+def test_stream_bank_monte_carlo(golden, norm_stats, name, S, n_mc, smooth, p_drop):
+    """ape_streams_set_mc: n_mc dropout samples per stream and frame inside the bank.  The stacked rows
+    (smooth x n_mc per stream, oldest prediction first: estimator.py:112-118), FK, sign-aligned means and tails are
+    checked against the oracle fed with the SAME samples, which come from ape_lstm_forward on explicitly repeated
+    windows with the bank's Philox key (the dropout arithmetic itself is pinned by the injected-mask tests); with
+    p = 0 every sample must equal the deterministic oracle model."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    g = golden(f"stream_trace_{name}.npz")
+    stats, body = norm_stats[name], g["body"]
+    m, sd, cfg = make_model(name, int(g["weights_seed"]), stats)
+    m.set_body(body)
+    T, I, O = cfg["T"], cfg["I"], cfg["O"]
+    seed = 0xABCDE12345
+    bank = StreamBank(m, S, T, smooth=smooth, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc,
+                      dropout=p_drop, seed=seed)
+    rng = np.random.default_rng(17)
+    F = 9
+    feats = _synthetic_windows(stats, S, F, I, 23)                  # [S,F,I] feature rows, frame f of stream s
+    lib = _hip.lib()
+    flags = _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_DROPOUT_PHILOX if p_drop > 0 and cfg["L"] > 1 else 0)
+    calls = 0
+    worst_msg = worst_tail = 0.0
+    for rnd in range(2):
+        shadow = [orc.WindowOracle(T, 1, None, lambda h: np.zeros((1, O))) for _ in range(S)]
+        samples = {}
+        wins = [orc.WindowOracle(T, smooth, None, (lambda h, s=s: samples[s])) for s in range(S)]
+        for f in range(F):
+            bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+            msg, tail = bank.step(with_tail=True)
+            msg, tail = msg.cpu().numpy(), tail.cpu().numpy()
+            assert msg.shape == (S, 25) and tail.shape == (S, smooth * n_mc, 6)
+            # the same windows, repeated n_mc times each, through the plain entry point with the bank's key
+            hist = []
+            for s in range(S):
+                shadow[s].push(feats[s, f])
+                hist.append(np.vstack(shadow[s].rows).astype(np.float32))
+            x = torch.from_numpy(np.repeat(np.stack(hist), n_mc, axis=0)).cuda()
+            y = torch.empty((S * n_mc, O), dtype=torch.float32, device="cuda")
+            _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), S * n_mc, T, flags, None, float(p_drop),
+                                            seed + calls, C.c_void_p(y.data_ptr()), None), "ape_lstm_forward")
+            calls += 1
+            torch.cuda.synchronize()
+            y = y.cpu().numpy().astype(np.float64) * stats["yy_s"] + stats["yy_m"]
+            if p_drop == 0.0:
+                det = orc.infer_windows(sd, stats, body, cfg["layout"], np.stack(hist))[0].astype(np.float64) * stats["yy_s"] + stats["yy_m"]
+                assert np.abs(y.reshape(S, n_mc, O) - det[:, None, :]).max() < 2e-5
+            else:
+                assert np.abs(y.reshape(S, n_mc, O) - y.reshape(S, n_mc, O)[:, :1]).max() > 1e-3      # samples differ
+            for s in range(S):
+                samples[s] = y[s * n_mc:(s + 1) * n_mc]
+                pred = wins[s].push(feats[s, f])
+                assert pred.shape == (smooth * n_mc, O)
+                est = orc.arm_pose_from_targets(pred, body, cfg["layout"], "eigh")
+                ref = orc.msg_from_est(est, body, cfg["layout"])
+                worst_msg = max(worst_msg, float(np.abs(msg[s] - ref).max()))
+                worst_tail = max(worst_tail, float(np.abs(tail[s] - est[:, :6]).max()))
+        bank.reset()
+    m.check()
+    assert worst_msg < 5e-6 and worst_tail < 5e-6, (worst_msg, worst_tail)
+    with pytest.raises(UserWarning):
+        StreamBank(m, S, T, smooth=64, monte_carlo_samples=65)      # smooth * n_mc > 4096
+
+
 @pytest.mark.parametrize("name,B", [("pocket", 2500), ("uarm", 4100)])
 def test_batches_beyond_one_cluster_launch(norm_stats, name, B):
     """more windows than one cluster launch covers (1024 / 2048 rows): the entry point chunks the batch; every chunk

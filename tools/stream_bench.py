@@ -64,3 +64,17 @@ for S, smooth in ((1, 1), (64, 5), (1024, 1), (1024, 5), (4096, 5)):
     m.check()
     print(f"stream bank S={S} smooth={smooth}: {el / n * 1e6:.0f} us per frame of all streams = {S * n / el:.0f} stream-frames/s "
           f"({S * n / el / 50:.0f} streams at 50 Hz)")
+
+# ---- the same with Monte-Carlo dropout per stream (ape_streams_set_mc), the reference estimators' default mode -----------
+for S, smooth, n_mc in ((1, 1, 25), (64, 5, 25), (1024, 1, 25), (1024, 5, 60), (8192, 1, 25)):
+    bank = StreamBank(m, S, 6, smooth=smooth, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc)
+    batch = [raw[(torch.arange(S, device="cuda") + f) % len(raw)].contiguous() for f in range(8)]
+    for f in range(10):
+        bank.push_rows(batch[f % 8], _hip.PARSE_WATCH_PHONE_POCKET); bank.step(with_tail=True)
+    torch.cuda.synchronize(); n = 50; t0 = time.perf_counter()
+    for f in range(n):
+        bank.push_rows(batch[f % 8], _hip.PARSE_WATCH_PHONE_POCKET); bank.step(with_tail=True)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    m.check()
+    print(f"stream bank S={S} smooth={smooth} mc={n_mc}: {el / n * 1e6:.0f} us per frame of all streams = {S * n / el:.0f} "
+          f"stream-frames/s ({S * n / el / 50:.0f} streams at 50 Hz), {S * n_mc * n / el:.0f} windows/s")
