@@ -187,9 +187,9 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, I = dims->input_size;
     const int NT = 4 * (H / 64);
     hipError_t e = hipSuccess;
-    // every fixed-size device buffer of the model comes out of ONE allocation (planned first, carved after): a few MB in
-    // one piece land on large pages next to each other, a dozen small hipMallocs need not (a second model created
-    // while another was alive ran its latency path 2.3x slower until this was one slab)
+    // every fixed-size device buffer of the model comes out of ONE allocation (planned first, carved after at
+    // 256-byte boundaries, zero-filled): one driver call to create, one to free, and the flag / ticket words start
+    // at zero without separate memsets
     std::vector<std::pair<void**, size_t>> plan_list;
     auto plan = [&](void** ptr, size_t bytes) { plan_list.emplace_back(ptr, bytes); return hipSuccess; };
     auto commit_plan = [&]() -> hipError_t {
@@ -838,8 +838,13 @@ int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* strea
 int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream) {
     if (!b || !msg_dev) return fail(APE_ERR_INVALID_ARG, "streams_step: NULL argument");
     if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
-    if (flags & ~(uint32_t)APE_FLAG_NORMALIZE_INPUT) return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT is accepted");
+    if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_PACKED_MSG))
+        return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT and PACKED_MSG are accepted");
     if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_step: unknown dtype selector");
+    const bool packed = (flags & APE_FLAG_PACKED_MSG) != 0;
+    if (packed && (out_dtype != APE_F32 || tail_dev))
+        return fail(APE_ERR_INVALID_ARG, "streams_step: PACKED_MSG rows are float32 and carry the tail themselves (tail_dev must be NULL)");
+    flags &= ~(uint32_t)APE_FLAG_PACKED_MSG;
     ape_model* m = b->model;
     const bool norm = (flags & APE_FLAG_NORMALIZE_INPUT) != 0;
     if (norm && !m->has_stats) return fail(APE_ERR_NOT_READY, "streams_step: NORMALIZE_INPUT without norm stats");
@@ -858,7 +863,7 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     q.smooth = b->smooth; q.n_mc = b->n_mc;
     q.pos = (int)(b->steps % b->smooth);
     q.cold = b->steps == 0 ? 1 : 0;
-    q.msg_dtype = out_dtype;
+    q.msg_dtype = out_dtype; q.packed = packed ? 1 : 0;
     hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
     ++b->steps;

@@ -105,6 +105,7 @@ struct StreamPostParams {
     int pos;             // ring slot of this step's prediction
     int cold;            // 1: first step after a reset -- every slot takes this prediction (estimator.py:114-115)
     int msg_dtype;
+    int packed;          // 1: msg rows are [25 + 6*smooth*n_mc] wide and carry the tail behind the message
 };
 
 struct MsgParams {

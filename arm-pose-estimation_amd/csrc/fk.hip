@@ -309,8 +309,9 @@ __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostPa
                 pr[c] = v;
             }
             fk_row(pr, p.body, p.layout, e);
-            if (p.tail) {                                   // estimator.py:131-137: est[i, :6] of every row
-                TMsg* t = static_cast<TMsg*>(p.tail) + ((size_t)s * N + i) * 6;
+            if (p.tail || p.packed) {                       // estimator.py:131-137: est[i, :6] of every row
+                TMsg* t = p.packed ? static_cast<TMsg*>(p.msg) + (size_t)s * (25 + 6 * N) + 25 + (size_t)i * 6
+                                   : static_cast<TMsg*>(p.tail) + ((size_t)s * N + i) * 6;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) t[c] = (TMsg)e[c];
             }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostPa
     if (lane != 0) return;
     double m[25];
     finish_msg(p.layout, N, out_q, orig_mean, e0, p.body, m);
-    TMsg* dst = static_cast<TMsg*>(p.msg) + (size_t)s * 25;
+    TMsg* dst = static_cast<TMsg*>(p.msg) + (size_t)s * (p.packed ? 25 + 6 * N : 25);
 #pragma unroll
     for (int c = 0; c < 25; ++c) dst[c] = (TMsg)m[c];
 }

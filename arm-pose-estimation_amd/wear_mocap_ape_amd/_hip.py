@@ -22,6 +22,7 @@ FLAG_NORMALIZE_INPUT = 0x1
 FLAG_ALL_STEPS = 0x2
 FLAG_DROPOUT_MASKS = 0x4
 FLAG_DROPOUT_PHILOX = 0x8
+FLAG_PACKED_MSG = 0x20
 FLAG_BROADCAST_X = 0x10
 KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER = 0, 1, 2
 PRECISION_F32, PRECISION_F16 = 0, 1

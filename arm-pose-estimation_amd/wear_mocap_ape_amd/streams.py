@@ -134,3 +134,20 @@ class StreamBank:
         self._hip.check(self._hip.lib().ape_streams_step(self._handle, self._flags, self._C.c_void_p(self._msg.data_ptr()),
                                                          tail, self._sel, self._stream()), "ape_streams_step")
         return (self._msg, self._tail) if with_tail else self._msg
+
+    def step_datagrams(self):
+        """-> float32 [S, 25 + 6*smooth*n_mc]: per stream the message followed by the hand/elbow xyz of every stacked
+        row -- byte for byte what ``PoseEstPublisherUDP`` sends for one estimator frame (pose_est_udp.py:47 packs
+        the list of estimator.py:131-137 as native float32), so ``row.cpu().numpy().tobytes()`` is the datagram.
+        Like the reference, rows only carry the tail when there is more than one stacked row."""
+        n = self._smooth * self._n_mc
+        if n == 1:
+            if self._dtype != torch.float32:
+                raise UserWarning("step_datagrams wants a float32 bank")
+            return self.step()
+        if getattr(self, "_packed", None) is None:
+            self._packed = torch.empty((self._n, 25 + 6 * n), dtype=torch.float32, device=self._device)
+        self._hip.check(self._hip.lib().ape_streams_step(self._handle, self._flags | self._hip.FLAG_PACKED_MSG,
+                                                         self._C.c_void_p(self._packed.data_ptr()), None, self._hip.F32,
+                                                         self._stream()), "ape_streams_step")
+        return self._packed

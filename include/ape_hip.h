@@ -83,6 +83,7 @@ enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2 };
  * (BASELINE.json configs[4]); last-step output without dropout; parity to a stated tolerance only. */
 enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1 };
 
+#define APE_FLAG_PACKED_MSG      0x20u /* ape_streams_step only: message and tail of a stream packed in one row  */
 #define APE_FLAG_BROADCAST_X     0x10u /* x_dev is ONE window [1,T,I] shared by all B rows: the x.repeat((n,1,1)) of
                                          monte_carlo_predictions (nn_models.py:206) without materialising it    */
 
@@ -203,7 +204,11 @@ int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev,
  *                              msg_dev  [S,25] of out_dtype, layout of compose_msg.py:72-78
  *                              tail_dev [S,smooth,6] of out_dtype or NULL: hand and elbow xyz of every smoothing row
  *                              (what msg_from_pred appends to the message when add_mc_samples is set and smooth > 1)
- *                              flags: APE_FLAG_NORMALIZE_INPUT or 0
+ *                              flags: APE_FLAG_NORMALIZE_INPUT and / or APE_FLAG_PACKED_MSG.  PACKED_MSG with
+ *                              out_dtype APE_F32: msg_dev is [S, 25+6N] (N = smooth*n_mc stacked rows), every row
+ *                              the message followed by its tail = the float32 payload the reference sends per
+ *                              estimator (pose_est_udp.py:47 struct.pack('f'*len(msg)) of estimator.py:131-137's
+ *                              list), tail_dev must be NULL
  *   ape_streams_reset          cold start: the next row fills the whole window, the next prediction the whole stack
  *   ape_streams_set_mc         Monte-Carlo dropout per stream, as every reference estimator runs it
  *                              (monte_carlo_samples, watch_phone_pocket_nn.py:105-110 -> nn_models.py:191-207): each
