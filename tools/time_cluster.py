@@ -16,6 +16,7 @@ sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0)
 m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], device=0); m.load_state_dict(sd)
 x = torch.randn(B, T, cfg["I"], device="cuda"); y = torch.empty(B, cfg["O"], device="cuda")
 lib = _hip.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+if os.environ.get('APE_PRECISION') == 'f16': m.set_precision('f16')
 lib.ape_model_set_kernel(m.handle, {'auto': 0, 'tile16': 1, 'cluster': 2}[os.environ.get('APE_KERNEL', 'cluster')])
 def run(n):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -213,6 +213,109 @@ void run3(float* out, float* w, int iters) {
            WAVES / 4, (double)cyc / iters);
 }
 
+// Symmetric split: every wave alternates a burst of MFMAs with a burst of gate-math-like VALU work (exp2 / rcp / fma).
+// WAVES = 4: one wave per SIMD does 256 MFMAs + 160 VALU per trip (the one-role kernel's shape: serial).
+// WAVES = 8: two waves per SIMD do 128 MFMAs + 80 VALU each per trip, the second wave of a SIMD starting with its VALU
+// burst (phase offset) -- does the pair keep the matrix pipe busier than one wave doing both jobs back to back?
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void k3t(float* out, const float* w_in, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[64 * 264];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 264; i += WAVES * 64) lds[i] = 0.001f * (i % 97);
+    constexpr int NB = (WAVES == 4) ? 16 : 8;            // k-blocks of 16 MFMAs per trip
+    constexpr int NV = (WAVES == 4) ? 160 : 80;          // VALU instructions per trip (half of them transcendental)
+    float w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = w_in[i * 64 + lane];
+    __syncthreads();
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.1f * (lane + i);
+    const float* src = lds + (lane & 15) * 264 + 4 * (lane >> 4);
+    auto valu_burst = [&]() {
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int e = 0; e < NV / 4; ++e) {
+            const int s = e & 7;
+            v[s] = __builtin_amdgcn_exp2f(v[s] * -1.4426950f);
+            v[s] = __builtin_amdgcn_rcpf(1.0f + v[s]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto mfma_burst = [&]() {
+        f32x4 a_cur[4], a_nxt[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a_cur[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * 264);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a_nxt[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * 264 + 16 * ((q + 1) & 15));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][j], w[(4 * q + j) & 31], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a_cur[mt] = a_nxt[mt];
+        }
+    };
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(out + 256 * 512 + 16) + (wave >= 4 ? 64 : 0);
+    const bool rec = blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+    for (int it = 0; it < iters; ++it) {
+        if (WAVES == 8) __syncthreads();                     // the two waves of a SIMD start every trip together
+        unsigned long long ta, tb, tc;
+        if (WAVES == 8 && wave >= 4) {                       // second wave of the SIMD: gate math first, matrix work second
+            valu_burst();
+            __builtin_amdgcn_sched_barrier(0);
+            ta = __builtin_amdgcn_s_memtime();
+            mfma_burst();
+            __builtin_amdgcn_sched_barrier(0);
+            tb = tc = __builtin_amdgcn_s_memtime();
+        } else {
+            ta = __builtin_amdgcn_s_memtime();
+            mfma_burst();
+            __builtin_amdgcn_sched_barrier(0);
+            tb = __builtin_amdgcn_s_memtime();
+            valu_burst();
+            __builtin_amdgcn_sched_barrier(0);
+            tc = __builtin_amdgcn_s_memtime();
+        }
+        if (rec && it >= 100 && it < 110) { tl[(it - 100) * 3] = ta - t0; tl[(it - 100) * 3 + 1] = tb - t0; tl[(it - 100) * 3 + 2] = tc - t0; }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sres = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sres += v[i];
+    out[blockIdx.x * WAVES * 64 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + sres;
+    if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(out + 256 * 512)[0] = t1 - t0;
+}
+
+template <int WAVES>
+void run3t(float* out, float* w, int iters) {
+    hipLaunchKernelGGL(k3t<WAVES>, dim3(256), dim3(WAVES * 64), 0, 0, out, w, iters);
+    (void)hipDeviceSynchronize();
+    hipEvent_t ea, eb; (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+    (void)hipEventRecord(ea);
+    hipLaunchKernelGGL(k3t<WAVES>, dim3(256), dim3(WAVES * 64), 0, 0, out, w, iters);
+    (void)hipEventRecord(eb); (void)hipEventSynchronize(eb);
+    float ms = 0; (void)hipEventElapsedTime(&ms, ea, eb);
+    unsigned long long tl[128]; (void)hipMemcpy(tl, out + 256 * 512 + 16, sizeof(tl), hipMemcpyDeviceToHost);
+    for (int wv = 0; wv < (WAVES == 8 ? 2 : 1); ++wv) {
+        printf("   timeline wave %d (mfma start, mfma len, valu len):", wv * 4);
+        for (int i = 0; i < 6; ++i) printf("  %llu %llu %llu |", tl[wv * 64 + i * 3] - tl[0], tl[wv * 64 + i * 3 + 1] - tl[wv * 64 + i * 3], tl[wv * 64 + i * 3 + 2] - tl[wv * 64 + i * 3 + 1]);
+        printf("\n");
+    }
+    unsigned long long cyc; (void)hipMemcpy(&cyc, out + 256 * 512, 8, hipMemcpyDeviceToHost);
+    printf("   whole kernel %.3f ms = %.1f TFLOP/s of MFMA work on the chip; ", ms, 256.0 * 4 * 256 * iters * 2048 / (ms * 1e-3) / 1e12);
+    // per SIMD and trip: 256 MFMAs (= 8192 pipe cycles) + 160 VALU instructions, whatever the number of waves
+    printf("%d wave(s) per SIMD, MFMA bursts alternating with VALU bursts: %.0f cycles per trip of 256 MFMAs + 160 VALU (pipe alone: 8192)\n",
+           WAVES / 4, (double)cyc / iters);
+}
+
 template <int VPM>
 void run(float* out, float* w, int iters) {
     hipLaunchKernelGGL(k<VPM>, dim3(256), dim3(256), 0, 0, out, w, iters);
@@ -230,13 +333,14 @@ void run(float* out, float* w, int iters) {
 
 int main() {
     float *out, *w;
-    hipMalloc(&out, (256 * 512 + 64) * 4); hipMalloc(&w, 64 * 64 * 4);
+    hipMalloc(&out, (256 * 512 + 1024) * 4); hipMalloc(&w, 64 * 64 * 4);
     std::vector<float> hw(64 * 64); for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.01f * (i % 31) - 0.1f;
     hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     run<0>(out, w, 200); run<1>(out, w, 200); run<2>(out, w, 200); run<3>(out, w, 200); run<4>(out, w, 200);
     run<6>(out, w, 200); run<8>(out, w, 200);
     // 200 iterations x 256 MFMAs x 32 cycles = 1.64M cycles of MFMA work per wave
     run3<4>(out, w, 200); run3<8>(out, w, 200);
+    run3t<4>(out, w, 200); run3t<8>(out, w, 200);
     run2(out, w, 200, 0); run2(out, w, 200, 3000); run2(out, w, 200, 12000);
     run2(out, w, 200, 0, 0x55); run2(out, w, 200, 3000, 0x55);      // MFMA on waves 0,2,4,6
     run2(out, w, 200, 0, 0x01); run2(out, w, 200, 3000, 0x01);      // ONE MFMA wave, seven helpers
