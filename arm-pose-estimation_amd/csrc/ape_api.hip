@@ -440,6 +440,24 @@ int ape_model_set_body(ape_model_t* m, const double body9[9]) {
     return APE_OK;
 }
 
+// APE_KERNEL_AUTO: how many whole 4096-row waves of the batch-tile kernel to peel off the front of a batch.  Measured
+// on MI355X (microseconds): a batch-tile wave sustains 103 TFLOP/s at H = 256 and 91 at H = 128 whatever T and the
+// dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
+// dropout variant) however few of its rows are used.
+static int auto_tile16_waves(const ape_model* m, int B, int T, bool cdrop, int rows_per_cluster_launch) {
+    const double t16 = 4096.0 * ape_flops_per_window(&m->dims, T) / (m->dims.hidden_size == 256 ? 1.03e14 : 0.91e14) * 1e6;
+    const double tcl = cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
+    auto cost = [&](int w) {
+        const int rest = B - 4096 * w;
+        return w * t16 + (rest > 0 ? (double)((rest + rows_per_cluster_launch - 1) / rows_per_cluster_launch) * tcl : 0.0);
+    };
+    int best = 0;
+    double best_cost = cost(0);
+    for (int w : {B / 4096, (B + 4095) / 4096})
+        if (w > 0 && cost(w) < best_cost) { best = w; best_cost = cost(w); }
+    return best;
+}
+
 // x_ring: time step t of every window lives in slot (t + x_ring) mod T (0 = the linear layout of the public entry)
 static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                              const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream,
@@ -508,28 +526,60 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
 
-    // the cluster kernel covers last-step output, with or without inter-layer dropout (dropout: <= 32 windows
-    // per cluster, so batches beyond 32 x clusters-per-chip go to the batch-tile kernel under AUTO)
+    // Two kernels serve an LSTM batch.  The weight-stationary cluster kernel fills the chip from one launch of
+    // 1..1024 rows (512 with inter-layer dropout) and is the faster one per row on long windows; the batch-tile kernel
+    // needs 4096 rows (256 workgroups x 16) to fill the chip, but then runs dropout at no extra cost and pays no
+    // per-launch prologue / head, which decides short windows.  Under APE_KERNEL_AUTO the front of the batch goes to
+    // the batch-tile kernel in whole 4096-row waves and the rest to the cluster kernel, by a cost model calibrated
+    // on MI355X (tools/time_big_batch.py).
     const int GHc = H / 16, max_clusters_c = 256 / GHc;
-    const bool fits_drop = !drop || L == 1 || B <= 32 * max_clusters_c || m->kernel_choice == APE_KERNEL_CLUSTER;
     const bool f16 = m->precision == APE_PRECISION_F16;
     // all-steps output: the cluster kernel also writes every step's top-layer output to a [B,T,H] workspace and the
     // head runs over those rows in a second, HBM-bound launch
     const bool all_steps = (flags & APE_FLAG_ALL_STEPS) != 0;
-    bool use_cluster = m->cluster_ok && fits_drop && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16);
+    const bool cdrop_c = drop && L > 1;
+    const int rows_per_cluster_launch = 16 * (cdrop_c ? 2 : 4) * max_clusters_c;
+    // injected masks are indexed over the whole batch, so such a call is served by ONE launch of one kernel
+    const bool masks_fit = !(flags & APE_FLAG_DROPOUT_MASKS) || !cdrop_c || B <= rows_per_cluster_launch ||
+                           m->kernel_choice == APE_KERNEL_CLUSTER;
+    bool use_cluster = m->cluster_ok && masks_fit && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16);
     if (f16 && (!m->cluster_ok || drop || (flags & APE_FLAG_ALL_STEPS)))
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant covers last-step output without dropout on "
                     "the cluster-kernel shapes only");
     if (f16) use_cluster = true;
     if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
+    int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
+    if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
+        const int w = auto_tile16_waves(m, B, T, cdrop_c, rows_per_cluster_launch);
+        n16 = (4096 * w < B) ? 4096 * w : B;
+    }
+    if (n16 > 0) {
+        LstmParams p{};
+        p.x = lstm_x;
+        p.y = y_dev;
+        for (int l = 0; l < L; ++l) { p.wpack[l] = m->wpack[l]; p.bias[l] = m->bias[l]; }
+        p.w_out = m->w_out;
+        p.b_out = m->b_out;
+        p.xx_m = m->stats;
+        p.xx_s = m->stats + m->dims.input_size;
+        p.masks = masks_dev;
+        p.B = n16; p.T = T; p.I = m->lstm_in; p.O = m->dims.output_size; p.KX = m->KX;
+        p.x_ring = x_ring;
+        p.flags = flags;
+        p.dropout_p = dropout_p;
+        p.seed = seed;
+        hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
+        if (n16 == B) return APE_OK;
+    }
     if (use_cluster) {
         // smallest row tile count that still fits the batch on the chip: more clusters = more CUs busy
         const int GH = H / 16, max_clusters = 256 / GH;
         const bool cdrop = drop && L > 1;
         int nmt = cdrop ? 2 : 4;
         for (int cand : {1, 2, 4})
-            if ((!cdrop || cand <= 2) && (B + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
+            if ((!cdrop || cand <= 2) && (B - n16 + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
         const int rows_per_launch = 16 * nmt * max_clusters;
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
         if (all_steps) {
@@ -544,7 +594,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 m->hseq_cap = rows;
             }
         }
-        for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
+        for (int b0 = n16; b0 < B; b0 += rows_per_launch) {
             const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
             ClusterParams c{};
             c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
@@ -586,23 +636,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return APE_OK;
     }
 
-    LstmParams p{};
-    p.x = lstm_x;
-    p.y = y_dev;
-    for (int l = 0; l < L; ++l) { p.wpack[l] = m->wpack[l]; p.bias[l] = m->bias[l]; }
-    p.w_out = m->w_out;
-    p.b_out = m->b_out;
-    p.xx_m = m->stats;
-    p.xx_s = m->stats + m->dims.input_size;
-    p.masks = masks_dev;
-    p.B = B; p.T = T; p.I = m->lstm_in; p.O = m->dims.output_size; p.KX = m->KX;
-    p.x_ring = x_ring;
-    p.flags = flags;
-    p.dropout_p = dropout_p;
-    p.seed = seed;
-    hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
-    return APE_OK;
+    return fail(APE_ERR_UNSUPPORTED, "lstm_forward: no kernel covers this call");     // not reached
 }
 
 int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
@@ -884,10 +918,15 @@ int ape_debug_read_wg(ape_model_t* m, unsigned long long out[256 * 8]) {
 }
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
-    (void)B; (void)T;
     if (!m) return "";
     if (m->precision == APE_PRECISION_F16) return "ape_lstm_cluster_f16";
-    return (m->cluster_ok && m->kernel_choice != APE_KERNEL_TILE16) ? m->cluster_name.c_str() : m->kernel_name.c_str();
+    if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
+    // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
+    if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
+        const int rpl = 16 * 4 * (256 / (m->dims.hidden_size / 16));
+        if (2 * 4096 * auto_tile16_waves(m, B, T, false, rpl) > B) return m->kernel_name.c_str();
+    }
+    return m->cluster_name.c_str();
 }
 
 }  // extern "C"

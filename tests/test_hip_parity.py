@@ -776,6 +776,46 @@ def test_stream_bank_monte_carlo(golden, norm_stats, name, S, n_mc, smooth, p_dr
         StreamBank(m, S, T, smooth=64, monte_carlo_samples=65)      # smooth * n_mc > 4096
 
 
+@pytest.mark.parametrize("T,philox", [(6, False), (6, True), (64, False)])
+def test_auto_dispatch_splits_large_batches(norm_stats, T, philox):
+    """APE_KERNEL_AUTO on batches of 4096 rows and more: whole 4096-row waves go to the batch-tile kernel
+    where that is cheaper (short windows, dropout), the rest to the cluster kernel.  Whatever the split, every row
+    must be what ONE of the two kernels yields for it and agree with the oracle."""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats["pocket"]
+    m, sd, cfg = make_model("pocket", 3, st)
+    B = 4096 + 300
+    raw = _synthetic_windows(st, B, T, cfg["I"], 31)
+    x = torch.from_numpy(raw).cuda()
+    lib = _hip.lib()
+    flags = _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_DROPOUT_PHILOX if philox else 0)
+    out = {}
+    for kern in ("auto", "tile16", "cluster"):
+        m.set_kernel(kern)
+        y = torch.zeros((B, cfg["O"]), dtype=torch.float32, device="cuda")
+        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, flags, None, 0.2 if philox else 0.0, 77,
+                                        C.c_void_p(y.data_ptr()), None), "ape_lstm_forward")
+        torch.cuda.synchronize()
+        m.check()
+        out[kern] = y.cpu().numpy()
+    m.set_kernel("auto")
+    a, t16, cl = out["auto"], out["tile16"], out["cluster"]
+    if T == 6:          # short windows: one batch-tile wave in front, the 300 remaining rows on the cluster kernel
+        assert np.array_equal(a[:4096], t16[:4096])
+        assert not np.array_equal(a[:4096], cl[:4096])          # (the two kernels do differ in the last bits)
+        # the tail ran on the cluster kernel, as a launch of 300 rows: its head sums in the order of that launch's
+        # row-tile count, so against the whole-batch cluster run it agrees to rounding, not to the bit
+        assert np.abs(a[4096:] - cl[4096:]).max() < 1e-6 and not np.array_equal(a[4096:], t16[4096:])
+    else:               # long windows without dropout: the cluster kernel keeps the whole batch
+        assert np.array_equal(a, cl)
+    if not philox:
+        pick = np.r_[0:8, 4090:4104, B - 8:B]
+        ref = orc.infer_windows(sd, st, orc.DEFAULT_BODY, cfg["layout"], raw[pick])[0]
+        assert np.abs(a[pick] - ref).max() < (TOL_Y_T64 if T == 64 else 1e-5)
+    else:               # the two kernels draw the same masks for the same (row, step, unit) within a launch
+        assert np.abs(t16[:512] - cl[:512]).max() < 1e-5
+
+
 @pytest.mark.parametrize("name,B", [("pocket", 2500), ("uarm", 4100)])
 def test_batches_beyond_one_cluster_launch(norm_stats, name, B):
     """more windows than one cluster launch covers (1024 / 2048 rows): the entry point chunks the batch; every chunk
