@@ -361,11 +361,19 @@ def main():
                 out["parity_vs_cpu_reference"] = cb.pop("parity")
                 out["cpu_baseline"] = cb
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
+# The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL's "Librccl path : ...", gloo's
+# connection notes, a stale-library rebuild), so file descriptor 1 is pointed at stderr for the whole run and the
+# result line goes out through a private duplicate of the original stdout.
+_JSON_FD = 1
+
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     main()
