@@ -441,11 +441,11 @@ int ape_model_set_body(ape_model_t* m, const double body9[9]) {
 }
 
 // APE_KERNEL_AUTO: how many whole 4096-row waves of the batch-tile kernel to peel off the front of a batch.  Measured
-// on MI355X (microseconds): a batch-tile wave sustains 103 TFLOP/s at H = 256 and 91 at H = 128 whatever T and the
+// on MI355X (microseconds): a batch-tile wave sustains 125 TFLOP/s at H = 256 and 109 at H = 128 whatever T and the
 // dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
 // dropout variant) however few of its rows are used.
 static int auto_tile16_waves(const ape_model* m, int B, int T, bool cdrop, int rows_per_cluster_launch) {
-    const double t16 = 4096.0 * ape_flops_per_window(&m->dims, T) / (m->dims.hidden_size == 256 ? 1.03e14 : 0.91e14) * 1e6;
+    const double t16 = 4096.0 * ape_flops_per_window(&m->dims, T) / (m->dims.hidden_size == 256 ? 1.25e14 : 1.09e14) * 1e6;
     const double tcl = cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
     auto cost = [&](int w) {
         const int rest = B - 4096 * w;
