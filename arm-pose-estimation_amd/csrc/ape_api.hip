@@ -109,6 +109,7 @@ struct ape_model {
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
     int precision = APE_PRECISION_F32;
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
+    bool upper_ok = false;          // 2 x 256 LSTM: layer 1 can run on its own over a shared layer-0 sequence (stream bank, MC mode)
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
@@ -243,6 +244,14 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     if (e != hipSuccess) {
         ape_model_destroy(m);
         return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
+    }
+    if (!imupose && H == 256 && L == 2) {
+        e = ape_prepare_lstm_tile16_upper(ape_lstm_tile16_smem_bytes(256, 1, 256, O, false));
+        if (e != hipSuccess) {
+            ape_model_destroy(m);
+            return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
+        }
+        m->upper_ok = true;
     }
     char nm[64];
     snprintf(nm, sizeof(nm), "ape_lstm_tile16<%d, %d, %d>", H, L, imupose ? 16 : 4);
@@ -759,6 +768,7 @@ struct ape_streams {
     int S = 0, T = 0, smooth = 0;
     int n_mc = 1;                // Monte-Carlo samples per stream and step
     bool mc = false;             // dropout on (ape_streams_set_mc was called)
+    bool shared_l0 = false;      // MC mode with layer 0 computed once per stream (two launches per step)
     float dropout_p = 0.0f;
     unsigned long long seed = 0, mc_calls = 0;
     float* xring = nullptr;      // [S,n_mc,T,I] feature rows, slot = frame mod T (a stream's n_mc windows are copies)
@@ -813,6 +823,20 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     b->frames = 0; b->steps = 0;
     hipError_t e = bank_alloc(b);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_set_mc: allocation failed: %s", hipGetErrorString(e));
+    // Layer 0 once per stream (nn.LSTM's dropout sits BETWEEN the layers, so h_0(t) is the same for all samples of a
+    // stream): worth its extra launch from two batch-tile waves of sample rows on.  The [S,T,H] sequence lives in the
+    // model's all-steps workspace, sized here so that the step itself never allocates.
+    ape_model* m = b->model;
+    b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
+                   dropout_p > 0.0f && n_mc >= 2 && (long long)b->S * n_mc >= 8192;
+    if (b->shared_l0) {
+        const size_t rows = (size_t)b->S * b->T;
+        if (rows > m->hseq_cap) {
+            if (m->hseq_ws) { HIP_TRY(hipFree(m->hseq_ws)); m->hseq_ws = nullptr; m->hseq_cap = 0; }
+            HIP_TRY(hipMalloc((void**)&m->hseq_ws, rows * m->dims.hidden_size * sizeof(float)));
+            m->hseq_cap = rows;
+        }
+    }
     return APE_OK;
 }
 
@@ -885,9 +909,37 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     // oldest row of every window: the slot after the newest one
     const int x_ring = (int)(b->frames % b->T);
     const bool drop = b->mc && b->dropout_p > 0.0f && m->dims.num_layers > 1;
-    if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
-                                   drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring)) return rc;
-    ++b->mc_calls;
+    if (b->shared_l0 && m->has_weights && (size_t)b->S * b->T <= m->hseq_cap) {
+        const int H = m->dims.hidden_size, I = m->dims.input_size, O = m->dims.output_size;
+        // launch A: layer 0 alone over the S windows (first copy of every stream's ring), all steps -> [S,T,H]
+        LstmParams a{};
+        a.x = b->xring; a.x_row_stride = (size_t)b->n_mc * b->T * I;
+        a.y = nullptr; a.hseq = m->hseq_ws;
+        a.wpack[0] = m->wpack[0]; a.bias[0] = m->bias[0];
+        a.w_out = m->w_out; a.b_out = m->b_out;
+        a.xx_m = m->stats; a.xx_s = m->stats + I;
+        a.B = b->S; a.T = b->T; a.I = I; a.O = O; a.KX = m->KX; a.x_ring = x_ring;
+        a.flags = flags & APE_FLAG_NORMALIZE_INPUT;
+        hipError_t e = ape_launch_lstm_tile16(H, 1, a, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 launch failed: %s", hipGetErrorString(e));
+        // launch B: layer 1 as a one-layer LSTM over the S x n_mc sample rows; row r reads stream r / n_mc's sequence
+        // under its own Philox mask (the counters of a fused launch over the same rows)
+        LstmParams q{};
+        q.x = m->hseq_ws; q.y = b->y_new;
+        q.wpack[0] = m->wpack[1]; q.bias[0] = m->bias[1];
+        q.w_out = m->w_out; q.b_out = m->b_out;
+        q.B = b->S * b->n_mc; q.T = b->T; q.I = H; q.O = O; q.KX = H; q.x_ring = 0;
+        q.flags = APE_FLAG_DROPOUT_PHILOX; q.dropout_p = b->dropout_p; q.seed = b->seed + b->mc_calls;
+        q.x_group = b->n_mc;
+        e = ape_launch_lstm_tile16(H, 1, q, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-1 launch failed: %s", hipGetErrorString(e));
+        ++b->mc_calls;
+    } else if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
+                                   drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring)) {
+        return rc;
+    } else {
+        ++b->mc_calls;
+    }
     StreamPostParams q{};
     q.y_new = b->y_new; q.yring = b->yring; q.msg = msg_dev; q.tail = tail_dev;
     q.yy_m = norm ? m->stats + 2 * m->dims.input_size : nullptr;      // one switch (estimator.py:103-109)

@@ -31,6 +31,11 @@ struct LstmParams {
     unsigned flags;
     float dropout_p;
     unsigned long long seed;
+    size_t x_row_stride;                // floats between the windows of consecutive rows (0: T*I, a dense [B,T,I])
+    float* hseq;                        // [B,T,H]: every step's top-layer output goes here too (or nullptr)
+    int x_group;                        // wide-input instantiations: row b reads window b / x_group of x, and with
+                                        // DROPOUT_PHILOX the input is masked as the output of a layer 0 would be
+                                        // (0: row b reads window b, no mask)
 };
 
 // Kernel arguments of the weight-stationary cluster LSTM kernel.
@@ -137,6 +142,7 @@ hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t
 size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout);
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
 hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes);
+hipError_t ape_prepare_lstm_tile16_upper(size_t smem_bytes);      // <256,1,wide>: layer 1 of a 2 x 256 model on its own
 bool ape_cluster_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,

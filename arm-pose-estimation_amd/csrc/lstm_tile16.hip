@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     // (the wide instantiation copies its 16 elements per thread straight to LDS in store_x -- one exposed
     //  round trip per step, ~4 % of a step -- instead of holding 16 more registers across the MFMAs)
     constexpr int XR = (XE > 4) ? 1 : XE;
+    const size_t x_rows = p.x_row_stride ? p.x_row_stride : (size_t)T * I;
     float xr[XR];
     int x_step = 0;
     auto fetch_x = [&](int t) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                 const int row = idx / KX, k = idx - row * KX;
                 const int b = row0 + row;
                 if (k < I && b < p.B) {
-                    const float v = p.x[((size_t)(bcast_x ? 0 : b) * T + (t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring)) * I + k];
+                    const float v = p.x[(size_t)(bcast_x ? 0 : b) * x_rows + (size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + k];
                     // f64 z-score then round to f32: estimator.py:103-104 + watch_phone_pocket_nn.py:100
                     xr[e] = normalize ? (float)(((double)v - p.xx_m[k]) / p.xx_s[k]) : v;
                 }
@@ -116,6 +117,36 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
         }
     };
     auto store_x = [&](int buf) {
+        if (XE > 4 && p.x_group > 0) {
+            // Monte-Carlo samples of shared windows (stream bank): the input is the layer below's output sequence
+            // [B / x_group, T, H], computed ONCE per stream, and row b is sample b % x_group of stream b / x_group.
+            // The inter-layer dropout mask is drawn here with the counters the fused kernel uses for its layer 0
+            // (rows b & ~3, step, unit, layer 0; value index b & 3), so the samples are the ones a fused launch over
+            // the same rows draws.  Thread = unit (KX = 256 threads), one Philox call per group of four rows.
+            const int slot = (x_step + p.x_ring >= T) ? x_step + p.x_ring - T : x_step + p.x_ring;
+            const float keep = 1.0f / (1.0f - p.dropout_p);
+#pragma unroll
+            for (int grp = 0; grp < APE_TILE_ROWS / 4; ++grp) {
+                uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (drop_philox)
+                    philox4x32((uint32_t)(row0 + 4 * grp), (uint32_t)x_step, (uint32_t)tid, 0u, (uint32_t)p.seed,
+                               (uint32_t)(p.seed >> 32), rnd);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * grp + i, b = row0 + row;
+                    float v = 0.0f;
+                    if (b < p.B) {
+                        v = p.x[((size_t)(b / p.x_group) * T + slot) * I + tid];
+                        if (drop_philox) {
+                            const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                            v = (uf >= p.dropout_p) ? v * keep : 0.0f;
+                        }
+                    }
+                    xin[(buf * APE_TILE_ROWS + row) * SX + tid] = v;
+                }
+            }
+            return;
+        }
         if (XE > 4) {                 // wide: rows are full (I == KX), already normalised by the layer in front
             const int slot = (x_step + p.x_ring >= T) ? x_step + p.x_ring - T : x_step + p.x_ring;
 #pragma unroll
@@ -227,6 +258,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                     const float h = ov * gate_act(c, true);
                     const int row = 4 * g + i;
                     hdst[row * SH + unit] = h;
+                    if (l == L - 1 && p.hseq != nullptr && row0 + row < p.B)
+                        p.hseq[((size_t)(row0 + row) * T + t) * H + unit] = h;
                     if (drop && l < L - 1) {
                         float m;
                         if (drop_masks) {
@@ -246,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
         }
 
         // ---- linear head on h^{L-1}_t: output_layer of nn_models.py:189 -----------------------------
-        if (all_steps || t == T - 1) {
+        if (p.y != nullptr && (all_steps || t == T - 1)) {
             if (tid < APE_TILE_ROWS * O) {
                 const int row = tid / O, o = tid - row * O;
                 const float* hv = hbuf + (((L - 1) * 2 + cur) * APE_TILE_ROWS + row) * SH;
@@ -305,11 +338,14 @@ size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout) {
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes) { APE_DISPATCH(prepare, smem_bytes) }
 
 hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream) {
-    if (p.KX > 64) {      // wide layer-0 input (ImuPoseLSTM: the 256 activations of its input layer), H=256 L=2 only
+    if (p.KX > 64) {      // wide layer-0 input: the 256 activations of ImuPoseLSTM's input layer (H=256 L=2), or
+                          // the layer-0 output sequence in front of layer 1 run on its own (H=256 L=1)
         if (H == 256 && L == 2 && p.KX == 256) return launch<256, 2, 16>(p, stream);
+        if (H == 256 && L == 1 && p.KX == 256) return launch<256, 1, 16>(p, stream);
         return hipErrorInvalidValue;
     }
     APE_DISPATCH(launch, p, stream)
 }
 
 hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes) { return prepare<256, 2, 16>(smem_bytes); }
+hipError_t ape_prepare_lstm_tile16_upper(size_t smem_bytes) { return prepare<256, 1, 16>(smem_bytes); }

@@ -776,6 +776,54 @@ def test_stream_bank_monte_carlo(golden, norm_stats, name, S, n_mc, smooth, p_dr
         StreamBank(m, S, T, smooth=64, monte_carlo_samples=65)      # smooth * n_mc > 4096
 
 
+def test_stream_bank_monte_carlo_shared_layer0(golden, norm_stats):
+    """From 8192 sample rows on, the bank computes layer 0 ONCE per stream and runs layer 1 alone over the S x n_mc
+    rows (nn.LSTM's dropout sits between the layers, nn_models.py:169-174, so h_0 is common to a
+    stream's samples).  The samples must be the ones a fused launch over the same rows draws: checked against
+    ape_lstm_forward on explicitly repeated windows (batch-tile kernel, same Philox key) through the oracle's FK --
+    every sample row's hand / elbow position, and the full message of a spread of streams."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    name, S, n_mc, p_drop, seed = "pocket", 330, 25, 0.2, 0x1234567
+    g = golden(f"stream_trace_{name}.npz")
+    stats, body = norm_stats[name], g["body"]
+    m, sd, cfg = make_model(name, int(g["weights_seed"]), stats)
+    m.set_body(body)
+    T, I, O = cfg["T"], cfg["I"], cfg["O"]
+    assert S * n_mc >= 8192
+    bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=p_drop, seed=seed)
+    F = 8                                                           # more frames than the window is long
+    feats = _synthetic_windows(stats, S, F, I, 41)
+    lib = _hip.lib()
+    shadow = [orc.WindowOracle(T, 1, None, lambda h: np.zeros((1, O))) for _ in range(S)]
+    worst_tail = worst_msg = 0.0
+    for f in range(F):
+        bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+        msg, tail = bank.step(with_tail=True)
+        msg, tail = msg.cpu().numpy(), tail.cpu().numpy()
+        hist = []
+        for s in range(S):
+            shadow[s].push(feats[s, f])
+            hist.append(np.vstack(shadow[s].rows).astype(np.float32))
+        x = torch.from_numpy(np.repeat(np.stack(hist), n_mc, axis=0)).cuda()
+        y = torch.empty((S * n_mc, O), dtype=torch.float32, device="cuda")
+        m.set_kernel("tile16")
+        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), S * n_mc, T,
+                                        _hip.FLAG_NORMALIZE_INPUT | _hip.FLAG_DROPOUT_PHILOX, None, p_drop, seed + f,
+                                        C.c_void_p(y.data_ptr()), None), "ape_lstm_forward")
+        torch.cuda.synchronize()
+        m.set_kernel("auto")
+        y = y.cpu().numpy().astype(np.float64) * stats["yy_s"] + stats["yy_m"]
+        assert np.abs(y.reshape(S, n_mc, O) - y.reshape(S, n_mc, O)[:, :1]).max() > 1e-3          # samples differ
+        est = orc.arm_pose_from_targets(y, body, cfg["layout"], "closed")
+        worst_tail = max(worst_tail, float(np.abs(tail.reshape(S * n_mc, 6) - est[:, :6]).max()))
+        for s in list(range(0, S, 37)) + [S - 1]:
+            e = orc.arm_pose_from_targets(y[s * n_mc:(s + 1) * n_mc], body, cfg["layout"], "eigh")
+            worst_msg = max(worst_msg, float(np.abs(msg[s] - orc.msg_from_est(e, body, cfg["layout"])).max()))
+    m.check()
+    assert worst_tail < 5e-6 and worst_msg < 5e-6, (worst_tail, worst_msg)
+
+
 @pytest.mark.parametrize("T,philox", [(6, False), (6, True), (64, False)])
 def test_auto_dispatch_splits_large_batches(norm_stats, T, philox):
     """APE_KERNEL_AUTO on batches of 4096 rows and more: whole 4096-row waves go to the batch-tile kernel
@@ -800,14 +848,20 @@ def test_auto_dispatch_splits_large_batches(norm_stats, T, philox):
         out[kern] = y.cpu().numpy()
     m.set_kernel("auto")
     a, t16, cl = out["auto"], out["tile16"], out["cluster"]
-    if T == 6:          # short windows: one batch-tile wave in front, the 300 remaining rows on the cluster kernel
-        assert np.array_equal(a[:4096], t16[:4096])
-        assert not np.array_equal(a[:4096], cl[:4096])          # (the two kernels do differ in the last bits)
-        # the tail ran on the cluster kernel, as a launch of 300 rows: its head sums in the order of that launch's
-        # row-tile count, so against the whole-batch cluster run it agrees to rounding, not to the bit
-        assert np.abs(a[4096:] - cl[4096:]).max() < 1e-6 and not np.array_equal(a[4096:], t16[4096:])
-    else:               # long windows without dropout: the cluster kernel keeps the whole batch
-        assert np.array_equal(a, cl)
+    # one batch-tile wave in front, the 300 remaining rows on the cluster kernel
+    assert np.array_equal(a[:4096], t16[:4096])
+    assert not np.array_equal(a[:4096], cl[:4096])          # (the two kernels do differ in the last bits)
+    # the tail ran on the cluster kernel, as a launch of 300 rows: its head sums in the order of that launch's
+    # row-tile count, so against the whole-batch cluster run it agrees to rounding, not to the bit
+    assert np.abs(a[4096:] - cl[4096:]).max() < 1e-6 and not np.array_equal(a[4096:], t16[4096:])
+    # well below a wave's worth of long windows the cluster kernel keeps the whole batch
+    n = 2500
+    y = torch.zeros((n, cfg["O"]), dtype=torch.float32, device="cuda")
+    _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), n, T, flags, None, 0.2 if philox else 0.0, 77,
+                                    C.c_void_p(y.data_ptr()), None), "ape_lstm_forward")
+    torch.cuda.synchronize()
+    if T == 64:                         # (2500 rows of SHORT windows cost about one batch-tile wave either way)
+        assert np.abs(y.cpu().numpy() - cl[:n]).max() < 1e-6 and not np.array_equal(y.cpu().numpy(), t16[:n])
     if not philox:
         pick = np.r_[0:8, 4090:4104, B - 8:B]
         ref = orc.infer_windows(sd, st, orc.DEFAULT_BODY, cfg["layout"], raw[pick])[0]
