@@ -860,7 +860,8 @@ int ape_streams_reset(ape_streams_t* b) {
 static void next_slot(const ape_streams* b, size_t I, float** out, int* rep, size_t* rep_stride) {
     const bool cold = b->frames == 0;
     *out = b->xring + (cold ? 0 : (size_t)(b->frames % b->T) * I);
-    *rep = cold ? b->T * b->n_mc : b->n_mc;
+    const int copies = b->shared_l0 ? 1 : b->n_mc;      // layer 0 shared: only a stream's first window copy is ever read
+    *rep = cold ? b->T * copies : copies;
     *rep_stride = cold ? I : (size_t)b->T * I;
 }
 
