@@ -910,7 +910,9 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     // oldest row of every window: the slot after the newest one
     const int x_ring = (int)(b->frames % b->T);
     const bool drop = b->mc && b->dropout_p > 0.0f && m->dims.num_layers > 1;
-    if (b->shared_l0 && m->has_weights && (size_t)b->S * b->T <= m->hseq_cap) {
+    if (b->shared_l0) {
+        if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
+        if ((size_t)b->S * b->T > m->hseq_cap) return fail(APE_ERR_CAPACITY, "streams_step: the layer-0 sequence workspace is gone");
         const int H = m->dims.hidden_size, I = m->dims.input_size, O = m->dims.output_size;
         // launch A: layer 0 alone over the S windows (first copy of every stream's ring), all steps -> [S,T,H]
         LstmParams a{};
