@@ -83,8 +83,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     float* hbuf = xin + 2 * APE_TILE_ROWS * SX;         // [L][2][16][SH]
     float* dbuf = hbuf + L * 2 * APE_TILE_ROWS * SH;    // [L-1][16][SH]   (carved only when dropout is on)
     float* wout_s = dbuf + (drop ? (L - 1) : 0) * APE_TILE_ROWS * SH;    // [O][H+1]
+    float* bias_s = wout_s + O * (H + 1);                                // [L][4H]: b_ih + b_hh, read at every layer-step
 
-    // ---- stage the head weights once ---------------------------------------------------------
+    // ---- stage the biases and the head weights once ------------------------------------------
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        for (int idx = tid; idx < 4 * H; idx += 256) bias_s[l * 4 * H + idx] = p.bias[l][idx];
     for (int idx = tid; idx < O * H; idx += 256) {
         const int o = idx / H, k = idx - o * H;
         wout_s[o * (H + 1) + k] = p.w_out[idx];
@@ -94,12 +98,28 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     const int n_el = KX / 16;         // 2 (KX=32), 4 (KX=64) or 16 (KX=256: XE=16 instantiation, ImuPoseLSTM)
     // (the wide instantiation copies its 16 elements per thread straight to LDS in store_x -- one exposed
     //  round trip per step, ~4 % of a step -- instead of holding 16 more registers across the MFMAs)
-    constexpr int XR = (XE > 4) ? 1 : XE;
+    //  The one-layer wide instantiation (layer 1 over a shared layer-0 sequence) has the registers to spare: its 16
+    //  values per thread are fetched a step ahead like the narrow inputs, so nothing of them is exposed.)
+    constexpr bool XPRE = (XE > 4 && L == 1);            // grouped wide input prefetched into registers
+    constexpr int XR = XPRE ? APE_TILE_ROWS : ((XE > 4) ? 1 : XE);
     const size_t x_rows = p.x_row_stride ? p.x_row_stride : (size_t)T * I;
     float xr[XR];
     int x_step = 0;
+    // source window of each of the tile's rows (grouped input: row b reads window b / x_group)
+    int xsrc[XPRE ? APE_TILE_ROWS : 1];
+    if (XPRE && p.x_group > 0) {
+#pragma unroll
+        for (int e = 0; e < APE_TILE_ROWS; ++e) xsrc[XPRE ? e : 0] = (row0 + e < p.B) ? (row0 + e) / p.x_group : -1;
+    }
     auto fetch_x = [&](int t) {
         x_step = t;
+        if (XPRE && p.x_group > 0) {
+            const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
+#pragma unroll
+            for (int e = 0; e < APE_TILE_ROWS; ++e)
+                xr[XPRE ? e : 0] = (xsrc[XPRE ? e : 0] >= 0) ? p.x[((size_t)xsrc[XPRE ? e : 0] * T + slot) * I + tid] : 0.0f;
+            return;
+        }
         if (XE > 4) return;
 #pragma unroll
         for (int e = 0; e < XR; ++e) {
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                     const int row = 4 * grp + i, b = row0 + row;
                     float v = 0.0f;
                     if (b < p.B) {
-                        v = p.x[((size_t)(b / p.x_group) * T + slot) * I + tid];
+                        v = XPRE ? xr[XPRE ? row : 0] : p.x[((size_t)(b / p.x_group) * T + slot) * I + tid];
                         if (drop_philox) {
                             const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
                             v = (uf >= p.dropout_p) ? v * keep : 0.0f;
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int gate = n / UB, u = n % UB;
-                const float bv = p.bias[l][gate * H + wave * (H / 4) + u * 16 + r];
+                const float bv = bias_s[l * 4 * H + gate * H + wave * (H / 4) + u * 16 + r];
                 acc[n] = f32x4{bv, bv, bv, bv};
             }
             // ---- A sources -------------------------------------------------------------------
@@ -317,7 +337,7 @@ hipError_t prepare(size_t smem) {
 size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout) {
     const size_t SX = KX + 8, SH = H + 8;
     size_t fl = 2 * APE_TILE_ROWS * SX + (size_t)L * 2 * APE_TILE_ROWS * SH +
-                (size_t)((dropout && L > 1) ? L - 1 : 0) * APE_TILE_ROWS * SH + (size_t)O * (H + 1);
+                (size_t)((dropout && L > 1) ? L - 1 : 0) * APE_TILE_ROWS * SH + (size_t)O * (H + 1) + (size_t)L * 4 * H;
     return fl * sizeof(float);
 }
 
