@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
 #pragma unroll
             for (int grp = 0; grp < APE_TILE_ROWS / 4; ++grp) {
                 uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#ifndef APE_T16_NOPHILOX
                 if (drop_philox)
+#else
+                if (drop_philox && p.seed == 1)
+#endif
                     philox4x32((uint32_t)(row0 + 4 * grp), (uint32_t)x_step, (uint32_t)tid, 0u, (uint32_t)p.seed,
                                (uint32_t)(p.seed >> 32), rnd);
 #pragma unroll
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     };
     fetch_x(0);
     store_x(0);
+    if (XPRE && T > 1) fetch_x(1);
 
     // ---- per-wave weight stream bases ------------------------------------------------------------
     const f32x4* wbase[L];
@@ -213,10 +218,21 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
     load_b<NT>(b0, wbase[0]);     // first k-block of (layer 0, t = 0)
     __syncthreads();              // xin[0], wout_s visible
 
+#ifdef APE_T16_STAMPS
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#define TS(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[i] += now_ - tlast; tlast = now_; }
+    unsigned long long tlast = t_begin;
+#else
+#define TS(i)
+#endif
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
-        if (t + 1 < T) fetch_x(t + 1);       // global loads fly under this step's MFMAs
+        // global loads fly under this step's MFMAs.  (XPRE: the 16 loads per thread come from HBM and would sit in
+        // front of the step's first weight loads in the in-order return queue; they are issued behind the k-loop
+        // instead, a whole step ahead of their use)
+        if (!XPRE && t + 1 < T) fetch_x(t + 1);
 
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
             else if (drop) in_src = dbuf + ((l - 1) * APE_TILE_ROWS + r) * SH + 4 * g;
             else in_src = hbuf + (((l - 1) * 2 + cur) * APE_TILE_ROWS + r) * SH + 4 * g;
             const float* rec_src = hbuf + ((l * 2 + prv) * APE_TILE_ROWS + r) * SH + 4 * g;
+            TS(0)                                        // 0: step/layer set-up (bias, pointers)
             // t == 0: h_{-1} = 0, the recurrent k-blocks contribute nothing and are skipped
             const int nq = (t == 0) ? qin : qtot[l];
             // first k-block of the NEXT layer-step, prefetched under this one's tail
@@ -258,6 +275,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                 }
             }
 
+            TS(1)                                        // 1: k-loop
+            if (XPRE) {                                  // (L == 1) x_{t+1} -> the other xin buffer, x_{t+2} into flight
+                if (t + 1 < T) store_x(prv);
+                if (t + 2 < T) fetch_x(t + 2);
+            }
+            TS(2)                                        // 2: x staging (XPRE)
             // ---- gates + cell update, lane-local: lane holds rows 4g..4g+3 of unit column r ----
             float* hdst = hbuf + ((l * 2 + cur) * APE_TILE_ROWS) * SH;
 #pragma unroll
@@ -294,8 +317,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                     }
                 }
             }
-            if (l == L - 1 && t + 1 < T) store_x(prv);   // x_{t+1} -> the other xin buffer
+            if (!XPRE && l == L - 1 && t + 1 < T) store_x(prv);   // x_{t+1} -> the other xin buffer
+            TS(3)                                        // 3: gates + h store (+ x staging of the other paths)
             __syncthreads();                             // h^l_t (and x_{t+1}) visible
+            TS(4)                                        // 4: barrier
         }
 
         // ---- linear head on h^{L-1}_t: output_layer of nn_models.py:189 -----------------------------
@@ -315,6 +340,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
             }
         }
     }
+#ifdef APE_T16_STAMPS
+    TS(5)                                                // 5: head
+    if (blockIdx.x == 300 && tid == 0 && p.x_group > 0)
+        printf("t16 stamps (cycles over %d steps): setup %llu  k-loop %llu  xstage %llu  gates %llu  barrier %llu  head %llu  total %llu\n",
+               T, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], __builtin_amdgcn_s_memtime() - t_begin);
+#endif
 }
 
 template <int H, int L, int XE = 4>
