@@ -169,6 +169,39 @@ def batch1_latency(model, stats, n_frames=300):
     return out
 
 
+def stream_bank_numbers(model, stats):
+    """SURVEY 8 rows a1/a15/f1/f2/f4 at scale: S streams stepped together with all state on the device
+    (ape_streams_*): raw 55-float rows in, window rings, regressor, FK, smoothing, packed datagram rows out.  T=6 as
+    deployed; eval mode and the estimators' default Monte-Carlo mode (25 dropout samples per stream)."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    out = {}
+    try:
+        rng = np.random.default_rng(3)
+        for S, n_mc, frames in ((1024, None, 100), (1024, 25, 30), (8192, 25, 8)):
+            rows = [torch.from_numpy(rng.normal(size=(S, 55)).astype(np.float32)).cuda() for _ in range(4)]
+            bank = StreamBank(model, S, 6, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc,
+                              dropout=0.2)
+            for f in range(6):
+                bank.push_rows(rows[f % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+                bank.step_datagrams()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for f in range(frames):
+                bank.push_rows(rows[f % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+                bank.step_datagrams()
+            b.record()
+            b.synchronize()
+            model.check()
+            ms = a.elapsed_time(b) / frames
+            out[f"S{S}_mc{n_mc or 1}"] = {"ms_per_frame_of_all_streams": ms, "stream_frames_per_s": S / (ms * 1e-3),
+                                          "sample_windows_per_s": S * (n_mc or 1) / (ms * 1e-3)}
+            del bank
+    except Exception as exc:                # reported, never fatal for the headline line
+        out["error"] = str(exc)[:200]
+    return out
+
+
 def fp16_config4(stats_watch, n_iter=10):
     """BASELINE configs[4]: watch-only model, 1024 windows x 64 frames x 20 features, fp16 hidden state /
     weights with fp32 accumulate (ape_model_set_precision F16), HIP-event timed; the exact-f32 kernel on the
@@ -353,6 +386,7 @@ def main():
                 pass
         if world == 1:
             out["batch1"] = batch1_latency(model, stats)
+            out["stream_bank_T6"] = stream_bank_numbers(model, stats)
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
                                                                          NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:
