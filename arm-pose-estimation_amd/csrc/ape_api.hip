@@ -109,7 +109,7 @@ struct ape_model {
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
     int precision = APE_PRECISION_F32;
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
-    bool upper_ok = false;          // 2 x 256 LSTM: layer 1 can run on its own over a shared layer-0 sequence (stream bank, MC mode)
+    bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
@@ -245,8 +245,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         ape_model_destroy(m);
         return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
-    if (!imupose && H == 256 && L == 2) {
-        e = ape_prepare_lstm_tile16_upper(ape_lstm_tile16_smem_bytes(256, 1, 256, O, false));
+    if (!imupose && ((H == 256 && L == 2) || (H == 128 && L == 3))) {     // the deployed shapes: layers 1.. can run on their own
+        e = ape_prepare_lstm_tile16_upper(H, L - 1, ape_lstm_tile16_smem_bytes(H, L - 1, H, O, true));
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
@@ -925,17 +925,18 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         a.flags = flags & APE_FLAG_NORMALIZE_INPUT;
         hipError_t e = ape_launch_lstm_tile16(H, 1, a, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 launch failed: %s", hipGetErrorString(e));
-        // launch B: layer 1 as a one-layer LSTM over the S x n_mc sample rows; row r reads stream r / n_mc's sequence
-        // under its own Philox mask (the counters of a fused launch over the same rows)
+        // launch B: the layers above as an LSTM of their own over the S x n_mc sample rows; row r reads stream
+        // r / n_mc's sequence under its own Philox mask (the counters of a fused launch over the same rows)
         LstmParams q{};
+        const int LU = m->dims.num_layers - 1;
         q.x = m->hseq_ws; q.y = b->y_new;
-        q.wpack[0] = m->wpack[1]; q.bias[0] = m->bias[1];
+        for (int j = 0; j < LU; ++j) { q.wpack[j] = m->wpack[j + 1]; q.bias[j] = m->bias[j + 1]; }
         q.w_out = m->w_out; q.b_out = m->b_out;
         q.B = b->S * b->n_mc; q.T = b->T; q.I = H; q.O = O; q.KX = H; q.x_ring = 0;
         q.flags = APE_FLAG_DROPOUT_PHILOX; q.dropout_p = b->dropout_p; q.seed = b->seed + b->mc_calls;
-        q.x_group = b->n_mc;
-        e = ape_launch_lstm_tile16(H, 1, q, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-1 launch failed: %s", hipGetErrorString(e));
+        q.x_group = b->n_mc; q.layer_base = 1;
+        e = ape_launch_lstm_tile16(H, LU, q, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
         ++b->mc_calls;
     } else if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
                                    drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring)) {

@@ -36,6 +36,8 @@ struct LstmParams {
     int x_group;                        // wide-input instantiations: row b reads window b / x_group of x, and with
                                         // DROPOUT_PHILOX the input is masked as the output of a layer 0 would be
                                         // (0: row b reads window b, no mask)
+    int layer_base;                     // model layer that this launch's layer 0 is (a launch over the UPPER layers of a
+                                        // model keeps the model's layer numbers in its Philox counters)
 };
 
 // Kernel arguments of the weight-stationary cluster LSTM kernel.
@@ -142,7 +144,7 @@ hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t
 size_t ape_lstm_tile16_smem_bytes(int H, int L, int KX, int O, bool dropout);
 hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
 hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes);
-hipError_t ape_prepare_lstm_tile16_upper(size_t smem_bytes);      // <256,1,wide>: layer 1 of a 2 x 256 model on its own
+hipError_t ape_prepare_lstm_tile16_upper(int H, int L, size_t smem_bytes);   // layers 1.. of a model on their own: <256,1,wide>, <128,2,wide>
 bool ape_cluster_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,

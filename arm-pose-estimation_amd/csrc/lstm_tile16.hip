@@ -142,31 +142,32 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
             // [B / x_group, T, H], computed ONCE per stream, and row b is sample b % x_group of stream b / x_group.
             // The inter-layer dropout mask is drawn here with the counters the fused kernel uses for its layer 0
             // (rows b & ~3, step, unit, layer 0; value index b & 3), so the samples are the ones a fused launch over
-            // the same rows draws.  Thread = unit (KX = 256 threads), one Philox call per group of four rows.
+            // the same rows draws.  Thread = unit (256 / KX row groups side by side), one Philox call per four rows.
             const int slot = (x_step + p.x_ring >= T) ? x_step + p.x_ring - T : x_step + p.x_ring;
             const float keep = 1.0f / (1.0f - p.dropout_p);
+            constexpr int KXC = 16 * XE;                 // input width = units of the layer below (256 or 128)
+            constexpr int NP = 256 / KXC;                // row groups staged side by side
+            const int unit = tid % KXC, part = tid / KXC;
+            const uint32_t below = (uint32_t)(p.layer_base > 0 ? p.layer_base - 1 : 0);     // the layer whose output this is
 #pragma unroll
-            for (int grp = 0; grp < APE_TILE_ROWS / 4; ++grp) {
+            for (int gi = 0; gi < APE_TILE_ROWS / 4 / NP; ++gi) {
+                const int grp = gi * NP + part;
                 uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#ifndef APE_T16_NOPHILOX
                 if (drop_philox)
-#else
-                if (drop_philox && p.seed == 1)
-#endif
-                    philox4x32((uint32_t)(row0 + 4 * grp), (uint32_t)x_step, (uint32_t)tid, 0u, (uint32_t)p.seed,
+                    philox4x32((uint32_t)(row0 + 4 * grp), (uint32_t)x_step, (uint32_t)unit, below, (uint32_t)p.seed,
                                (uint32_t)(p.seed >> 32), rnd);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 4 * grp + i, b = row0 + row;
                     float v = 0.0f;
                     if (b < p.B) {
-                        v = XPRE ? xr[XPRE ? row : 0] : p.x[((size_t)(b / p.x_group) * T + slot) * I + tid];
+                        v = XPRE ? xr[XPRE ? row : 0] : p.x[((size_t)(b / p.x_group) * T + slot) * I + unit];
                         if (drop_philox) {
                             const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
                             v = (uf >= p.dropout_p) ? v * keep : 0.0f;
                         }
                     }
-                    xin[(buf * APE_TILE_ROWS + row) * SX + tid] = v;
+                    xin[(buf * APE_TILE_ROWS + row) * SX + unit] = v;
                 }
             }
             return;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
                 const int unit = wave * (H / 4) + u * 16 + r;
                 uint32_t rnd[4] = {0, 0, 0, 0};
                 if (drop_philox && l < L - 1)
-                    philox4x32((uint32_t)(row0 + 4 * g), (uint32_t)t, (uint32_t)unit, (uint32_t)l,
+                    philox4x32((uint32_t)(row0 + 4 * g), (uint32_t)t, (uint32_t)unit, (uint32_t)(l + p.layer_base),
                                (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -393,10 +394,15 @@ hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t
                           // the layer-0 output sequence in front of layer 1 run on its own (H=256 L=1)
         if (H == 256 && L == 2 && p.KX == 256) return launch<256, 2, 16>(p, stream);
         if (H == 256 && L == 1 && p.KX == 256) return launch<256, 1, 16>(p, stream);
+        if (H == 128 && L == 2 && p.KX == 128) return launch<128, 2, 8>(p, stream);       // layers 1-2 of the 3 x 128 upper-arm model
         return hipErrorInvalidValue;
     }
     APE_DISPATCH(launch, p, stream)
 }
 
 hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes) { return prepare<256, 2, 16>(smem_bytes); }
-hipError_t ape_prepare_lstm_tile16_upper(size_t smem_bytes) { return prepare<256, 1, 16>(smem_bytes); }
+hipError_t ape_prepare_lstm_tile16_upper(int H, int L, size_t smem_bytes) {
+    if (H == 256 && L == 1) return prepare<256, 1, 16>(smem_bytes);
+    if (H == 128 && L == 2) return prepare<128, 2, 8>(smem_bytes);
+    return hipErrorInvalidValue;
+}

@@ -776,15 +776,16 @@ def test_stream_bank_monte_carlo(golden, norm_stats, name, S, n_mc, smooth, p_dr
         StreamBank(m, S, T, smooth=64, monte_carlo_samples=65)      # smooth * n_mc > 4096
 
 
-def test_stream_bank_monte_carlo_shared_layer0(golden, norm_stats):
-    """From 8192 sample rows on, the bank computes layer 0 ONCE per stream and runs layer 1 alone over the S x n_mc
+@pytest.mark.parametrize("name,S,n_mc", [("pocket", 330, 25), ("watch", 330, 25), ("uarm", 170, 50)])
+def test_stream_bank_monte_carlo_shared_layer0(golden, norm_stats, name, S, n_mc):
+    """From 8192 sample rows on, the bank computes layer 0 ONCE per stream and runs the layers above alone over the S x n_mc
     rows (nn.LSTM's dropout sits between the layers, nn_models.py:169-174, so h_0 is common to a
     stream's samples).  The samples must be the ones a fused launch over the same rows draws: checked against
     ape_lstm_forward on explicitly repeated windows (batch-tile kernel, same Philox key) through the oracle's FK --
     every sample row's hand / elbow position, and the full message of a spread of streams."""
     from wear_mocap_ape_amd import _hip
     from wear_mocap_ape_amd.streams import StreamBank
-    name, S, n_mc, p_drop, seed = "pocket", 330, 25, 0.2, 0x1234567
+    p_drop, seed = 0.2, 0x1234567
     g = golden(f"stream_trace_{name}.npz")
     stats, body = norm_stats[name], g["body"]
     m, sd, cfg = make_model(name, int(g["weights_seed"]), stats)
