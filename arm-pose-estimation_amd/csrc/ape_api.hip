@@ -540,7 +540,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     // needs 4096 rows (256 workgroups x 16) to fill the chip, but then runs dropout at no extra cost and pays no
     // per-launch prologue / head, which decides short windows.  Under APE_KERNEL_AUTO the front of the batch goes to
     // the batch-tile kernel in whole 4096-row waves and the rest to the cluster kernel, by a cost model calibrated
-    // on MI355X (tools/time_big_batch.py).
+    // on MI355X (tests/tools/time_big_batch.py).
     const int GHc = H / 16, max_clusters_c = 256 / GHc;
     const bool f16 = m->precision == APE_PRECISION_F16;
     // all-steps output: the cluster kernel also writes every step's top-layer output to a [B,T,H] workspace and the

@@ -1,6 +1,6 @@
 """Soak run of the LSTM entry point: random shapes, kernels and dropout modes back to back for a fixed time, every result
 checked against the batch-tile kernel on the same inputs and the cluster health word after every call.
-python tools/soak.py [seconds]"""
+python tests/tools/soak.py [seconds]"""
 import ctypes as C, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")

@@ -1,5 +1,5 @@
 """Large batches of short windows (the stream bank's shape: S*n_mc rows, T=6), cluster vs tile16, with and without dropout:
-python tools/time_big_batch.py [B] [T]"""
+python tests/tools/time_big_batch.py [B] [T]"""
 import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")

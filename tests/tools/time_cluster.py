@@ -1,5 +1,5 @@
 """Median launch time of the cluster LSTM kernel alone (HIP events), for A/B runs of build variants:
-APE_HIP_LIB=<lib> python tools/time_cluster.py [pocket|watch|uarm] [B] [T]"""
+APE_HIP_LIB=<lib> python tests/tools/time_cluster.py [pocket|watch|uarm] [B] [T]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
