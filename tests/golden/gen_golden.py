@@ -382,8 +382,23 @@ def gen_bookkeeping():
     (OUT / "bookkeeping.json").write_text(json.dumps(names, indent=1))
 
 
+def gen_csv_header():
+    """the header line the reference's recorder writes (record/est_output.py:16-32), as data"""
+    import tempfile
+    from wear_mocap_ape.record.est_output import EstOutputRecorder
+    with tempfile.TemporaryDirectory() as d:
+        f = Path(d) / "est.csv"
+        EstOutputRecorder(f)
+        header = f.read_text().strip().split(",")
+    (OUT / "est_csv_header.json").write_text(json.dumps(header))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if sys.argv[1:] == ["csv"]:              # add this one fixture without rewriting the others
+        gen_csv_header()
+        print("wrote", OUT / "est_csv_header.json")
+        return
     if sys.argv[1:] == ["imupose"]:          # add this one fixture without rewriting the others
         gen_imupose()
         print("wrote", OUT / "imupose.npz")
@@ -396,6 +411,7 @@ def main():
     gen_quat_ops()
     gen_fk(stats)
     gen_stream_traces()
+    gen_csv_header()
     total = sum(f.stat().st_size for f in OUT.glob("*.np*")) + (OUT / "norm_stats.json").stat().st_size
     print("golden fixtures written to", OUT, f"({total / 1024:.0f} KiB)")
 

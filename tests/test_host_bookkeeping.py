@@ -191,3 +191,31 @@ def test_c_caller_compiles_and_links(tmp_path):
     """the header is valid C (not only C++) and every entry point the C caller uses resolves at link time"""
     exe = build_c_caller(tmp_path)
     assert exe.exists() and exe.stat().st_size > 0
+
+
+def test_csv_recorder_header_and_rows(tmp_path):
+    """the on-disk format of the pose messages -- header identical to the reference recorder's (fixture
+    written by the reference, record/est_output.py:16-32), one line per queued message, queue protocol unchanged"""
+    import json, queue, time
+    from wear_mocap_ape_amd.record.est_output import EstOutputRecorder, msg_columns
+    want = json.loads((GOLDEN / "est_csv_header.json").read_text())
+    assert ["time"] + msg_columns() == want and len(msg_columns()) == 25
+    with pytest.raises(UserWarning):
+        EstOutputRecorder(tmp_path / "missing_dir" / "est.csv")
+    f = tmp_path / "est.csv"
+    rec = EstOutputRecorder(f)
+    assert f.read_text().strip().split(",") == want
+    q = queue.Queue()
+    rec.record_in_thread(q)
+    msgs = [np.arange(25, dtype=np.float64) + 0.5 * i for i in range(3)]
+    for m in msgs:
+        q.put(m)
+    deadline = time.time() + 10
+    while len(f.read_text().strip().splitlines()) < 4 and time.time() < deadline:
+        time.sleep(0.05)
+    rec.terminate()
+    lines = f.read_text().strip().splitlines()
+    assert len(lines) == 4
+    for line, m in zip(lines[1:], msgs):
+        cells = line.split(",")
+        assert len(cells) == 26 and [float(c) for c in cells[1:]] == list(m)
