@@ -113,6 +113,7 @@ struct ape_model {
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
+    unsigned* xcc_slots = nullptr; // small-batch kernel: 64 words its members publish their XCD in (zero between launches)
     unsigned* xflags = nullptr;    // [flag words..., status word]
     size_t xflag_bytes = 0;        // bytes of the flag block (multiple of 16), status word follows
     // MLP regressor (APE_MODEL_FF)
@@ -267,6 +268,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = plan((void**)&m->hx, m->hx_bytes);
         if (e == hipSuccess) e = plan((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
         if (e == hipSuccess) e = plan((void**)&m->xflags, m->xflag_bytes + 256);
+        if (e == hipSuccess) e = plan((void**)&m->xcc_slots, 64 * sizeof(unsigned));
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
@@ -627,6 +629,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             // so a masked call is served by one launch only (checked below)
             c.masks = masks_dev; c.dropout_p = dropout_p; c.seed = seed;
             c.dbg_wg = m->dbg_wg;
+            c.xcc_slots = m->xcc_slots;
             if ((flags & APE_FLAG_DROPOUT_MASKS) && b0 + nb < B && cdrop)
                 return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
@@ -684,6 +687,7 @@ int ape_model_check(ape_model_t* m) {
     if (st != 0) {
         // an aborted launch skipped its self-cleaning: reset flags, counters and the status word from the host
         HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
+        HIP_TRY(hipMemset(m->xcc_slots, 0, 64 * sizeof(unsigned)));
         return fail(APE_ERR_HIP, "cluster kernel gave up waiting for a peer workgroup (status %u): not all of its "
                     "workgroups were resident; outputs of that launch are invalid", st);
     }

@@ -11,6 +11,8 @@
 #define APE_DIAG_NO_EXCHANGE 0x40000000u
 #define APE_DIAG_NO_ACT      0x20000000u
 #define APE_DIAG_STAMP       0x10000000u
+#define APE_DIAG_WRITE_THROUGH 0x08000000u   // small-batch kernel: use the any-placement (sc1) exchange even when the
+                                            // members share an XCD -- results are the same; lets tests run that path
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -65,6 +67,7 @@ struct ClusterParams {
     unsigned long long seed;
     float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
+    unsigned* xcc_slots;                // small-batch kernel: [GH] words (0x10 | XCC id) its members publish, zero between launches
 };
 
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor

@@ -72,15 +72,26 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     float* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
     float* own = xin + 2 * MR * SX;                // [L][MR][SO]
     int* ctl = reinterpret_cast<int*>(own + L * MR * SO);
+    // Membership is fixed by the block index: the launch has 8 x GH workgroups and only every eighth one takes part
+    // (the others leave at once).  Under the placement observed on this hardware -- blocks are dealt round-robin over
+    // the 8 XCDs -- those GH workgroups share ONE XCD, hence one L2, and the exchange can stay inside it: plain stores
+    // (acknowledged by the L2, not written through to memory) and L1-bypassing loads, ~0.8 us less per phase.  HIP
+    // guarantees no placement, so nothing is assumed: every member publishes the XCD it really runs on (a non-zero
+    // word; the last member out zeroes the words again, like the flags), all members read all GH words once the
+    // weights are in, and only if they agree is the in-L2 form used; otherwise the write-through form that is valid for any placement.  One cluster, one launch: a member
+    // that is dispatched late delays the launch, it cannot deadlock it.
+    if (blockIdx.x % 8 != 0) return;
+    const int cluster = 0, member = blockIdx.x / 8;
+    const int row0 = 0;
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
     if (tid == 0) {
         ctl[0] = 0;
-        ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.xcc_slots + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int i = tid; i < L * MR * SH; i += 256) hbuf[i] = 0.0f;       // h_{-1} = 0: the first step reads zeros
     __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
-    const int cluster = ticket / GH, member = ticket % GH;
-    const int row0 = cluster * MR;
 
     // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel) ----------------
     static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
@@ -137,7 +148,29 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         }
     };
     stage_x(0);
+    // ---- do all members really share an XCD?  (their words have been on the way since the weights were requested)
+    if (wave == 0) {
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(p.xcc_slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
     __syncthreads();
+    if (ctl[0] != 0) return;
+    // uniform over the cluster: every member read the same GH words
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
 
     const int P = T + L - 1;
 #pragma unroll 1
@@ -192,15 +225,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             if (l < L && t >= 0 && t < T) {
                 const int row = idx >> 2, quad = idx & 3;
                 const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (l * MR + row) * SO + 4 * quad);
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
-                    hx_base(l, t & 1) + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */);
+                const auto hvu = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv);
+                const unsigned off = hx_base(l, t & 1) + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float));
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 0);          // stays in the XCD's L2
+                else __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 16 /* sc1: write-through */);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(myflag + member, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            if (in_l2) *reinterpret_cast<volatile unsigned*>(myflag + member) = (unsigned)(ph + 1);      // plain: in L2
+            else __hip_atomic_store(myflag + member, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // ---- wait for every member's phase-ph flag, gather all layers' slices (one piece per thread and layer) -------
         if (wave == 0) {
             unsigned spins = 0;
@@ -253,12 +289,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     }
     __syncthreads();
     if (tid == 0)
-        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GH - 1) ? 1 : 0;
     __syncthreads();
     if (ctl[2] != 0) {
-        const int n_words = (int)(gridDim.x / GH) * L * GH;
+        const int n_words = L * GH;
         for (int i = tid; i < n_words; i += 256)
             __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < GH) __hip_atomic_store(p.xcc_slots + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
 template <int H, int L, int KX, int NR>
 hipError_t launch_small(const ClusterParams& p, hipStream_t stream) {
     constexpr size_t smem = ((size_t)L * MR * (H + 8) + 2 * MR * (KX + 8) + (size_t)L * MR * 20 + 4) * sizeof(float);
-    hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR>), dim3(H / 16), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR>), dim3(8 * (H / 16)), dim3(256), smem, stream, p);
     return hipGetLastError();
 }
 

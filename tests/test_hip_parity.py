@@ -226,6 +226,15 @@ def test_small_batch_latency_kernel(norm_stats, name):
             assert np.abs(y_mfma - y_ref).max() < TOL_Y_SHORT
             again = model.set_kernel("auto")(xt, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
             assert np.array_equal(again, y_small)                  # self-cleaning state, deterministic
+            # the kernel exchanges inside one XCD's L2 when its members turn out to share an XCD, write-through
+            # otherwise; the internal flag forces the second form: same arithmetic, same bits
+            from wear_mocap_ape_amd import _hip
+            y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+            _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xt.data_ptr()), B, T,
+                                                   _hip.FLAG_NORMALIZE_INPUT | 0x08000000, None, 0.0, 0,
+                                                   C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
+            torch.cuda.synchronize()
+            assert np.array_equal(y_wt.cpu().numpy(), y_small)
     assert "cluster" in model.kernel_name(1, 6)
     model.check()
 

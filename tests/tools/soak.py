@@ -21,7 +21,7 @@ t0 = time.time(); n = 0; worst = 0.0; kinds = {}
 while time.time() - t0 < budget:
     name = ("pocket", "uarm", "watch")[rng.integers(3)]
     m, cfg = models[name]
-    B = int(rng.choice([1, 2, 3, 4, 5, 16, 17, 25, 60, 64, 100, 333, 512, 1000, 1024, 1025, 1500, 2049, 4096, 4500]))
+    B = int(rng.choice([1, 1, 1, 2, 2, 3, 4, 4, 5, 16, 17, 25, 60, 64, 100, 333, 512, 1000, 1024, 1025, 1500, 2049, 4096, 4500]))
     T = int(rng.choice([1, 2, 5, 6, 8, 9, 20, 64]))
     philox = bool(rng.integers(2))
     prec = "f16" if (not philox and rng.integers(5) == 0) else "f32"
