@@ -381,6 +381,31 @@ def test_error_behaviour():
         estimate_joints.arm_pose_from_nn_targets(np.zeros((3, 12)), orc.DEFAULT_BODY, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)
     with pytest.raises(RuntimeError):
         model.load_state_dict({"lstm.weight_ih_l0": np.zeros((4, 4))})
+    # C-ABI status codes of the stream bank (they reach Python as UserWarning through _hip.check)
+    from wear_mocap_ape_amd import _hip
+    lib = _hip.lib()
+    model.set_body(orc.DEFAULT_BODY)
+    h = C.c_void_p()
+    assert lib.ape_streams_create(model.handle, 0, 6, 1, C.byref(h)) != 0            # no streams
+    assert lib.ape_streams_create(model.handle, 4, 6, 65, C.byref(h)) != 0           # smooth beyond one wave
+    assert lib.ape_streams_create(model.handle, 4, 6, 2, C.byref(h)) == 0
+    assert lib.ape_streams_set_mc(h, 0, 0.2, 1) != 0                                 # no samples
+    assert lib.ape_streams_set_mc(h, 4096, 0.2, 1) != 0                              # smooth * n_mc beyond 4096
+    assert lib.ape_streams_set_mc(h, 3, 1.0, 1) != 0                                 # dropout_p must stay below 1
+    assert lib.ape_streams_set_mc(h, 3, 0.2, 1) == 0
+    msg = torch.empty((4, 25 + 6 * 6), dtype=torch.float32, device="cuda")
+    assert lib.ape_streams_step(h, 0, C.c_void_p(msg.data_ptr()), None, _hip.F32, None) != 0      # nothing pushed yet
+    xx = torch.zeros((4, cfg["I"]), dtype=torch.float32, device="cuda")
+    assert lib.ape_streams_push_features(h, C.c_void_p(xx.data_ptr()), None) == 0
+    assert lib.ape_streams_push_rows(h, _hip.PARSE_WATCH_ONLY, C.c_void_p(xx.data_ptr()), None) != 0   # 20 features, model takes 22
+    assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), None, _hip.F64, None) != 0   # packed rows are f32
+    assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), C.c_void_p(msg.data_ptr()), _hip.F32, None) != 0
+    assert lib.ape_streams_step(h, _hip.FLAG_ALL_STEPS, C.c_void_p(msg.data_ptr()), None, _hip.F32, None) != 0     # not a step flag
+    assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), None, _hip.F32, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(msg).all()
+    assert len(lib.ape_last_error()) > 0                                             # the last failure left its text
+    assert lib.ape_streams_destroy(h) == 0
 
 
 # ---------------- the estimator classes: streaming traces of the reference ----------------------------
