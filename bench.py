@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the arm-pose hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without RANK/WORLD_SIZE in the environment: this
+                                                            process starts the N ranks itself -- as children, before
+                                                            it touches the GPU -- and relays rank 0's JSON line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -41,6 +43,7 @@ import torch.distributed as dist  # noqa: E402
 WINDOWS_PER_GPU = 1024
 T_FRAMES = 64
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0      # same table, "Peak BF16/FP16 MFMA": ~2.5 PF dense (never the 2:1-sparsity figure)
 POCKET = dict(I=22, H=256, L=2, O=14, layout=0)
 
 
@@ -77,24 +80,80 @@ def synthetic_windows(stats, lo, hi, T, I):
     return out
 
 
-def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0, gpu_y=None, gpu_est=None):
-    """reference-equivalent CPU path of the oracle on this host: torch-CPU nn.LSTM + Linear (the
-    reference's third-party arithmetic) + float64 FK with one 4x4 eigh per quaternion.  The thread
-    count is chosen by a short probe (torch's default of one thread per core is far from the best
-    for 2x256 LSTM GEMMs), then the 1024-window batch is repeated until ~budget_s of CPU work is done."""
+def cpu_baseline(sd, stats, body, layout, x, budget_s=8.0, gpu_y=None, gpu_est=None):
+    """SURVEY 8(d) "CPU baseline, same run": the oracle's reference-equivalent CPU path on this host -- torch-CPU
+    nn.LSTM + Linear (the reference's third-party arithmetic, nn_models.py:169-174) + float64 FK -- timed for
+      config1_B1_T6_mc1   one 50 Hz stream, window 6, one frame per call (estimator.py:145-178 from the feature row on:
+                          window/pad/trim, f64 z-score, model, de-normalise, FK, message),
+      config1_B1_T6_mc25  the same with the estimators' default 25 Monte-Carlo dropout samples per frame
+                          (nn_models.py:191-207: lstm.train() + x.repeat),
+      config3_B1024_T64   the benchmark shape, one batched forward + FK over 1024 windows,
+    each at 1 thread and at the best thread count of a short probe (torch's default of one thread per core is far from
+    the best for 2x256 LSTM GEMMs), each with the reference's FK route (one 4x4 `eigh` per quaternion,
+    transformations.py:521-545) and with the vectorisable closed form -- so the GPU/CPU ratio is not won on a strawman.
+    The headline `value` is config3 / best threads / eigh, i.e. what a user of the reference gets today on this host;
+    its outputs are also what the timed GPU outputs are compared with."""
     from oracle import ape_oracle as orc          # the checker: imported by this leg only
     default_threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
+    T6 = 6
+    run_eval = orc.torch_reference_model(sd)
+    run_mc = orc.torch_reference_model(sd, train=True)
+
+    def batch_leg(xb, route):
+        return lambda: orc.infer_windows(sd, stats, body, layout, xb, route=route, use_torch=True)
+
+    def stream_leg(n_mc, route):
+        # the per-frame loop of one estimator from the feature row on (the row -> feature step is the HIP path's
+        # ape_parse_rows and is not part of either side's timing here)
+        predict = (lambda hist: run_eval(hist[None].astype(np.float32))[:, -1, :]) if n_mc == 1 else \
+                  (lambda hist: run_mc(np.repeat(hist[None].astype(np.float32), n_mc, axis=0))[:, -1, :])
+        win = orc.WindowOracle(T6, 1, stats, predict)
+        frames = x[0]                               # 64 feature rows of stream 0, replayed as a 50 Hz sequence
+        state = {"i": 0}
+
+        def one():
+            pred = win.push(frames[state["i"] % frames.shape[0]])
+            state["i"] += 1
+            est = orc.arm_pose_from_targets(pred, body, layout, route)
+            return orc.msg_with_mc_samples(orc.msg_from_est(est, body, layout), est, True)
+        return one
+
+    def timed(fn, units, budget, max_calls=1 << 30):
+        fn()                                        # warm-up call (thread pool, allocator)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= max_calls:
+                return n * units / el, n * units, el
+
+    # thread-count probe on the benchmark shape
     probe = {}
-    for n in sorted({8, 16, 32, 64, default_threads}):
-        if n > (os.cpu_count() or 1):
+    for n in sorted({8, 16, 32, 64} | ({default_threads} if default_threads <= 64 else set())):
+        if n > ncpu:
             continue
         torch.set_num_threads(n)
-        orc.infer_windows(sd, stats, body, layout, x[:64], route="eigh", use_torch=True)   # warm-up
+        batch_leg(x[:64], "closed")()
         t0 = time.perf_counter()
-        orc.infer_windows(sd, stats, body, layout, x[:256], route="eigh", use_torch=True)
+        batch_leg(x[:256], "closed")()
         probe[n] = 256 / (time.perf_counter() - t0)
-    threads = max(probe, key=probe.get)
-    torch.set_num_threads(threads)
+    best = max(probe, key=probe.get)
+
+    legs = {}
+    for threads, tname in ((1, "threads1"), (best, f"threads{best}_best")):
+        torch.set_num_threads(threads)
+        for route in ("eigh", "closed"):
+            xb = x if threads > 1 else x[:256]      # a 1-thread pass over 1024 x 64 windows takes > 1 s: bounded sample
+            v, n, el = timed(batch_leg(xb, route), xb.shape[0], 1.0, max_calls=8)
+            legs[f"config3_B1024_T64/{tname}/fk_{route}"] = {"windows_per_s": v, "sample_windows": n, "seconds": el}
+            for n_mc in (1, 25):
+                v, n, el = timed(stream_leg(n_mc, route), 1, 0.8)
+                legs[f"config1_B1_T6_mc{n_mc}/{tname}/fk_{route}"] = {"frames_per_s": v, "sample_frames": n, "seconds": el,
+                                                                      "sample_windows_per_s": v * n_mc}
+    # headline leg: config3, best threads, reference FK route; its outputs are the parity reference of the timed GPU run
+    torch.set_num_threads(best)
     done, t0 = 0, time.perf_counter()
     while True:
         y_ref, est_ref = orc.infer_windows(sd, stats, body, layout, x, route="eigh", use_torch=True)
@@ -116,10 +175,12 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=12.0, gpu_y=None, gpu_est=
         parity = {"windows": int(x.shape[0]), "max_abs_nn_targets": dy, "max_abs_quaternions": worst_q,
                   "max_abs_origins": float(np.abs(e[:, :9] - est_ref[:, :9]).max()),
                   "budget": "1e-4 targets / 5e-5 quaternions and origins at T=64 (SURVEY 8d); est rows stored as f32"}
-    return {"parity": parity, "value": done / el, "unit": "windows/s", "cores": threads, "kind": "port",
+    return {"parity": parity, "value": done / el, "unit": "windows/s", "cores": best, "kind": "port",
             "sample": f"{done} windows (B={x.shape[0]}, T={x.shape[1]}) in {el:.1f} s: oracle torch-CPU nn.LSTM+Linear "
-                      f"+ per-row eigh FK; best of thread probe {{{', '.join(f'{k}: {v:.0f}/s' for k, v in probe.items())}}} "
-                      f"on {os.cpu_count()} cpus"}
+                      f"+ per-row eigh FK at the best thread count of the probe "
+                      f"{{{', '.join(f'{k}: {v:.0f}/s' for k, v in probe.items())}}} on {ncpu} cpus; `legs` = the other "
+                      f"SURVEY 8(d) configurations, ~1 s of CPU work each",
+            "legs": legs}
 
 
 def batch1_latency(model, stats, n_frames=300):
@@ -202,7 +263,23 @@ def stream_bank_numbers(model, stats):
     return out
 
 
-def fp16_config4(stats_watch, n_iter=10):
+def load_traffic(kernel_name, windows):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/traffic_latest.json, written by tools/summarize_prof.py from separate counter runs of this very
+    command; counters cannot be collected from inside the timed run)"""
+    tfile = REPO / "profiles" / "traffic_latest.json"
+    try:
+        tj = json.loads(tfile.read_text())
+        for ent in tj.get("kernels", [tj]):
+            a = ent.get("kernel", "")
+            if a and (a in kernel_name or kernel_name in a) and ent.get("windows") == windows:
+                return ent["hbm_bytes_per_launch"], ent.get("tag")
+    except Exception:
+        pass
+    return None, None
+
+
+def fp16_config4(stats_watch, n_iter=20):
     """BASELINE configs[4]: watch-only model, 1024 windows x 64 frames x 20 features, fp16 hidden state /
     weights with fp32 accumulate (ape_model_set_precision F16), HIP-event timed; the exact-f32 kernel on the
     same windows beside it, and the max-abs difference of the NN targets between the two"""
@@ -217,9 +294,10 @@ def fp16_config4(stats_watch, n_iter=10):
     y = {p: torch.empty((WINDOWS_PER_GPU, cfg["O"]), dtype=torch.float32, device="cuda") for p in ("f32", "f16")}
     lib = _hip.lib()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    out = {}
+    out, names = {}, {}
     for prec in ("f32", "f16"):
         m.set_precision(prec)
+        names[prec] = m.kernel_name(WINDOWS_PER_GPU, T_FRAMES)
         run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), WINDOWS_PER_GPU, T_FRAMES,
                                                       _hip.FLAG_NORMALIZE_INPUT, None, 0.0, 0,
                                                       C.c_void_p(y[prec].data_ptr()), stream), "ape_lstm_forward")
@@ -234,13 +312,56 @@ def fp16_config4(stats_watch, n_iter=10):
         out[prec] = a.elapsed_time(b) / n_iter
     m.check()
     flop = m.flops_per_window(T_FRAMES) * WINDOWS_PER_GPU
+    tf16 = flop / (out["f16"] * 1e-3) / 1e12
+    traffic, ttag = load_traffic(names["f16"], WINDOWS_PER_GPU)
+    alg_bytes = WINDOWS_PER_GPU * (T_FRAMES * cfg["I"] * 4 + cfg["O"] * 4)
     return {"workload": "configs[4]: watch-only (I=20,H=256,L=2,O=12), 1024 windows x 64 frames, fp16 W/x/h, fp32 accumulate",
             "kernel_ms_f16": out["f16"], "kernel_ms_f32": out["f32"], "windows_per_s_f16": WINDOWS_PER_GPU / out["f16"] * 1e3,
-            "algorithmic_tflops_f16": flop / (out["f16"] * 1e-3) / 1e12,
-            "max_abs_diff_targets_f16_vs_f32": float((y["f16"] - y["f32"]).abs().max().item())}
+            "algorithmic_tflops_f16": tf16,
+            "max_abs_diff_targets_f16_vs_f32": float((y["f16"] - y["f32"]).abs().max().item()),
+            "roofline": {"bound": "mfma", "achieved": tf16, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf16 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag,
+                         "kernel": names["f16"], "kernel_ms": out["f16"], "flop_per_launch": flop,
+                         "hbm_algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "latency-bound, not matrix-bound: per layer-step a wave has 2 x 16 f16 MFMAs (~0.5K cycles) "
+                                 "between two cluster-wide exchanges of h; the f16 dense MFMA peak is the stated roofline"}}
 
 
 PREROLL = 40        # untimed clock-ramp steps in front of the warmup steps
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no RANK/WORLD_SIZE in the environment: start the N single-GPU ranks as CHILD
+    processes (torch.distributed.run, one rank per GPU, RCCL) and relay rank 0's JSON line.  This parent never
+    initialises the GPU (torch.cuda.device_count() does not on this image) and never replaces itself (no exec)."""
+    import socket
+    import subprocess
+    share_gpu = os.environ.get("APE_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()
+    if not share_gpu and n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)     # stderr passes through
+    line = None
+    for ln in proc.stdout.decode("utf-8", "replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank launch failed (exit code {proc.returncode}, "
+                         f"{'no ' if line is None else ''}result line)")
+    os.write(_JSON_FD, (line + "\n").encode())
 
 
 def main():
@@ -250,12 +371,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        if args.gpus > 1:
+            return spawn_ranks(args)           # before any GPU call in this process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # rehearsal switch for a 1-GPU box: APE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (two
@@ -265,6 +391,8 @@ def main():
     # rank too -- the rehearsal of the N > 1 plumbing that a 1-GPU box allows
     use_dist = world > 1 or os.environ.get("APE_BENCH_FORCE_DIST") == "1"
     dev_index = 0 if share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{dev_index} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if use_dist:
@@ -276,6 +404,10 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group formed {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        world = dist.get_world_size()
+    comm_dev = torch.device("cpu") if share_gpu else dev
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -313,6 +445,13 @@ def main():
     lib = _hip.lib()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     xp, yp, ep = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(est.data_ptr())
+    # what every rank really holds (rank, first stream, end, device, checksum of the weight blob it received)
+    mine = torch.tensor([rank, lo, hi, dev_index, float(blob_dev.double().sum().item())], dtype=torch.float64, device=comm_dev)
+    shards = [mine]
+    if use_dist:
+        shards = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(shards, mine)
+    shards = [t.cpu().tolist() for t in shards]
 
     ev_k = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -328,9 +467,18 @@ def main():
 
     # The chip raises its clock over the first ~20 ms of continuous work (launch durations in the rocprofv3 trace
     # fall from ~1.03 ms to ~0.90 ms over the first 20 launches after any idle gap): PREROLL untimed steps precede
-    # the W warmup steps so that a small --warmup still measures the steady state.
-    for _ in range(PREROLL + args.warmup):
-        step()
+    # the W warmup steps so that a small --warmup still measures the steady state.  The cold numbers are reported
+    # too (`cold_start`): the very first step of the process and the mean of the first ten from an idle chip.
+    cold = []
+    for i in range(PREROLL + args.warmup):
+        if i < 10:
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            cold.append((time.perf_counter() - tc) * 1e3)
+        else:
+            step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -344,7 +492,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     model.check()           # blocking health check of the cluster kernel (bounded spins never expired)
@@ -354,36 +502,38 @@ def main():
     achieved_tf = flop_per_launch / (kernel_ms * 1e-3) / 1e12
 
     if rank == 0:
-        total_windows = WINDOWS_PER_GPU * world * args.steps
+        total_windows = sum(int(s_[2] - s_[1]) for s_ in shards) * args.steps
+        kname = model.kernel_name(B, T_FRAMES)
+        traffic, ttag = load_traffic(kname, B)
         out = {
             "metric": "IMU windows/sec", "value": total_windows / elapsed, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: watch_phone_pocket_lstm path, 1024 windows/GPU x 64 frames x 22 "
-                                   "features (I=22,H=256,L=2,O=14), z-score+LSTM+head+denorm+FK, inputs resident in HBM",
+                                   "features (I=22,H=256,L=2,O=14), z-score+LSTM+head+denorm+FK, inputs resident in HBM"
+                                   + ("" if world == 1 else f"; configs[3] pattern on {world} GPUs: {WINDOWS_PER_GPU * world} streams"),
                        "windows_per_gpu": WINDOWS_PER_GPU, "frames": T_FRAMES, "features": POCKET["I"],
-                       "sharding": f"{world} ranks x {WINDOWS_PER_GPU} contiguous streams, weights by one RCCL broadcast",
+                       "sharding": {"ranks": world, "backend": (dist.get_backend() if use_dist else "none"),
+                                    "collectives": "one broadcast of the weight blob + stats at start-up; none per step",
+                                    "per_rank": [{"rank": int(s_[0]), "streams": [int(s_[1]), int(s_[2])], "device": int(s_[3]),
+                                                  "weight_blob_sum": s_[4]} for s_ in shards]},
                        "preroll_steps": PREROLL},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": model.kernel_name(B, T_FRAMES), "kernel_ms": kernel_ms,
+                         "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag,
+                         "kernel": kname, "kernel_ms": kernel_ms,
                          "flop_per_launch": flop_per_launch,
                          "hbm_algorithmic_bytes_per_launch": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4),
                          # the other roofline, stated plainly: ~1.8e4 FLOP per algorithmic byte, so HBM is idle by construction
                          "hbm_algorithmic_GBps": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4) / (kernel_ms * 1e-3) / 1e9,
                          "hbm_peak_GBps": 8000.0,
                          "hbm_frac": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4) / (kernel_ms * 1e-3) / 8e12},
+            "cold_start": {"first_step_ms": cold[0] if cold else None,
+                           "mean_of_first_10_steps_ms": float(np.mean(cold)) if cold else None,
+                           "note": "host-synchronised single steps from an idle chip (clock ramp + first-touch), rank 0"},
         }
-        tfile = REPO / "profiles" / "traffic_latest.json"
-        if tfile.exists():      # HBM bytes per launch from the committed rocprofv3 --pmc pass
-            try:
-                tj = json.loads(tfile.read_text())
-                a, b = tj.get("kernel", ""), out["roofline"]["kernel"]
-                if a and (a in b or b in a) and tj.get("windows") == B:
-                    out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-            except Exception:
-                pass
+        if len({round(s_[4], 6) for s_ in shards}) != 1:
+            raise SystemExit("bench.py: ranks hold different weight blobs after the broadcast")
         if world == 1:
             out["batch1"] = batch1_latency(model, stats)
             out["stream_bank_T6"] = stream_bank_numbers(model, stats)
@@ -395,6 +545,10 @@ def main():
                 out["parity_vs_cpu_reference"] = cb.pop("parity")
                 out["cpu_baseline"] = cb
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                best = [k for k in cb["legs"] if k.startswith("config1_B1_T6_mc1/") and "best" in k and k.endswith("fk_eigh")]
+                if best:
+                    out["batch1"]["cpu_frames_per_s"] = cb["legs"][best[0]]["frames_per_s"]
+                    out["batch1"]["cpu_leg"] = best[0]
         os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

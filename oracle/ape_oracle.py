@@ -208,11 +208,14 @@ def imupose_forward(sd: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray:
     return lstm_forward({k: v for k, v in sd.items() if not k.startswith("input_layer.")}, z)
 
 
-def torch_reference_model(sd: Dict[str, np.ndarray], dropout: float = 0.2):
+def torch_reference_model(sd: Dict[str, np.ndarray], dropout: float = 0.2, train: bool = False):
     """The third-party modules the reference instantiates (nn_models.py:169-174):
     ``torch.nn.LSTM(I,H,L,batch_first=True,dropout)`` + ``torch.nn.Linear(H,O)``, loaded
-    with ``sd``.  Returns ``f(x_f32[B,T,I]) -> y[B,T,O]`` running on torch-CPU in eval mode.
-    Used as the "reference-equivalent" CPU baseline in bench.py."""
+    with ``sd``.  Returns ``f(x_f32[B,T,I]) -> y[B,T,O]`` running on torch-CPU in eval mode, or --
+    ``train=True`` -- with the LSTM in train mode, which is what ``monte_carlo_predictions`` switches on
+    (nn_models.py:204: inter-layer dropout active, masks from torch's global generator).
+    Used as the "reference-equivalent" CPU baseline in bench.py and as the sampler of the statistical
+    Monte-Carlo checks."""
     import torch
 
     L = sum(1 for k in sd if k.startswith("lstm.weight_ih_l"))
@@ -227,7 +230,7 @@ def torch_reference_model(sd: Dict[str, np.ndarray], dropout: float = 0.2):
                 getattr(lstm, f"{nm}_l{k}").copy_(torch.from_numpy(sd[f"lstm.{nm}_l{k}"]))
         head.weight.copy_(torch.from_numpy(sd["output_layer.weight"]))
         head.bias.copy_(torch.from_numpy(sd["output_layer.bias"]))
-    lstm.eval()
+    lstm.train(train)
     head.eval()
 
     def run(x: np.ndarray) -> np.ndarray:
@@ -305,30 +308,25 @@ def rotmat_to_quat_eigh(r9: np.ndarray) -> np.ndarray:
 
 def rotmat_to_quat_closed(r9: np.ndarray) -> np.ndarray:
     """Closed-form equivalent for proper rotation matrices (what the HIP kernel computes):
-    pick the largest of (trace, m00, m11, m22) as the pivot (Shepperd), then flip to w >= 0."""
+    pick the largest of (trace, m00, m11, m22) as the pivot (Shepperd), then flip to w >= 0.
+    Vectorised over rows (the "vectorised closed form" CPU baseline of SURVEY 8d); a row holding a NaN
+    takes the trace branch, like the scalar form the kernel runs."""
     r9 = np.asarray(r9, dtype=np.float64)
     m00, m01, m02, m10, m11, m12, m20, m21, m22 = r9.T
     tr = m00 + m11 + m22
-    out = np.empty((r9.shape[0], 4))
+    cand = np.stack([tr, m00, m11, m22], axis=1)
+    piv = np.where(np.isnan(cand).any(axis=1), 0, np.argmax(np.nan_to_num(cand, nan=-np.inf), axis=1))
     with np.errstate(invalid="ignore", divide="ignore"):
-        for n in range(r9.shape[0]):
-            cand = (tr[n], m00[n], m11[n], m22[n])
-            p = int(np.argmax(cand)) if not np.any(np.isnan(cand)) else 0
-            if p == 0:
-                s = math.sqrt(tr[n] + 1.0) * 2.0 if tr[n] + 1.0 >= 0 else float("nan")
-                q = (0.25 * s, (m21[n] - m12[n]) / s, (m02[n] - m20[n]) / s, (m10[n] - m01[n]) / s)
-            elif p == 1:
-                s = math.sqrt(1.0 + m00[n] - m11[n] - m22[n]) * 2.0
-                q = ((m21[n] - m12[n]) / s, 0.25 * s, (m01[n] + m10[n]) / s, (m02[n] + m20[n]) / s)
-            elif p == 2:
-                s = math.sqrt(1.0 + m11[n] - m00[n] - m22[n]) * 2.0
-                q = ((m02[n] - m20[n]) / s, (m01[n] + m10[n]) / s, 0.25 * s, (m12[n] + m21[n]) / s)
-            else:
-                s = math.sqrt(1.0 + m22[n] - m00[n] - m11[n]) * 2.0
-                q = ((m10[n] - m01[n]) / s, (m02[n] + m20[n]) / s, (m12[n] + m21[n]) / s, 0.25 * s)
-            q = np.array(q)
-            out[n] = -q if q[0] < 0 else q
-    return out
+        s0 = np.sqrt(tr + 1.0) * 2.0                       # negative radicand -> NaN, as math.sqrt would refuse
+        s1 = np.sqrt(1.0 + m00 - m11 - m22) * 2.0
+        s2 = np.sqrt(1.0 + m11 - m00 - m22) * 2.0
+        s3 = np.sqrt(1.0 + m22 - m00 - m11) * 2.0
+        q0 = np.stack([0.25 * s0, (m21 - m12) / s0, (m02 - m20) / s0, (m10 - m01) / s0], axis=1)
+        q1 = np.stack([(m21 - m12) / s1, 0.25 * s1, (m01 + m10) / s1, (m02 + m20) / s1], axis=1)
+        q2 = np.stack([(m02 - m20) / s2, (m01 + m10) / s2, 0.25 * s2, (m12 + m21) / s2], axis=1)
+        q3 = np.stack([(m10 - m01) / s3, (m02 + m20) / s3, (m12 + m21) / s3, 0.25 * s3], axis=1)
+    q = np.choose(piv[:, None], [q0, q1, q2, q3])
+    return np.where(q[:, :1] < 0, -q, q)
 
 
 def six_drr_to_quat(s: np.ndarray, route: str = "eigh") -> np.ndarray:
