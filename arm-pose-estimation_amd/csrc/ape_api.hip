@@ -82,10 +82,47 @@ bool parse_kind_dims(int kind, int* width, int* I) {
 
 }  // namespace
 
+// ---- how a batch is split over the device's CUs (pure arithmetic: unit-tested on the CPU via ape_debug_plan) ----
+// A cluster is GH = H/16 workgroups, one per CU, so a device with n_cus CUs runs n_cus / GH clusters at once
+// (16 on a whole MI355X at H = 256); a batch-tile "wave" is one 16-row workgroup per CU (4096 rows on 256 CUs).
+static int cluster_capacity(int n_cus, int H) { return n_cus / (H / 16); }
+static int tile16_wave_rows(int n_cus) { return APE_TILE_ROWS * n_cus; }
+// smallest row-tile count (16 rows each) per cluster that fits `rows` into one launch; the dropout variants are
+// built for at most 2 tiles
+static int cluster_nmt(int n_cus, int H, int rows, bool cdrop) {
+    const int cap = cluster_capacity(n_cus, H);
+    for (int cand : {1, 2, 4})
+        if ((!cdrop || cand <= 2) && (rows + 16 * cand - 1) / (16 * cand) <= cap) return cand;
+    return cdrop ? 2 : 4;
+}
+static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (cdrop ? 2 : 4) * cluster_capacity(n_cus, H); }
+
+// APE_KERNEL_AUTO: how many whole waves of the batch-tile kernel to peel off the front of a batch.  Measured on a
+// whole MI355X (microseconds): a batch-tile wave sustains 125 TFLOP/s at H = 256 and 109 at H = 128 whatever T and
+// the dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
+// dropout variant) however few of its rows are used.  Both rates scale with the CU count of the device.
+static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop) {
+    const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop);
+    if (rpl == 0) return (B + wave - 1) / wave;          // no cluster fits on this device
+    const double rate = (dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
+    const double t16 = (double)wave * ape_flops_per_window(dims, T) / rate * 1e6;
+    const double tcl = cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
+    auto cost = [&](int w) {
+        const int rest = B - wave * w;
+        return w * t16 + (rest > 0 ? (double)((rest + rpl - 1) / rpl) * tcl : 0.0);
+    };
+    int best = 0;
+    double best_cost = cost(0);
+    for (int w : {B / wave, (B + wave - 1) / wave})
+        if (w > 0 && cost(w) < best_cost) { best = w; best_cost = cost(w); }
+    return best;
+}
+
 struct ape_model {
     ape_dims_t dims{};
     void* slab = nullptr;          // the one device allocation every fixed-size buffer below points into
     size_t slab_bytes = 0;
+    int n_cus = 0;                 // hipDeviceProp_t::multiProcessorCount of the model's device (256 on a whole MI355X)
     int KX = 0;                    // LSTM layer-0 input width, padded to the kernels' k-blocking
     int lstm_in = 0;               // LSTM layer-0 input width (input_size; 256 behind ImuPoseLSTM's input layer)
     int KXpre = 0;                 // ImuPoseLSTM: padded width of the input layer's input
@@ -180,6 +217,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     ape_model* m = new (std::nothrow) ape_model();
     if (!m) return fail(APE_ERR_HIP, "out of host memory");
     m->dims = *dims;
+    m->n_cus = prop.multiProcessorCount;            // 256 on a whole MI355X; fewer on a partitioned / CU-masked device
     const bool imupose = dims->model_kind == APE_MODEL_IMUPOSE;
     m->lstm_in = imupose ? dims->hidden_size : dims->input_size;
     m->KX = padded_input(m->lstm_in);
@@ -259,8 +297,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     m->kernel_name = nm;
     snprintf(nm, sizeof(nm), "ape_lstm_cluster<%d, %d, %d", H, L, m->KX);
     m->cluster_name = nm;
-    if (ape_cluster_supported(H, L, m->KX)) {
-        const int GH = H / 16, max_clusters = 256 / GH;
+    // the cluster kernels need one whole cluster (GH workgroups, one per CU) resident at once: a device with fewer
+    // CUs than that gets the batch-tile kernel only (set_kernel(CLUSTER) then answers APE_ERR_UNSUPPORTED)
+    if (ape_cluster_supported(H, L, m->KX) && cluster_capacity(m->n_cus, H) >= 1) {
+        const int GH = H / 16, max_clusters = cluster_capacity(m->n_cus, H);
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = plan((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
@@ -451,28 +491,10 @@ int ape_model_set_body(ape_model_t* m, const double body9[9]) {
     return APE_OK;
 }
 
-// APE_KERNEL_AUTO: how many whole 4096-row waves of the batch-tile kernel to peel off the front of a batch.  Measured
-// on MI355X (microseconds): a batch-tile wave sustains 125 TFLOP/s at H = 256 and 109 at H = 128 whatever T and the
-// dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
-// dropout variant) however few of its rows are used.
-static int auto_tile16_waves(const ape_model* m, int B, int T, bool cdrop, int rows_per_cluster_launch) {
-    const double t16 = 4096.0 * ape_flops_per_window(&m->dims, T) / (m->dims.hidden_size == 256 ? 1.25e14 : 1.09e14) * 1e6;
-    const double tcl = cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
-    auto cost = [&](int w) {
-        const int rest = B - 4096 * w;
-        return w * t16 + (rest > 0 ? (double)((rest + rows_per_cluster_launch - 1) / rows_per_cluster_launch) * tcl : 0.0);
-    };
-    int best = 0;
-    double best_cost = cost(0);
-    for (int w : {B / 4096, (B + 4095) / 4096})
-        if (w > 0 && cost(w) < best_cost) { best = w; best_cost = cost(w); }
-    return best;
-}
-
 // x_ring: time step t of every window lives in slot (t + x_ring) mod T (0 = the linear layout of the public entry)
 static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                              const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream,
-                             int x_ring) {
+                             int x_ring, const float* h0_dev = nullptr, const float* c0_dev = nullptr) {
     if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
     if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
@@ -486,6 +508,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return fail(APE_ERR_INVALID_ARG, "lstm_forward: dropout_p %f outside [0,1)", dropout_p);
     const int H = m->dims.hidden_size, L = m->dims.num_layers;
     const bool drop = (flags & (APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX)) != 0;
+    const bool have_hs = h0_dev != nullptr || c0_dev != nullptr;
+    if (have_hs && (!h0_dev || !c0_dev)) return fail(APE_ERR_INVALID_ARG, "lstm_forward: h0 and c0 come together");
+    if (have_hs && m->dims.model_kind == APE_MODEL_FF)
+        return fail(APE_ERR_INVALID_ARG, "lstm_forward: the MLP regressor has no recurrent state");
     if (m->dims.model_kind == APE_MODEL_FF) {
         if (flags & APE_FLAG_BROADCAST_X) return fail(APE_ERR_UNSUPPORTED, "lstm_forward: BROADCAST_X is an LSTM-path flag");
         if ((flags & APE_FLAG_DROPOUT_MASKS) && !masks_dev)
@@ -543,17 +569,18 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     // per-launch prologue / head, which decides short windows.  Under APE_KERNEL_AUTO the front of the batch goes to
     // the batch-tile kernel in whole 4096-row waves and the rest to the cluster kernel, by a cost model calibrated
     // on MI355X (tests/tools/time_big_batch.py).
-    const int GHc = H / 16, max_clusters_c = 256 / GHc;
     const bool f16 = m->precision == APE_PRECISION_F16;
     // all-steps output: the cluster kernel also writes every step's top-layer output to a [B,T,H] workspace and the
     // head runs over those rows in a second, HBM-bound launch
     const bool all_steps = (flags & APE_FLAG_ALL_STEPS) != 0;
     const bool cdrop_c = drop && L > 1;
-    const int rows_per_cluster_launch = 16 * (cdrop_c ? 2 : 4) * max_clusters_c;
+    const int rows_per_cluster_launch = cluster_rows_per_launch(m->n_cus, H, cdrop_c);
     // injected masks are indexed over the whole batch, so such a call is served by ONE launch of one kernel
     const bool masks_fit = !(flags & APE_FLAG_DROPOUT_MASKS) || !cdrop_c || B <= rows_per_cluster_launch ||
                            m->kernel_choice == APE_KERNEL_CLUSTER;
-    bool use_cluster = m->cluster_ok && masks_fit && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16);
+    // a caller-given initial state (h0, c0) is served by the batch-tile kernel, which loads it at step 0
+    bool use_cluster = m->cluster_ok && masks_fit && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16) && !have_hs;
+    if (have_hs && f16) return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant starts from the zero state only");
     if (f16 && (!m->cluster_ok || drop || (flags & APE_FLAG_ALL_STEPS)))
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant covers last-step output without dropout on "
                     "the cluster-kernel shapes only");
@@ -562,8 +589,9 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
-        const int w = auto_tile16_waves(m, B, T, cdrop_c, rows_per_cluster_launch);
-        n16 = (4096 * w < B) ? 4096 * w : B;
+        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c);
+        const long long front = (long long)tile16_wave_rows(m->n_cus) * w;
+        n16 = (front < B) ? (int)front : B;
     }
     if (n16 > 0) {
         LstmParams p{};
@@ -580,18 +608,16 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         p.flags = flags;
         p.dropout_p = dropout_p;
         p.seed = seed;
+        p.h0 = h0_dev; p.c0 = c0_dev; p.hs_rows = B;
         hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
         if (n16 == B) return APE_OK;
     }
     if (use_cluster) {
         // smallest row tile count that still fits the batch on the chip: more clusters = more CUs busy
-        const int GH = H / 16, max_clusters = 256 / GH;
         const bool cdrop = drop && L > 1;
-        int nmt = cdrop ? 2 : 4;
-        for (int cand : {1, 2, 4})
-            if ((!cdrop || cand <= 2) && (B - n16 + 16 * cand - 1) / (16 * cand) <= max_clusters) { nmt = cand; break; }
-        const int rows_per_launch = 16 * nmt * max_clusters;
+        const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop);
+        const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
         if (all_steps) {
             const size_t rows = (size_t)B * T;
@@ -656,12 +682,19 @@ int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, u
     return lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0);
 }
 
+int ape_lstm_forward_hs(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+                        const float* masks_dev, float dropout_p, uint64_t seed, const float* h0_dev,
+                        const float* c0_dev, float* y_dev, void* stream) {
+    return lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0, h0_dev, c0_dev);
+}
+
 int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "set_kernel: NULL model");
     if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER)
         return fail(APE_ERR_INVALID_ARG, "set_kernel: unknown choice %d", choice);
     if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
-        return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d", m->dims.hidden_size, m->dims.num_layers);
+        return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d on a device with %d CUs (a cluster "
+                    "needs %d)", m->dims.hidden_size, m->dims.num_layers, m->n_cus, m->dims.hidden_size / 16);
     m->kernel_choice = choice;
     m->small_batch_path = (choice == APE_KERNEL_AUTO);
     return APE_OK;
@@ -682,14 +715,20 @@ int ape_model_check(ape_model_t* m) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "check: NULL model");
     if (!m->cluster_ok) return APE_OK;
     HIP_TRY(hipSetDevice(m->dims.device));
+    // every stream of the device, non-blocking ones included: a launch that is still spinning must have ended (its
+    // status word written) before the word is read, and nothing may be in flight when the flags are reset below
+    HIP_TRY(hipDeviceSynchronize());
     unsigned st = 0;
     HIP_TRY(hipMemcpy(&st, m->xflags + m->xflag_bytes / sizeof(unsigned), sizeof(st), hipMemcpyDeviceToHost));
     if (st != 0) {
         // an aborted launch skipped its self-cleaning: reset flags, counters and the status word from the host
         HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
         HIP_TRY(hipMemset(m->xcc_slots, 0, 64 * sizeof(unsigned)));
-        return fail(APE_ERR_HIP, "cluster kernel gave up waiting for a peer workgroup (status %u): not all of its "
-                    "workgroups were resident; outputs of that launch are invalid", st);
+        HIP_TRY(hipDeviceSynchronize());
+        return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
+                    "since the last successful check are invalid; the model is usable again", st,
+                    st == 1 ? "a workgroup gave up waiting for a peer -- not all workgroups of a cluster were resident"
+                            : "a launch found the state of an earlier aborted launch");
     }
     return APE_OK;
 }
@@ -806,8 +845,8 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
     ape_streams* b = new (std::nothrow) ape_streams();
     if (!b) return fail(APE_ERR_HIP, "out of host memory");
     b->model = m; b->S = n_streams; b->T = seq_len; b->smooth = smooth;
-    HIP_TRY(hipSetDevice(m->dims.device));
-    hipError_t e = bank_alloc(b);
+    hipError_t e = hipSetDevice(m->dims.device);
+    if (e == hipSuccess) e = bank_alloc(b);
     if (e != hipSuccess) {
         ape_streams_destroy(b);
         return fail(APE_ERR_HIP, "streams_create: allocation failed: %s", hipGetErrorString(e));
@@ -826,13 +865,21 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     b->n_mc = n_mc; b->mc = true; b->dropout_p = dropout_p; b->seed = seed; b->mc_calls = 0;
     b->frames = 0; b->steps = 0;
     hipError_t e = bank_alloc(b);
-    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_set_mc: allocation failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        // the old rings are gone and the new ones are incomplete: the bank stays unusable (every push / step refuses)
+        // until a later ape_streams_set_mc succeeds
+        if (b->xring) (void)hipFree(b->xring);
+        if (b->yring) (void)hipFree(b->yring);
+        if (b->y_new) (void)hipFree(b->y_new);
+        b->xring = b->yring = b->y_new = nullptr;
+        return fail(APE_ERR_HIP, "streams_set_mc: allocation failed: %s", hipGetErrorString(e));
+    }
     // Layer 0 once per stream (nn.LSTM's dropout sits BETWEEN the layers, so h_0(t) is the same for all samples of a
     // stream): worth its extra launch from two batch-tile waves of sample rows on.  The [S,T,H] sequence lives in the
     // model's all-steps workspace, sized here so that the step itself never allocates.
     ape_model* m = b->model;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
-                   dropout_p > 0.0f && n_mc >= 2 && (long long)b->S * n_mc >= 8192;
+                   dropout_p > 0.0f && n_mc >= 2 && (long long)b->S * n_mc >= 2LL * tile16_wave_rows(m->n_cus);
     if (b->shared_l0) {
         const size_t rows = (size_t)b->S * b->T;
         if (rows > m->hseq_cap) {
@@ -871,6 +918,7 @@ static void next_slot(const ape_streams* b, size_t I, float** out, int* rep, siz
 
 int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev, void* stream) {
     if (!b || !rows_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_rows: NULL argument");
+    if (!b->xring) return fail(APE_ERR_NOT_READY, "streams_push_rows: the bank lost its rings in a failed ape_streams_set_mc");
     int width, I;
     const int big_endian = (kind & APE_PARSE_BIG_ENDIAN) ? 1 : 0;
     kind &= ~APE_PARSE_BIG_ENDIAN;
@@ -889,6 +937,7 @@ int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev,
 
 int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* stream) {
     if (!b || !xx_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_features: NULL argument");
+    if (!b->xring) return fail(APE_ERR_NOT_READY, "streams_push_features: the bank lost its rings in a failed ape_streams_set_mc");
     const int I = b->model->dims.input_size;
     float* out; int rep; size_t rep_stride;
     next_slot(b, (size_t)I, &out, &rep, &rep_stride);
@@ -900,6 +949,8 @@ int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* strea
 
 int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream) {
     if (!b || !msg_dev) return fail(APE_ERR_INVALID_ARG, "streams_step: NULL argument");
+    if (!b->xring || !b->yring || !b->y_new)
+        return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
     if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
     if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_PACKED_MSG))
         return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT and PACKED_MSG are accepted");
@@ -977,14 +1028,49 @@ int ape_debug_read_wg(ape_model_t* m, unsigned long long out[256 * 8]) {
     return APE_OK;
 }
 
+// internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
+// 2 departure counter -- so that tests can stage the state an aborted launch leaves behind
+int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
+    if (!m || !m->cluster_ok || which < 0 || which > 2) return APE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(m->dims.device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned* status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+    unsigned* word = which == 0 ? status : (which == 1 ? status - 4 : status - 3);
+    HIP_TRY(hipMemcpy(word, &value, sizeof(value), hipMemcpyHostToDevice));
+    return APE_OK;
+}
+
+// internal: the batch split of lstm_forward for a device with `n_cus` CUs, no GPU needed.
+// out = {rows to the batch-tile kernel, row tiles per cluster, clusters per launch, cluster launches, cluster capacity}
+int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, int out[5]) {
+    if (!dims || !out || n_cus < 1 || B < 1 || T < 1) return APE_ERR_INVALID_ARG;
+    const int H = dims->hidden_size;
+    const int cap = cluster_capacity(n_cus, H);
+    out[4] = cap;
+    if (cap < 1) { out[0] = B; out[1] = out[2] = out[3] = 0; return APE_OK; }
+    long long n16 = 0;
+    if (B > 4) n16 = (long long)tile16_wave_rows(n_cus) * auto_tile16_waves(dims, n_cus, B, T, cdrop != 0);
+    if (n16 > B) n16 = B;
+    out[0] = (int)n16;
+    const int rest = B - (int)n16;
+    out[1] = out[2] = out[3] = 0;
+    if (rest > 0) {
+        const int nmt = cluster_nmt(n_cus, H, rest, cdrop != 0), rpl = 16 * nmt * cap;
+        out[1] = nmt;
+        out[3] = (rest + rpl - 1) / rpl;
+        const int first = rest < rpl ? rest : rpl;
+        out[2] = (first + 16 * nmt - 1) / (16 * nmt);
+    }
+    return APE_OK;
+}
+
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m) return "";
     if (m->precision == APE_PRECISION_F16) return "ape_lstm_cluster_f16";
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
-        const int rpl = 16 * 4 * (256 / (m->dims.hidden_size / 16));
-        if (2 * 4096 * auto_tile16_waves(m, B, T, false, rpl) > B) return m->kernel_name.c_str();
+        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false) > B) return m->kernel_name.c_str();
     }
     return m->cluster_name.c_str();
 }

@@ -7,6 +7,7 @@
 #define APE_MAX_INPUT 64
 #define APE_MAX_OUTPUT 32
 #define APE_TILE_ROWS 16          // windows per workgroup in the batch-tile LSTM kernel
+#define APE_LDS_BYTES (160 * 1024) // LDS of a gfx950 CU: the dynamic-LDS limit every kernel instantiation is raised to, once
 // internal timing-only diagnostics (never set by the public API's documented flags; outputs are wrong)
 #define APE_DIAG_NO_EXCHANGE 0x40000000u
 #define APE_DIAG_NO_ACT      0x20000000u
@@ -40,6 +41,9 @@ struct LstmParams {
                                         // (0: row b reads window b, no mask)
     int layer_base;                     // model layer that this launch's layer 0 is (a launch over the UPPER layers of a
                                         // model keeps the model's layer numbers in its Philox counters)
+    const float* h0;                    // [L,hs_rows,H] initial hidden state (DropoutLSTM.forward(x, hs), nn_models.py:180-189)
+    const float* c0;                    // [L,hs_rows,H] initial cell state; both nullptr: zeros
+    int hs_rows;                        // batch size of h0 / c0
 };
 
 // Kernel arguments of the weight-stationary cluster LSTM kernel.

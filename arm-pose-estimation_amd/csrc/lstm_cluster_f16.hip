@@ -92,11 +92,20 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16(const ClusterPara
     _Float16* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
     _Float16* own = xin + 2 * MR * SX;                // [L][MR][SO]
     int* ctl = reinterpret_cast<int*>(own + L * MR * SO); // [0] abort, [1] ticket, [2] last-out
+    // A launch that finds the sticky status word set -- an earlier launch on this model aborted and skipped its
+    // self-cleaning, so tickets, flags and counters are stale -- leaves without touching anything (status 2 tells
+    // ape_model_check that later launches ran into it), and so does a workgroup whose ticket lies outside the grid.
     if (threadIdx.x == 0) {
         ctl[0] = 0;
-        ctl[1] = (int)__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl[1] = -1;
+        if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned tk = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < gridDim.x) ctl[1] = (int)tk;
+            else __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
+    if (ctl[1] < 0) return;
     const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
     const int cluster = ticket / GH, member = ticket % GH;
     const int row0 = cluster * MR;
@@ -326,8 +335,9 @@ hipError_t launch(const ClusterParams& p, int clusters, hipStream_t stream) {
 
 template <int H, int L, int KX, int NMT>
 hipError_t prepare() {
+    if (smem_bytes<H, L, KX, NMT>() > APE_LDS_BYTES) return hipErrorInvalidValue;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster_f16<H, L, KX, NMT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<H, L, KX, NMT>());
+                               hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
 }
 
 }  // namespace

@@ -86,12 +86,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xFu;
+    // a launch that finds the sticky status word set (an earlier launch on this model aborted and left stale epochs
+    // behind) leaves without touching anything; ape_model_check reports and resets
     if (tid == 0) {
-        ctl[0] = 0;
-        __hip_atomic_store(p.xcc_slots + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl[0] = (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+        if (ctl[0] == 0)
+            __hip_atomic_store(p.xcc_slots + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int i = tid; i < L * MR * SH; i += 256) hbuf[i] = 0.0f;       // h_{-1} = 0: the first step reads zeros
     __syncthreads();
+    if (ctl[0] != 0) return;
 
     // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel) ----------------
     static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");

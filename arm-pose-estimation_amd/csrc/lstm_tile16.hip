@@ -215,9 +215,29 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) cst[l][u][i] = 0.0f;
 
+    // caller-given initial state (DropoutLSTM.forward(x, hs=(h0, c0)), nn_models.py:180-189): h0 into the buffer step 0
+    // reads as h_{-1}, c0 into the cell registers
+    const bool have_hs = p.h0 != nullptr;
+    if (have_hs) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            for (int idx = tid; idx < APE_TILE_ROWS * H; idx += 256) {
+                const int row = idx / H, unit = idx - row * H, b = row0 + row;
+                hbuf[((l * 2 + 1) * APE_TILE_ROWS + row) * SH + unit] = (b < p.B) ? p.h0[((size_t)l * p.hs_rows + b) * H + unit] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = row0 + 4 * g + i;
+                    if (b < p.B) cst[l][u][i] = p.c0[((size_t)l * p.hs_rows + b) * H + wave * (H / 4) + u * 16 + r];
+                }
+        }
+    }
+
     f32x4 b0[NT], b1[NT];
     load_b<NT>(b0, wbase[0]);     // first k-block of (layer 0, t = 0)
-    __syncthreads();              // xin[0], wout_s visible
+    __syncthreads();              // xin[0], wout_s (and h0) visible
 
 #ifdef APE_T16_STAMPS
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
@@ -253,8 +273,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_tile16(const LstmParams p) {
             else in_src = hbuf + (((l - 1) * 2 + cur) * APE_TILE_ROWS + r) * SH + 4 * g;
             const float* rec_src = hbuf + ((l * 2 + prv) * APE_TILE_ROWS + r) * SH + 4 * g;
             TS(0)                                        // 0: step/layer set-up (bias, pointers)
-            // t == 0: h_{-1} = 0, the recurrent k-blocks contribute nothing and are skipped
-            const int nq = (t == 0) ? qin : qtot[l];
+            // t == 0 without an initial state: h_{-1} = 0, the recurrent k-blocks contribute nothing and are skipped
+            const int nq = (t == 0 && !have_hs) ? qin : qtot[l];
             // first k-block of the NEXT layer-step, prefetched under this one's tail
             const f32x4* wnext = wbase[(l + 1) % L];
             const f32x4* wl = wbase[l];
@@ -358,10 +378,13 @@ hipError_t launch(const LstmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// the attribute is per kernel instantiation and process-wide: it is raised to the CU's whole LDS, never to one
+// model's own need (a later model with a smaller layout must not lower it under an earlier one's launches)
 template <int H, int L, int XE = 4>
 hipError_t prepare(size_t smem) {
+    if (smem > APE_LDS_BYTES) return hipErrorInvalidValue;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_tile16<H, L, XE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
 }
 
 }  // namespace

@@ -186,7 +186,7 @@ class DropoutLSTM:
     def _mask_shape(self, B, T, last_step_only):
         return (self.hidden_layer_count - 1, B, T, self.hidden_layer_size)
 
-    def _run(self, x, flags, masks=None, dropout_p=0.0, seed=0, last_step_only=False, rows=None):
+    def _run(self, x, flags, masks=None, dropout_p=0.0, seed=0, last_step_only=False, rows=None, hs=None):
         import ctypes as C
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
@@ -218,25 +218,45 @@ class DropoutLSTM:
                 mptr = C.c_void_p(masks.data_ptr())
                 flags |= _hip.FLAG_DROPOUT_MASKS
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _hip.check(_hip.lib().ape_lstm_forward(self._handle, C.c_void_p(xd.data_ptr()), B, T, flags, mptr,
-                                                   float(dropout_p), int(seed), C.c_void_p(y.data_ptr()), stream),
-                       "ape_lstm_forward")
-        return y.cpu() if on_host else y
+            if hs is not None:
+                # (h_0, c_0), each [L,B,H], as nn.LSTM takes them (nn_models.py:188: self.lstm(x, hs))
+                if not isinstance(hs, (tuple, list)) or len(hs) != 2:
+                    raise UserWarning("hs must be a tuple (h_0, c_0)")
+                want = (self.hidden_layer_count, B, self.hidden_layer_size)
+                hc = []
+                for a in hs:
+                    a = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+                    if tuple(a.shape) != want:
+                        raise UserWarning(f"h_0 / c_0 must have shape {want}, got {tuple(a.shape)}")
+                    hc.append(a.to(device=dev, dtype=torch.float32).contiguous())
+                _hip.check(_hip.lib().ape_lstm_forward_hs(self._handle, C.c_void_p(xd.data_ptr()), B, T, flags, mptr,
+                                                          float(dropout_p), int(seed), C.c_void_p(hc[0].data_ptr()),
+                                                          C.c_void_p(hc[1].data_ptr()), C.c_void_p(y.data_ptr()), stream),
+                           "ape_lstm_forward_hs")
+            else:
+                _hip.check(_hip.lib().ape_lstm_forward(self._handle, C.c_void_p(xd.data_ptr()), B, T, flags, mptr,
+                                                       float(dropout_p), int(seed), C.c_void_p(y.data_ptr()), stream),
+                           "ape_lstm_forward")
+        if on_host:
+            out = y.cpu()            # synchronises: the one place where results reach the host, so the health of the
+            self.check()             # launch is checked here (an aborted cluster launch leaves `y` unwritten)
+            return out
+        return y
 
     def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False, rows=None):
         """``masks`` (float32 ``[L-1,B,T,H]`` of 0 or 1/(1-p)) injects explicit dropout masks;
         ``last_step_only`` returns ``[B,1,O]`` (only the step the estimators consume);
-        ``normalize_input`` fuses the f64 z-score of raw features into the load."""
-        if hs is not None:
-            raise UserWarning("an initial (h_0, c_0) is not supported: the path always starts from zeros")
+        ``normalize_input`` fuses the f64 z-score of raw features into the load;
+        ``hs = (h_0, c_0)``, each ``[L,B,H]``: initial state, as the reference passes it on to ``nn.LSTM``
+        (nn_models.py:180-189); ``None`` = zeros."""
         flags = _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0
         if masks is not None:
-            return self._run(x, flags, masks=masks, last_step_only=last_step_only, rows=rows)
+            return self._run(x, flags, masks=masks, last_step_only=last_step_only, rows=rows, hs=hs)
         if self.lstm.training and self.dropout > 0.0 and self.hidden_layer_count > 1:
             self._mc_calls += 1
             return self._run(x, flags | _hip.FLAG_DROPOUT_PHILOX, dropout_p=self.dropout,
-                             seed=(self._seed << 20) + self._mc_calls, last_step_only=last_step_only, rows=rows)
-        return self._run(x, flags, last_step_only=last_step_only, rows=rows)
+                             seed=(self._seed << 20) + self._mc_calls, last_step_only=last_step_only, rows=rows, hs=hs)
+        return self._run(x, flags, last_step_only=last_step_only, rows=rows, hs=hs)
 
     __call__ = forward
 
@@ -385,11 +405,10 @@ class ImuPoseLSTM(DropoutLSTM):
         return want
 
     def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False, rows=None):
-        if hs is not None:
-            raise UserWarning("an initial (h_0, c_0) is not supported: the path always starts from zeros")
         if masks is not None:
             raise UserWarning("ImuPoseLSTM has no dropout mode")
-        return self._run(x, _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0, last_step_only=last_step_only, rows=rows)
+        return self._run(x, _hip.FLAG_NORMALIZE_INPUT if normalize_input else 0, last_step_only=last_step_only, rows=rows,
+                         hs=hs)
 
     __call__ = forward
 

@@ -111,6 +111,12 @@ class StreamBank:
     def reset(self):
         self._hip.check(self._hip.lib().ape_streams_reset(self._handle), "ape_streams_reset")
 
+    def check(self):
+        """blocking health check of the model's launches (``ape_model_check``): the bank's outputs stay on the device,
+        so the caller decides where to pay for the synchronisation -- e.g. once per batch of frames, before the
+        datagrams leave the host"""
+        self._model.check()
+
     def push_rows(self, rows: torch.Tensor, kind: int, big_endian: bool = False):
         """rows: float32 [S, 55|28] on the device -- one raw message per stream (data_types/messaging.py layouts)"""
         width = self._hip.PARSE_SHAPES[kind][0]

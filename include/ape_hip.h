@@ -18,9 +18,16 @@
  *   - return value 0 = success; anything else is an APE_ERR_* code and `ape_last_error()`
  *     (thread-local) describes it.  The Python mirror raises `UserWarning` for a non-zero
  *     status, the reference's exception convention (nn_models.py:385-400, transformations.py:98-116).
- *   - a handle holds no per-stream mutable state besides its workspace: use one handle per
- *     concurrently running stream/thread (reference: one Estimator per consumer thread,
- *     estimator.py:139-143).
+ *   - ONE model handle serialises on ONE stream at a time: the handle owns the exchange buffers, flag words, arrival
+ *     tickets and workspaces its kernels use, so two calls on the same handle (ape_lstm_forward, ape_infer,
+ *     ape_streams_step of any bank built on it) must not run concurrently -- enqueue them on the same stream, or
+ *     order the streams with events.  Use one handle per concurrently running stream/thread (reference: one
+ *     Estimator, with its own model, per consumer thread, estimator.py:139-143).  Different handles are independent.
+ *   - a launch of the weight-stationary kernels that cannot make progress (its workgroups never all resident, e.g. on
+ *     a GPU shared with other long-running kernels) gives up after a bounded wait, sets a sticky status word and
+ *     leaves its outputs unwritten; every later launch on that handle then leaves at once, also without writing.
+ *     ape_model_check() reports (and clears) that state; call it wherever results are consumed on the host (the
+ *     Python mirror does, whenever it copies results to host memory).
  *   - quaternions are [w,x,y,z]; all joint/column indices are fixed by the layouts below.
  */
 #ifndef APE_HIP_H
@@ -33,7 +40,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 2
+#define APE_ABI_VERSION 3
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -160,6 +167,12 @@ int ape_model_set_body(ape_model_t* model, const double body9[9]);
 int ape_lstm_forward(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                      const float* masks_dev, float dropout_p, uint64_t seed,
                      float* y_dev, void* stream);
+/* the same with a caller-given initial state: DropoutLSTM.forward(x, hs=(h0, c0)) (nn_models.py:180-189 hands hs to
+ * nn.LSTM).  h0_dev, c0_dev: f32 [L,B,H] (both or neither; NULL, NULL = ape_lstm_forward).  Not for APE_MODEL_FF
+ * and not with the fp16 variant. */
+int ape_lstm_forward_hs(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
+                        const float* masks_dev, float dropout_p, uint64_t seed,
+                        const float* h0_dev, const float* c0_dev, float* y_dev, void* stream);
 
 /* replaces: estimate_joints.arm_pose_from_nn_targets (estimate_joints.py:16-17) and, with
  * `denormalize` != 0, the `pred * yy_s + yy_m` of estimator.py:108-109 in front of it.
@@ -235,8 +248,9 @@ int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint
 /* kernel selection for A/B runs and tests; no effect on results beyond float32 summation order */
 int ape_model_set_kernel(ape_model_t* model, int32_t choice);
 int ape_model_set_precision(ape_model_t* model, int32_t precision);
-/* BLOCKING health check (synchronises the device): non-zero if a cluster-kernel launch since the last
- * check gave up waiting for a peer workgroup (its bounded spins expired) -- its outputs are invalid. */
+/* BLOCKING health check (hipDeviceSynchronize, i.e. every stream of the device): non-zero if a cluster-kernel launch
+ * since the last check gave up waiting for a peer workgroup (its bounded spins expired) -- the outputs of that launch
+ * and of every later one on this handle are invalid.  A failing check also resets the handle: the next launch works. */
 int ape_model_check(ape_model_t* model);
 
 /* introspection for benchmarks: name of the dominant kernel for (B,T) and its algorithmic

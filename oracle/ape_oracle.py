@@ -104,8 +104,9 @@ def _sigmoid(v):
 
 def lstm_forward(sd: Dict[str, np.ndarray], x: np.ndarray,
                  masks: Optional[Sequence[np.ndarray]] = None,
-                 dtype=np.float32, storage: Optional[str] = None) -> np.ndarray:
-    """x [B,T,I] -> y [B,T,O].  Zero initial state per call (nn_models.py:188 with hs=None).
+                 dtype=np.float32, storage: Optional[str] = None, hs=None) -> np.ndarray:
+    """x [B,T,I] -> y [B,T,O].  Zero initial state per call (nn_models.py:188 with hs=None), or
+    ``hs = (h0, c0)``, both [L,B,H], as ``DropoutLSTM.forward(x, hs)`` hands them to ``nn.LSTM`` (:180-189).
 
     ``masks``: optional list of L-1 arrays [B,T,H] multiplied onto the output sequence of
     layers 0..L-2 (already holding 0 or 1/(1-p)) -- inter-layer dropout of
@@ -125,8 +126,8 @@ def lstm_forward(sd: Dict[str, np.ndarray], x: np.ndarray,
         b_ih = sd[f"lstm.bias_ih_l{k}"].astype(dtype)
         b_hh = sd[f"lstm.bias_hh_l{k}"].astype(dtype)
         H = w_hh.shape[1]
-        h = np.zeros((B, H), dtype=dtype)
-        c = np.zeros((B, H), dtype=dtype)
+        h = np.zeros((B, H), dtype=dtype) if hs is None else q16(np.asarray(hs[0][k], dtype=dtype))
+        c = np.zeros((B, H), dtype=dtype) if hs is None else np.asarray(hs[1][k], dtype=dtype)
         out = np.empty((B, T, H), dtype=dtype)
         for t in range(T):
             pre = (seq[:, t, :] @ w_ih.T + b_ih) + (h @ w_hh.T + b_hh)

@@ -158,6 +158,74 @@ def gen_lstm(stats):
         np.savez_compressed(OUT / f"lstm_{name}.npz", **blob)
 
 
+# ---- 2b. non-zero initial state: DropoutLSTM.forward(x, hs=(h0, c0)) (nn_models.py:180-189) ----------
+def gen_lstm_hs():
+    blob = {}
+    for name, cfg in orc.MODEL_CONFIGS.items():
+        model, p, sd = ref_model(name, 0)
+        rng = np.random.default_rng(400)
+        for (B, T) in ((1, cfg["T"]), (5, cfg["T"]), (3, 64), (18, 2)):
+            x = rng.normal(size=(B, T, cfg["I"])).astype(np.float32)
+            h0 = (0.5 * rng.normal(size=(cfg["L"], B, cfg["H"]))).astype(np.float32)
+            c0 = (0.7 * rng.normal(size=(cfg["L"], B, cfg["H"]))).astype(np.float32)
+            with torch.no_grad():
+                y = model(torch.from_numpy(x), (torch.from_numpy(h0), torch.from_numpy(c0))).numpy()
+            for k, v in (("x", x), ("h0", h0), ("c0", c0), ("y", y)):
+                blob[f"{k}_{name}_B{B}_T{T}"] = v
+    np.savez_compressed(OUT / "lstm_hs.npz", **blob)
+
+
+# ---- 2c. Monte-Carlo dropout statistics of the reference itself (nn_models.py:191-207) ---------------------
+MC_QUANTILES = (0.05, 0.25, 0.5, 0.75, 0.95)
+MC_SAMPLES = 24000
+
+
+def gen_mc_stats():
+    """`ref_model.monte_carlo_predictions(n, x)[:, -1]` -- self.lstm.train() + x.repeat, torch's own mask stream --
+    drawn MC_SAMPLES times for three fixed windows per deployed model; mean, covariance and quantiles of the NN targets
+    and of the FK'd hand / elbow positions (est[:, :6]).  The masks themselves cannot be replayed, their
+    DISTRIBUTION can: scale 1/(1-p), placement between the layers only, every step, probability p."""
+    blob = {"quantile_levels": np.array(MC_QUANTILES), "n_samples": np.array(MC_SAMPLES)}
+    for name, cfg in orc.MODEL_CONFIGS.items():
+        model, p, sd = ref_model(name, 0)
+        tgt = NNS_TARGETS[p["y_targets_n"]]
+        rng = np.random.default_rng(500)
+        xs = rng.normal(size=(3, cfg["T"], cfg["I"])).astype(np.float32)
+        xs[2] *= 2.5                                      # one window far from the mean (saturating gates)
+        torch.manual_seed(1234)
+        stats_y, stats_e = [], []
+        for w in range(3):
+            chunks = []
+            with torch.no_grad():
+                for _ in range(MC_SAMPLES // 4000):
+                    chunks.append(model.monte_carlo_predictions(4000, torch.from_numpy(xs[w:w + 1])).numpy()[:, -1, :])
+            y = np.concatenate(chunks).astype(np.float64)                # [n, O]
+            est6 = ref_fk.arm_pose_from_nn_targets(y, orc.DEFAULT_BODY, tgt)[:, :6]
+            for arr, dst in ((y, stats_y), (est6, stats_e)):
+                dst.append((arr.mean(axis=0), np.cov(arr, rowvar=False), np.quantile(arr, MC_QUANTILES, axis=0)))
+        assert model.lstm.training                      # nn_models.py:204: permanent
+        blob[f"x_{name}"] = xs
+        for tag, st in (("y", stats_y), ("est6", stats_e)):
+            blob[f"{tag}_mean_{name}"] = np.array([s_[0] for s_ in st])
+            blob[f"{tag}_cov_{name}"] = np.array([s_[1] for s_ in st])
+            blob[f"{tag}_quant_{name}"] = np.array([s_[2] for s_ in st])
+        blob[f"dropout_{name}"] = np.array(p["dropout"])
+    # DropoutFF: dropout in front of the output layer (nn_models.py:356-370)
+    I, H, n_hidden, O = 22, 256, 2, 14
+    sdf = orc.make_ff_state_dict(I, H, n_hidden, O, 0)
+    ff = ref_nn.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=n_hidden, input_size=I, dropout=0.2)
+    ff.load_state_dict({k: torch.from_numpy(v) for k, v in sdf.items()})
+    ff.eval()
+    xf = np.random.default_rng(501).normal(size=(1, 1, I)).astype(np.float32)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        yf = ff.monte_carlo_predictions(MC_SAMPLES, torch.from_numpy(xf)).numpy()[:, -1, :].astype(np.float64)
+    blob["x_ff"], blob["dims_ff"] = xf, np.array([I, H, n_hidden, O])
+    blob["y_mean_ff"], blob["y_cov_ff"] = yf.mean(axis=0)[None], np.cov(yf, rowvar=False)[None]
+    blob["y_quant_ff"] = np.quantile(yf, MC_QUANTILES, axis=0)[None]
+    np.savez_compressed(OUT / "mc_stats.npz", **blob)
+
+
 def gen_ff():
     """DropoutFF (the MLP regressor the loader can dispatch, nn_models.py:313-370,395-396) in eval mode"""
     blob = {}
@@ -399,6 +467,14 @@ def main():
         gen_csv_header()
         print("wrote", OUT / "est_csv_header.json")
         return
+    if sys.argv[1:] == ["hs"]:               # add these fixtures without rewriting the others
+        gen_lstm_hs()
+        print("wrote", OUT / "lstm_hs.npz")
+        return
+    if sys.argv[1:] == ["mc"]:
+        gen_mc_stats()
+        print("wrote", OUT / "mc_stats.npz")
+        return
     if sys.argv[1:] == ["imupose"]:          # add this one fixture without rewriting the others
         gen_imupose()
         print("wrote", OUT / "imupose.npz")
@@ -406,6 +482,8 @@ def main():
     stats = export_stats_and_configs()
     gen_bookkeeping()
     gen_lstm(stats)
+    gen_lstm_hs()
+    gen_mc_stats()
     gen_ff()
     gen_imupose()
     gen_quat_ops()

@@ -1,0 +1,240 @@
+"""GPU parity tests added in round 2 (all through the C ABI of libape_hip.so):
+  * BASELINE configs[3]: 8192 streams sharded over G ranks == the unsharded call, bit for bit,
+  * Monte-Carlo dropout against the DISTRIBUTION of the reference's own `monte_carlo_predictions` samples
+    (tests/golden/mc_stats.npz, drawn by the reference, nn_models.py:191-207),
+  * `DropoutLSTM.forward(x, hs=(h0, c0))` against the reference's outputs (tests/golden/lstm_hs.npz),
+  * an aborted cluster launch fails loudly and the handle recovers.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ape_oracle as orc
+from tests import mc_check
+from tests.test_hip_parity import make_model, _synthetic_windows, quat_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as entry
+    entry.build()
+
+
+# ---------------- configs[3]: the 8192-stream split -------------------------------------------------------------
+@pytest.mark.parametrize("T", [6, 64])
+def test_sharded_streams_equal_unsharded(norm_stats, T):
+    """8192 independent streams on G ranks (contiguous `shard_range`s, one GPU each) must give what ONE call over all
+    8192 windows gives: windows are independent (zero state per window, nn_models.py:180-189), so the concatenation of
+    the shards' outputs is bit-equal to the unsharded output when every shard runs the kernel the unsharded call
+    ran for those rows.  G = 2 (4096 rows per rank: one batch-tile wave each, like the unsharded call's two) and
+    G = 8 (1024 rows per rank: the cluster kernel; the unsharded call is pinned to the same kernel), plus the oracle
+    on a sampled subset.  The shards run one after the other on this one GPU, each on its own model handle that got
+    the weights the way a rank gets them (flat blob, `load_weight_blob`)."""
+    from wear_mocap_ape_amd import _hip, streams
+    from wear_mocap_ape_amd.estimate import nn_models
+    name, S = "pocket", 8192
+    stats = norm_stats[name]
+    m_all, sd, cfg = make_model(name, 0, stats)
+    m_all.set_body(orc.DEFAULT_BODY)
+    x = _synthetic_windows(stats, S, T, cfg["I"], 5)
+    xd = torch.from_numpy(x).cuda()
+    lib = _hip.lib()
+
+    def run(model, xs):
+        n = xs.shape[0]
+        y = torch.empty((n, cfg["O"]), dtype=torch.float32, device="cuda")
+        est = torch.empty((n, 21), dtype=torch.float64, device="cuda")
+        _hip.check(lib.ape_infer(model.handle, C.c_void_p(xs.data_ptr()), n, T, _hip.FLAG_NORMALIZE_INPUT,
+                                 C.c_void_p(y.data_ptr()), C.c_void_p(est.data_ptr()), _hip.F64, None), "ape_infer")
+        torch.cuda.synchronize()
+        model.check()
+        return y.cpu().numpy(), est.cpu().numpy()
+
+    blob = streams.flatten_state_dict(sd, nn_models.state_dict_keys(cfg["L"]))
+    for G, kernel in ((2, "auto"), (8, "cluster"), (8, "tile16")):
+        m_all.set_kernel(kernel)
+        y_all, est_all = run(m_all, xd)
+        ys, es = [], []
+        for r in range(G):
+            lo, hi = streams.shard_range(S, r, G)
+            assert hi - lo == S // G
+            m_r = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], device=0)
+            m_r.load_weight_blob(torch.from_numpy(blob).cuda())           # what the RCCL broadcast leaves on a rank
+            m_r.set_norm_stats(stats["xx_m"], stats["xx_s"], stats["yy_m"], stats["yy_s"])
+            m_r.set_body(orc.DEFAULT_BODY)
+            m_r.set_kernel(kernel)
+            y_r, e_r = run(m_r, xd[lo:hi].contiguous())
+            ys.append(y_r)
+            es.append(e_r)
+        y_cat, e_cat = np.concatenate(ys), np.concatenate(es)
+        assert np.array_equal(y_cat, y_all), (G, kernel, float(np.abs(y_cat - y_all).max()))
+        assert np.array_equal(e_cat, est_all), (G, kernel)
+        # and the oracle on a sample of the streams (tolerances of the module header)
+        idx = np.r_[0:3, 1023:1026, 4095:4098, 8189:8192]
+        y_ref, est_ref = orc.infer_windows(sd, stats, orc.DEFAULT_BODY, cfg["layout"], x[idx])
+        assert np.abs(y_all[idx] - y_ref).max() < 1e-6
+        assert np.abs(est_all[idx][:, :9] - est_ref[:, :9]).max() < 2e-6
+        for c in (9, 13, 17):
+            assert quat_err(est_all[idx][:, c:c + 4], est_ref[:, c:c + 4]) < 2e-6
+    m_all.set_kernel("auto")
+
+
+def test_sharded_stream_banks_equal_one_bank(norm_stats):
+    """the same for the device-side stream bank (window rings, smoothing, messages): 8192 streams in one bank vs
+    8 banks of 1024, four frames from a cold start; eval mode, so no random stream is involved"""
+    from wear_mocap_ape_amd import _hip, streams
+    from wear_mocap_ape_amd.streams import StreamBank
+    name, S, G, T = "pocket", 8192, 8, 6
+    stats = norm_stats[name]
+    m, sd, cfg = make_model(name, 0, stats)
+    m.set_body(orc.DEFAULT_BODY)
+    m.set_kernel("cluster")                     # 8192 rows would otherwise go to the batch-tile kernel, 1024 to this one
+    rng = np.random.default_rng(9)
+    rows = rng.normal(size=(4, S, 55)).astype(np.float32)
+    whole = StreamBank(m, S, T, smooth=3, normalize=True, dtype=torch.float32)
+    parts = [StreamBank(m, S // G, T, smooth=3, normalize=True, dtype=torch.float32) for _ in range(G)]
+    for f in range(4):
+        whole.push_rows(torch.from_numpy(rows[f]).cuda(), _hip.PARSE_WATCH_PHONE_POCKET)
+        msg_all = whole.step().cpu().numpy().copy()
+        got = []
+        for r in range(G):
+            lo, hi = streams.shard_range(S, r, G)
+            parts[r].push_rows(torch.from_numpy(rows[f, lo:hi]).cuda(), _hip.PARSE_WATCH_PHONE_POCKET)
+            got.append(parts[r].step().cpu().numpy().copy())
+        assert np.array_equal(np.concatenate(got), msg_all), f
+    m.check()
+    m.set_kernel("auto")
+
+
+# ---------------- Monte-Carlo dropout vs the reference's own sample distribution ----------------------------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_monte_carlo_predictions_match_reference_distribution(golden, name):
+    """`model.monte_carlo_predictions(n, x)` (in-kernel Philox masks) against mean / variance / quantiles /
+    correlations of 24 000 samples the REFERENCE drew for the same weights and windows (nn_models.py:191-207:
+    self.lstm.train() + x.repeat).  n = 24 000 rows under APE_KERNEL_AUTO (whole batch-tile waves for a sample this
+    large), then each kernel on its own with 8192 rows (the cluster kernel in 16 launches of 512 rows, each with its
+    own Philox key)."""
+    g = golden("mc_stats.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    m, sd, _ = make_model(name, 0)
+    p, n_ref, levels = float(g[f"dropout_{name}"]), int(g["n_samples"]), g["quantile_levels"]
+    assert abs(m.dropout - p) < 1e-12
+    m.manual_seed(2024)
+    for w in range(3):
+        x = torch.from_numpy(g[f"x_{name}"][w:w + 1]).cuda()
+        args = (g[f"y_mean_{name}"][w], g[f"y_cov_{name}"][w], g[f"y_quant_{name}"][w], levels, n_ref)
+        y = m.monte_carlo_predictions(24000, x, last_step_only=True)
+        assert tuple(y.shape) == (24000, 1, cfg["O"]) and m.lstm.training
+        bad = mc_check.compare(y[:, 0].cpu().numpy(), *args, what=f"{name} w{w} auto")
+        assert not bad, bad
+        for kernel, n in (("tile16", 8192), ("cluster", 8192)):
+            m.set_kernel(kernel)
+            yk = m.monte_carlo_predictions(n, x, last_step_only=True)[:, 0].cpu().numpy()
+            m.set_kernel("auto")
+            bad = mc_check.compare(yk, *args, what=f"{name} w{w} {kernel}")
+            assert not bad, bad
+    # negative control on the device path: the same sampler with a different rate must be flagged
+    m.dropout = 0.5 * p
+    y = m.monte_carlo_predictions(24000, torch.from_numpy(g[f"x_{name}"][0:1]).cuda(), last_step_only=True)
+    assert mc_check.compare(y[:, 0].cpu().numpy(), g[f"y_mean_{name}"][0], g[f"y_cov_{name}"][0], g[f"y_quant_{name}"][0],
+                            levels, n_ref)
+    m.check()
+
+
+@pytest.mark.parametrize("name,S,n_mc", [("pocket", 375, 64), ("uarm", 375, 64)])
+def test_stream_bank_mc_matches_reference_distribution(golden, name, S, n_mc):
+    """the stream bank's Monte-Carlo mode on its shared-layer-0 route (layer 0 once per stream, layers above over the
+    S x n_mc sample rows): S streams are fed the SAME window, so their S * n_mc = 24 000 hand / elbow
+    positions (message tail) are samples of one window's distribution -- compared with the statistics of the
+    reference's samples pushed through the reference's FK (mc_stats.npz `est6_*`)."""
+    from wear_mocap_ape_amd.streams import StreamBank
+    g = golden("mc_stats.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    m, sd, _ = make_model(name, 0)
+    m.set_body(orc.DEFAULT_BODY)
+    p, n_ref, levels = float(g[f"dropout_{name}"]), int(g["n_samples"]), g["quantile_levels"]
+    assert S * n_mc >= 8192
+    for w in (0, 2):
+        x = g[f"x_{name}"][w]                                       # [T, I] normalised model input
+        bank = StreamBank(m, S, cfg["T"], smooth=1, normalize=False, dtype=torch.float64, monte_carlo_samples=n_mc,
+                          dropout=p, seed=99 + w)
+        for t in range(cfg["T"]):
+            bank.push_features(torch.from_numpy(np.repeat(x[t][None], S, axis=0)).cuda())
+        msg, tail = bank.step(with_tail=True)
+        tail = tail.cpu().numpy().reshape(S * n_mc, 6)
+        bad = mc_check.compare(tail, g[f"est6_mean_{name}"][w], g[f"est6_cov_{name}"][w], g[f"est6_quant_{name}"][w], levels,
+                               n_ref, what=f"{name} w{w} bank")
+        assert not bad, bad
+        del bank
+    m.check()
+
+
+def test_mlp_monte_carlo_matches_reference_distribution(golden):
+    """DropoutFF.monte_carlo_predictions (dropout in front of the output layer, nn_models.py:356-370)"""
+    from wear_mocap_ape_amd.estimate import nn_models
+    g = golden("mc_stats.npz")
+    I, H, n_hidden, O = (int(v) for v in g["dims_ff"])
+    sd = orc.make_ff_state_dict(I, H, n_hidden, O, 0)
+    m = nn_models.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=n_hidden, input_size=I, dropout=0.2, device=0)
+    m.load_state_dict(sd)
+    m.manual_seed(7)
+    y = m.monte_carlo_predictions(int(g["n_samples"]), torch.from_numpy(g["x_ff"]).cuda(), last_step_only=True)
+    bad = mc_check.compare(y[:, 0].cpu().numpy(), g["y_mean_ff"][0], g["y_cov_ff"][0], g["y_quant_ff"][0],
+                           g["quantile_levels"], int(g["n_samples"]), what="ff")
+    assert not bad, bad
+
+
+# ---------------- non-zero initial state ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_initial_state_vs_reference_golden(golden, name):
+    """DropoutLSTM.forward(x, hs=(h0, c0)) (nn_models.py:180-189) against the reference module's outputs"""
+    g = golden("lstm_hs.npz")
+    m, sd, cfg = make_model(name, 0)
+    for (B, T) in ((1, cfg["T"]), (5, cfg["T"]), (3, 64), (18, 2)):
+        k = f"{name}_B{B}_T{T}"
+        hs = (torch.from_numpy(g["h0_" + k]), torch.from_numpy(g["c0_" + k]))
+        y = m(torch.from_numpy(g["x_" + k]), hs)                       # host in -> host out, all steps
+        assert tuple(y.shape) == (B, T, cfg["O"])
+        assert np.abs(y.numpy() - g["y_" + k]).max() < 1e-6, (name, B, T)
+        y_last = m(torch.from_numpy(g["x_" + k]).cuda(), (hs[0].cuda(), hs[1].cuda()), last_step_only=True)
+        assert np.abs(y_last.cpu().numpy()[:, 0] - g["y_" + k][:, -1]).max() < 1e-6
+        # zero state given explicitly == no state given (any kernel)
+        z = torch.zeros_like(hs[0])
+        assert np.abs(m(torch.from_numpy(g["x_" + k]), (z, z)).numpy() - m(torch.from_numpy(g["x_" + k])).numpy()).max() < 1e-6
+    with pytest.raises(UserWarning):
+        m(torch.from_numpy(g[f"x_{name}_B5_T{cfg['T']}"]), (torch.zeros(1, 5, cfg["H"]), torch.zeros(1, 5, cfg["H"])))
+    with pytest.raises(UserWarning):
+        m(torch.from_numpy(g[f"x_{name}_B5_T{cfg['T']}"]), torch.zeros(cfg["L"], 5, cfg["H"]))
+
+
+# ---------------- aborted launches are loud and recoverable ----------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 64])
+def test_aborted_cluster_launch_fails_loudly_and_recovers(norm_stats, B):
+    """state an aborted launch leaves behind (sticky status word set, tickets consumed) -> the next call on that
+    handle must not return garbage silently: results copied to the host raise, `check()` raises, and after that
+    check the handle works again (bit-equal results)."""
+    from wear_mocap_ape_amd import _hip
+    name = "pocket"
+    m, sd, cfg = make_model(name, 0, norm_stats[name])
+    lib = _hip.lib()
+    lib.ape_debug_poke.restype, lib.ape_debug_poke.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_uint]
+    x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, cfg["T"], cfg["I"], 3))
+    good = m(x, last_step_only=True, normalize_input=True).numpy().copy()
+    # status word set / tickets beyond any grid (the one-cluster latency kernel at B = 1 takes no tickets)
+    for which, value in (((0, 1),) if B == 1 else ((0, 1), (1, 100000))):
+        assert lib.ape_debug_poke(m.handle, which, value) == 0
+        with pytest.raises(UserWarning, match="aborted"):
+            m(x, last_step_only=True, normalize_input=True)  # host output: checked before it is handed out
+        again = m(x, last_step_only=True, normalize_input=True).numpy()
+        assert np.array_equal(again, good)
+        # device output: the caller checks
+        assert lib.ape_debug_poke(m.handle, which, value) == 0
+        m(x.cuda(), last_step_only=True, normalize_input=True)
+        with pytest.raises(UserWarning, match="aborted"):
+            m.check()
+        m.check()
+        assert np.array_equal(m(x, last_step_only=True, normalize_input=True).numpy(), good)

@@ -181,3 +181,49 @@ def test_stream_trace(golden, norm_stats, name):
             n_rows = pred_ref.shape[0]
             assert len(msg) == (25 + 6 * n_rows if n_rows > 1 else 25) == len(msg_ref)
             assert np.allclose(np.asarray(msg), msg_ref, rtol=0, atol=1e-11)
+
+
+# ---------------- non-zero initial state and Monte-Carlo statistics vs the reference's own outputs ----------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_lstm_initial_state_vs_reference_golden(golden, name):
+    """DropoutLSTM.forward(x, hs=(h0, c0)) (nn_models.py:180-189): the cell loop started from the given state"""
+    g = golden("lstm_hs.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0)
+    for (B, T) in ((1, cfg["T"]), (5, cfg["T"]), (3, 64), (18, 2)):
+        k = f"{name}_B{B}_T{T}"
+        y = orc.lstm_forward(sd, g["x_" + k], hs=(g["h0_" + k], g["c0_" + k]))
+        assert np.abs(y - g["y_" + k]).max() < 2e-6
+        assert np.abs(orc.lstm_forward(sd, g["x_" + k]) - g["y_" + k]).max() > 1e-3      # the state matters
+
+
+def _oracle_mc_samples(sd, cfg, x, n, p, rng, scale=None, all_layers=False):
+    """n Monte-Carlo samples of the last step through the oracle's masked cell loop: Bernoulli(1-p) masks scaled by
+    1/(1-p) on the output sequence of every layer below the top one (what nn.LSTM(dropout=p) does in train mode)"""
+    scale = 1.0 / (1.0 - p) if scale is None else scale
+    T = x.shape[0]
+    masks = [(rng.random((n, T, cfg["H"])) >= p).astype(np.float32) * np.float32(scale) for _ in range(cfg["L"] - 1)]
+    return orc.lstm_forward(sd, np.repeat(x[None], n, axis=0), masks=masks)[:, -1, :]
+
+
+@pytest.mark.parametrize("name", ["pocket", "uarm"])
+def test_oracle_mc_dropout_matches_reference_distribution(golden, name):
+    """the oracle's injected-mask loop with Bernoulli masks reproduces the DISTRIBUTION of the reference's
+    `monte_carlo_predictions` samples (nn_models.py:191-207) -- and a wrong scale, rate or placement does not"""
+    from tests import mc_check
+    g = golden("mc_stats.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0)
+    p, n_ref, levels = float(g[f"dropout_{name}"]), int(g["n_samples"]), g["quantile_levels"]
+    rng = np.random.default_rng(77)
+    n = 8000
+    for w in (0, 2):
+        x = g[f"x_{name}"][w]
+        args = (g[f"y_mean_{name}"][w], g[f"y_cov_{name}"][w], g[f"y_quant_{name}"][w], levels, n_ref)
+        ok = mc_check.compare(_oracle_mc_samples(sd, cfg, x, n, p, rng), *args, what=f"{name} w{w}")
+        assert not ok, ok
+        if w == 0:       # negative controls: each must be flagged
+            assert mc_check.compare(_oracle_mc_samples(sd, cfg, x, n, p, rng, scale=1.0), *args)          # no 1/(1-p)
+            assert mc_check.compare(_oracle_mc_samples(sd, cfg, x, n, 0.5 * p, rng), *args)               # wrong rate
+            assert mc_check.compare(orc.lstm_forward(sd, np.repeat(x[None], 64, axis=0))[:, -1, :] +
+                                    np.zeros((64, 1), np.float32), *args)                                  # no dropout

@@ -1,0 +1,51 @@
+"""CPU unit test of the batch-split arithmetic of `ape_lstm_forward` (no GPU: `ape_debug_plan` is pure host code).
+The split follows the device's CU count (`hipDeviceProp_t::multiProcessorCount`), not a hard-coded 256:
+a cluster needs GH = H/16 CUs at once, a batch-tile wave is 16 rows per CU."""
+import ctypes as C
+
+import pytest
+
+
+def _plan(dims, n_cus, B, T, cdrop=0):
+    from wear_mocap_ape_amd import _hip
+    lib = _hip.lib()
+    lib.ape_debug_plan.restype = C.c_int
+    lib.ape_debug_plan.argtypes = [C.POINTER(_hip.ApeDims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 5)]
+    out = (C.c_int * 5)()
+    assert lib.ape_debug_plan(C.byref(dims), n_cus, B, T, cdrop, C.byref(out)) == 0
+    return dict(n16=out[0], nmt=out[1], clusters=out[2], launches=out[3], capacity=out[4])
+
+
+def test_batch_split_follows_the_cu_count():
+    from wear_mocap_ape_amd import _hip
+    pocket = _hip.ApeDims(22, 256, 2, 14, 0, 0, _hip.MODEL_LSTM)
+    uarm = _hip.ApeDims(38, 128, 3, 12, 1, 0, _hip.MODEL_LSTM)
+    # whole MI355X: 16 clusters of 16 CUs; the benchmark shape is ONE launch of 16 clusters x 64 rows
+    assert _plan(pocket, 256, 1024, 64) == dict(n16=0, nmt=4, clusters=16, launches=1, capacity=16)
+    assert _plan(pocket, 256, 1, 6) == dict(n16=0, nmt=1, clusters=1, launches=1, capacity=16)
+    assert _plan(pocket, 256, 256, 6)["nmt"] == 1 and _plan(pocket, 256, 257, 6)["nmt"] == 2
+    assert _plan(pocket, 256, 512, 6, cdrop=1) == dict(n16=0, nmt=2, clusters=16, launches=1, capacity=16)
+    assert _plan(pocket, 256, 513, 6, cdrop=1)["launches"] == 2          # dropout variants: at most 2 row tiles
+    assert _plan(uarm, 256, 2048, 6) == dict(n16=0, nmt=4, clusters=32, launches=1, capacity=32)
+    # whole 4096-row waves go to the batch-tile kernel, the rest to clusters
+    p = _plan(pocket, 256, 8192 + 100, 6)
+    assert p["n16"] == 8192 and p["launches"] == 1 and p["clusters"] == 7 and p["nmt"] == 1
+    # half the CUs (a partitioned device): 8 clusters, a wave is 2048 rows
+    assert _plan(pocket, 128, 1024, 64) == dict(n16=0, nmt=4, clusters=8, launches=2, capacity=8)
+    assert _plan(pocket, 128, 4096 + 10, 6)["n16"] == 4096
+    # 40 CUs: two clusters and 8 spare CUs; 15 CUs: no cluster can ever form -> everything to the batch-tile kernel
+    assert _plan(pocket, 40, 100, 6) == dict(n16=0, nmt=4, clusters=2, launches=1, capacity=2)
+    assert _plan(pocket, 15, 100, 6) == dict(n16=100, nmt=0, clusters=0, launches=0, capacity=0)
+    assert _plan(uarm, 15, 100, 6)["capacity"] == 1                      # H = 128: a cluster is 8 CUs
+    # every row is served exactly once
+    for n_cus in (256, 128, 40, 304):
+        for B in (1, 5, 63, 64, 65, 1000, 1024, 1025, 5000, 12345):
+            for cd in (0, 1):
+                p = _plan(pocket, n_cus, B, 6, cd)
+                rest = B - p["n16"]
+                assert 0 <= p["n16"] <= B and p["n16"] % (16 * n_cus) == 0 or p["n16"] == B
+                if rest:
+                    assert p["nmt"] in ((1, 2) if cd else (1, 2, 4))
+                    per_launch = 16 * p["nmt"] * p["capacity"]
+                    assert (p["launches"] - 1) * per_launch < rest <= p["launches"] * per_launch
+                    assert p["clusters"] <= p["capacity"]
