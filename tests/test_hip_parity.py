@@ -928,7 +928,7 @@ def test_c_caller(tmp_path):
     """tests/c_abi/demo.c -- plain C on the C ABI, no Python or torch in the process -- against the oracle on the same
     LCG-seeded weights, statistics and windows: ape_infer rows and the stream bank's messages"""
     import subprocess
-    from test_host_bookkeeping import build_c_caller
+    from tests.test_host_bookkeeping import build_c_caller
     exe = build_c_caller(tmp_path)
     out = tmp_path / "demo.bin"
     run = subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=120)
