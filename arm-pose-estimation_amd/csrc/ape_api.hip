@@ -95,6 +95,9 @@ static int cluster_nmt(int n_cus, int H, int rows, bool cdrop) {
         if ((!cdrop || cand <= 2) && (rows + 16 * cand - 1) / (16 * cand) <= cap) return cand;
     return cdrop ? 2 : 4;
 }
+// fp16 v2 kernel: 8-member clusters of 32 rows, formed within the 8 block-index classes, so a launch carries whole
+// groups of 8 clusters = 64 workgroups, all of which must be able to be resident together
+static int f16v2_capacity(int n_cus) { return (n_cus / 64) * 8; }
 static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (cdrop ? 2 : 4) * cluster_capacity(n_cus, H); }
 
 // APE_KERNEL_AUTO: how many whole waves of the batch-tile kernel to peel off the front of a batch.  Measured on a
@@ -146,6 +149,7 @@ struct ape_model {
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
     int precision = APE_PRECISION_F32;
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
+    bool f16_v2 = true;             // fp16 precision: batches > 256 rows on the row-set-pipelined kernel (lstm_cluster_f16v2.hip)
     bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
@@ -304,15 +308,21 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = plan((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
-        m->xflag_bytes = (((size_t)max_clusters * L * GH * 4 * sizeof(unsigned)) + 15) / 16 * 16 + 16;   // one flag per (cluster, layer, member, wave) + ticket word
+        // one flag per (cluster, layer, member, wave) -- or, fp16 v2 kernel, per (32-row cluster, row set, member wave) --
+        // + the ticket / departure words
+        size_t flag_words = (size_t)max_clusters * L * GH * 4;
+        if (ape_cluster_f16v2_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * 2 * 32 > flag_words)
+            flag_words = (size_t)f16v2_capacity(m->n_cus) * 2 * 32;
+        m->xflag_bytes = ((flag_words * sizeof(unsigned)) + 15) / 16 * 16 + 16;
         if (e == hipSuccess) e = plan((void**)&m->hx, m->hx_bytes);
         if (e == hipSuccess) e = plan((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
         if (e == hipSuccess) e = plan((void**)&m->xflags, m->xflag_bytes + 256);
-        if (e == hipSuccess) e = plan((void**)&m->xcc_slots, 64 * sizeof(unsigned));
+        if (e == hipSuccess) e = plan((void**)&m->xcc_slots, APE_XCC_WORDS * sizeof(unsigned));
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
+        if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "cluster kernel set-up failed: %s", hipGetErrorString(e));
@@ -619,6 +629,29 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop);
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        if (f16 && m->f16_v2 && ape_cluster_f16v2_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0 && B > 256) {
+            // second-generation fp16 kernel: 8-member clusters x 2 row sets of 16 that take turns (lstm_cluster_f16v2.hip)
+            const int rpl2 = 32 * f16v2_capacity(m->n_cus);
+            for (int b0 = 0; b0 < B; b0 += rpl2) {
+                const int nb = (B - b0 < rpl2) ? B - b0 : rpl2;
+                ClusterParams c{};
+                c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
+                c.y = y_dev + (size_t)b0 * m->dims.output_size;
+                for (int l = 0; l < L; ++l) { c.wcl[l] = reinterpret_cast<const float*>(m->wcl16[l]); c.bias[l] = m->bias[l]; }
+                c.w_out = m->w_out; c.b_out = m->b_out;
+                c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
+                c.xx_r = m->stats + 2 * m->dims.input_size + 2 * m->dims.output_size;
+                c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+                c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+                c.ticket = c.status - 4; c.done = c.status - 3;
+                c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
+                c.flags = flags; c.x_ring = x_ring;
+                c.xcc_slots = m->xcc_slots;
+                hipError_t e = ape_launch_lstm_cluster_f16v2(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
+                if (e != hipSuccess) return fail(APE_ERR_HIP, "fp16 cluster lstm launch failed: %s", hipGetErrorString(e));
+            }
+            return APE_OK;
+        }
         if (all_steps) {
             const size_t rows = (size_t)B * T;
             if (rows > m->hseq_cap) {
@@ -702,8 +735,10 @@ int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
 
 int ape_model_set_precision(ape_model_t* m, int32_t precision) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "set_precision: NULL model");
-    if (precision != APE_PRECISION_F32 && precision != APE_PRECISION_F16)
+    if (precision != APE_PRECISION_F32 && precision != APE_PRECISION_F16 && precision != APE_PRECISION_F16_GEN1)
         return fail(APE_ERR_INVALID_ARG, "set_precision: unknown precision %d", precision);
+    m->f16_v2 = precision != APE_PRECISION_F16_GEN1;
+    if (precision == APE_PRECISION_F16_GEN1) precision = APE_PRECISION_F16;
     if (precision == APE_PRECISION_F16 && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_precision: no fp16 kernel for H=%d L=%d", m->dims.hidden_size,
                     m->dims.num_layers);
@@ -723,7 +758,7 @@ int ape_model_check(ape_model_t* m) {
     if (st != 0) {
         // an aborted launch skipped its self-cleaning: reset flags, counters and the status word from the host
         HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
-        HIP_TRY(hipMemset(m->xcc_slots, 0, 64 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(m->xcc_slots, 0, APE_XCC_WORDS * sizeof(unsigned)));
         HIP_TRY(hipDeviceSynchronize());
         return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
                     "since the last successful check are invalid; the model is usable again", st,
@@ -1066,7 +1101,9 @@ int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, i
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m) return "";
-    if (m->precision == APE_PRECISION_F16) return "ape_lstm_cluster_f16";
+    if (m->precision == APE_PRECISION_F16)
+        return (m->f16_v2 && ape_cluster_f16v2_supported(m->dims.hidden_size, m->dims.num_layers, m->KX) &&
+                f16v2_capacity(m->n_cus) > 0 && B > 256) ? "ape_lstm_cluster_f16v2" : "ape_lstm_cluster_f16";
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {

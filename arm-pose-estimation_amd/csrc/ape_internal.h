@@ -7,6 +7,7 @@
 #define APE_MAX_INPUT 64
 #define APE_MAX_OUTPUT 32
 #define APE_TILE_ROWS 16          // windows per workgroup in the batch-tile LSTM kernel
+#define APE_XCC_WORDS 1024
 #define APE_LDS_BYTES (160 * 1024) // LDS of a gfx950 CU: the dynamic-LDS limit every kernel instantiation is raised to, once
 // internal timing-only diagnostics (never set by the public API's documented flags; outputs are wrong)
 #define APE_DIAG_NO_EXCHANGE 0x40000000u
@@ -71,7 +72,9 @@ struct ClusterParams {
     unsigned long long seed;
     float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
-    unsigned* xcc_slots;                // small-batch kernel: [GH] words (0x10 | XCC id) its members publish, zero between launches
+    unsigned* xcc_slots;                // APE_XCC_WORDS words, zero between launches.  [0,64): small-batch kernel, (0x10 | XCC id) of
+                                        // its members; [64,192): fp16 v2 kernel's 8 class tickets, one per 64-byte line;
+                                        // [192, ...): its per-workgroup XCD words
 };
 
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor
@@ -159,6 +162,9 @@ hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, 
 hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
+bool ape_cluster_f16v2_supported(int H, int L, int KX);
+hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
+hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
                                  size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream);
 hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size_t out_stride, int rep,

@@ -25,7 +25,7 @@ FLAG_DROPOUT_PHILOX = 0x8
 FLAG_PACKED_MSG = 0x20
 FLAG_BROADCAST_X = 0x10
 KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER = 0, 1, 2
-PRECISION_F32, PRECISION_F16 = 0, 1
+PRECISION_F32, PRECISION_F16, PRECISION_F16_GEN1 = 0, 1, 2
 MODEL_LSTM, MODEL_FF, MODEL_IMUPOSE = 0, 1, 2
 PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3
 PARSE_SHAPES = {0: (55, 22), 1: (28, 20), 2: (55, 20), 3: (55, 38)}

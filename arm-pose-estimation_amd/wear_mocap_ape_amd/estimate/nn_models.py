@@ -278,8 +278,9 @@ class DropoutLSTM:
 
     def set_precision(self, precision: str = "f32"):
         """'f32' (exact float32 MFMA, default) | 'f16' (binary16 weights / inputs / hidden state, float32
-        accumulate and cell state: BASELINE configs[4]; last-step output without dropout)"""
-        code = {"f32": _hip.PRECISION_F32, "f16": _hip.PRECISION_F16}[precision]
+        accumulate and cell state: BASELINE configs[4]; last-step output without dropout) | 'f16_gen1' (the same
+        arithmetic pinned to the first-generation fp16 kernel, for A/B runs)"""
+        code = {"f32": _hip.PRECISION_F32, "f16": _hip.PRECISION_F16, "f16_gen1": _hip.PRECISION_F16_GEN1}[precision]
         _hip.check(_hip.lib().ape_model_set_precision(self._handle, code), "ape_model_set_precision")
         return self
 

@@ -87,8 +87,10 @@ enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2 };
 
 /* Storage precision of W, x and h inside the LSTM (ape_model_set_precision).  F32 (default): exact float32
  * MFMA.  F16: binary16 weights / inputs / hidden state with float32 accumulate, cell state and head
- * (BASELINE.json configs[4]); last-step output without dropout; parity to a stated tolerance only. */
-enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1 };
+ * (BASELINE.json configs[4]); last-step output without dropout; parity to a stated tolerance only.
+ * F16_GEN1: the same arithmetic on the first-generation fp16 kernel for every batch size (A/B runs, tests); F16
+ * serves batches above 256 rows of the 2 x 256 models with the row-set-pipelined kernel. */
+enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1, APE_PRECISION_F16_GEN1 = 2 };
 
 #define APE_FLAG_PACKED_MSG      0x20u /* ape_streams_step only: message and tail of a stream packed in one row  */
 #define APE_FLAG_BROADCAST_X     0x10u /* x_dev is ONE window [1,T,I] shared by all B rows: the x.repeat((n,1,1)) of

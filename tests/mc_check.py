@@ -6,7 +6,7 @@ Bounds (z = 5.5 standard errors each; ~130 comparisons per model set, false-alar
   mean      |m - m_ref| <= z * sqrt(var_ref / n_ref + var / n)                      per target
   std       |s / s_ref - 1| <= z * sqrt((k - 1) / 4 * (1 / n + 1 / n_ref)), k = sample kurtosis (>= 3 assumed)
   quantiles fraction of samples below the reference's q-quantile = q +- z * sqrt(q (1 - q) (1 / n + 1 / n_ref))
-  correlations of target pairs within 0.06 absolute (n >= 8000)
+  correlations of target pairs within z * sqrt(1 / n + 1 / n_ref) absolute (n >= 8000; 0.07 at n = 8192)
 A sampler with a wrong mask scale (no 1/(1-p)), a wrong p or a mask in the wrong place moves the means by tens of
 standard errors (negative controls in the tests)."""
 import numpy as np
@@ -43,6 +43,6 @@ def compare(samples, ref_mean, ref_cov, ref_quant, levels, n_ref, what=""):
         sd = np.sqrt(rv[idx])
         rc = ref_cov[np.ix_(idx, idx)] / np.outer(sd, sd)
         worst = float(np.abs(c - rc).max())
-        if worst > 0.06:
+        if worst > Z * np.sqrt(1.0 / n + 1.0 / n_ref):
             bad.append(f"{what} correlation matrix differs by {worst:.3f}")
     return bad

@@ -238,3 +238,40 @@ def test_aborted_cluster_launch_fails_loudly_and_recovers(norm_stats, B):
             m.check()
         m.check()
         assert np.array_equal(m(x, last_step_only=True, normalize_input=True).numpy(), good)
+
+
+# ---------------- fp16 kernel, second generation (row-set pipelined, 8-member clusters) ----------------------------
+@pytest.mark.parametrize("name,B,T", [("watch", 1024, 64), ("pocket", 700, 8), ("watch", 257, 3), ("pocket", 2081, 6),
+                                      ("watch", 1024, 1)])
+def test_fp16_second_generation_kernel(norm_stats, name, B, T):
+    """configs[4] on lstm_cluster_f16v2.hip (batches above 256 rows): against the oracle's binary16-storage emulation
+    (layout / indexing), the float32 oracle (stated tolerance 5e-3), the first-generation fp16 kernel (same arithmetic:
+    differences only from float32 summation order), ragged and multi-launch batches, the forced any-placement
+    (write-through) exchange (same bits as the in-L2 form), and run-to-run determinism (self-cleaning state)."""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats[name]
+    model, sd, cfg = make_model(name, 0, st)
+    x = _synthetic_windows(st, B, T, cfg["I"], 8)
+    xd = torch.from_numpy(x).cuda()
+    xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    model.set_precision("f16")
+    assert model.kernel_name(B, T) == "ape_lstm_cluster_f16v2"
+    y2 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    model.check()
+    y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    assert np.array_equal(y2, y2b)
+    y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | 0x08000000,
+                                           None, 0.0, 0, C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
+    torch.cuda.synchronize()
+    model.check()
+    assert np.array_equal(y_wt.cpu().numpy(), y2)
+    model.set_precision("f16_gen1")
+    assert model.kernel_name(B, T) == "ape_lstm_cluster_f16"
+    y1 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    model.set_precision("f32")
+    y_ref = orc.lstm_forward(sd, xn)[:, -1]
+    y_emu = orc.lstm_forward(sd, xn, storage="f16")[:, -1]
+    e_ref, e_emu, e_gen = (float(np.abs(y2 - v).max()) for v in (y_ref, y_emu, y1))
+    print(f"\n[{name} B={B} T={T} fp16 v2] vs f32 oracle {e_ref:.2e}, vs f16-emulating oracle {e_emu:.2e}, vs gen-1 kernel {e_gen:.2e}")
+    assert e_ref < 5e-3 and e_emu < 3e-4 and e_gen < 3e-4
