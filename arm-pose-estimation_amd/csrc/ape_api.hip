@@ -647,6 +647,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
                 c.flags = flags; c.x_ring = x_ring;
                 c.xcc_slots = m->xcc_slots;
+                c.dbg_wg = m->dbg_wg;
                 hipError_t e = ape_launch_lstm_cluster_f16v2(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "fp16 cluster lstm launch failed: %s", hipGetErrorString(e));
             }

@@ -37,19 +37,50 @@ __device__ __forceinline__ float gate_act(float v, bool is_tanh) {
     return is_tanh ? 2.0f * s - 1.0f : s;
 }
 
-// acc[t] += W_t (registers) x A (LDS, 16 rows x 32 k per block) over NQ k-blocks; one ds_read_b128 feeds NTW MFMAs
-template <int NTW, int NQ, int NW>
-__device__ __forceinline__ void span(f32x4 (&acc)[NTW], const _Float16* __restrict__ src, const half8 (&w)[NTW][NW], int w_off) {
-    half8 a_cur = *reinterpret_cast<const half8*>(src), a_nxt = a_cur;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (q + 1 < NQ) a_nxt = *reinterpret_cast<const half8*>(src + 32 * (q + 1));
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t][w_off + q], a_cur, acc[t], 0, 0, 0);   // A = weights, B = activations
-        a_cur = a_nxt;
-    }
+// v_mfma_f32_16x16x32_f16 with the A operand (a weight fragment that lives in AGPRs for the whole launch) pinned to
+// the accumulator register file, so that the 256 architectural VGPRs stay free for a whole section's activation
+// fragments (fetched up front: a single ds_read_b128 feeds only two of these 16-cycle MFMAs, so reads issued one
+// block ahead leave the matrix pipe waiting on LDS latency -- 100 cycles per block instead of 32).  hipcc does not
+// model an asm MFMA's result hazard: the accumulators are read only after mfma_drain().
+__device__ __forceinline__ void mfma_wa(f32x4& acc, const f32x4 w, const f32x4 a) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
 }
+// (the accumulators are in/out operands of the drain: the gate math, which reads them, cannot be scheduled above it)
+template <int NTW>
+__device__ __forceinline__ void mfma_drain(f32x4 (&acc)[NTW]) {
+    static_assert(NTW == 2, "two tiles per wave");
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+}
+
+// NQ 32-deep k-blocks of LDS activations (16 rows x 32 k each) into registers
+template <int NQ>
+__device__ __forceinline__ void load_frags(f32x4 (&a)[NQ], const _Float16* __restrict__ src) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(src + 32 * q);
+}
+// acc[t] += W_t (registers) x A over NQ k-blocks
+template <int NTW, int NQ, int NW>
+__device__ __forceinline__ void span(f32x4 (&acc)[NTW], const f32x4 (&a)[NQ], const f32x4 (&w)[NTW][NW], int w_off) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) mfma_wa(acc[t], w[t][w_off + q], a[q]);
+}
+
+// Diagnostic build (make diag: -DAPE_CLUSTER_STAMPS): shader-cycle sums per section kind of one workgroup's wave 0,
+// written to the model's debug words (memory nothing else reads).  The shipped library has none of this code.
+#ifdef APE_CLUSTER_STAMPS
+#define V2_STAMP(k)                                                       \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        st_acc[k] += now_ - st_t0;                                        \
+        st_t0 = now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define V2_STAMP(k) do {} while (0)
+#endif
 
 template <int H, int L, int KX>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterParams p) {
@@ -72,12 +103,21 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
     const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;
+#if defined(APE_CLUSTER_STAMPS) || defined(APE_ABLATE)
+    // timing-only ablations (outputs are wrong): what a part really costs = the launch time with and without it
+    // (`make ablate` builds them without the stamps, whose own waits distort a kernel this short)
+    const bool d_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0, d_noact = (p.flags & APE_DIAG_NO_ACT) != 0;
+    const bool d_nomfma = (p.flags & APE_DIAG_NO_MFMA) != 0, d_nox = (p.flags & APE_DIAG_NO_XSTAGE) != 0;
+#else
+    constexpr bool d_noex = false, d_noact = false, d_nomfma = false, d_nox = false;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
     _Float16* hbuf = smem16;                              // [NS][L][SR][SH]   gathered h of the set's last phase
-    _Float16* xin = hbuf + NS * L * SR * SH;              // [NS][SR][SX]
-    _Float16* own = xin + NS * SR * SX;                   // [wave 4][L][SR][UPW]  fresh slice of this wave (wave-private)
-    int* ctl = reinterpret_cast<int*>(own + 4 * L * SR * UPW);   // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    _Float16* xin = hbuf + NS * L * SR * SH;              // [NS][2 parity][SR][SX]
+    _Float16* own = xin + NS * 2 * SR * SX;               // [wave 4][L][SR][UPW]  fresh slice of this wave (wave-private)
+    f32x4* bias_s = reinterpret_cast<f32x4*>(own + 4 * L * SR * UPW);   // [wave 4][L][NTW][lane 64]: the accumulators' start values
+    int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * NTW * 64);   // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
 
     // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words][done]
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -106,33 +146,37 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
 
     // ---- weights: registers (binary16 pairs), for the whole launch; host layout [member16][wave][32-deep block][lane][8]
     //      with 16 units per "member16": this wave's two tiles are waves (2*wave, 2*wave + 1) of member16 = 2*member + (wave >> 1)
-    half8 w0[NTW][NB0];
-    half8 w1[NTW][NB1];
+    f32x4 w0[NTW][NB0];                 // binary16 octets, held as 4-register tuples
+    f32x4 w1[NTW][NB1];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int m16 = 2 * member + (wave >> 1), w16 = 2 * (wave & 1) + t;
-        const half8* s0 = reinterpret_cast<const half8*>(p.wcl[0]) + ((size_t)(m16 * 4 + w16) * NB0) * 64 + lane;
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(m16 * 4 + w16) * NB0) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NB0; ++i) w0[t][i] = s0[i * 64];
-        const half8* s1 = reinterpret_cast<const half8*>(p.wcl[1]) + ((size_t)(m16 * 4 + w16) * NB1) * 64 + lane;
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(m16 * 4 + w16) * NB1) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NB1; ++i) w1[t][i] = s1[i * 64];
     }
     // unit of (tile t, lane group g): member*32 + wave*8 + t*4 + g
-    f32x4 bias_r[L][NTW];
+    // (b_ih + b_hh, f32) of this lane's four gates per (layer, tile): the accumulators start from it; kept in LDS, not in
+    // 16 registers -- the register file is the weight store
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < NTW; ++t) {
+            f32x4 bv;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bias_r[l][t][k] = p.bias[l][k * H + member * 32 + wave * 8 + t * 4 + g];
-    float cst[NS][L][NTW];
+            for (int k = 0; k < 4; ++k) bv[k] = p.bias[l][k * H + member * 32 + wave * 8 + t * 4 + g];
+            bias_s[((wave * L + l) * NTW + t) * 64 + lane] = bv;
+        }
+    // per-set register state is kept as "this section's set" / "the other set" and swapped at the end of every section,
+    // so the section body exists once (no unrolling over the sets, no dynamically indexed register arrays)
+    float cst[L][NTW], cst_o[L][NTW];
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) cst[s][l][t] = 0.0f;
+        for (int t = 0; t < NTW; ++t) cst[l][t] = cst_o[l][t] = 0.0f;
 
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
     unsigned* const flags_of = p.xflags + (size_t)cluster * NS * NFL;      // [set][member*4 + wave] epoch = phases published
@@ -144,26 +188,50 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     const int xk = tid % KX;
     const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
     const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
-    float xr[NS][NE];
-    auto fetch_x = [&](int s, int t) {
+    const double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;     // 1 / std, rounded once on the host
+    float xr[NE], xr_o[NE];
+    // loads go through a buffer descriptor over this cluster's rows: rows past the batch and the padded columns k >= I
+    // fall outside it and read as 0 (no predicates, no 64-bit per-lane addresses: one 32-bit offset per element)
+    const int rows_here = bcast_x ? NS * SR : max(0, min(NS * SR, p.B - row0));
+    // (the descriptor's words are forced into scalar registers: left to the compiler they end up in vector registers
+    //  and every load becomes a readfirstlane waterfall loop)
+    const unsigned long long x_addr = reinterpret_cast<unsigned long long>(p.x + (bcast_x ? (size_t)0 : (size_t)row0 * T * I));
+    const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)x_addr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(x_addr >> 32));
+    const int x_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)(bcast_x ? 1 : rows_here) * T * I * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(((unsigned long long)x_hi << 32) | x_lo), 0, x_bytes, 0x00020000);
+    const unsigned x_rowbytes = bcast_x ? 0u : (unsigned)(T * I * sizeof(float));
+    auto fetch_x = [&](float (&dst)[NE], int s, int t) {
         const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int b = row0 + s * SR + (tid + 256 * e) / KX;
-            xr[s][e] = (xk < I && b < p.B) ? p.x[((size_t)(bcast_x ? 0 : b) * T + slot) * I + xk] : 0.0f;
+            const int row = s * SR + (tid + 256 * e) / KX;
+            const unsigned off = (xk < I && row < rows_here) ? (unsigned)row * x_rowbytes + (unsigned)(xk * sizeof(float)) : 0x80000000u;
+            dst[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (unsigned)(slot * I * sizeof(float)), 0));
         }
     };
-    auto stage_x = [&](int s) {
+    // (x - m) / s in f64, correctly rounded: q0 = d * (1/s), one residual step q0 + (d - q0 s)(1/s) -- the tail of the
+    // hardware division sequence, bit-identical to the division (as in lstm_cluster.hip); (0, 1, 1) passes x through
+    auto stage_x = [&](const float (&src)[NE], int s, int t) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int row = (tid + 256 * e) / KX;
-            float v = xr[s][e];
-            if (normalize && xk < I && row0 + s * SR + row < p.B) v = (float)(((double)v - x_mean) / x_std);
-            xin[(s * SR + row) * SX + xk] = (_Float16)v;
+            const double d = (double)src[e] - x_mean;
+            const double q0 = d * x_rstd;
+            const double rr = fma(-q0, x_std, d);
+            const double q1 = fma(rr, x_rstd, q0);
+            // f64 -> f32 -> binary16 in two roundings, as the reference path's float32 model input stored as binary16 (kept
+            // apart by the empty asm: fused, the compiler emits a ~45-instruction software f64 -> f16 conversion)
+            float xf = (float)((rr == rr) ? q1 : q0);
+            asm volatile("" : "+v"(xf));
+            xin[((s * 2 + (t & 1)) * SR + row) * SX + xk] = (_Float16)xf;
         }
     };
-    fetch_x(0, 0);
-    fetch_x(1, 0);
+    fetch_x(xr, 0, 0);
+    fetch_x(xr_o, 1, 0);
+    stage_x(xr, 0, 0);
+    stage_x(xr_o, 1, 0);
+    if (T > 1) { fetch_x(xr, 0, 1); fetch_x(xr_o, 1, 1); }
 
     // ---- do all members of this cluster really share an XCD? ------------------------------------------------------
     if (wave == 0) {
@@ -234,65 +302,142 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     };
 
     const int P = T + L - 1;
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Section (ph, s) = row set s in phase ph.  What a section needs from the exchange -- the slices its set published a
+    // phase ago -- is PREFETCHED by the section in front of it (the other set's): that section looks at the flags
+    // after its layer-1 MFMAs (one load per lane, in flight under the gate math) and, if every peer wave has
+    // published, puts the whole gather into flight before its own publish store; the needing section then only waits for
+    // loads that have had a section's tail to land, side by side with the drain of that publish store, whose flag goes up
+    // right after the same wait.  If a peer was late the section falls back to the blocking form.
+    bool prefetched = false;
+    f32x4 gv[NGV];
 #pragma unroll 1
-    for (int ph = 0; ph <= P; ++ph) {          // phase P: only the final gather of both sets (for the head)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            // ---- bring in what this set's last phase published (nothing before phase 0: h_{-1} = 0 is skipped below) ----
-            f32x4 gv[NGV];
-            if (ph > 0) {
+    for (int sec = 0; sec < NS * (P + 1); ++sec) {     // phase P: only the final gather of both sets (for the head)
+        {
+            const int ph = sec >> 1, s = sec & 1;
+            // ---- S0: bring in what this set's last phase published (nothing before phase 0) ----------------------------------
+            if (ph > 0 && !prefetched && !d_noex) {               // first phases, a late peer, the final gathers
                 wait_flags(s, (unsigned)ph);
+                V2_STAMP(0);                                      // 0: blocking flag poll
                 issue_gather(s, (ph - 1) & 1, gv);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gather, and the OTHER set's publish stores issued before it
-            raise_pending();
-            if (ph > 0) commit_gather(s, gv);
-            if (ph < T) stage_x(s);                               // x_ph of this set (its last readers are a whole section back)
+            // the gather (prefetched a section's tail ago, or just issued) and the other set's publish store, which in the
+            // steady state was issued right behind the prefetch: both have been in flight side by side
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V2_STAMP(1);                                          // 1: wait for the gather / the store drain
+            if (!d_noex) raise_pending();                         // the flag owed for that store
+            if (ph > 0 && !d_noex) commit_gather(s, gv);
+            prefetched = false;
+            V2_STAMP(2);                                          // 2: LDS commit
             __syncthreads();
+            V2_STAMP(3);                                          // 3: barrier
             if (ctl[0] != 0) return;
-            if (ph == P) continue;
-            if (ph + 1 < T) fetch_x(s, ph + 1);                   // flies under the compute
+            if (ph == P) continue;                                // gather-only tail (no per-set register state is needed any more)
+            // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
+            // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
+            f32x4 ax[QX], a0r[QH], a1i[QH], a1r[QH];
+            if (ph < T) {
+                load_frags<QX>(ax, xin + ((s * 2 + (ph & 1)) * SR + r) * SX + 8 * g);
+                if (ph > 0) load_frags<QH>(a0r, hbuf + ((s * L + 0) * SR + r) * SH + 8 * g);
+            }
+            V2_STAMP(7);                                          // 7: fragment read issue
+            // the next section: the other set, in this phase (s = 0) or the next (s = 1); it needs epoch `want`
+            const int sn = s ^ 1, phn = ph + s;
+            const unsigned want = (unsigned)phn;
+            unsigned peek = want;
 
             // ---- every active layer of this set, back to back (layer l works on step t = ph - l) -------------------------
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const int t = ph - l;
-                if (t < 0 || t >= T) continue;                    // uniform over the grid
+                const bool active = t >= 0 && t < T;              // uniform over the grid
                 f32x4 acc[NTW];
+                if (active) {
 #pragma unroll
-                for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias_r[l][tt];
-                const _Float16* rec_src = hbuf + ((s * L + l) * SR + r) * SH + 8 * g;
-                if (l == 0) {
-                    span<NTW, QX, NB0>(acc, xin + (s * SR + r) * SX + 8 * g, w0, 0);
-                    if (t > 0) span<NTW, QH, NB0>(acc, rec_src, w0, QX);
-                } else {
-                    span<NTW, QH, NB1>(acc, hbuf + ((s * L + l - 1) * SR + r) * SH + 8 * g, w1, 0);
-                    if (t > 0) span<NTW, QH, NB1>(acc, rec_src, w1, QH);
+                    for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias_s[((wave * L + l) * NTW + tt) * 64 + lane];
+                    if (d_nomfma) {
+                    } else if (l == 0) {
+                        span<NTW, QX, NB0>(acc, ax, w0, 0);
+                        if (t > 0) span<NTW, QH, NB0>(acc, a0r, w0, QX);
+                    } else {
+                        span<NTW, QH, NB1>(acc, a1i, w1, 0);
+                        if (t > 0) span<NTW, QH, NB1>(acc, a1r, w1, QH);
+                    }
+                    mfma_drain<NTW>(acc);
                 }
+                V2_STAMP(4);                                      // 4: MFMA spans (incl. the wait for the LDS reads feeding them)
+                if (l == 0) {
+                    if (ph >= 1) load_frags<QH>(a1i, hbuf + ((s * L + 0) * SR + r) * SH + 8 * g);
+                    if (ph > 1) load_frags<QH>(a1r, hbuf + ((s * L + 1) * SR + r) * SH + 8 * g);
+                    // x of the next step: registers -> the other parity buffer (its readers are two sections back), next fetch
+                    if (ph + 1 < T && !d_nox) {
+                        stage_x(xr, s, ph + 1);
+                        if (ph + 2 < T) fetch_x(xr, s, ph + 2);
+                    }
+                } else if (want > 0u && lane < NFL && !d_noex) {
+                    // [B0] look at the flags the next section needs; the load flies under the gate math below
+                    peek = __hip_atomic_load(flags_of + sn * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                V2_STAMP(2);
+                if (!active) continue;
                 // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit tt*4 + g, batch row r)
 #pragma unroll
                 for (int tt = 0; tt < NTW; ++tt) {
-                    const float iv = gate_act(acc[tt][0], false), fv = gate_act(acc[tt][1], false);
-                    const float gg = gate_act(acc[tt][2], true), ov = gate_act(acc[tt][3], false);
-                    const float c = fv * cst[s][l][tt] + iv * gg;
-                    cst[s][l][tt] = c;
-                    own[((wave * L + l) * SR + r) * UPW + tt * 4 + g] = (_Float16)(ov * gate_act(c, true));
+                    float hval;
+                    if (d_noact) {
+                        const float c = acc[tt][1] * cst[l][tt] + acc[tt][0] * acc[tt][2];
+                        cst[l][tt] = c;
+                        hval = acc[tt][3] * c;
+                    } else {
+                        const float iv = gate_act(acc[tt][0], false), fv = gate_act(acc[tt][1], false);
+                        const float gg = gate_act(acc[tt][2], true), ov = gate_act(acc[tt][3], false);
+                        const float c = fv * cst[l][tt] + iv * gg;
+                        cst[l][tt] = c;
+                        hval = ov * gate_act(c, true);
+                    }
+                    own[((wave * L + l) * SR + r) * UPW + tt * 4 + g] = (_Float16)hval;
                 }
+                V2_STAMP(5);                                      // 5: gates + cell update + own-slice staging
+            }
+            // [B] every peer wave has published what the next section needs: its whole gather goes into flight now
+            if (want > 0u && !d_noex && __all((int)(peek >= want))) {
+                issue_gather(sn, (phn - 1) & 1, gv);
+                prefetched = true;
             }
             // ---- publish: lanes 0..15 send layer 0's row, lanes 16..31 layer 1's (this wave's 8 units = 16 bytes each) ----
+            //      (exactly ONE store instruction per wave: the counted wait at the top of the next section relies on it)
             {
                 const int l = lane >> 4, row = lane & 15, t = ph - l;
-                if (lane < 16 * L && t >= 0 && t < T) {
-                    const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + l) * SR + row) * UPW);
-                    const unsigned off = hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16);
-                    if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
-                }
+                const bool live = lane < 16 * L && t >= 0 && t < T;
+                const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
+                // dead lanes aim outside the buffer descriptor: the store instruction is issued by every wave, writes nothing there
+                const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16) : 0x80000000u;
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
                 pend_set = s;
                 pend_epoch = (unsigned)(ph + 1);
             }
+            V2_STAMP(6);                                          // 6: publish (LDS read + store issue)
+            // the other set is next: swap the per-set register state
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) { const float tmp = cst[l][tt]; cst[l][tt] = cst_o[l][tt]; cst_o[l][tt] = tmp; }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { const float tmp = xr[e]; xr[e] = xr_o[e]; xr_o[e] = tmp; }
         }
     }
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && lane == 0 && wave == 0 && cluster == 0 && member == 0) {
+        for (int k = 0; k < 8; ++k) p.dbg_wg[k] = st_acc[k];
+        p.dbg_wg[8] = __builtin_amdgcn_s_memtime() - st_begin;
+        p.dbg_wg[9] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raise_pending();
 
@@ -328,7 +473,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
 
 template <int H, int L, int KX>
 constexpr size_t smem_bytes() {
-    return ((size_t)2 * L * 16 * (H + 16) + (size_t)2 * 16 * (KX + 16) + (size_t)4 * L * 16 * 8) * sizeof(_Float16) + 16;
+    return ((size_t)2 * L * 16 * (H + 16) + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * 8) * sizeof(_Float16) +
+           (size_t)4 * L * 2 * 64 * 16 + 16;
 }
 
 }  // namespace
