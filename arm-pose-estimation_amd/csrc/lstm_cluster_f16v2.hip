@@ -21,7 +21,18 @@
 //     buffer loads either way (MI355X guide G16 / visibility table row 1: per-wave flag after the wave's own
 //     vmcnt(0), consumer polls then loads).  A class has exactly gridDim/8 workgroups = whole clusters, so every
 //     cluster forms once its workgroups are dispatched; spins are bounded and raise the sticky status word.
+//   * the gathered slices never pass through registers: the exchange buffer's order [layer][member][wave][row][8 units]
+//     IS the MFMA fragment order of the activation operand (k-block = member, k-group = wave), so a set's 16 KB are copied
+//     global -> LDS by 16 LDS-DMA instructions per workgroup (`buffer_load_dwordx4 ... lds`, inline asm: outside the
+//     compiler's s_waitcnt bookkeeping, waited for with a counted vmcnt), PREFETCHED by the section in front -- the other
+//     set's -- which looks at the flags after its layer-1 MFMAs and starts the copy before its own publish store; the
+//     needing section only waits for what is left of it, and nothing in the steady state waits for a store, a flag or a
+//     gather right after issuing it.
+//   * the steady-state section (both layers active, every condition constant) is compiled separately from the general
+//     one (pipeline fill / drain, late peers): with one wave per SIMD every scalar branch instruction is on the critical path.
 //   * self-cleaning like the other cluster kernels: the last workgroup out re-zeroes every polled word.
+#include <type_traits>
+
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
 
@@ -52,11 +63,18 @@ __device__ __forceinline__ void mfma_drain(f32x4 (&acc)[NTW]) {
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
 }
 
-// NQ 32-deep k-blocks of LDS activations (16 rows x 32 k each) into registers
+// NQ 32-deep k-blocks of LDS activations (16 rows x 32 k each) into registers; `stride` halves between k-blocks
 template <int NQ>
-__device__ __forceinline__ void load_frags(f32x4 (&a)[NQ], const _Float16* __restrict__ src) {
+__device__ __forceinline__ void load_frags(f32x4 (&a)[NQ], const _Float16* __restrict__ src, int stride) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(src + 32 * q);
+    for (int q = 0; q < NQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(src + stride * q);
+}
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
+// the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes.  M0 is written in the
+// same statement that reads it (the compiler does not preserve it across statements).
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 // acc[t] += W_t (registers) x A over NQ k-blocks
 template <int NTW, int NQ, int NW>
@@ -88,13 +106,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     constexpr int NTW = UPW / 4;            // 16-column MFMA tiles per wave (column = unit * 4 + gate)
     constexpr int GH = H / (4 * UPW);       // members per cluster
     constexpr int SR = 16, NS = 2;          // rows per set, sets per cluster
-    constexpr int SH = H + 16, SX = KX + 16; // LDS row strides in halves (16-byte multiples, conflict-free b128 reads)
+    constexpr int SX = KX + 16;             // LDS row stride of the x slabs in halves (16-byte multiple, conflict-free b128 reads)
     constexpr int QX = KX / 32, QH = H / 32;
     constexpr int NB0 = QX + QH, NB1 = 2 * QH;
     constexpr int NFL = 4 * GH;             // flags per (cluster, set): one per member wave
     constexpr int PIECES = L * GH * 4 * SR; // 16-byte pieces of one set's gathered slices
-    constexpr int NGV = PIECES / 256;
-    static_assert(GH == 8 && L == 2 && PIECES % 256 == 0, "built for 8-member clusters of the 2 x 256 models");
+    constexpr int NDMA = PIECES / 256;      // LDS-DMA instructions per wave and gather
+    constexpr int HL = GH * 4 * SR * 8;     // halves of one (set, layer) block: [member][wave][row][8 units]
+    static_assert(GH == 8 && QH == GH && L == 2 && PIECES % 256 == 0, "built for 8-member clusters of the 2 x 256 models");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -113,8 +132,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
 #endif
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
-    _Float16* hbuf = smem16;                              // [NS][L][SR][SH]   gathered h of the set's last phase
-    _Float16* xin = hbuf + NS * L * SR * SH;              // [NS][2 parity][SR][SX]
+    _Float16* hbuf = smem16;                              // [NS][L][member][wave][row][8]: gathered h of the set's last phase, in
+                                                          //  the exchange order = MFMA fragment order (k-block = member, k-group = wave)
+    _Float16* xin = hbuf + NS * L * HL;                   // [NS][2 parity][SR][SX]
     _Float16* own = xin + NS * 2 * SR * SX;               // [wave 4][L][SR][UPW]  fresh slice of this wave (wave-private)
     f32x4* bias_s = reinterpret_cast<f32x4*>(own + 4 * L * SR * UPW);   // [wave 4][L][NTW][lane 64]: the accumulators' start values
     int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * NTW * 64);   // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
@@ -171,17 +191,25 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
             bias_s[((wave * L + l) * NTW + t) * 64 + lane] = bv;
         }
     // per-set register state is kept as "this section's set" / "the other set" and swapped at the end of every section,
-    // so the section body exists once (no unrolling over the sets, no dynamically indexed register arrays)
+    // so the section body exists once per kind (no unrolling over the sets, no dynamically indexed register arrays)
     float cst[L][NTW], cst_o[L][NTW];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) cst[l][t] = cst_o[l][t] = 0.0f;
 
+    // exchange buffer: descriptor for the compiler's loads / stores, and the same words as a scalar tuple for the DMA asm
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    u32x4 hx_desc;
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[3] = 0x00020000u;
     unsigned* const flags_of = p.xflags + (size_t)cluster * NS * NFL;      // [set][member*4 + wave] epoch = phases published
     constexpr unsigned SET_BYTES = PIECES * 16;                            // one (set, parity): [layer][member][wave][row][8 halves]
     auto hx_base = [&](int s, int par) -> unsigned { return (unsigned)((((size_t)cluster * NS + s) * 2 + par) * SET_BYTES); };
+    const unsigned hbuf_lds = (unsigned)reinterpret_cast<unsigned long long>(hbuf);     // LDS byte address (low half of the flat one)
 
     // ---- x staging (f64 z-score, then binary16); thread owns NE elements of a set's [SR][KX] step slab ------------
     constexpr int NE = (SR * KX) / 256;
@@ -201,12 +229,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<float*>(((unsigned long long)x_hi << 32) | x_lo), 0, x_bytes, 0x00020000);
     const unsigned x_rowbytes = bcast_x ? 0u : (unsigned)(T * I * sizeof(float));
+    unsigned x_off[NE];                      // byte offset of this thread's elements inside set 0 (set 1: + SR rows)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) x_off[e] = (unsigned)((tid + 256 * e) / KX) * x_rowbytes + (unsigned)(xk * sizeof(float));
     auto fetch_x = [&](float (&dst)[NE], int s, int t) {
         const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int row = s * SR + (tid + 256 * e) / KX;
-            const unsigned off = (xk < I && row < rows_here) ? (unsigned)row * x_rowbytes + (unsigned)(xk * sizeof(float)) : 0x80000000u;
+            const unsigned off = (xk < I && row < rows_here) ? x_off[e] + (unsigned)(s * SR) * x_rowbytes : 0x80000000u;
             dst[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (unsigned)(slot * I * sizeof(float)), 0));
         }
     };
@@ -273,22 +304,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    // piece q = tid + 256 k of a set: byte q * 16 of the (set, parity) block = (layer, member, wave, row) in that order
-    auto issue_gather = [&](int s, int par, f32x4 (&gv)[NGV]) {
-        const unsigned base = hx_base(s, par);
+    // a set's 16 KB straight from the exchange buffer into its LDS block: wave w copies KiB w, w + 4, w + 8, w + 12
+    const unsigned dma_voff = (unsigned)(lane * 16);
+    auto issue_gather = [&](int s, int par) {
+        const unsigned src = hx_base(s, par) + (unsigned)(wave * 1024), dst = hbuf_lds + (unsigned)(s * L * HL * 2 + wave * 1024);
 #pragma unroll
-        for (int k = 0; k < NGV; ++k)
-            gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, base + (unsigned)((tid + 256 * k) * 16), 0, 16 /* sc1 */));
+        for (int k = 0; k < NDMA; ++k) dma_1k(dst + (unsigned)(k * 4096), dma_voff, hx_desc, src + (unsigned)(k * 4096));
     };
-    auto commit_gather = [&](int s, const f32x4 (&gv)[NGV]) {
-#pragma unroll
-        for (int k = 0; k < NGV; ++k) {
-            const int q = tid + 256 * k;
-            const int row = q & 15, wv = (q >> 4) & 3, mem = (q >> 6) & 7, l = q >> 9;
-            *reinterpret_cast<f32x4*>(hbuf + ((s * L + l) * SR + row) * SH + mem * 32 + wv * 8) = gv[k];
-        }
-    };
-    // the flag a wave owes for the slices it stored last (other set): raised once those stores have drained
+    // the flag a wave owes for the slices it stored last: raised once that store has drained
     int pend_set = -1;
     unsigned pend_epoch = 0u;
     auto raise_pending = [&]() {              // caller has waited vmcnt(0)
@@ -300,6 +323,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         }
         pend_set = -1;
     };
+    // workgroup barrier that waits for this wave's LDS traffic only (not for the publish store or a DMA in flight)
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     const int P = T + L - 1;
 #ifdef APE_CLUSTER_STAMPS
@@ -307,129 +332,142 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // Section (ph, s) = row set s in phase ph.  What a section needs from the exchange -- the slices its set published a
-    // phase ago -- is PREFETCHED by the section in front of it (the other set's): that section looks at the flags
-    // after its layer-1 MFMAs (one load per lane, in flight under the gate math) and, if every peer wave has
-    // published, puts the whole gather into flight before its own publish store; the needing section then only waits for
-    // loads that have had a section's tail to land, side by side with the drain of that publish store, whose flag goes up
-    // right after the same wait.  If a peer was late the section falls back to the blocking form.
+    // Section (ph, s) = row set s in phase ph; the sets alternate.  Per wave the vector-memory queue of a steady-state
+    // section is, in issue order:  [publish store of the section in front]  x fetch (2 loads)  flag look (1 load)
+    // gather DMA of the NEXT section's set (4)  publish store (1) -- so at the top of a section everything but the
+    // youngest entry, the publish store, is waited for (`vmcnt(1)`: the set's slices are in LDS), and that store's flag
+    // goes up after the layer-0 MFMAs, when it has long drained (`vmcnt(0)` with nothing else in the queue).
     bool prefetched = false;
-    f32x4 gv[NGV];
-#pragma unroll 1
-    for (int sec = 0; sec < NS * (P + 1); ++sec) {     // phase P: only the final gather of both sets (for the head)
-        {
-            const int ph = sec >> 1, s = sec & 1;
-            // ---- S0: bring in what this set's last phase published (nothing before phase 0) ----------------------------------
-            if (ph > 0 && !prefetched && !d_noex) {               // first phases, a late peer, the final gathers
+    auto section = [&](auto steady_tag, const int ph, const int s) -> bool {
+        constexpr bool ST = decltype(steady_tag)::value;          // steady state: 2 <= ph <= T - 3, every condition below holds
+        // ---- S0: this set's slices of the last phase into LDS ------------------------------------------------------------
+        if (ST || ph > 0) {
+            if (!prefetched && !d_noex) {                         // first phases, a late peer, the final gathers
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_pending();
                 wait_flags(s, (unsigned)ph);
                 V2_STAMP(0);                                      // 0: blocking flag poll
-                issue_gather(s, (ph - 1) & 1, gv);
+                issue_gather(s, (ph - 1) & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the prefetched copy; only the publish store is younger
             }
-            // the gather (prefetched a section's tail ago, or just issued) and the other set's publish store, which in the
-            // steady state was issued right behind the prefetch: both have been in flight side by side
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V2_STAMP(1);                                          // 1: wait for the gather / the store drain
-            if (!d_noex) raise_pending();                         // the flag owed for that store
-            if (ph > 0 && !d_noex) commit_gather(s, gv);
-            prefetched = false;
-            V2_STAMP(2);                                          // 2: LDS commit
-            __syncthreads();
-            V2_STAMP(3);                                          // 3: barrier
-            if (ctl[0] != 0) return;
-            if (ph == P) continue;                                // gather-only tail (no per-set register state is needed any more)
-            // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
-            // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
-            f32x4 ax[QX], a0r[QH], a1i[QH], a1r[QH];
-            if (ph < T) {
-                load_frags<QX>(ax, xin + ((s * 2 + (ph & 1)) * SR + r) * SX + 8 * g);
-                if (ph > 0) load_frags<QH>(a0r, hbuf + ((s * L + 0) * SR + r) * SH + 8 * g);
-            }
-            V2_STAMP(7);                                          // 7: fragment read issue
-            // the next section: the other set, in this phase (s = 0) or the next (s = 1); it needs epoch `want`
-            const int sn = s ^ 1, phn = ph + s;
-            const unsigned want = (unsigned)phn;
-            unsigned peek = want;
-
-            // ---- every active layer of this set, back to back (layer l works on step t = ph - l) -------------------------
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int t = ph - l;
-                const bool active = t >= 0 && t < T;              // uniform over the grid
-                f32x4 acc[NTW];
-                if (active) {
-#pragma unroll
-                    for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias_s[((wave * L + l) * NTW + tt) * 64 + lane];
-                    if (d_nomfma) {
-                    } else if (l == 0) {
-                        span<NTW, QX, NB0>(acc, ax, w0, 0);
-                        if (t > 0) span<NTW, QH, NB0>(acc, a0r, w0, QX);
-                    } else {
-                        span<NTW, QH, NB1>(acc, a1i, w1, 0);
-                        if (t > 0) span<NTW, QH, NB1>(acc, a1r, w1, QH);
-                    }
-                    mfma_drain<NTW>(acc);
-                }
-                V2_STAMP(4);                                      // 4: MFMA spans (incl. the wait for the LDS reads feeding them)
-                if (l == 0) {
-                    if (ph >= 1) load_frags<QH>(a1i, hbuf + ((s * L + 0) * SR + r) * SH + 8 * g);
-                    if (ph > 1) load_frags<QH>(a1r, hbuf + ((s * L + 1) * SR + r) * SH + 8 * g);
-                    // x of the next step: registers -> the other parity buffer (its readers are two sections back), next fetch
-                    if (ph + 1 < T && !d_nox) {
-                        stage_x(xr, s, ph + 1);
-                        if (ph + 2 < T) fetch_x(xr, s, ph + 2);
-                    }
-                } else if (want > 0u && lane < NFL && !d_noex) {
-                    // [B0] look at the flags the next section needs; the load flies under the gate math below
-                    peek = __hip_atomic_load(flags_of + sn * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                V2_STAMP(2);
-                if (!active) continue;
-                // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit tt*4 + g, batch row r)
-#pragma unroll
-                for (int tt = 0; tt < NTW; ++tt) {
-                    float hval;
-                    if (d_noact) {
-                        const float c = acc[tt][1] * cst[l][tt] + acc[tt][0] * acc[tt][2];
-                        cst[l][tt] = c;
-                        hval = acc[tt][3] * c;
-                    } else {
-                        const float iv = gate_act(acc[tt][0], false), fv = gate_act(acc[tt][1], false);
-                        const float gg = gate_act(acc[tt][2], true), ov = gate_act(acc[tt][3], false);
-                        const float c = fv * cst[l][tt] + iv * gg;
-                        cst[l][tt] = c;
-                        hval = ov * gate_act(c, true);
-                    }
-                    own[((wave * L + l) * SR + r) * UPW + tt * 4 + g] = (_Float16)hval;
-                }
-                V2_STAMP(5);                                      // 5: gates + cell update + own-slice staging
-            }
-            // [B] every peer wave has published what the next section needs: its whole gather goes into flight now
-            if (want > 0u && !d_noex && __all((int)(peek >= want))) {
-                issue_gather(sn, (phn - 1) & 1, gv);
-                prefetched = true;
-            }
-            // ---- publish: lanes 0..15 send layer 0's row, lanes 16..31 layer 1's (this wave's 8 units = 16 bytes each) ----
-            //      (exactly ONE store instruction per wave: the counted wait at the top of the next section relies on it)
-            {
-                const int l = lane >> 4, row = lane & 15, t = ph - l;
-                const bool live = lane < 16 * L && t >= 0 && t < T;
-                const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
-                // dead lanes aim outside the buffer descriptor: the store instruction is issued by every wave, writes nothing there
-                const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16) : 0x80000000u;
-                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
-                pend_set = s;
-                pend_epoch = (unsigned)(ph + 1);
-            }
-            V2_STAMP(6);                                          // 6: publish (LDS read + store issue)
-            // the other set is next: swap the per-set register state
-#pragma unroll
-            for (int l = 0; l < L; ++l)
-#pragma unroll
-                for (int tt = 0; tt < NTW; ++tt) { const float tmp = cst[l][tt]; cst[l][tt] = cst_o[l][tt]; cst_o[l][tt] = tmp; }
-#pragma unroll
-            for (int e = 0; e < NE; ++e) { const float tmp = xr[e]; xr[e] = xr_o[e]; xr_o[e] = tmp; }
         }
+        prefetched = false;
+        V2_STAMP(1);                                              // 1: wait for the gather
+        bar();
+        V2_STAMP(3);                                              // 3: barrier
+        if (ph == P) {                                            // gather-only tail (no per-set register state is needed any more)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            raise_pending();
+            return ctl[0] == 0;
+        }
+        const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
+        // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
+        // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
+        f32x4 ax[QX], a0r[QH], a1i[QH], a1r[QH];
+        const _Float16* hset = hbuf + s * L * HL + g * 128 + r * 8;
+        if (ST || ph < T) {
+            load_frags<QX>(ax, xin + ((s * 2 + (ph & 1)) * SR + r) * SX + 8 * g, 32);
+            if (ST || ph > 0) load_frags<QH>(a0r, hset, 512);
+        }
+        V2_STAMP(7);                                              // 7: fragment read issue
+        // the next section: the other set, in this phase (s = 0) or the next (s = 1); it needs epoch `want`
+        const int sn = s ^ 1, phn = ph + s;
+        const unsigned want = (unsigned)phn;
+        unsigned peek = want;
+
+        // ---- every active layer of this set, back to back (layer l works on step t = ph - l) -----------------------------
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = ph - l;
+            const bool active = ST || (t >= 0 && t < T);          // uniform over the grid
+            f32x4 acc[NTW];
+            if (active) {
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias_s[((wave * L + l) * NTW + tt) * 64 + lane];
+                if (d_nomfma) {
+                } else if (l == 0) {
+                    span<NTW, QX, NB0>(acc, ax, w0, 0);
+                    if (ST || t > 0) span<NTW, QH, NB0>(acc, a0r, w0, QX);
+                } else {
+                    span<NTW, QH, NB1>(acc, a1i, w1, 0);
+                    if (ST || t > 0) span<NTW, QH, NB1>(acc, a1r, w1, QH);
+                }
+                mfma_drain<NTW>(acc);
+            }
+            V2_STAMP(4);                                          // 4: MFMA spans (incl. the wait for the LDS reads feeding them)
+            if (l == 0) {
+                if (ST || ph >= 1) load_frags<QH>(a1i, hset, 512);
+                if (ST || ph > 1) load_frags<QH>(a1r, hset + HL, 512);
+                // [A] the flag owed for the OTHER set's publish store (issued a whole layer-0 span ago: drained; nothing
+                //     else is in the queue)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!d_noex) raise_pending();
+                // x of the next step: registers -> the other parity buffer (its readers are two sections back), next fetch
+                if ((ST || ph + 1 < T) && !d_nox) {
+                    stage_x(xr, s, ph + 1);
+                    if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
+                }
+            } else if ((ST || want > 0u) && lane < NFL && !d_noex) {
+                // [B0] look at the flags the next section needs; the load flies under the gate math below
+                peek = __hip_atomic_load(flags_of + sn * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            V2_STAMP(2);
+            if (!active) continue;
+            // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit tt*4 + g, batch row r)
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) {
+                float hval;
+                if (d_noact) {
+                    const float c = acc[tt][1] * cst[l][tt] + acc[tt][0] * acc[tt][2];
+                    cst[l][tt] = c;
+                    hval = acc[tt][3] * c;
+                } else {
+                    const float iv = gate_act(acc[tt][0], false), fv = gate_act(acc[tt][1], false);
+                    const float gg = gate_act(acc[tt][2], true), ov = gate_act(acc[tt][3], false);
+                    const float c = fv * cst[l][tt] + iv * gg;
+                    cst[l][tt] = c;
+                    hval = ov * gate_act(c, true);
+                }
+                own[((wave * L + l) * SR + r) * UPW + tt * 4 + g] = (_Float16)hval;
+            }
+            V2_STAMP(5);                                          // 5: gates + cell update + own-slice staging
+        }
+        if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
+        // [B] every peer wave has published what the next section needs: its whole gather goes into flight now
+        if ((ST || want > 0u) && !d_noex && __all((int)(peek >= want))) {
+            issue_gather(sn, (phn - 1) & 1);
+            prefetched = true;
+        }
+        // ---- publish: lanes 0..15 send layer 0's row, lanes 16..31 layer 1's (this wave's 8 units = 16 bytes each) ----
+        //      (exactly ONE store instruction per wave: the counted wait at the top of the next section relies on it)
+        {
+            const int l = lane >> 4, row = lane & 15, t = ph - l;
+            const bool live = lane < 16 * L && (ST || (t >= 0 && t < T));
+            const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
+            // dead lanes aim outside the buffer descriptor: the store instruction is issued by every wave, writes nothing there
+            const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16) : 0x80000000u;
+            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            pend_set = s;
+            pend_epoch = (unsigned)(ph + 1);
+        }
+        V2_STAMP(6);                                              // 6: publish (LDS read + store issue)
+        // the other set is next: swap the per-set register state
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) { const float tmp = cst[l][tt]; cst[l][tt] = cst_o[l][tt]; cst_o[l][tt] = tmp; }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const float tmp = xr[e]; xr[e] = xr_o[e]; xr_o[e] = tmp; }
+        return true;
+    };
+#pragma unroll 1
+    for (int sec = 0; sec < NS * (P + 1); ++sec) {     // phase P: only the final gather of both sets (for the head)
+        const int ph = sec >> 1, s = sec & 1;
+        const bool ok = (ph >= 2 && ph <= T - 3) ? section(std::true_type{}, ph, s) : section(std::false_type{}, ph, s);
+        if (!ok) return;
     }
 #ifdef APE_CLUSTER_STAMPS
     if (p.dbg_wg != nullptr && lane == 0 && wave == 0 && cluster == 0 && member == 0) {
@@ -449,10 +487,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
             const int row = member * RPM + rr;                    // 0..31: set = row / 16
             const int b = row0 + row;
             if (b < p.B) {
-                const _Float16* hv = hbuf + (((row >> 4) * L + (L - 1)) * SR + (row & 15)) * SH;
+                const _Float16* hv = hbuf + ((row >> 4) * L + (L - 1)) * HL + (row & 15) * 8;    // unit k at [k / 8][row][k % 8]
                 const float* wv = p.w_out + (size_t)o * H;
                 float sacc = 0.0f;
-                for (int k = 0; k < H; ++k) sacc = fmaf((float)hv[k], wv[k], sacc);
+                for (int k = 0; k < H; ++k) sacc = fmaf((float)hv[(k >> 3) * 128 + (k & 7)], wv[k], sacc);
                 p.y[(size_t)b * O + o] = sacc + p.b_out[o];
             }
         }
@@ -473,7 +511,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
 
 template <int H, int L, int KX>
 constexpr size_t smem_bytes() {
-    return ((size_t)2 * L * 16 * (H + 16) + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * 8) * sizeof(_Float16) +
+    return ((size_t)2 * L * 16 * H + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * 8) * sizeof(_Float16) +
            (size_t)4 * L * 2 * 64 * 16 + 16;
 }
 
