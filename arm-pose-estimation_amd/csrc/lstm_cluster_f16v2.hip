@@ -318,8 +318,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         if (pend_set < 0) return;
         if (lane == 0) {
             unsigned* f = flags_of + pend_set * NFL + member * 4 + wave;
-            if (in_l2) *reinterpret_cast<volatile unsigned*>(f) = pend_epoch;           // plain: stays in the XCD's L2
-            else __hip_atomic_store(f, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // always the agent-scope (sc1) store, also when the payload stays in the XCD's L2: a plain flag store takes
+            // its time to leave the CU, and the peers look at these words early to prefetch (measured: 252 vs 289 us)
+            __hip_atomic_store(f, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         pend_set = -1;
     };
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     // Section (ph, s) = row set s in phase ph; the sets alternate.  Per wave the vector-memory queue of a steady-state
     // section is, in issue order:  [publish store of the section in front]  x fetch (2 loads)  flag look (1 load)
     // gather DMA of the NEXT section's set (4)  publish store (1) -- so at the top of a section everything but the
-    // youngest entry, the publish store, is waited for (`vmcnt(1)`: the set's slices are in LDS), and that store's flag
-    // goes up after the layer-0 MFMAs, when it has long drained (`vmcnt(0)` with nothing else in the queue).
+    // youngest entry, the publish store, is waited for (`vmcnt(1)`: the set's slices are in LDS); behind the barrier the
+    // store itself is waited for and its flag goes up.
     bool prefetched = false;
     auto section = [&](auto steady_tag, const int ph, const int s) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 2 <= ph <= T - 3, every condition below holds
@@ -357,11 +358,17 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         V2_STAMP(1);                                              // 1: wait for the gather
         bar();
         V2_STAMP(3);                                              // 3: barrier
-        if (ph == P) {                                            // gather-only tail (no per-set register state is needed any more)
+        if (!ST && ph == P) {                                     // gather-only tail (no per-set register state is needed any more)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             raise_pending();
             return ctl[0] == 0;
         }
+        // the flag owed for the OTHER set's publish store, issued at the end of the section in front: right behind the
+        // barrier, so that the peers' look at these words (after THEIR layer-1 MFMAs) finds it.  Measured on configs[4]:
+        // here 244 us; after the layer-0 MFMAs (the store certainly drained, nothing waits) 252 us; after layer 0's gate
+        // math 292 us -- the later the flag, the more gathers miss their prefetch and fall back to the blocking form
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!d_noex) raise_pending();
         const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
         // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
         // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
@@ -400,10 +407,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
             if (l == 0) {
                 if (ST || ph >= 1) load_frags<QH>(a1i, hset, 512);
                 if (ST || ph > 1) load_frags<QH>(a1r, hset + HL, 512);
-                // [A] the flag owed for the OTHER set's publish store (issued a whole layer-0 span ago: drained; nothing
-                //     else is in the queue)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!d_noex) raise_pending();
                 // x of the next step: registers -> the other parity buffer (its readers are two sections back), next fetch
                 if ((ST || ph + 1 < T) && !d_nox) {
                     stage_x(xr, s, ph + 1);
@@ -414,10 +417,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
                 peek = __hip_atomic_load(flags_of + sn * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             V2_STAMP(2);
-            if (!active) continue;
             // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit tt*4 + g, batch row r)
 #pragma unroll
-            for (int tt = 0; tt < NTW; ++tt) {
+            for (int tt = 0; active && tt < NTW; ++tt) {
                 float hval;
                 if (d_noact) {
                     const float c = acc[tt][1] * cst[l][tt] + acc[tt][0] * acc[tt][2];
