@@ -147,6 +147,9 @@ struct ape_model {
     int kernel_choice = APE_KERNEL_AUTO;
     float* wcl[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
+    float* wcl32[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};  // 32x32x2 fragments of the second-generation f32 cluster kernel
+    bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
+    bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
     int precision = APE_PRECISION_F32;
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
     bool f16_v2 = true;             // fp16 precision: batches > 256 rows on the row-set-pipelined kernel (lstm_cluster_f16v2.hip)
@@ -323,6 +326,12 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
+        if (ape_cluster32_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0) {
+            for (int l = 0; l < L && e == hipSuccess; ++l)
+                e = plan((void**)&m->wcl32[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
+            if (e == hipSuccess) e = ape_prepare_lstm_cluster32(H, L, m->KX);
+            m->c32_ok = true;
+        }
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "cluster kernel set-up failed: %s", hipGetErrorString(e));
@@ -466,6 +475,26 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                             }
                         }
             HIP_TRY(hipMemcpy(m->wcl16[l], ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        }
+        if (m->c32_ok) {
+            // second-generation f32 cluster kernel (v_mfma_f32_32x32x2_f32, weights = A operand): 8 members x 4 waves, a wave owns
+            // 8 units = 32 columns ordered gate * 8 + unit.  [member][wave][i / 4][lane][i % 4] with register i = 4 kb + j of
+            // lane (column m = lane & 31, half hh = lane >> 5) = Wcat[gate(m) * H + member*32 + wave*8 + (m & 7)][8 kb + 4 hh + j]
+            const int NW = (KXl + H) / 2;                   // registers per lane: 32 columns x K / 64 lanes
+            std::vector<float> pc((size_t)8 * 4 * NW * 64);
+            for (int mem = 0; mem < 8; ++mem)
+                for (int w = 0; w < 4; ++w)
+                    for (int i = 0; i < NW; ++i)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int mcol = lane & 31, hh = lane >> 5;
+                            const int row = (mcol >> 3) * H + mem * 32 + w * 8 + (mcol & 7);
+                            const int k = 8 * (i / 4) + 4 * hh + (i % 4);
+                            float v;
+                            if (k < KXl) v = (k < in_l) ? w_ih[(size_t)row * in_l + k] : 0.0f;
+                            else v = w_hh[(size_t)row * H + (k - KXl)];
+                            pc[((((size_t)(mem * 4 + w) * (NW / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] = v;
+                        }
+            HIP_TRY(hipMemcpy(m->wcl32[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         std::vector<float> bsum(4 * H);
         for (int i = 0; i < 4 * H; ++i) bsum[i] = b_ih[i] + b_hh[i];
@@ -629,6 +658,30 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop);
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        if (!f16 && !cdrop && !drop && !all_steps && !small && m->c32_ok && m->c32_on && B - n16 > 512) {
+            // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
+            const int rpl2 = 32 * f16v2_capacity(m->n_cus);
+            for (int b0 = n16; b0 < B; b0 += rpl2) {
+                const int nb = (B - b0 < rpl2) ? B - b0 : rpl2;
+                ClusterParams c{};
+                c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
+                c.y = y_dev + (size_t)b0 * m->dims.output_size;
+                for (int l = 0; l < L; ++l) { c.wcl[l] = m->wcl32[l]; c.bias[l] = m->bias[l]; }
+                c.w_out = m->w_out; c.b_out = m->b_out;
+                c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
+                c.xx_r = m->stats + 2 * m->dims.input_size + 2 * m->dims.output_size;
+                c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+                c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+                c.ticket = c.status - 4; c.done = c.status - 3;
+                c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
+                c.flags = flags; c.x_ring = x_ring;
+                c.xcc_slots = m->xcc_slots;
+                c.dbg_wg = m->dbg_wg;
+                hipError_t e = ape_launch_lstm_cluster32(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
+                if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster32 lstm launch failed: %s", hipGetErrorString(e));
+            }
+            return APE_OK;
+        }
         if (f16 && m->f16_v2 && ape_cluster_f16v2_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0 && B > 256) {
             // second-generation fp16 kernel: 8-member clusters x 2 row sets of 16 that take turns (lstm_cluster_f16v2.hip)
             const int rpl2 = 32 * f16v2_capacity(m->n_cus);
@@ -724,8 +777,10 @@ int ape_lstm_forward_hs(ape_model_t* m, const float* x_dev, int32_t B, int32_t T
 
 int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "set_kernel: NULL model");
-    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER)
+    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER && choice != APE_KERNEL_CLUSTER_GEN1)
         return fail(APE_ERR_INVALID_ARG, "set_kernel: unknown choice %d", choice);
+    m->c32_on = choice != APE_KERNEL_CLUSTER_GEN1;
+    if (choice == APE_KERNEL_CLUSTER_GEN1) choice = APE_KERNEL_CLUSTER;
     if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d on a device with %d CUs (a cluster "
                     "needs %d)", m->dims.hidden_size, m->dims.num_layers, m->n_cus, m->dims.hidden_size / 16);
@@ -1110,6 +1165,7 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
         if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false) > B) return m->kernel_name.c_str();
     }
+    if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
     return m->cluster_name.c_str();
 }
 

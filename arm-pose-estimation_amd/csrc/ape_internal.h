@@ -164,6 +164,9 @@ hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, 
 hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
+bool ape_cluster32_supported(int H, int L, int KX);
+hipError_t ape_prepare_lstm_cluster32(int H, int L, int KX);
+hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);
 bool ape_cluster_f16v2_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);

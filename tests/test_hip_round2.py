@@ -275,3 +275,38 @@ def test_fp16_second_generation_kernel(norm_stats, name, B, T):
     e_ref, e_emu, e_gen = (float(np.abs(y2 - v).max()) for v in (y_ref, y_emu, y1))
     print(f"\n[{name} B={B} T={T} fp16 v2] vs f32 oracle {e_ref:.2e}, vs f16-emulating oracle {e_emu:.2e}, vs gen-1 kernel {e_gen:.2e}")
     assert e_ref < 5e-3 and e_emu < 3e-4 and e_gen < 3e-4
+
+
+# ---------------- f32 cluster kernel, second generation (32x32x2 MFMA chain, 8-member clusters) ----------------------
+@pytest.mark.parametrize("name,B,T", [("pocket", 1024, 64), ("watch", 700, 8), ("pocket", 513, 3), ("watch", 2081, 6),
+                                      ("pocket", 1024, 1), ("pocket", 1024, 2)])
+def test_f32_second_generation_cluster_kernel(norm_stats, name, B, T):
+    """lstm_cluster32.hip (eval-mode batches above 512 rows of the 2 x 256 models) against the float32 oracle (module
+    tolerance 1e-6), the first-generation cluster kernel (other summation order only), ragged and multi-launch batches,
+    the forced any-placement (write-through) exchange (same bits as the in-L2 form) and run-to-run determinism."""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats[name]
+    model, sd, cfg = make_model(name, 3, st)
+    x = _synthetic_windows(st, B, T, cfg["I"], 11)
+    xd = torch.from_numpy(x).cuda()
+    xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    model.set_kernel("cluster")
+    assert model.kernel_name(B, T) == "ape_lstm_cluster32<256, 2, 32>"
+    y2 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    model.check()
+    y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    assert np.array_equal(y2, y2b)
+    y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | 0x08000000,
+                                           None, 0.0, 0, C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
+    torch.cuda.synchronize()
+    model.check()
+    assert np.array_equal(y_wt.cpu().numpy(), y2)
+    model.set_kernel("cluster_gen1")
+    assert "ape_lstm_cluster<" in model.kernel_name(B, T)
+    y1 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    model.set_kernel("auto")
+    y_ref = orc.lstm_forward(sd, xn)[:, -1]
+    e_ref, e_gen = float(np.abs(y2 - y_ref).max()), float(np.abs(y2 - y1).max())
+    print(f"\n[{name} B={B} T={T} cluster32] vs oracle {e_ref:.2e}, vs gen-1 kernel {e_gen:.2e}")
+    assert e_ref < 1e-6 and e_gen < 1e-6

@@ -17,7 +17,7 @@ m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], device=0); m.l
 x = torch.randn(B, T, cfg["I"], device="cuda"); y = torch.empty(B, cfg["O"], device="cuda")
 lib = _hip.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 if os.environ.get('APE_PRECISION') == 'f16': m.set_precision('f16')
-lib.ape_model_set_kernel(m.handle, {'auto': 0, 'tile16': 1, 'cluster': 2}[os.environ.get('APE_KERNEL', 'cluster')])
+lib.ape_model_set_kernel(m.handle, {'auto': 0, 'tile16': 1, 'cluster': 2, 'cluster_gen1': 3}[os.environ.get('APE_KERNEL', 'cluster')])
 def run(n):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -32,4 +32,4 @@ ref = orc.lstm_forward(sd, x.cpu().numpy()[pick])[:, -1]
 err = float(np.abs(y.cpu().numpy()[pick] - ref).max())
 m.check()
 flop = m.flops_per_window(T) * B
-print(f"{os.environ.get('APE_HIP_LIB', 'default'):60s} {name} B={B} T={T}: median {np.median(v):8.1f} us  min {min(v):8.1f}  {flop / np.median(v) / 1e6:6.1f} TFLOP/s  max|dy| {err:.1e}")
+print(f"{os.environ.get('APE_HIP_LIB', 'default'):20s} {m.kernel_name(B, T):34s} {name} B={B} T={T}: median {np.median(v):8.1f} us  min {min(v):8.1f}  {flop / np.median(v) / 1e6:6.1f} TFLOP/s  max|dy| {err:.1e}")
