@@ -12,14 +12,28 @@
 //     quad broadcasts, the cell update is a handful of VALU ops;
 //   * ALL layers of a phase are computed back to back and published together, so there is ONE exchange
 //     round trip per phase (layer l works on step p - l, as in the big kernel) instead of one per layer.
+//   * that round trip has ONE workgroup barrier in it (round 2; it had three): every wave sends the 16-byte pieces of its own
+//     four units straight from a wave-private LDS patch, drains and raises ITS flag (an agent-scope store also when the
+//     payload stays in the XCD's L2: a plain flag store takes its time to leave the CU); every wave polls all 4 GH flags
+//     itself (one load per lane) and then copies one window row of every layer global -> LDS with one LDS-DMA instruction
+//     per layer (the exchange order [row][member][wave][4 units] is the LDS order of h), and only then the barrier.
 // Same arithmetic as the other kernels up to float32 summation order.
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int MR = 4;                      // rows per cluster (row = lane group)
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
+// the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes.  M0 is written in the
+// same statement that reads it (the compiler does not preserve it across statements).
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 
 __device__ __forceinline__ float gate_act(float v, bool is_tanh) {
     const float e = __builtin_amdgcn_exp2f((is_tanh ? -2.885390081777927f : -1.4426950408889634f) * v);
@@ -34,29 +48,58 @@ __device__ __forceinline__ float quad_bcast(float x) {
                                                                  K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, false));
 }
 
-// part[m] += sum over this lane's k-slice of w * act[m]; NQ 16-deep blocks starting at weight register w0
+// part[m] += sum over this lane's k-slice of w * act[m]; NQ 16-deep blocks starting at weight register w0.
+// The activation fragments of up to 16 k-blocks are fetched up front, then multiplied: one dependent LDS read per k-block
+// costs its whole latency at one wave per SIMD (measured: 1.13 us of a 3.3 us phase was this loop).
 template <int NR, int NQ, int NW>
-__device__ __forceinline__ void gemv_span(float (&part)[NR], const float* __restrict__ src, int row_stride,
+__device__ __forceinline__ void gemv_span(f32x4 (&part)[NR], const float* __restrict__ src, int row_stride,
                                           const float (&w)[NW], int w0) {
+    // k-blocks per chunk: CH * NR fragments (4 registers each) in flight.  The weights of a VALU GEMV must sit in
+    // ARCHITECTURAL registers (200 of the 256): a larger chunk pushes some of them into the accumulator file and every
+    // phase pays a v_accvgpr_read per weight
+    constexpr int CH = (NR == 1) ? 8 : ((NR == 2) ? 4 : 2);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q0 = 0; q0 < NQ; q0 += CH) {
+        f32x4 a[CH][NR];
 #pragma unroll
-        for (int m = 0; m < NR; ++m) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + m * row_stride + 16 * q);
+        for (int q = 0; q < CH; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[m] = fmaf(a[j], w[w0 + 4 * q + j], part[m]);
-        }
+            for (int m = 0; m < NR; ++m)
+                if (q0 + q < NQ) a[q][m] = *reinterpret_cast<const f32x4*>(src + m * row_stride + 16 * (q0 + q));
+        // four independent accumulation chains per row (one per k of a quad): a single chain of 200+ dependent FMAs runs at
+        // the FMA's dependent latency, not at its issue rate
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+#pragma unroll
+            for (int m = 0; m < NR; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q0 + q < NQ) part[m][j] = fmaf(a[q][m][j], w[w0 + 4 * (q0 + q) + j], part[m][j]);
     }
 }
+
+// Diagnostic build (make diag: -DAPE_CLUSTER_STAMPS): shader-cycle sums per part of member 0's wave 0, written to the
+// model's debug words (memory nothing else reads).  The shipped library has none of this code.
+#ifdef APE_CLUSTER_STAMPS
+#define SM_STAMP(k)                                                       \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        st_acc[k] += now_ - st_t0;                                        \
+        st_t0 = now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define SM_STAMP(k) do {} while (0)
+#endif
 
 template <int H, int L, int KX, int NR>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterParams p) {
     constexpr int GH = H / 16;
-    constexpr int SH = H + 8, SX = KX + 8, SO = 20;
+    constexpr int SH = H, SX = KX + 8;       // h rows unpadded: a row (H floats = 1 KiB at H = 256) is what one LDS-DMA instruction delivers
     constexpr int QX = KX / 16, QH = H / 16;
     constexpr int NW0 = (KX + H) / 4, NW1 = (2 * H) / 4;
-    constexpr int PIECES = GH * MR * 4;            // 16-byte pieces of one layer's gathered slices (<= 256)
-    static_assert(PIECES <= 256 && NR <= MR, "one gather piece per thread");
+    static_assert(NR <= MR && (H == 128 || H == 256), "a window row of h = one or half an LDS-DMA instruction");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -70,8 +113,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                            // [L][MR][SH]
     float* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
-    float* own = xin + 2 * MR * SX;                // [L][MR][SO]
-    int* ctl = reinterpret_cast<int*>(own + L * MR * SO);
+    float* own = xin + 2 * MR * SX;                // [wave 4][L][MR][4]  fresh slice of this wave (wave-private)
+    int* ctl = reinterpret_cast<int*>(own + 4 * L * MR * 4);
     // Membership is fixed by the block index: the launch has 8 x GH workgroups and only every eighth one takes part
     // (the others leave at once).  Under the placement observed on this hardware -- blocks are dealt round-robin over
     // the 8 XCDs -- those GH workgroups share ONE XCD, hence one L2, and the exchange can stay inside it: plain stores
@@ -81,6 +124,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     // weights are in, and only if they agree is the in-L2 form used; otherwise the write-through form that is valid for any placement.  One cluster, one launch: a member
     // that is dispatched late delays the launch, it cannot deadlock it.
     if (blockIdx.x % 8 != 0) return;
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int cluster = 0, member = blockIdx.x / 8;
     const int row0 = 0;
     unsigned my_xcc;
@@ -127,6 +175,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             }
         }
     }
+    // head weights of this thread (16 lanes per target, H / 16 consecutive k each): requested in the last phase, under its exchange
+    const int hw_o = tid >> 4, hw_part = tid & 15;
+    const bool hw_live = member < MR && hw_o < O;
+    f32x4 hw[H / 64];
+    float hw_b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < H / 64; ++i) hw[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float bias_r[L], cst[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -135,23 +190,43 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     }
 
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
-    unsigned* const myflag = p.xflags + (size_t)cluster * L * GH;       // one epoch word per member (all layers at once)
-    constexpr unsigned SET_BYTES = GH * MR * 16 * sizeof(float);        // one (layer, parity)
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    u32x4 hx_desc;                                 // the same descriptor as a scalar tuple for the DMA asm
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[3] = 0x00020000u;
+    constexpr int NFL = 4 * GH;                    // one epoch word per member WAVE (all layers at once)
+    unsigned* const myflag = p.xflags + (size_t)cluster * NFL;
+    constexpr unsigned ROW_BYTES = H * sizeof(float);                   // [row][member][wave][4 units]: a window row of one layer
+    constexpr unsigned SET_BYTES = MR * ROW_BYTES;                      // one (layer, parity)
     auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SET_BYTES); };
+    const unsigned hbuf_lds = (unsigned)reinterpret_cast<unsigned long long>(hbuf);
 
-    auto stage_x = [&](int t) {                    // x_t: f64 z-score, cast f32 (estimator.py:103-104)
+    // x_t: f64 z-score, cast f32 (estimator.py:103-104) -- (x - m) / s correctly rounded via the host-rounded reciprocal
+    // and one residual step (bit-identical to the division, as in lstm_cluster.hip); fetched a phase ahead
+    const int xrow = tid / KX, xk = tid - xrow * KX;
+    const bool x_live = tid < MR * KX && xk < I && row0 + xrow < p.B;
+    const double x_mean = (normalize && x_live) ? p.xx_m[xk] : 0.0;
+    const double x_std = (normalize && x_live) ? p.xx_s[xk] : 1.0;
+    const double x_rstd = (normalize && x_live) ? p.xx_r[xk] : 1.0;
+    const float* const x_src = p.x + (x_live ? (size_t)(bcast_x ? 0 : row0 + xrow) * T * I + xk : (size_t)0);
+    float xr = 0.0f;
+    auto fetch_x = [&](int t) {
+        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I];
+    };
+    auto stage_x = [&](int t) {
         if (tid < MR * KX) {
-            const int row = tid / KX, k = tid - row * KX;
-            const int b = row0 + row;
-            float v = 0.0f;
-            if (k < I && b < p.B) {
-                v = p.x[((size_t)(bcast_x ? 0 : b) * T + (t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring)) * I + k];
-                if (normalize) v = (float)(((double)v - p.xx_m[k]) / p.xx_s[k]);
-            }
-            xin[((t & 1) * MR + row) * SX + k] = v;
+            const double d = (double)xr - x_mean;
+            const double q0 = d * x_rstd;
+            const double rr = fma(-q0, x_std, d);
+            const double q1 = fma(rr, x_rstd, q0);
+            xin[((t & 1) * MR + xrow) * SX + xk] = x_live ? (float)((rr == rr) ? q1 : q0) : 0.0f;
         }
     };
+    fetch_x(0);
     stage_x(0);
+    if (T > 1) fetch_x(1);
     // ---- do all members really share an XCD?  (their words have been on the way since the weights were requested)
     if (wave == 0) {
         unsigned spins = 0, v = 0u;
@@ -171,22 +246,29 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         const int same = __all((int)((v & 0xFu) == my_xcc));
         if (lane == 0) ctl[3] = same;
     }
-    __syncthreads();
+    // (a barrier that waits for LDS traffic only: the weight loads of the layers above may still be in flight, phase 0 needs
+    //  layer 0's only)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ctl[0] != 0) return;
     // uniform over the cluster: every member read the same GH words
     const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
 
     const int P = T + L - 1;
+    SM_STAMP(0);                                    // 0: prologue (weights into registers, x_0, XCD rendezvous)
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
+        // x of the next step: registers (fetched a phase ago) -> the other xin buffer (its readers finished a phase ago), and
+        // the fetch of the step after it goes out now, under this phase's compute
+        if (ph + 1 < T) stage_x(ph + 1);
+        if (ph + 2 < T) fetch_x(ph + 2);
         // ---- every layer of this phase, back to back (layer l works on step t = ph - l) ----------------------------
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int t = ph - l;
             if (t < 0 || t >= T) continue;         // uniform
-            float part[NR];
+            f32x4 part[NR];
 #pragma unroll
-            for (int m = 0; m < NR; ++m) part[m] = 0.0f;
+            for (int m = 0; m < NR; ++m) part[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             const float* rec_src = hbuf + l * MR * SH + 4 * g;
             if (l == 0) {
                 gemv_span<NR, QX, NW0>(part, xin + (t & 1) * MR * SX + 4 * g, SX, w0, 0);
@@ -209,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             float pre = 0.0f;
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
-                float v = part[m];
+                float v = (part[m][0] + part[m][1]) + (part[m][2] + part[m][3]);
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 if (g == m) pre = v;               // lane group g owns batch row g from here on
@@ -218,85 +300,105 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             const float iv = quad_bcast<0>(a), fv = quad_bcast<1>(a), gv = quad_bcast<2>(a), ov = quad_bcast<3>(a);
             const float cn = fv * cst[l] + iv * gv;
             cst[l] = cn;
-            if (gate == 0 && g < NR) own[(l * MR + g) * SO + wave * 4 + u] = ov * gate_act(cn, true);
+            if (gate == 0 && g < NR) own[((wave * L + l) * MR + g) * 4 + u] = ov * gate_act(cn, true);
         }
-        if (ph + 1 < T) stage_x(ph + 1);           // into the other xin buffer (its readers finished a phase ago)
-        __syncthreads();                            // own slices of every active layer complete
-        // ---- publish all active layers' slices, drain, barrier, ONE flag ----------------------------------------------
+        if (ph == P - 1 && hw_live) {              // the head's weights: their latency hides behind this phase's exchange
+#pragma unroll
+            for (int i = 0; i < H / 64; ++i)
+                hw[i] = *reinterpret_cast<const f32x4*>(p.w_out + (size_t)hw_o * H + hw_part * (H / 16) + 4 * i);
+            hw_b = p.b_out[hw_o];
+        }
+        SM_STAMP(1);                                // 1: x staging + GEMVs + gates of every layer
+        // ---- publish: lane (l, row) of this wave sends the 16-byte piece of its four units, drain, THIS wave's flag ------
         {
-            const int l = tid / (MR * 4), idx = tid - l * (MR * 4);      // 16 pieces per layer slice
+            const int l = lane / MR, row = lane - l * MR;
             const int t = ph - l;
-            if (l < L && t >= 0 && t < T) {
-                const int row = idx >> 2, quad = idx & 3;
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (l * MR + row) * SO + 4 * quad);
-                const auto hvu = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv);
-                const unsigned off = hx_base(l, t & 1) + (unsigned)(((member * MR + row) * 16 + 4 * quad) * sizeof(float));
-                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 0);          // stays in the XCD's L2
-                else __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 16 /* sc1: write-through */);
-            }
+            const bool live = lane < L * MR && t >= 0 && t < T;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(own + ((wave * L + (live ? l : 0)) * MR + row) * 4);
+            const auto hvu = __builtin_bit_cast(u32x4, hv);
+            const unsigned off = live ? hx_base(l, t & 1) + (unsigned)(row * ROW_BYTES + (member * 4 + wave) * 16) : 0x80000000u;
+            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 0);          // stays in the XCD's L2
+            else __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 16 /* sc1: write-through */);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (in_l2) *reinterpret_cast<volatile unsigned*>(myflag + member) = (unsigned)(ph + 1);      // plain: in L2
-            else __hip_atomic_store(myflag + member, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SM_STAMP(2);                                // 2: publish store issued -> acknowledged (and the x fetch)
+        if (lane == 0) {
+            unsigned* f = myflag + member * 4 + wave;
+            if (in_l2) *reinterpret_cast<volatile unsigned*>(f) = (unsigned)(ph + 1);    // plain: stays in the XCD's L2
+            else __hip_atomic_store(f, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // ---- wait for every member's phase-ph flag, gather all layers' slices (one piece per thread and layer) -------
-        if (wave == 0) {
+        // ---- every wave polls every member wave's flag of this phase, then copies window row `wave` of every layer --------
+        //      (one polling wave per workgroup + a barrier instead: no difference, 22.9 vs 23.1 us)
+        {
             unsigned spins = 0;
             while (true) {
                 unsigned v = (unsigned)(ph + 1);
-                if (lane < GH) v = __hip_atomic_load(myflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < NFL) v = __hip_atomic_load(myflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((int)(v >= (unsigned)(ph + 1)))) break;
-                if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                // (the sticky status word is looked at every 256th spin only: a second dependent load per spin doubles the
+                //  time a late flag costs, measured 0.96 us per phase)
+                if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                             __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     if (lane == 0) {
                         ctl[0] = 1;
                         __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                if (spins > 64u) __builtin_amdgcn_s_sleep(1);
             }
         }
-        __syncthreads();
+        SM_STAMP(3);                                // 3: own flag store -> every member wave's flag seen
+        if (wave < NR) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = ph - l;
+                if (t >= 0 && t < T && lane * 16 < (int)ROW_BYTES)
+                    dma_1k(hbuf_lds + (unsigned)((l * MR + wave) * ROW_BYTES), (unsigned)(lane * 16), hx_desc,
+                           hx_base(l, t & 1) + (unsigned)(wave * ROW_BYTES));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SM_STAMP(4);                                // 4: gather DMA issued -> landed in LDS
+        __syncthreads();                            // gathered h and x_{ph+1} visible
+        SM_STAMP(5);                                // 5: barrier
         if (ctl[0] != 0) return;
-        if (tid < PIECES) {
-            const int m = tid / (MR * 4), idx = tid - m * (MR * 4);
-            const int row = idx >> 2, quad = idx & 3;
-            f32x4 gv[L];
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int t = ph - l;
-                if (t >= 0 && t < T)
-                    gv[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        hx_rsrc, hx_base(l, t & 1) + (unsigned)(((m * MR + row) * 16 + 4 * quad) * sizeof(float)), 0, 16 /* sc1 */));
-            }
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int t = ph - l;
-                if (t >= 0 && t < T) *reinterpret_cast<f32x4*>(hbuf + (l * MR + row) * SH + m * 16 + 4 * quad) = gv[l];
-            }
-        }
-        __syncthreads();
     }
 
-    // ---- head: member m finishes row m (rows < NR <= 4 <= GH) ------------------------------------------------------------
-    if (member < MR && tid < O) {
+    // ---- head: member m finishes row m (rows < NR <= 4 <= GH): 16 lanes per target (16 k each), combined by lane shuffles;
+    //      this thread's share of the head weights was requested at the top of the kernel
+    if (member < MR) {
         const int b = row0 + member;
-        if (b < p.B) {
-            const float* hv = hbuf + ((L - 1) * MR + member) * SH;
-            const float* wv = p.w_out + (size_t)tid * H;
-            float s = 0.0f;
-            for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
-            p.y[(size_t)b * O + tid] = s + p.b_out[tid];
+        float s_acc = 0.0f;
+        if (hw_live) {
+            const float* hv = hbuf + ((L - 1) * MR + member) * SH + hw_part * (H / 16);
+#pragma unroll
+            for (int i = 0; i < H / 64; ++i) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(hv + 4 * i);
+                s_acc = fmaf(av[0], hw[i][0], s_acc); s_acc = fmaf(av[1], hw[i][1], s_acc);
+                s_acc = fmaf(av[2], hw[i][2], s_acc); s_acc = fmaf(av[3], hw[i][3], s_acc);
+            }
         }
+        s_acc += __shfl_xor(s_acc, 1, 64);
+        s_acc += __shfl_xor(s_acc, 2, 64);
+        s_acc += __shfl_xor(s_acc, 4, 64);
+        s_acc += __shfl_xor(s_acc, 8, 64);
+        if (hw_live && hw_part == 0 && b < p.B) p.y[(size_t)b * O + hw_o] = s_acc + hw_b;
     }
+    SM_STAMP(6);                                    // 6: head
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && tid == 0 && member == 0) {
+        for (int k = 0; k < 8; ++k) p.dbg_wg[k] = st_acc[k];
+        p.dbg_wg[8] = __builtin_amdgcn_s_memtime() - st_begin;
+        p.dbg_wg[9] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    }
+#endif
     __syncthreads();
     if (tid == 0)
         ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GH - 1) ? 1 : 0;
     __syncthreads();
     if (ctl[2] != 0) {
-        const int n_words = L * GH;
+        const int n_words = 4 * GH;
         for (int i = tid; i < n_words; i += 256)
             __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < GH) __hip_atomic_store(p.xcc_slots + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
 
 template <int H, int L, int KX, int NR>
 hipError_t launch_small(const ClusterParams& p, hipStream_t stream) {
-    constexpr size_t smem = ((size_t)L * MR * (H + 8) + 2 * MR * (KX + 8) + (size_t)L * MR * 20 + 4) * sizeof(float);
+    constexpr size_t smem = ((size_t)L * MR * H + 2 * MR * (KX + 8) + (size_t)4 * L * MR * 4 + 4) * sizeof(float);
     hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR>), dim3(8 * (H / 16)), dim3(256), smem, stream, p);
     return hipGetLastError();
 }

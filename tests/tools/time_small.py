@@ -15,11 +15,12 @@ sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0)
 m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], device=0); m.load_state_dict(sd)
 x = torch.randn(B, T, cfg["I"], device="cuda"); y = torch.empty(B, cfg["O"], device="cuda")
 lib = _hip.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+FLAGS = int(os.environ.get("APE_FLAGS", "0"), 0)
 def run(n):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
-        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0, None, 0.0, 0, C.c_void_p(y.data_ptr()), st), "fwd")
+        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, FLAGS, None, 0.0, 0, C.c_void_p(y.data_ptr()), st), "fwd")
     b.record(); b.synchronize()
     return a.elapsed_time(b) / n * 1e3
 run(50)
