@@ -104,12 +104,13 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // whole MI355X (microseconds): a batch-tile wave sustains 125 TFLOP/s at H = 256 and 109 at H = 128 whatever T and
 // the dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
 // dropout variant) however few of its rows are used.  Both rates scale with the CU count of the device.
-static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop) {
+static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, bool c32 = false) {
     const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop);
     if (rpl == 0) return (B + wave - 1) / wave;          // no cluster fits on this device
     const double rate = (dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
     const double t16 = (double)wave * ape_flops_per_window(dims, T) / rate * 1e6;
-    const double tcl = cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
+    // (second-generation f32 cluster kernel, eval mode: 16 + 12.4 T per launch of up to 1024 rows, round 2)
+    const double tcl = cdrop ? 22.0 + 8.4 * T : (c32 ? 16.0 + 12.4 * T : 25.0 + 13.7 * T);
     auto cost = [&](int w) {
         const int rest = B - wave * w;
         return w * t16 + (rest > 0 ? (double)((rest + rpl - 1) / rpl) * tcl : 0.0);
@@ -628,7 +629,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
-        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c);
+        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c, m->c32_ok && m->c32_on && !drop);
         const long long front = (long long)tile16_wave_rows(m->n_cus) * w;
         n16 = (front < B) ? (int)front : B;
     }
@@ -1163,7 +1164,7 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
-        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false) > B) return m->kernel_name.c_str();
+        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, m->c32_ok && m->c32_on) > B) return m->kernel_name.c_str();
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
     return m->cluster_name.c_str();
