@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     // barrier the store itself is waited for and its flag goes up.
     const int P = T + L - 1;                 // phases 0 .. P-1 compute; "phase" P: the final gather for the head
     bool prefetched = false;
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long dg_block[2] = {0, 0}, dg_go[2] = {0, 0};      // diagnostic counters per layer (cluster 0, member 0)
+#endif
     auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 1 <= t <= T - 2 for both layers
         constexpr int l = decltype(layer_tag)::value;
@@ -308,6 +311,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         // ---- S0: this layer's slices of its last step into LDS ------------------------------------------------------------
         if (need) {
             if (!prefetched) {                                    // pipeline fill, a late peer, the final gather
+#ifdef APE_CLUSTER_STAMPS
+                dg_block[l] += 1;
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
                 wait_flags(l, (unsigned)t);
@@ -379,6 +385,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         }
         // (first step of a layer, idle sections: the hooks did not run, the next section gathers in the blocking form)
         if (go) prefetched = true;
+#ifdef APE_CLUSTER_STAMPS
+        if (go) dg_go[ln] += 1;
+#endif
         if constexpr (l == L - 1) {
             // x of the next layer-0 step: registers -> LDS (layer 0's readers of xin finished a section ago), next fetch
             if (ST || (ph + 1 < T)) {
@@ -425,6 +434,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         if (ctl[0] != 0) return;
     }
 
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0)
+        for (int k = 0; k < 2; ++k) { p.dbg_wg[16 + k] = dg_block[k]; p.dbg_wg[18 + k] = dg_go[k]; }
+#endif
     // ---- head: member m finishes windows 4m .. 4m+3 of the cluster's 32 ----------------------------------------------------------------
     {
         constexpr int RPM = MR / GH;
