@@ -569,7 +569,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         q.I = m->dims.input_size; q.O = m->dims.output_size; q.KX = m->KX; q.n_hidden = L;
         q.flags = flags; q.dropout_p = dropout_p; q.seed = seed;
         q.neg_slope = 0.01f;                      // torch's leaky_relu default (nn_models.py:347,349)
-        hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream);
+        hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream, m->n_cus);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "mlp kernel launch failed: %s", hipGetErrorString(e));
         return APE_OK;
     }
@@ -595,7 +595,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         q.row_stride = (size_t)m->dims.input_size; q.row_offset = 0;
         q.N = (int)rows; q.I = m->dims.input_size; q.O = m->dims.output_size; q.KX = m->KXpre; q.n_hidden = 0;
         q.flags = flags & APE_FLAG_NORMALIZE_INPUT; q.neg_slope = 0.0f;
-        hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream);
+        hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream, m->n_cus);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "input-layer kernel launch failed: %s", hipGetErrorString(e));
         lstm_x = m->z_ws;
         flags &= ~(uint32_t)APE_FLAG_NORMALIZE_INPUT;        // done in front of the input layer

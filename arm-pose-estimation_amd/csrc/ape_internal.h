@@ -175,7 +175,7 @@ hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, 
 hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size_t out_stride, int rep,
                                  size_t rep_stride, hipStream_t stream);
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream);
-hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream);
+hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream, int n_cus = 0);
 hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const float* w_out, const float* b_out, float* y,
                                 hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);

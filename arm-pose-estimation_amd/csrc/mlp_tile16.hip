@@ -3,7 +3,11 @@
 //     Linear(I,H) -> leaky_relu -> n x [Linear(H,H) -> leaky_relu] -> dropout -> Linear(H,O)
 // applied to the last axis of x, i.e. independently to every row (window step).
 //
-// One workgroup (4 wave64, one per SIMD) owns 16 rows and walks the layers; activations ping-pong between
+// One workgroup (4 wave64, one per SIMD) owns 16 * NMT rows (NMT = 2 once the batch is 64 rows per CU or more: every weight
+// fragment streamed from L2 then feeds two row tiles; NMT = 1 below that, for the latency of small batches.  Measured on MI355X,
+// 22 -> 256 -> 256 -> 256 -> 14: 65 536 rows 245 us with either, 262 144 rows 888 us = 82.8 TFLOP/s with NMT = 2; NMT = 4 -- one
+// workgroup per CU, 145 KB of LDS -- is SLOWER, 291 us / 1173 us: this kernel lives on several workgroups per CU hiding each
+// other's L2 latency, not on weight reuse) and walks the layers; activations ping-pong between
 // two LDS buffers (row stride H+8 floats: conflict-free ds_read_b128), wave w owns output columns
 // [w*H/4, (w+1)*H/4).  Each layer is a [16 x K] x [K x H] product on v_mfma_f32_16x16x4_f32 (exact f32):
 // A operand from LDS (one ds_read_b128 per 16 k-values, reused by all the wave's tiles), B operand = the
@@ -23,36 +27,39 @@ __device__ __forceinline__ void load_b(f32x4 (&b)[NT], const f32x4* __restrict__
     for (int n = 0; n < NT; ++n) b[n] = p[n * 64];
 }
 
-template <int NT>
-__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NT], const f32x4 a, const f32x4 (&b)[NT]) {
+template <int NMT, int NT>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NMT][NT], const f32x4 (&a)[NMT], const f32x4 (&b)[NT]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[n][j], acc[n], 0, 0, 0);
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[n][j], acc[mt][n], 0, 0, 0);
     }
 }
 
-template <int H>
+template <int H, int NMT>
 __global__ __launch_bounds__(256, 1) void ape_mlp_tile16(const MlpParams p) {
     constexpr int NT = H / 64;        // 16-column tiles per wave
     constexpr int SH = H + 8;
+    constexpr int ROWS = APE_TILE_ROWS * NMT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int row0 = blockIdx.x * APE_TILE_ROWS;
+    const int row0 = blockIdx.x * ROWS;
     const int KX = p.KX, SX = KX + 8;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
     const bool drop_masks = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
     const bool drop_philox = (p.flags & APE_FLAG_DROPOUT_PHILOX) != 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xin = smem;                              // [16][SX]
-    float* act = xin + APE_TILE_ROWS * SX;          // [2][16][SH]
+    float* xin = smem;                              // [ROWS][SX]
+    float* act = xin + ROWS * SX;                   // [2][ROWS][SH]
 
     // ---- inputs: row n of the batch lives at x[n * row_stride + row_offset + k] ------------------------------
-    for (int idx = tid; idx < APE_TILE_ROWS * KX; idx += 256) {
+    for (int idx = tid; idx < ROWS * KX; idx += 256) {
         const int row = idx / KX, k = idx - row * KX;
         const int n = row0 + row;
         float v = 0.0f;
@@ -70,36 +77,46 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_tile16(const MlpParams p) {
     for (int j = 0; j < n_layers; ++j) {
         const int K = (j == 0) ? KX : H;
         const int nq = K / 16;                      // even (KX % 32 == 0, H % 64 == 0)
-        const float* src = (j == 0) ? xin + r * SX + 4 * g : act + (((j - 1) & 1) * APE_TILE_ROWS + r) * SH + 4 * g;
+        const int sstride = (j == 0) ? SX : SH;      // row stride of the layer's input
+        const float* src = (j == 0) ? xin + r * SX + 4 * g : act + (((j - 1) & 1) * ROWS + r) * SH + 4 * g;
         const f32x4* wl = p.wpack[j] + (size_t)wave * nq * NT * 64 + lane;
-        f32x4 acc[NT];
+        f32x4 acc[NMT][NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const float bv = p.bias[j][wave * (H / 4) + n * 16 + r];
-            acc[n] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) acc[mt][n] = f32x4{bv, bv, bv, bv};
         }
-        f32x4 b0[NT], b1[NT];
+        auto load_a = [&](f32x4 (&a)[NMT], int q) {
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(src + mt * 16 * sstride + 16 * q);
+        };
+        f32x4 b0[NT], b1[NT], a0[NMT], a1[NMT];
         load_b<NT>(b0, wl);
 #pragma unroll 1
         for (int q = 0; q < nq; q += 2) {
             load_b<NT>(b1, wl + (size_t)(q + 1) * NT * 64);
-            mfma_block<NT>(acc, *reinterpret_cast<const f32x4*>(src + 16 * q), b0);
+            load_a(a0, q);
+            mfma_block<NMT, NT>(acc, a0, b0);
             if (q + 2 < nq) load_b<NT>(b0, wl + (size_t)(q + 2) * NT * 64);
-            mfma_block<NT>(acc, *reinterpret_cast<const f32x4*>(src + 16 * (q + 1)), b1);
+            load_a(a1, q + 1);
+            mfma_block<NMT, NT>(acc, a1, b1);
         }
         // leaky_relu (+ dropout on the last hidden activation, nn_models.py:351) into the other buffer
-        float* dst = act + ((j & 1) * APE_TILE_ROWS) * SH;
+        float* dst = act + ((j & 1) * ROWS) * SH;
         const bool last = (j == n_layers - 1);
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int col = wave * (H / 4) + n * 16 + r;
             uint32_t rnd[4] = {0, 0, 0, 0};
             if (last && drop_philox)
-                philox4x32((uint32_t)(row0 + 4 * g), 0u, (uint32_t)col, 0xFFu, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+                philox4x32((uint32_t)(row0 + 16 * mt + 4 * g), 0u, (uint32_t)col, 0xFFu, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = 4 * g + i;
-                float v = acc[n][i];
+                const int row = 16 * mt + 4 * g + i;
+                float v = acc[mt][n][i];
                 v = (v > 0.0f) ? v : p.neg_slope * v;
                 if (last && (drop_masks || drop_philox)) {
                     float m;
@@ -120,22 +137,24 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_tile16(const MlpParams p) {
         __syncthreads();
     }
 
-    // ---- output layer: one (row, target) dot product per thread ---------------------------------------------------
-    if (p.hidden_out == nullptr && tid < APE_TILE_ROWS * p.O) {
-        const int row = tid / p.O, o = tid - row * p.O;
-        const int n = row0 + row;
-        if (n < p.N) {
-            const float* hv = act + (((n_layers - 1) & 1) * APE_TILE_ROWS + row) * SH;
-            const float* wv = p.w_out + (size_t)o * H;
-            float s = 0.0f;
-            for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
-            p.y[(size_t)n * p.O + o] = s + p.b_out[o];
+    // ---- output layer: (row, target) dot products, k ascending, one fma per term -----------------------------------------
+    if (p.hidden_out == nullptr) {
+        for (int idx = tid; idx < ROWS * p.O; idx += 256) {
+            const int row = idx / p.O, o = idx - row * p.O;
+            const int n = row0 + row;
+            if (n < p.N) {
+                const float* hv = act + (((n_layers - 1) & 1) * ROWS + row) * SH;
+                const float* wv = p.w_out + (size_t)o * H;
+                float s = 0.0f;
+                for (int k = 0; k < H; ++k) s = fmaf(hv[k], wv[k], s);
+                p.y[(size_t)n * p.O + o] = s + p.b_out[o];
+            }
         }
     }
 }
 
-template <int H>
-size_t smem_of(int KX) { return ((size_t)APE_TILE_ROWS * (KX + 8) + 2 * (size_t)APE_TILE_ROWS * (H + 8)) * sizeof(float); }
+template <int H, int NMT>
+size_t smem_of(int KX) { return ((size_t)APE_TILE_ROWS * NMT * (KX + 8) + 2 * (size_t)APE_TILE_ROWS * NMT * (H + 8)) * sizeof(float); }
 
 }  // namespace
 
@@ -185,14 +204,27 @@ hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const fl
     return hipGetLastError();
 }
 
-hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream) {
-    const int grid = (p.N + APE_TILE_ROWS - 1) / APE_TILE_ROWS;
-    if (H == 256) {
-        hipLaunchKernelGGL(ape_mlp_tile16<256>, dim3(grid), dim3(256), smem_of<256>(p.KX), stream, p);
-    } else if (H == 128) {
-        hipLaunchKernelGGL(ape_mlp_tile16<128>, dim3(grid), dim3(256), smem_of<128>(p.KX), stream, p);
-    } else {
-        return hipErrorInvalidValue;
+template <int H, int NMT>
+static hipError_t launch_mlp(const MlpParams& p, hipStream_t stream) {
+    const size_t smem = smem_of<H, NMT>(p.KX);
+    static bool prepared = false;                   // per instantiation, raised once to the CU's whole LDS
+    if (!prepared && smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_tile16<H, NMT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        prepared = true;
     }
+    const int rows = APE_TILE_ROWS * NMT;
+    hipLaunchKernelGGL((ape_mlp_tile16<H, NMT>), dim3((p.N + rows - 1) / rows), dim3(256), smem, stream, p);
     return hipGetLastError();
+}
+
+// `n_cus`: CU count of the device -- 32-row workgroups from 64 rows per CU on (a weight fragment then feeds two row tiles),
+// 16-row workgroups below that (more workgroups, shorter latency); KX > 64 keeps the 16-row form (for safety: the input
+// layers this kernel serves are narrow)
+hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream, int n_cus) {
+    const bool wide = p.N >= 64 * (n_cus > 0 ? n_cus : 256) && p.KX <= 64;
+    if (H == 256) return wide ? launch_mlp<256, 2>(p, stream) : launch_mlp<256, 1>(p, stream);
+    if (H == 128) return wide ? launch_mlp<128, 2>(p, stream) : launch_mlp<128, 1>(p, stream);
+    return hipErrorInvalidValue;
 }

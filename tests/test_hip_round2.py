@@ -310,3 +310,25 @@ def test_f32_second_generation_cluster_kernel(norm_stats, name, B, T):
     e_ref, e_gen = float(np.abs(y2 - y_ref).max()), float(np.abs(y2 - y1).max())
     print(f"\n[{name} B={B} T={T} cluster32] vs oracle {e_ref:.2e}, vs gen-1 kernel {e_gen:.2e}")
     assert e_ref < 1e-6 and e_gen < 1e-6
+
+
+# ---------------- MLP regressor, 32-row workgroups (batches that fill the chip) ------------------------------------------
+@pytest.mark.parametrize("n_hidden,N", [(2, 16384 + 37), (1, 20000)])
+def test_mlp_regressor_large_batches(n_hidden, N):
+    """DropoutFF on the 32-row-per-workgroup instantiation of ape_mlp_tile16 (N >= 64 rows per CU): against the oracle's
+    restatement of nn_models.py:340-354 incl. an injected dropout mask in front of the output layer, ragged last workgroup;
+    the 16-row instantiation (same model, small slice of the rows) must give the same bits for its rows"""
+    from wear_mocap_ape_amd.estimate import nn_models
+    I, H, O = 22, 256, 14
+    sd = orc.make_ff_state_dict(I, H, n_hidden, O, 5)
+    m = nn_models.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=n_hidden, input_size=I, dropout=0.2, device=0)
+    m.load_state_dict(sd)
+    rng = np.random.default_rng(17)
+    x = rng.normal(size=(N, I)).astype(np.float32)
+    mask = ((rng.random((N, H)) >= 0.2) / 0.8).astype(np.float32)
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(y - orc.ff_forward(sd, x)).max() < 2e-6
+    ym = m(torch.from_numpy(x).cuda(), masks=torch.from_numpy(mask).cuda()).cpu().numpy()
+    assert np.abs(ym - orc.ff_forward(sd, x, mask=mask)).max() < 2e-6
+    y_small = m(torch.from_numpy(x[:100]).cuda()).cpu().numpy()              # 16-row workgroups
+    assert np.array_equal(y_small, y[:100])
