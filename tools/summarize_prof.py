@@ -170,7 +170,7 @@ if pmc:
                 lines.append(f"| {k} / SQ_WAVE_CYCLES | {m[k] / m['SQ_WAVE_CYCLES'] * 100:.1f} % |")
 lines += ["", "## all kernels in the trace (name, grid threads, calls, mean us)", ""]
 for (n, g), v in sorted(allk.items(), key=lambda kv: -sum(kv[1])):
-    lines.append(f"- `{n}` grid {g}: {len(v)} calls, mean {statistics.mean(v):.1f} us, total {sum(v) / 1e3:.2f} ms")
+    lines.append(f"- `{n if len(n) <= 160 else n[:157] + '...'}` grid {g}: {len(v)} calls, mean {statistics.mean(v):.1f} us, total {sum(v) / 1e3:.2f} ms")
 (REPO / "profiles").mkdir(exist_ok=True)
 (REPO / "profiles" / f"{args.tag}.md").write_text("\n".join(lines) + "\n")
 if hbm is not None:
