@@ -149,6 +149,8 @@ struct ape_model {
     float* wcl[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
     float* wcl32[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};  // 32x32x2 fragments of the second-generation f32 cluster kernel
+    float* wcls[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // the latency kernel's H/8-member form (two units per wave)
+    int small_uw = 4;                // hidden units per wave of the latency kernel: 2 when one XCD holds H/8 members
     bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
     bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
     int precision = APE_PRECISION_F32;
@@ -327,6 +329,12 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
         if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
+        // latency kernel with H/8 members (every CU of a 32-CU XCD at H = 256): only where an XCD has that many CUs
+        if (m->n_cus / 8 >= H / 8) {
+            for (int l = 0; l < L && e == hipSuccess; ++l)
+                e = plan((void**)&m->wcls[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
+            m->small_uw = 2;
+        }
         if (ape_cluster32_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0) {
             for (int l = 0; l < L && e == hipSuccess; ++l)
                 e = plan((void**)&m->wcl32[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
@@ -458,6 +466,25 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                             pc[((((size_t)(mem * 4 + w) * (NW / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] = v;
                         }
             HIP_TRY(hipMemcpy(m->wcl[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (m->small_uw == 2) {
+                // latency kernel, H/8 members: a wave owns 2 units = 8 columns, 8 k-groups; lane = (g << 3) | (u << 2) | gate holds
+                // Wcat[gate*H + (member*4 + wave)*2 + u][32q + 4g + j] in register 4q + j; same [i/4][lane][i%4] storage
+                const int GS = H / 8, NWS = (KXl + H) / 8;
+                std::vector<float> ps((size_t)GS * 4 * NWS * 64);
+                for (int mem = 0; mem < GS; ++mem)
+                    for (int w = 0; w < 4; ++w)
+                        for (int i = 0; i < NWS; ++i)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int c = lane & 7, g = lane >> 3, u = c >> 2, gate = c & 3;
+                                const int row = gate * H + (mem * 4 + w) * 2 + u;
+                                const int k = 32 * (i / 4) + 4 * g + (i % 4);
+                                float v;
+                                if (k < KXl) v = (k < in_l) ? w_ih[(size_t)row * in_l + k] : 0.0f;
+                                else v = w_hh[(size_t)row * H + (k - KXl)];
+                                ps[((((size_t)(mem * 4 + w) * (NWS / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] = v;
+                            }
+                HIP_TRY(hipMemcpy(m->wcls[l], ps.data(), ps.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             // fp16 variant: [member][wave][32-deep k-block q][lane][8]: lane holds Wcat[row][32q + 8g + j] as binary16
             const int NB = (KXl + H) / 32;
             std::vector<_Float16> ph((size_t)GH * 4 * NB * 64 * 8);
@@ -659,6 +686,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop);
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        const int small_uw = (flags & APE_DIAG_SMALL_UW4) ? 4 : m->small_uw;
         if (!f16 && !cdrop && !drop && !all_steps && !small && m->c32_ok && m->c32_on && B - n16 > 512) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
             const int rpl2 = 32 * f16v2_capacity(m->n_cus);
@@ -726,7 +754,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             c.y = all_steps ? nullptr : y_dev + (size_t)b0 * m->dims.output_size;
             c.hseq = all_steps ? m->hseq_ws + (size_t)b0 * T * H : nullptr;
             for (int l = 0; l < L; ++l) {
-                c.wcl[l] = f16 ? reinterpret_cast<const float*>(m->wcl16[l]) : m->wcl[l];
+                c.wcl[l] = f16 ? reinterpret_cast<const float*>(m->wcl16[l]) : (small && small_uw == 2) ? m->wcls[l] : m->wcl[l];
                 c.bias[l] = m->bias[l];
             }
             c.w_out = m->w_out; c.b_out = m->b_out;
@@ -749,7 +777,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
             const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
-            hipError_t e = small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), c, (hipStream_t)stream)
+            hipError_t e = small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), small_uw, c, (hipStream_t)stream)
                            : f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
                                  : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster lstm launch failed: %s", hipGetErrorString(e));

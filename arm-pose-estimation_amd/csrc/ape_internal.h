@@ -18,6 +18,9 @@
 #define APE_DIAG_WRITE_THROUGH 0x08000000u   // small-batch kernel: use the any-placement (sc1) exchange even when the
                                             // members share an XCD -- results are the same; lets tests run that path
 
+#define APE_DIAG_SMALL_UW4   0x01000000u   // small-batch kernel: the H/16-member form also where the H/8-member one is available
+                                            // (same results up to f32 summation order; lets tests run that form)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Kernel arguments of the batch-tile LSTM kernel (passed by value).
@@ -161,7 +164,7 @@ bool ape_cluster_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,
                                    hipStream_t stream);
-hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, const ClusterParams& p, hipStream_t stream);
+hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, int uw, const ClusterParams& p, hipStream_t stream);
 hipError_t ape_prepare_lstm_cluster_f16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int clusters, const ClusterParams& p, hipStream_t stream);
 bool ape_cluster32_supported(int H, int L, int KX);

@@ -18,12 +18,15 @@
 //     itself (one load per lane) and then copies one window row of every layer global -> LDS with one LDS-DMA instruction
 //     per layer (the exchange order [row][member][wave][4 units] is the LDS order of h), and only then the barrier.
 // Same arithmetic as the other kernels up to float32 summation order.
+#include <type_traits>
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int MR = 4;                      // rows per cluster (row = lane group)
 
@@ -48,10 +51,31 @@ __device__ __forceinline__ float quad_bcast(float x) {
                                                                  K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, false));
 }
 
-// part[m] += sum over this lane's k-slice of w * act[m]; NQ 16-deep blocks starting at weight register w0.
+// x + (x of lane ^ 16), x + (x of lane ^ 32): gfx950's row / half swaps instead of a trip through the LDS crossbar
+// (ds_bpermute, ~100+ cycles each, and the k-group sums of a phase are a chain of them).  v_permlane16_swap exchanges the odd
+// 16-lane rows of its first operand with the even rows of its second: with both = x the operands become [x0 x0 x2 x2] and
+// [x1 x1 x3 x3], whose sum is the xor-16 all-reduce; v_permlane32_swap does the same with the wave's halves.  (Inline asm:
+// the builtin's two results are folded into one by this compiler when both inputs are the same value.)
+__device__ __forceinline__ float sum_xor16(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// x + (x of the lane 8 further within its 16-lane row): one DPP row rotation
+__device__ __forceinline__ float sum_ror8(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+}
+
+// part[m] += sum over this lane's k-slice of w * act[m]; NQ KB-deep blocks (KB = 4 x the k-groups of a wave) starting at
+// weight register w0.
 // The activation fragments of up to 16 k-blocks are fetched up front, then multiplied: one dependent LDS read per k-block
 // costs its whole latency at one wave per SIMD (measured: 1.13 us of a 3.3 us phase was this loop).
-template <int NR, int NQ, int NW>
+template <int NR, int NQ, int KB, int NW>
 __device__ __forceinline__ void gemv_span(f32x4 (&part)[NR], const float* __restrict__ src, int row_stride,
                                           const float (&w)[NW], int w0) {
     // k-blocks per chunk: CH * NR fragments (4 registers each) in flight.  The weights of a VALU GEMV must sit in
@@ -65,7 +89,7 @@ __device__ __forceinline__ void gemv_span(f32x4 (&part)[NR], const float* __rest
         for (int q = 0; q < CH; ++q)
 #pragma unroll
             for (int m = 0; m < NR; ++m)
-                if (q0 + q < NQ) a[q][m] = *reinterpret_cast<const f32x4*>(src + m * row_stride + 16 * (q0 + q));
+                if (q0 + q < NQ) a[q][m] = *reinterpret_cast<const f32x4*>(src + m * row_stride + KB * (q0 + q));
         // four independent accumulation chains per row (one per k of a quad): a single chain of 200+ dependent FMAs runs at
         // the FMA's dependent latency, not at its issue rate
 #pragma unroll
@@ -93,18 +117,23 @@ __device__ __forceinline__ void gemv_span(f32x4 (&part)[NR], const float* __rest
 #define SM_STAMP(k) do {} while (0)
 #endif
 
-template <int H, int L, int KX, int NR>
+// UW = hidden units per wave: 4 (GH = H/16 members; the register layout of the MFMA cluster kernel) or 2 (GH = H/8 members
+// = every CU of a 32-CU XCD at H = 256: half the weights, FMAs and LDS reads per lane and phase -- the phase is bound by the
+// instruction count at one wave per SIMD -- and a 100-register weight set that stays in the architectural file).
+template <int H, int L, int KX, int NR, int UW>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterParams p) {
-    constexpr int GH = H / 16;
+    constexpr int GH = H / (4 * UW);
+    constexpr int CW = 4 * UW, NG = 64 / CW, KB = 4 * NG;   // columns (unit*4 + gate) per wave; k-groups; k-block depth
     constexpr int SH = H, SX = KX + 8;       // h rows unpadded: a row (H floats = 1 KiB at H = 256) is what one LDS-DMA instruction delivers
-    constexpr int QX = KX / 16, QH = H / 16;
-    constexpr int NW0 = (KX + H) / 4, NW1 = (2 * H) / 4;
+    constexpr int QX = KX / KB, QH = H / KB;
+    constexpr int NW0 = (KX + H) / NG, NW1 = (2 * H) / NG;
     static_assert(NR <= MR && (H == 128 || H == 256), "a window row of h = one or half an LDS-DMA instruction");
+    static_assert((UW == 4 || UW == 2) && KX % KB == 0 && GH >= MR && GH <= 64, "cluster shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g = lane >> 4;        // column = unit*4 + gate; k-group, later batch row
+    const int c = lane % CW, g = lane / CW;        // column = unit*4 + gate; k-group, later batch row
     const int gate = c & 3, u = c >> 2;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
@@ -113,8 +142,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hbuf = smem;                            // [L][MR][SH]
     float* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
-    float* own = xin + 2 * MR * SX;                // [wave 4][L][MR][4]  fresh slice of this wave (wave-private)
-    int* ctl = reinterpret_cast<int*>(own + 4 * L * MR * 4);
+    float* own = xin + 2 * MR * SX;                // [wave 4][L][MR][UW]  fresh slice of this wave (wave-private)
+    int* ctl = reinterpret_cast<int*>(own + 4 * L * MR * UW);
     // Membership is fixed by the block index: the launch has 8 x GH workgroups and only every eighth one takes part
     // (the others leave at once).  Under the placement observed on this hardware -- blocks are dealt round-robin over
     // the 8 XCDs -- those GH workgroups share ONE XCD, hence one L2, and the exchange can stay inside it: plain stores
@@ -185,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     float bias_r[L], cst[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        bias_r[l] = p.bias[l][gate * H + member * 16 + wave * 4 + u];
+        bias_r[l] = p.bias[l][gate * H + (member * 4 + wave) * UW + u];
         cst[l] = 0.0f;
     }
 
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     hx_desc[3] = 0x00020000u;
     constexpr int NFL = 4 * GH;                    // one epoch word per member WAVE (all layers at once)
     unsigned* const myflag = p.xflags + (size_t)cluster * NFL;
-    constexpr unsigned ROW_BYTES = H * sizeof(float);                   // [row][member][wave][4 units]: a window row of one layer
+    constexpr unsigned ROW_BYTES = H * sizeof(float);                   // [row][member][wave][UW units]: a window row of one layer
     constexpr unsigned SET_BYTES = MR * ROW_BYTES;                      // one (layer, parity)
     auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SET_BYTES); };
     const unsigned hbuf_lds = (unsigned)reinterpret_cast<unsigned long long>(hbuf);
@@ -261,47 +290,64 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         // the fetch of the step after it goes out now, under this phase's compute
         if (ph + 1 < T) stage_x(ph + 1);
         if (ph + 2 < T) fetch_x(ph + 2);
-        // ---- every layer of this phase, back to back (layer l works on step t = ph - l) ----------------------------
+        // ---- every layer of this phase (layer l works on step t = ph - l).  In the steady state (all layers active) the body
+        //      is straight-line code: all GEMVs, then all k-group sums, then all cell updates, so that the layers' dependent
+        //      chains (LDS read -> FMA chain -> lane sums -> exp/rcp chains) overlap instead of following each other
+        auto layers = [&](auto all_tag) {
+            constexpr bool ALL = decltype(all_tag)::value;
+            f32x4 part[L][NR];
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int t = ph - l;
-            if (t < 0 || t >= T) continue;         // uniform
-            f32x4 part[NR];
+            for (int l = 0; l < L; ++l) {
+                const int t = ph - l;
 #pragma unroll
-            for (int m = 0; m < NR; ++m) part[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* rec_src = hbuf + l * MR * SH + 4 * g;
-            if (l == 0) {
-                gemv_span<NR, QX, NW0>(part, xin + (t & 1) * MR * SX + 4 * g, SX, w0, 0);
-                gemv_span<NR, QH, NW0>(part, rec_src, SH, w0, 4 * QX);
-            } else {
-                const float* in_src = hbuf + (l - 1) * MR * SH + 4 * g;
-                if (l == 1) {
-                    if constexpr (L > 1) {
-                        gemv_span<NR, QH, NW1>(part, in_src, SH, w1, 0);
-                        gemv_span<NR, QH, NW1>(part, rec_src, SH, w1, 4 * QH);
-                    }
+                for (int m = 0; m < NR; ++m) part[l][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (!ALL && (t < 0 || t >= T)) continue;         // uniform
+                const float* rec_src = hbuf + l * MR * SH + 4 * g;
+                if (l == 0) {
+                    gemv_span<NR, QX, KB, NW0>(part[l], xin + (t & 1) * MR * SX + 4 * g, SX, w0, 0);
+                    gemv_span<NR, QH, KB, NW0>(part[l], rec_src, SH, w0, 4 * QX);
                 } else {
-                    if constexpr (L > 2) {
-                        gemv_span<NR, QH, NW1>(part, in_src, SH, w2, 0);
-                        gemv_span<NR, QH, NW1>(part, rec_src, SH, w2, 4 * QH);
+                    const float* in_src = hbuf + (l - 1) * MR * SH + 4 * g;
+                    if (l == 1) {
+                        if constexpr (L > 1) {
+                            gemv_span<NR, QH, KB, NW1>(part[l], in_src, SH, w1, 0);
+                            gemv_span<NR, QH, KB, NW1>(part[l], rec_src, SH, w1, 4 * QH);
+                        }
+                    } else {
+                        if constexpr (L > 2) {
+                            gemv_span<NR, QH, KB, NW1>(part[l], in_src, SH, w2, 0);
+                            gemv_span<NR, QH, KB, NW1>(part[l], rec_src, SH, w2, 4 * QH);
+                        }
                     }
                 }
             }
-            // sum the four k-groups (lanes c, c+16, c+32, c+48): two wave shuffles per row
-            float pre = 0.0f;
+            // sum the NG k-groups (lanes c, c + CW, ...): row rotation / row swap / half swap, no LDS crossbar
+            float pre[L];
 #pragma unroll
-            for (int m = 0; m < NR; ++m) {
-                float v = (part[m][0] + part[m][1]) + (part[m][2] + part[m][3]);
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (g == m) pre = v;               // lane group g owns batch row g from here on
+            for (int l = 0; l < L; ++l) {
+                pre[l] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    float v = (part[l][m][0] + part[l][m][1]) + (part[l][m][2] + part[l][m][3]);
+                    if constexpr (CW == 8) v = sum_ror8(v);
+                    v = sum_xor16(v);
+                    v = sum_xor32(v);
+                    if (g == m) pre[l] = v;            // lane group g owns batch row g from here on
+                }
             }
-            const float a = gate_act(pre + bias_r[l], gate == 2);
-            const float iv = quad_bcast<0>(a), fv = quad_bcast<1>(a), gv = quad_bcast<2>(a), ov = quad_bcast<3>(a);
-            const float cn = fv * cst[l] + iv * gv;
-            cst[l] = cn;
-            if (gate == 0 && g < NR) own[((wave * L + l) * MR + g) * 4 + u] = ov * gate_act(cn, true);
-        }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = ph - l;
+                if (!ALL && (t < 0 || t >= T)) continue;
+                const float a = gate_act(pre[l] + bias_r[l], gate == 2);
+                const float iv = quad_bcast<0>(a), fv = quad_bcast<1>(a), gv = quad_bcast<2>(a), ov = quad_bcast<3>(a);
+                const float cn = fv * cst[l] + iv * gv;
+                cst[l] = cn;
+                if (gate == 0 && g < NR) own[((wave * L + l) * MR + g) * UW + u] = ov * gate_act(cn, true);
+            }
+        };
+        if (ph >= L - 1 && ph < T) layers(std::true_type{});
+        else layers(std::false_type{});
         if (ph == P - 1 && hw_live) {              // the head's weights: their latency hides behind this phase's exchange
 #pragma unroll
             for (int i = 0; i < H / 64; ++i)
@@ -309,16 +355,22 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             hw_b = p.b_out[hw_o];
         }
         SM_STAMP(1);                                // 1: x staging + GEMVs + gates of every layer
-        // ---- publish: lane (l, row) of this wave sends the 16-byte piece of its four units, drain, THIS wave's flag ------
+        // ---- publish: lane (l, row) of this wave sends the piece of its UW units (16 or 8 bytes), drain, THIS wave's flag ------
         {
             const int l = lane / MR, row = lane - l * MR;
             const int t = ph - l;
             const bool live = lane < L * MR && t >= 0 && t < T;
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(own + ((wave * L + (live ? l : 0)) * MR + row) * 4);
-            const auto hvu = __builtin_bit_cast(u32x4, hv);
-            const unsigned off = live ? hx_base(l, t & 1) + (unsigned)(row * ROW_BYTES + (member * 4 + wave) * 16) : 0x80000000u;
-            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 0);          // stays in the XCD's L2
-            else __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            const float* piece = own + ((wave * L + (live ? l : 0)) * MR + row) * UW;
+            const unsigned off = live ? hx_base(l, t & 1) + (unsigned)(row * ROW_BYTES + (member * 4 + wave) * UW * 4) : 0x80000000u;
+            if constexpr (UW == 4) {
+                const auto hvu = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(piece));
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 0);          // stays in the XCD's L2
+                else __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            } else {
+                const auto hvu = __builtin_bit_cast(u32x2, *reinterpret_cast<const f32x2*>(piece));
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b64(hvu, hx_rsrc, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(hvu, hx_rsrc, off, 0, 16);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SM_STAMP(2);                                // 2: publish store issued -> acknowledged (and the x fetch)
@@ -334,6 +386,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             while (true) {
                 unsigned v = (unsigned)(ph + 1);
                 if (lane < NFL) v = __hip_atomic_load(myflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (NFL > 64) {          // 32 members: a second word per lane
+                    const unsigned v2 = __hip_atomic_load(myflag + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = v2 < v ? v2 : v;
+                }
                 if (__all((int)(v >= (unsigned)(ph + 1)))) break;
                 // (the sticky status word is looked at every 256th spin only: a second dependent load per spin doubles the
                 //  time a late flag costs, measured 0.96 us per phase)
@@ -379,10 +435,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
                 s_acc = fmaf(av[2], hw[i][2], s_acc); s_acc = fmaf(av[3], hw[i][3], s_acc);
             }
         }
-        s_acc += __shfl_xor(s_acc, 1, 64);
-        s_acc += __shfl_xor(s_acc, 2, 64);
-        s_acc += __shfl_xor(s_acc, 4, 64);
-        s_acc += __shfl_xor(s_acc, 8, 64);
+        // the 16 lanes of a target: quad swaps, half-row mirror, row mirror (DPP)
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0xB1, 0xF, 0xF, false));
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x4E, 0xF, 0xF, false));
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x141, 0xF, 0xF, false));
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x140, 0xF, 0xF, false));
         if (hw_live && hw_part == 0 && b < p.B) p.y[(size_t)b * O + hw_o] = s_acc + hw_b;
     }
     SM_STAMP(6);                                    // 6: head
@@ -409,25 +466,27 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     }
 }
 
-template <int H, int L, int KX, int NR>
+template <int H, int L, int KX, int NR, int UW>
 hipError_t launch_small(const ClusterParams& p, hipStream_t stream) {
-    constexpr size_t smem = ((size_t)L * MR * H + 2 * MR * (KX + 8) + (size_t)4 * L * MR * 4 + 4) * sizeof(float);
-    hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR>), dim3(8 * (H / 16)), dim3(256), smem, stream, p);
+    constexpr size_t smem = ((size_t)L * MR * H + 2 * MR * (KX + 8) + (size_t)4 * L * MR * UW + 4) * sizeof(float);
+    hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR, UW>), dim3(8 * (H / (4 * UW))), dim3(256), smem, stream, p);
     return hipGetLastError();
+}
+
+template <int H, int L, int KX, int UW>
+hipError_t launch_small_nr(int nr, const ClusterParams& p, hipStream_t stream) {
+    if (nr == 1) return launch_small<H, L, KX, 1, UW>(p, stream);
+    if (nr == 2) return launch_small<H, L, KX, 2, UW>(p, stream);
+    if (nr == 4) return launch_small<H, L, KX, 4, UW>(p, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-// one cluster, B <= 4 windows (nr = 1, 2 or 4 rows computed)
-hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, const ClusterParams& p, hipStream_t stream) {
-    if (H == 256 && L == 2 && KX == 32) {
-        if (nr == 1) return launch_small<256, 2, 32, 1>(p, stream);
-        if (nr == 2) return launch_small<256, 2, 32, 2>(p, stream);
-        if (nr == 4) return launch_small<256, 2, 32, 4>(p, stream);
-    } else if (H == 128 && L == 3 && KX == 64) {
-        if (nr == 1) return launch_small<128, 3, 64, 1>(p, stream);
-        if (nr == 2) return launch_small<128, 3, 64, 2>(p, stream);
-        if (nr == 4) return launch_small<128, 3, 64, 4>(p, stream);
-    }
+// one cluster, B <= 4 windows (nr = 1, 2 or 4 rows computed); uw = hidden units per wave (4: H/16 members, weights p.wcl in
+// the MFMA cluster kernel's order; 2: H/8 members, weights in the [member][wave][k-quad][lane][4] order of 8-column waves)
+hipError_t ape_launch_lstm_cluster_small(int H, int L, int KX, int nr, int uw, const ClusterParams& p, hipStream_t stream) {
+    if (H == 256 && L == 2 && KX == 32) return uw == 2 ? launch_small_nr<256, 2, 32, 2>(nr, p, stream) : launch_small_nr<256, 2, 32, 4>(nr, p, stream);
+    if (H == 128 && L == 3 && KX == 64) return uw == 2 ? launch_small_nr<128, 3, 64, 2>(nr, p, stream) : launch_small_nr<128, 3, 64, 4>(nr, p, stream);
     return hipErrorInvalidValue;
 }

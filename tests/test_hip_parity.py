@@ -235,6 +235,14 @@ def test_small_batch_latency_kernel(norm_stats, name):
                                                    C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
             torch.cuda.synchronize()
             assert np.array_equal(y_wt.cpu().numpy(), y_small)
+            # on a device whose XCDs hold H/8 CUs the kernel runs with H/8 members (two units per wave); the internal flag
+            # forces the H/16-member form: same arithmetic up to the f32 summation order
+            y_w4 = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+            _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xt.data_ptr()), B, T,
+                                                   _hip.FLAG_NORMALIZE_INPUT | 0x01000000, None, 0.0, 0,
+                                                   C.c_void_p(y_w4.data_ptr()), None), "ape_lstm_forward")
+            torch.cuda.synchronize()
+            assert np.abs(y_w4.cpu().numpy() - y_ref).max() < TOL_Y_SHORT
     assert "cluster" in model.kernel_name(1, 6)
     model.check()
 
