@@ -150,6 +150,8 @@ struct ape_model {
     void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
     float* wcl32[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};  // 32x32x2 fragments of the second-generation f32 cluster kernel
     float* wcls[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // the latency kernel's H/8-member form (two units per wave)
+    char* hxs = nullptr;             // latency kernel: [256 B: launch number][granules {h, tag}: layer, parity, 4 rows, H units]
+    size_t hxs_bytes = 0;
     int small_uw = 4;                // hidden units per wave of the latency kernel: 2 when one XCD holds H/8 members
     bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
     bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
@@ -324,6 +326,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = plan((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
         if (e == hipSuccess) e = plan((void**)&m->xflags, m->xflag_bytes + 256);
         if (e == hipSuccess) e = plan((void**)&m->xcc_slots, APE_XCC_WORDS * sizeof(unsigned));
+        m->hxs_bytes = (size_t)L * 2 * 4 * H * 8;
+        if (e == hipSuccess) e = plan((void**)&m->hxs, 256 + m->hxs_bytes);
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
@@ -685,7 +689,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const bool cdrop = drop && L > 1;
         const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop);
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
-        const bool small = !f16 && !cdrop && !all_steps && B <= 4 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
         const int small_uw = (flags & APE_DIAG_SMALL_UW4) ? 4 : m->small_uw;
         if (!f16 && !cdrop && !drop && !all_steps && !small && m->c32_ok && m->c32_on && B - n16 > 512) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
@@ -761,6 +765,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
             c.xx_r = m->stats + 2 * m->dims.input_size + 2 * m->dims.output_size;
             c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+            if (small) { c.hx = reinterpret_cast<float*>(m->hxs + 256); c.hx_bytes = m->hxs_bytes; c.seq = reinterpret_cast<unsigned*>(m->hxs); }
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
             c.done = c.ticket + 1;
@@ -844,6 +849,7 @@ int ape_model_check(ape_model_t* m) {
         // an aborted launch skipped its self-cleaning: reset flags, counters and the status word from the host
         HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
         HIP_TRY(hipMemset(m->xcc_slots, 0, APE_XCC_WORDS * sizeof(unsigned)));
+        HIP_TRY(hipMemset(m->hxs, 0, 256 + m->hxs_bytes));     // the aborted launch's granules carry tags the next launch would await
         HIP_TRY(hipDeviceSynchronize());
         return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
                     "since the last successful check are invalid; the model is usable again", st,

@@ -77,6 +77,7 @@ struct ClusterParams {
     unsigned long long seed;
     float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
+    unsigned* seq;                      // latency kernel: [1] launch number of this model (the upper bits of its granule tags)
     unsigned* xcc_slots;                // APE_XCC_WORDS words, zero between launches.  [0,64): small-batch kernel, (0x10 | XCC id) of
                                         // its members; [64,192): fp16 v2 kernel's 8 class tickets, one per 64-byte line;
                                         // [192, ...): its per-workgroup XCD words

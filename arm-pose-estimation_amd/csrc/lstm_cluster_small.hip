@@ -30,12 +30,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int MR = 4;                      // rows per cluster (row = lane group)
 
-// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
-// the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes.  M0 is written in the
-// same statement that reads it (the compiler does not preserve it across statements).
-__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+// NI polling loads (16 bytes per lane, L1-bypassing) and the wait for them in ONE statement: the compiler knows nothing of the
+// asynchronous return, so no use (or copy) of a result may be scheduled between a load and the wait
+template <int NI>
+__device__ __forceinline__ void poll_granules(u32x4 (&v)[NI], const unsigned (&off)[NI], u32x4 rsrc) {
+    static_assert(NI >= 1 && NI <= 4, "pairs per thread");
+    if constexpr (NI == 1)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]) : "v"(off[0]), "s"(rsrc) : "memory");
+    else if constexpr (NI == 2)
+        asm volatile("buffer_load_dwordx4 %0, %2, %4, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(off[0]), "v"(off[1]), "s"(rsrc) : "memory");
+    else if constexpr (NI == 3)
+        asm volatile("buffer_load_dwordx4 %0, %3, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen sc1\n\t"
+                     "buffer_load_dwordx4 %2, %5, %6, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "s"(rsrc) : "memory");
+    else
+        asm volatile("buffer_load_dwordx4 %0, %4, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen sc1\n\t"
+                     "buffer_load_dwordx4 %2, %6, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %3, %7, %8, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                     : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(rsrc) : "memory");
 }
 
 __device__ __forceinline__ float gate_act(float v, bool is_tanh) {
@@ -140,10 +154,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;   // monte_carlo_predictions: one window, B rows
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* hbuf = smem;                            // [L][MR][SH]
-    float* xin = hbuf + L * MR * SH;               // [2][MR][SX]  double-buffered by step parity
-    float* own = xin + 2 * MR * SX;                // [wave 4][L][MR][UW]  fresh slice of this wave (wave-private)
-    int* ctl = reinterpret_cast<int*>(own + 4 * L * MR * UW);
+    float* hbuf = smem;                            // [2][L][MR][SH]  by phase parity: a phase reads one, its exchange fills the other
+    float* xin = hbuf + 2 * L * MR * SH;           // [2][MR][SX]  double-buffered by step parity
+    int* ctl = reinterpret_cast<int*>(xin + 2 * MR * SX);
     // Membership is fixed by the block index: the launch has 8 x GH workgroups and only every eighth one takes part
     // (the others leave at once).  Under the placement observed on this hardware -- blocks are dealt round-robin over
     // the 8 XCDs -- those GH workgroups share ONE XCD, hence one L2, and the exchange can stay inside it: plain stores
@@ -158,23 +171,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int cluster = 0, member = blockIdx.x / 8;
+    const int member = blockIdx.x / 8;
     const int row0 = 0;
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xFu;
-    // a launch that finds the sticky status word set (an earlier launch on this model aborted and left stale epochs
-    // behind) leaves without touching anything; ape_model_check reports and resets
-    if (tid == 0) {
-        ctl[0] = (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
-        if (ctl[0] == 0)
-            __hip_atomic_store(p.xcc_slots + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (int i = tid; i < L * MR * SH; i += 256) hbuf[i] = 0.0f;       // h_{-1} = 0: the first step reads zeros
-    __syncthreads();
-    if (ctl[0] != 0) return;
-
-    // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel) ----------------
+    // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel); requested before
+    //      anything else -- everything up to the first phase runs under their latency
     static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
     float w0[NW0];
     float w1[L > 1 ? NW1 : 1];
@@ -204,6 +207,20 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             }
         }
     }
+    // the launch number of this model's latency kernel (bumped by the last member out): the upper bits of every tag
+    const unsigned seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu;
+    // a launch that finds the sticky status word set (an earlier launch on this model aborted and left stale epochs
+    // behind) leaves without touching anything; ape_model_check reports and resets
+    if (tid == 0) {
+        ctl[0] = (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+        if (ctl[0] == 0)
+            __hip_atomic_store(p.xcc_slots + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = tid; i < 2 * L * MR * SH; i += 256) hbuf[i] = 0.0f;   // h_{-1} = 0: the first step of a layer reads zeros
+    // (barriers that wait for LDS traffic only: the weight loads stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ctl[0] != 0) return;
+
     // head weights of this thread (16 lanes per target, H / 16 consecutive k each): requested in the last phase, under its exchange
     const int hw_o = tid >> 4, hw_part = tid & 15;
     const bool hw_live = member < MR && hw_o < O;
@@ -225,12 +242,24 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
     hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
     hx_desc[3] = 0x00020000u;
-    constexpr int NFL = 4 * GH;                    // one epoch word per member WAVE (all layers at once)
-    unsigned* const myflag = p.xflags + (size_t)cluster * NFL;
-    constexpr unsigned ROW_BYTES = H * sizeof(float);                   // [row][member][wave][UW units]: a window row of one layer
+    // exchange: 8-byte granules {h, tag} at [layer][step parity][row][unit]; tag = launch number << 12 | phase + 1.  A granule
+    // is written with one 8-byte store and is valid exactly when its tag is the awaited one, so the data IS the flag: one
+    // hop (store -> polled load) per phase instead of store -> acknowledge -> flag -> poll -> copy.
+    constexpr unsigned ROW_BYTES = H * 8;                               // a window row of one layer
     constexpr unsigned SET_BYTES = MR * ROW_BYTES;                      // one (layer, parity)
-    auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SET_BYTES); };
-    const unsigned hbuf_lds = (unsigned)reinterpret_cast<unsigned long long>(hbuf);
+    auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((l * 2 + par) * SET_BYTES); };
+    constexpr int PAIRS = NR * H / 2;                                   // 16-byte pairs of granules per layer
+    constexpr int NI = (L * PAIRS + 255) / 256;                         // pairs this thread collects per phase
+    int it_l[NI], it_lds[NI];
+    unsigned it_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + 256 * i;
+        const int l = e / PAIRS, r = e - l * PAIRS, row = r / (H / 2), pair = r - row * (H / 2);
+        it_l[i] = (e < L * PAIRS) ? l : -1;
+        it_lds[i] = (l * MR + row) * SH + 2 * pair;
+        it_off[i] = hx_base(l, 0) + (unsigned)(row * ROW_BYTES + pair * 16);
+    }
 
     // x_t: f64 z-score, cast f32 (estimator.py:103-104) -- (x - m) / s correctly rounded via the host-rounded reciprocal
     // and one residual step (bit-identical to the division, as in lstm_cluster.hip); fetched a phase ahead
@@ -293,6 +322,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         // ---- every layer of this phase (layer l works on step t = ph - l).  In the steady state (all layers active) the body
         //      is straight-line code: all GEMVs, then all k-group sums, then all cell updates, so that the layers' dependent
         //      chains (LDS read -> FMA chain -> lane sums -> exp/rcp chains) overlap instead of following each other
+        const float* const hrd = hbuf + (ph & 1) * (L * MR * SH);
+        const unsigned want = (seq << 12) | (unsigned)(ph + 1);
         auto layers = [&](auto all_tag) {
             constexpr bool ALL = decltype(all_tag)::value;
             f32x4 part[L][NR];
@@ -302,12 +333,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
 #pragma unroll
                 for (int m = 0; m < NR; ++m) part[l][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 if (!ALL && (t < 0 || t >= T)) continue;         // uniform
-                const float* rec_src = hbuf + l * MR * SH + 4 * g;
+                const float* rec_src = hrd + l * MR * SH + 4 * g;
                 if (l == 0) {
                     gemv_span<NR, QX, KB, NW0>(part[l], xin + (t & 1) * MR * SX + 4 * g, SX, w0, 0);
                     gemv_span<NR, QH, KB, NW0>(part[l], rec_src, SH, w0, 4 * QX);
                 } else {
-                    const float* in_src = hbuf + (l - 1) * MR * SH + 4 * g;
+                    const float* in_src = hrd + (l - 1) * MR * SH + 4 * g;
                     if (l == 1) {
                         if constexpr (L > 1) {
                             gemv_span<NR, QH, KB, NW1>(part[l], in_src, SH, w1, 0);
@@ -343,7 +374,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
                 const float iv = quad_bcast<0>(a), fv = quad_bcast<1>(a), gv = quad_bcast<2>(a), ov = quad_bcast<3>(a);
                 const float cn = fv * cst[l] + iv * gv;
                 cst[l] = cn;
-                if (gate == 0 && g < NR) own[((wave * L + l) * MR + g) * UW + u] = ov * gate_act(cn, true);
+                // publish: the lane that holds h of (row g, unit) sends its granule {h, tag} -- fire and forget
+                const float hval = ov * gate_act(cn, true);
+                u32x2 gran;
+                gran[0] = __builtin_bit_cast(unsigned, hval);
+                gran[1] = want;
+                const unsigned off = (gate == 0 && g < NR)
+                                         ? hx_base(l, t & 1) + (unsigned)(g * ROW_BYTES + ((member * 4 + wave) * UW + u) * 8) : 0x80000000u;
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b64(gran, hx_rsrc, off, 0, 0);      // stays in the XCD's L2
+                else __builtin_amdgcn_raw_buffer_store_b64(gran, hx_rsrc, off, 0, 16 /* sc1: write-through */);
             }
         };
         if (ph >= L - 1 && ph < T) layers(std::true_type{});
@@ -354,45 +393,36 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
                 hw[i] = *reinterpret_cast<const f32x4*>(p.w_out + (size_t)hw_o * H + hw_part * (H / 16) + 4 * i);
             hw_b = p.b_out[hw_o];
         }
-        SM_STAMP(1);                                // 1: x staging + GEMVs + gates of every layer
-        // ---- publish: lane (l, row) of this wave sends the piece of its UW units (16 or 8 bytes), drain, THIS wave's flag ------
+        SM_STAMP(1);                                // 1: x staging + GEMVs + gates + granule stores of every layer
+        // ---- collect: every thread polls ITS pairs of granules (16 bytes: two units of one row and layer) until both carry this
+        //      phase's tag, then puts the two values into the h buffer of the next phase
         {
-            const int l = lane / MR, row = lane - l * MR;
-            const int t = ph - l;
-            const bool live = lane < L * MR && t >= 0 && t < T;
-            const float* piece = own + ((wave * L + (live ? l : 0)) * MR + row) * UW;
-            const unsigned off = live ? hx_base(l, t & 1) + (unsigned)(row * ROW_BYTES + (member * 4 + wave) * UW * 4) : 0x80000000u;
-            if constexpr (UW == 4) {
-                const auto hvu = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(piece));
-                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 0);          // stays in the XCD's L2
-                else __builtin_amdgcn_raw_buffer_store_b128(hvu, hx_rsrc, off, 0, 16 /* sc1: write-through */);
-            } else {
-                const auto hvu = __builtin_bit_cast(u32x2, *reinterpret_cast<const f32x2*>(piece));
-                if (in_l2) __builtin_amdgcn_raw_buffer_store_b64(hvu, hx_rsrc, off, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b64(hvu, hx_rsrc, off, 0, 16);
+            unsigned off[NI];
+            bool act[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int t = ph - it_l[i];
+                act[i] = it_l[i] >= 0 && t >= 0 && t < T;
+                off[i] = act[i] ? it_off[i] + (unsigned)(t & 1) * SET_BYTES : 0x80000000u;   // out of range: reads zeros
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SM_STAMP(2);                                // 2: publish store issued -> acknowledged (and the x fetch)
-        if (lane == 0) {
-            unsigned* f = myflag + member * 4 + wave;
-            if (in_l2) *reinterpret_cast<volatile unsigned*>(f) = (unsigned)(ph + 1);    // plain: stays in the XCD's L2
-            else __hip_atomic_store(f, (unsigned)(ph + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- every wave polls every member wave's flag of this phase, then copies window row `wave` of every layer --------
-        //      (one polling wave per workgroup + a barrier instead: no difference, 22.9 vs 23.1 us)
-        {
+            // (the four words of a pair leave the vector inside the loop, one by one: building the float pair for the LDS
+            //  write from elements 0 and 2 of the asm's vector result after the loop is miscompiled by this hipcc -- it
+            //  writes element 0 twice)
+            unsigned val0[NI], val1[NI];
             unsigned spins = 0;
             while (true) {
-                unsigned v = (unsigned)(ph + 1);
-                if (lane < NFL) v = __hip_atomic_load(myflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if constexpr (NFL > 64) {          // 32 members: a second word per lane
-                    const unsigned v2 = __hip_atomic_load(myflag + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v = v2 < v ? v2 : v;
+                u32x4 v[NI];
+                poll_granules<NI>(v, off, hx_desc);
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    val0[i] = v[i][0];
+                    val1[i] = v[i][2];
+                    bad = bad || (act[i] && (v[i][1] != want || v[i][3] != want));
                 }
-                if (__all((int)(v >= (unsigned)(ph + 1)))) break;
+                if (!__any((int)bad)) break;
                 // (the sticky status word is looked at every 256th spin only: a second dependent load per spin doubles the
-                //  time a late flag costs, measured 0.96 us per phase)
+                //  time a late granule costs)
                 if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                              __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     if (lane == 0) {
@@ -403,19 +433,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
                 }
                 if (spins > 64u) __builtin_amdgcn_s_sleep(1);
             }
-        }
-        SM_STAMP(3);                                // 3: own flag store -> every member wave's flag seen
-        if (wave < NR) {
+            SM_STAMP(3);                            // 3: last granule store issued -> every awaited granule seen
+            float* const hwr = hbuf + ((ph + 1) & 1) * (L * MR * SH);
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int t = ph - l;
-                if (t >= 0 && t < T && lane * 16 < (int)ROW_BYTES)
-                    dma_1k(hbuf_lds + (unsigned)((l * MR + wave) * ROW_BYTES), (unsigned)(lane * 16), hx_desc,
-                           hx_base(l, t & 1) + (unsigned)(wave * ROW_BYTES));
-            }
+            for (int i = 0; i < NI; ++i)
+                if (act[i]) {
+                    hwr[it_lds[i]] = __builtin_bit_cast(float, val0[i]);
+                    hwr[it_lds[i] + 1] = __builtin_bit_cast(float, val1[i]);
+                }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SM_STAMP(4);                                // 4: gather DMA issued -> landed in LDS
+        SM_STAMP(4);                                // 4: values into LDS
         __syncthreads();                            // gathered h and x_{ph+1} visible
         SM_STAMP(5);                                // 5: barrier
         if (ctl[0] != 0) return;
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         const int b = row0 + member;
         float s_acc = 0.0f;
         if (hw_live) {
-            const float* hv = hbuf + ((L - 1) * MR + member) * SH + hw_part * (H / 16);
+            const float* hv = hbuf + (P & 1) * (L * MR * SH) + ((L - 1) * MR + member) * SH + hw_part * (H / 16);
 #pragma unroll
             for (int i = 0; i < H / 64; ++i) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(hv + 4 * i);
@@ -455,9 +482,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GH - 1) ? 1 : 0;
     __syncthreads();
     if (ctl[2] != 0) {
-        const int n_words = 4 * GH;
-        for (int i = tid; i < n_words; i += 256)
-            __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the next launch's tags differ from every tag of this one; when the 20-bit launch number wraps, the granules go
+        // back to zero (tag 0 is never awaited) so that a tag of 2^20 launches ago cannot be taken for a fresh one
+        if (seq == 0xFFFFFu)
+            for (int i = tid; i < (int)(p.hx_bytes / 4); i += 256)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(p.hx) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.seq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < GH) __hip_atomic_store(p.xcc_slots + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -468,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
 
 template <int H, int L, int KX, int NR, int UW>
 hipError_t launch_small(const ClusterParams& p, hipStream_t stream) {
-    constexpr size_t smem = ((size_t)L * MR * H + 2 * MR * (KX + 8) + (size_t)4 * L * MR * UW + 4) * sizeof(float);
+    constexpr size_t smem = ((size_t)2 * L * MR * H + 2 * MR * (KX + 8) + 4) * sizeof(float);
     hipLaunchKernelGGL((ape_lstm_cluster_small<H, L, KX, NR, UW>), dim3(8 * (H / (4 * UW))), dim3(256), smem, stream, p);
     return hipGetLastError();
 }
