@@ -1,22 +1,23 @@
 // Small-batch (1..4 windows) variant of the weight-stationary cluster LSTM kernel: the latency path
 // (BASELINE.json configs[1]: batch=1 streaming at 50 Hz).
 //
-// At 1-4 windows a 16-row MFMA tile is 75-94 % padding, so this variant keeps everything else of
-// lstm_cluster.hip (GH = H/16 workgroups per cluster, member m owns hidden units [16m,16m+16) of every layer,
-// its weights resident in registers for the whole launch in the same fragment layout, h slices exchanged with
-// sc1 write-through stores + epoch flags, self-cleaning, arrival tickets) but
-//   * the stacked-gate product is a register-resident GEMV on the VALU: lane (column c = unit*4+gate, k-group
-//     g) multiplies its 4 weights of every 16-deep k-block with the matching activations (one broadcast
-//     ds_read_b128 per block and row) and the four k-groups are summed with two wave shuffles;
-//   * lane group g then owns batch row g: one activation per lane, the four gates of a unit meet by DPP
-//     quad broadcasts, the cell update is a handful of VALU ops;
-//   * ALL layers of a phase are computed back to back and published together, so there is ONE exchange
-//     round trip per phase (layer l works on step p - l, as in the big kernel) instead of one per layer.
-//   * that round trip has ONE workgroup barrier in it (round 2; it had three): every wave sends the 16-byte pieces of its own
-//     four units straight from a wave-private LDS patch, drains and raises ITS flag (an agent-scope store also when the
-//     payload stays in the XCD's L2: a plain flag store takes its time to leave the CU); every wave polls all 4 GH flags
-//     itself (one load per lane) and then copies one window row of every layer global -> LDS with one LDS-DMA instruction
-//     per layer (the exchange order [row][member][wave][4 units] is the LDS order of h), and only then the barrier.
+// At 1-4 windows a 16-row MFMA tile is 75-94 % padding, so this variant keeps the cluster idea (one workgroup per CU, member m
+// owns a slice of the hidden units of every layer, its weights resident in registers for the whole launch, h exchanged
+// through memory every phase) but
+//   * the stacked-gate product is a register-resident GEMV on the VALU: lane (column c = unit*4+gate, k-group g) multiplies
+//     its 4 weights of every k-block with the matching activations (one broadcast ds_read_b128 per block and row); the
+//     k-groups are summed with a DPP row rotation and gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap) --
+//     no trip through the LDS crossbar;
+//   * lane group g then owns batch row g: one activation per lane, the four gates of a unit meet by DPP quad broadcasts;
+//   * ALL layers of a phase are computed together (layer l works on step p - l) -- in the steady state as straight-line
+//     code, so the layers' dependent chains overlap -- and there is ONE exchange per phase;
+//   * the cluster is H/8 members (UW = 2 units per wave: every CU of a 32-CU XCD at H = 256) where an XCD has that many CUs:
+//     100 weight registers per lane, all architectural; H/16 members (UW = 4) otherwise;
+//   * the exchange is ONE hop: the lane that holds a fresh h value stores the 8-byte granule {h, tag} (tag = launch number
+//     of the model << 12 | phase + 1); every thread polls its own pair of granules (16 bytes, L1-bypassing) until both carry
+//     the awaited tag and puts the two values into the LDS buffer of the next phase (h is double-buffered in LDS by phase
+//     parity, in memory by step parity).  The data is the flag: no store drain, no flag store, no copy after the poll.  The
+//     launch number lives in device memory (bumped by the last member out), so a captured launch replays correctly.
 // Same arithmetic as the other kernels up to float32 summation order.
 #include <type_traits>
 #include "ape_internal.h"
@@ -116,6 +117,22 @@ __device__ __forceinline__ void gemv_span(f32x4 (&part)[NR], const float* __rest
     }
 }
 
+// The same in two halves for the one-row instantiations: every fragment of a span requested at once (NQ ds_read_b128 in
+// flight), multiplied later -- the caller orders requests and multiplications of different spans by hand (left alone the
+// scheduler keeps two fragments in flight and pays the LDS latency per pair)
+template <int NQ, int KB>
+__device__ __forceinline__ void span_load(f32x4 (&a)[NQ], const float* __restrict__ src) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(src + KB * q);
+}
+template <int NQ, int NW>
+__device__ __forceinline__ void span_fma(f32x4& part, const f32x4 (&a)[NQ], const float (&w)[NW], int w0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[j] = fmaf(a[q][j], w[w0 + 4 * q + j], part[j]);
+}
+
 // Diagnostic build (make diag: -DAPE_CLUSTER_STAMPS): shader-cycle sums per part of member 0's wave 0, written to the
 // model's debug words (memory nothing else reads).  The shipped library has none of this code.
 #ifdef APE_CLUSTER_STAMPS
@@ -176,6 +193,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xFu;
+    // the bias of this lane's gate row: requested ahead of the weights and consumed (see below) before the phase loop, so that
+    // the loop carries no pending load of it -- otherwise the first use in the loop waits for everything but the newest
+    // memory operation, i.e. for the x fetch issued at the top of the same phase
+    float bias_r[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) bias_r[l] = p.bias[l][gate * H + (member * 4 + wave) * UW + u];
     // ---- weights: registers for the whole launch (same fragment layout as the MFMA cluster kernel); requested before
     //      anything else -- everything up to the first phase runs under their latency
     static_assert(NW0 % 4 == 0 && NW1 % 4 == 0, "weight registers are loaded four at a time");
@@ -228,12 +251,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     float hw_b = 0.0f;
 #pragma unroll
     for (int i = 0; i < H / 64; ++i) hw[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float bias_r[L], cst[L];
+    float cst[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        bias_r[l] = p.bias[l][gate * H + (member * 4 + wave) * UW + u];
-        cst[l] = 0.0f;
-    }
+    for (int l = 0; l < L; ++l) cst[l] = 0.0f;
 
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
     const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
@@ -312,6 +332,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
 
     const int P = T + L - 1;
+#pragma unroll
+    for (int l = 0; l < L; ++l) asm volatile("" :: "v"(bias_r[l]));     // the bias has arrived (it was requested first)
     SM_STAMP(0);                                    // 0: prologue (weights into registers, x_0, XCD rendezvous)
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
@@ -328,10 +350,25 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
             constexpr bool ALL = decltype(all_tag)::value;
             f32x4 part[L][NR];
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int t = ph - l;
+            for (int l = 0; l < L; ++l)
 #pragma unroll
                 for (int m = 0; m < NR; ++m) part[l][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (ALL && NR == 1 && L == 2) {
+                // one row, two layers, steady state: requests of the next span under the multiplications of the last
+                // (layer 1's input IS layer 0's recurrent input: h of layer 0 from the last phase, fetched once)
+                f32x4 ax[QX], ah[QH], bh[QH];
+                span_load<QX, KB>(ax, xin + (ph & 1) * MR * SX + 4 * g);
+                span_load<QH, KB>(ah, hrd + 4 * g);
+                span_load<QH, KB>(bh, hrd + MR * SH + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+                span_fma<QX, NW0>(part[0][0], ax, w0, 0);
+                span_fma<QH, NW0>(part[0][0], ah, w0, 4 * QX);
+                span_fma<QH, NW1>(part[1][0], ah, w1, 0);
+                span_fma<QH, NW1>(part[1][0], bh, w1, 4 * QH);
+            } else
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = ph - l;
                 if (!ALL && (t < 0 || t >= T)) continue;         // uniform
                 const float* rec_src = hrd + l * MR * SH + 4 * g;
                 if (l == 0) {

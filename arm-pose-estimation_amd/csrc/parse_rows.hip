@@ -8,7 +8,10 @@
 // Message layouts: data_types/messaging.py:20-68 (28 floats, watch only) and :96-187 (55 floats).
 //
 // One thread per row; float64 arithmetic (the reference computes on Python floats); rows are staged through
-// LDS so the global reads are coalesced.  HBM-bound and tiny: 220 B in, 88-304 B out per row.
+// LDS both ways so the global reads AND writes are coalesced and shared by the block's threads (a row's features go out
+// rep times -- T slots on a cold start, n_mc window copies in Monte-Carlo mode: as a per-thread loop over a private array
+// that was 68 us for ONE stream with 25 copies, scratch loads and dependent scalar stores).  HBM-bound and tiny: 220 B in,
+// 88-304 B out per row.
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
 
@@ -61,7 +64,8 @@ __device__ __forceinline__ int sw_sensor_col(int i) { return i == 0 ? 0 : (i <= 
 // ph gyro, lvel, lacc at 33..41; grav at 43..45
 __device__ __forceinline__ int ph_sensor_col(int i) { return i < 9 ? 33 + i : 34 + i; }
 
-constexpr int PR_BLOCK = 128;
+constexpr int PR_BLOCK = 64;
+constexpr int XW = 39;                          // feature row stride in LDS (odd: conflict-free per-thread rows)
 
 // Output row n goes to out[n * out_stride + j * rep_stride + 0..I) for j < rep: rep = 1 and out_stride = I is the
 // plain [N,I] matrix; the stream bank (ape_streams_push_rows) points it at one slot of every stream's window ring
@@ -82,11 +86,12 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
         if (big_endian) v = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, v)));
         slab[rr * 57 + c] = v;
     }
+    __shared__ double xout[PR_BLOCK * XW];
     __syncthreads();
-    if (tid >= n) return;
+    if (tid < n) {
     const float* row = slab + tid * 57;
     const Cols cl = cols_of(width);
-    double xx[38];
+    double* xx = xout + tid * XW;
     int o = 0;
 #pragma unroll
     for (int i = 0; i < 13; ++i) xx[o++] = (double)row[sw_sensor_col(i)];
@@ -116,9 +121,13 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
             xx[o++] = cos(hy);
         }
     }
-    for (int j = 0; j < rep; ++j) {
-        TOut* dst = out + (r0 + tid) * out_stride + j * rep_stride;
-        for (int i = 0; i < I; ++i) dst[i] = (TOut)xx[i];
+    }
+    __syncthreads();
+    // all threads of the block write all rows: consecutive threads = consecutive features of one (row, copy)
+    const int per_row = rep * I;
+    for (int idx = tid; idx < n * per_row; idx += PR_BLOCK) {
+        const int rr = idx / per_row, rem = idx - rr * per_row, j = rem / I, i = rem - j * I;
+        out[(r0 + rr) * out_stride + j * rep_stride + i] = (TOut)xout[rr * XW + i];
     }
 }
 

@@ -227,6 +227,29 @@ def batch1_latency(model, stats, n_frames=300):
         out["graph_replay_p99_us"] = float(np.percentile(gus, 99))
     except Exception as exc:            # reported, never fatal for the headline line
         out["graph_replay_error"] = str(exc)[:200]
+    # the estimators' default mode (watch_phone_pocket_nn.py:13-19): ONE stream, 25 Monte-Carlo dropout samples per frame,
+    # the whole frame step on the device (raw 55-float row in -> window ring -> 25 samples -> FK -> mean pose datagram)
+    try:
+        from wear_mocap_ape_amd.streams import StreamBank
+        rng = np.random.default_rng(4)
+        rows = [torch.from_numpy(rng.normal(size=(1, 55)).astype(np.float32)).cuda() for _ in range(4)]
+        bank = StreamBank(model, 1, 6, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=25, dropout=0.2)
+        mus = []
+        for i in range(20 + n_frames):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            bank.push_rows(rows[i % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+            bank.step_datagrams()
+            b.record(); b.synchronize()
+            if i >= 20:
+                mus.append(a.elapsed_time(b) * 1e3)
+        model.check()
+        out["mc25_stream_p50_us"] = float(np.percentile(mus, 50))
+        out["mc25_stream_p99_us"] = float(np.percentile(mus, 99))
+        out["mc25_note"] = "one stream, 25 dropout samples per frame (the deployed estimators' default), push_rows + step_datagrams per frame"
+        del bank
+    except Exception as exc:
+        out["mc25_error"] = str(exc)[:200]
     return out
 
 

@@ -28,8 +28,8 @@ for it in range(60):
         acc.append(np.array(buf[:10], dtype=np.float64))
 v = np.median(np.array(acc), axis=0)
 P = T + cfg["L"] - 1
-names = ["prologue: weights into registers, x_0, XCD rendezvous", "x staging + GEMVs + gates (all layers)", "publish store -> acknowledged",
-         "own flag -> every member wave's flag seen", "gather DMA issued -> landed", "barrier", "head"]
+names = ["prologue: weights into registers, x_0, XCD rendezvous", "x staging + GEMVs + gates + granule stores (all layers)", "(unused)",
+         "last granule store -> every awaited granule seen", "values into LDS", "barrier", "head"]
 mhz = v[8] / v[9] * 100
 print(f"{name} B={B} T={T}: kernel (member 0, wave 0) {v[8]:.0f} cycles = {v[9] / 100:.2f} us at {mhz:.0f} MHz; {P} phases")
 for k, n in enumerate(names):
