@@ -171,6 +171,8 @@ struct ape_model {
     std::string kernel_name, cluster_name;
 };
 
+int ape_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 int ape_abi_version(void) { return APE_ABI_VERSION; }

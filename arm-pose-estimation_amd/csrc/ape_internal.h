@@ -154,6 +154,9 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 
 #endif
 
+// sets the thread's error string (ape_last_error) and returns `code`: for the entry points outside ape_api.hip
+int ape_set_error(int code, const char* msg);
+
 // launchers implemented in the .hip files --------------------------------------------------
 // returns hipSuccess or the launch error; `smem_bytes` out for diagnostics
 hipError_t ape_launch_lstm_tile16(int H, int L, const LstmParams& p, hipStream_t stream);

@@ -30,7 +30,7 @@ MODEL_LSTM, MODEL_FF, MODEL_IMUPOSE = 0, 1, 2
 PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3
 PARSE_SHAPES = {0: (55, 22), 1: (28, 20), 2: (55, 20), 3: (55, 38)}
 PARSE_BIG_ENDIAN = 0x100          # OR-ed into a kind: rows are big-endian float32 (the UDP payload as received)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EST_WIDTH = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 21, LAYOUT_ORI_CAL_LARM_UARM: 14, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 21}
 NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 20}
@@ -40,6 +40,10 @@ class ApeDims(C.Structure):
     _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
                 ("output_size", C.c_int32), ("target_layout", C.c_int32), ("device", C.c_int32),
                 ("model_kind", C.c_int32)]
+
+
+class ApeKalmanDims(C.Structure):
+    _fields_ = [("num_ensemble", C.c_int32), ("win_size", C.c_int32), ("device", C.c_int32)]
 
 
 # every symbol include/ape_hip.h declares: name -> (restype, argtypes)
@@ -75,6 +79,14 @@ SIGNATURES = {
     "ape_model_check": (C.c_int, [C.c_void_p]),
     "ape_lstm_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "ape_flops_per_window": (C.c_double, [C.POINTER(ApeDims), C.c_int32]),
+    "ape_kalman_create": (C.c_int, [C.POINTER(ApeKalmanDims), C.POINTER(C.c_void_p)]),
+    "ape_kalman_destroy": (C.c_int, [C.c_void_p]),
+    "ape_kalman_weight_floats": (C.c_size_t, [C.c_void_p]),
+    "ape_kalman_noise_floats": (C.c_size_t, [C.c_void_p, C.c_int32]),
+    "ape_kalman_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ape_kalman_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p] + [C.c_void_p] * 6),
+    "ape_kalman_format_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ape_kalman_check": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

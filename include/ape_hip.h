@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 3
+#define APE_ABI_VERSION 4
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -260,6 +260,47 @@ int ape_model_check(ape_model_t* model);
  * FLOP per window (sum_layers 2*4H*(in_l+H) per step, + 2*O*H head once). */
 const char* ape_lstm_kernel_name(const ape_model_t* model, int32_t B, int32_t T);
 double ape_flops_per_window(const ape_dims_t* dims, int32_t T);
+
+/* ---- ensemble Kalman estimator (tail; ABI 4) ----------------------------------------
+ * Replaces KalmanSmartwatchModel (reference estimate/kalman_models.py:139-220: ProcessModelWindow :8-50,
+ * ObservationNoise :53-80, SensorModelWindow :83-136) behind WatchPhonePocketKalman (watch_phone_pocket_kalman.py:12-169).
+ * PARITY UNPINNED: the reference module imports bayesian_torch (absent) and its checkpoint is absent; the checker is
+ * oracle/kalman_oracle.py, a restatement of the cited lines and of the published LinearFlipout algorithm.
+ *
+ * Rows are (stream s, ensemble member e), batch-major.  One forward = one draw of the flipout weight perturbations,
+ * shared by all rows of the call (LinearFlipout draws eps once per call), and per-element +-1 signs; the Kalman update
+ * (means, observation noise, 14 x 14 innovation, inverse, gain: kalman_models.py:181-208) is per stream, i.e. the
+ * reference's batch size 1 (watch_phone_pocket_kalman.py:135) for every stream.
+ *
+ * Weight blob (float32, ape_kalman_weight_floats values), layers in this order with the reference's names:
+ *   process_model.bayes1, process_model.bayes3 (flipout), process_model.bayes_m2 (linear),
+ *   sensor_model.fc2 (linear), sensor_model.fc3, .fc5, .fc6 (flipout), observation_noise.fc1, .fc2 (linear);
+ *   a flipout layer contributes mu_weight [N,K], rho_weight [N,K], mu_bias [N], rho_bias [N]; a linear one weight [N,K], bias [N].
+ * noise_dev: NULL (device-side Philox draws from `seed`) or ape_kalman_noise_floats(S) floats of injected draws, per flipout
+ *   layer in blob order: eps_weight [N,K], eps_bias [N] (standard normal), sign_in [S*E,K], sign_out [S*E,N] (+-1).
+ * win_size must be even (rows are read 16 bytes at a time). */
+typedef struct ape_kalman ape_kalman_t;
+typedef struct {
+    int32_t num_ensemble;   /* E: ensemble members (watch_phone_pocket_kalman.py:16; 2..128) */
+    int32_t win_size;       /* W: window of previous states / raw observations (:17) */
+    int32_t device;
+} ape_kalman_dims_t;
+int ape_kalman_create(const ape_kalman_dims_t* dims, ape_kalman_t** out_model);
+int ape_kalman_destroy(ape_kalman_t* model);
+size_t ape_kalman_weight_floats(const ape_kalman_t* model);
+size_t ape_kalman_noise_floats(const ape_kalman_t* model, int32_t S);
+int ape_kalman_load_weights(ape_kalman_t* model, const float* blob_host, size_t n_floats);
+/* KalmanSmartwatchModel.forward (kalman_models.py:175-220): raw_obs [S,W,22], state_prev [S,E,W,14] ->
+ * state_corrected [S,E,14], m_state_corrected [S,14], m_state_pred [S,14], z [S,14], ensemble_z [S,E,14] (all device, f32) */
+int ape_kalman_forward(ape_kalman_t* model, const float* raw_obs_dev, const float* state_prev_dev, int32_t S, uint64_t seed,
+                       const float* noise_dev, float* state_corrected_dev, float* m_state_corrected_dev,
+                       float* m_state_pred_dev, float* z_dev, float* ensemble_z_dev, void* stream);
+/* KalmanSmartwatchModel.format_state (kalman_models.py:164-173): state [S,14] -> [S,E,14] = state + N(0, 0.1 I);
+ * noise_dev NULL or [S,E,14] standard-normal draws */
+int ape_kalman_format_state(ape_kalman_t* model, const float* state_dev, int32_t S, uint64_t seed, const float* noise_dev,
+                            float* out_dev, void* stream);
+/* BLOCKING: non-zero if a forward since the last check met an exactly singular innovation matrix (torch.linalg.inv raises) */
+int ape_kalman_check(ape_kalman_t* model);
 
 #ifdef __cplusplus
 }
