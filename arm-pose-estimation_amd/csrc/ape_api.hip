@@ -104,13 +104,15 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // whole MI355X (microseconds): a batch-tile wave sustains 125 TFLOP/s at H = 256 and 109 at H = 128 whatever T and
 // the dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
 // dropout variant) however few of its rows are used.  Both rates scale with the CU count of the device.
-static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, bool c32 = false) {
-    const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop);
+// `wide` (ImuPoseLSTM, 256-wide layer-0 input): a full batch-tile wave sustains 123 TFLOP/s, the two-tile cluster launch
+// (512 rows) costs 20 + 11 T -- 95 TFLOP/s when full, so whole waves go to the batch-tile kernel and the rest to the cluster.
+static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, bool c32 = false, bool wide = false) {
+    const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop || wide);
     if (rpl == 0) return (B + wave - 1) / wave;          // no cluster fits on this device
-    const double rate = (dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
+    const double rate = (wide ? 1.23e14 : dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
     const double t16 = (double)wave * ape_flops_per_window(dims, T) / rate * 1e6;
     // (second-generation f32 cluster kernel, eval mode: 16 + 12.4 T per launch of up to 1024 rows, round 2)
-    const double tcl = cdrop ? 22.0 + 8.4 * T : (c32 ? 16.0 + 12.4 * T : 25.0 + 13.7 * T);
+    const double tcl = wide ? 20.0 + 11.0 * T : cdrop ? 22.0 + 8.4 * T : (c32 ? 16.0 + 12.4 * T : 25.0 + 13.7 * T);
     auto cost = [&](int w) {
         const int rest = B - wave * w;
         return w * t16 + (rest > 0 ? (double)((rest + rpl - 1) / rpl) * tcl : 0.0);
@@ -156,6 +158,7 @@ struct ape_model {
     bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
     bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
     int precision = APE_PRECISION_F32;
+    bool wide_cluster = false;      // ImuPoseLSTM: the f32 first-generation cluster kernel with a 256-wide layer-0 input, nothing else
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
     bool f16_v2 = true;             // fp16 precision: batches > 256 rows on the row-set-pipelined kernel (lstm_cluster_f16v2.hip)
     bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
@@ -330,13 +333,14 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = plan((void**)&m->xcc_slots, APE_XCC_WORDS * sizeof(unsigned));
         m->hxs_bytes = (size_t)L * 2 * 4 * H * 8;
         if (e == hipSuccess) e = plan((void**)&m->hxs, 256 + m->hxs_bytes);
-        for (int l = 0; l < L && e == hipSuccess; ++l)
+        m->wide_cluster = imupose;
+        for (int l = 0; l < L && e == hipSuccess && !imupose; ++l)
             e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
-        if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
-        if (e == hipSuccess) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
+        if (e == hipSuccess && !imupose) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
+        if (e == hipSuccess && !imupose) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
         // latency kernel with H/8 members (every CU of a 32-CU XCD at H = 256): only where an XCD has that many CUs
-        if (m->n_cus / 8 >= H / 8) {
+        if (m->n_cus / 8 >= H / 8 && !imupose) {
             for (int l = 0; l < L && e == hipSuccess; ++l)
                 e = plan((void**)&m->wcls[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
             m->small_uw = 2;
@@ -508,7 +512,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                                 ph[((((size_t)(mem * 4 + w) * NB) + q) * 64 + lane) * 8 + j] = (_Float16)v;
                             }
                         }
-            HIP_TRY(hipMemcpy(m->wcl16[l], ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+            if (m->wcl16[l]) HIP_TRY(hipMemcpy(m->wcl16[l], ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         }
         if (m->c32_ok) {
             // second-generation f32 cluster kernel (v_mfma_f32_32x32x2_f32, weights = A operand): 8 members x 4 waves, a wave owns
@@ -647,7 +651,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     // head runs over those rows in a second, HBM-bound launch
     const bool all_steps = (flags & APE_FLAG_ALL_STEPS) != 0;
     const bool cdrop_c = drop && L > 1;
-    const int rows_per_cluster_launch = cluster_rows_per_launch(m->n_cus, H, cdrop_c);
+    const int rows_per_cluster_launch = cluster_rows_per_launch(m->n_cus, H, cdrop_c || m->wide_cluster);
     // injected masks are indexed over the whole batch, so such a call is served by ONE launch of one kernel
     const bool masks_fit = !(flags & APE_FLAG_DROPOUT_MASKS) || !cdrop_c || B <= rows_per_cluster_launch ||
                            m->kernel_choice == APE_KERNEL_CLUSTER;
@@ -662,7 +666,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
-        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c, m->c32_ok && m->c32_on && !drop);
+        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c, m->c32_ok && m->c32_on && !drop, m->wide_cluster);
         const long long front = (long long)tile16_wave_rows(m->n_cus) * w;
         n16 = (front < B) ? (int)front : B;
     }
@@ -689,9 +693,9 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     if (use_cluster) {
         // smallest row tile count that still fits the batch on the chip: more clusters = more CUs busy
         const bool cdrop = drop && L > 1;
-        const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop);
+        const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop || m->wide_cluster);      // (wide: at most two row tiles, like dropout)
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
-        const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path;   // latency path: VALU GEMV, one exchange per phase
+        const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path && !m->wide_cluster;   // latency path: VALU GEMV, one exchange per phase
         const int small_uw = (flags & APE_DIAG_SMALL_UW4) ? 4 : m->small_uw;
         if (!f16 && !cdrop && !drop && !all_steps && !small && m->c32_ok && m->c32_on && B - n16 > 512) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
@@ -756,7 +760,8 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         for (int b0 = n16; b0 < B; b0 += rows_per_launch) {
             const int nb = (B - b0 < rows_per_launch) ? B - b0 : rows_per_launch;
             ClusterParams c{};
-            c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
+            // (lstm_x / lstm_in: the LSTM's own input -- ImuPoseLSTM's is the 256-wide activation of its input layer)
+            c.x = (flags & APE_FLAG_BROADCAST_X) ? lstm_x : lstm_x + (size_t)b0 * T * m->lstm_in;
             c.y = all_steps ? nullptr : y_dev + (size_t)b0 * m->dims.output_size;
             c.hseq = all_steps ? m->hseq_ws + (size_t)b0 * T * H : nullptr;
             for (int l = 0; l < L; ++l) {
@@ -771,7 +776,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
             c.ticket = m->xflags + m->xflag_bytes / sizeof(unsigned) - 4;
             c.done = c.ticket + 1;
-            c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
+            c.B = nb; c.T = T; c.I = m->lstm_in; c.O = m->dims.output_size;
             c.flags = flags & ~(uint32_t)APE_FLAG_ALL_STEPS;
             c.x_ring = x_ring;
             // injected masks are indexed [L-1, B, T, H] over the WHOLE batch: chunks need the full B stride,
@@ -831,7 +836,7 @@ int ape_model_set_precision(ape_model_t* m, int32_t precision) {
         return fail(APE_ERR_INVALID_ARG, "set_precision: unknown precision %d", precision);
     m->f16_v2 = precision != APE_PRECISION_F16_GEN1;
     if (precision == APE_PRECISION_F16_GEN1) precision = APE_PRECISION_F16;
-    if (precision == APE_PRECISION_F16 && !m->cluster_ok)
+    if (precision == APE_PRECISION_F16 && (!m->cluster_ok || m->wide_cluster))
         return fail(APE_ERR_UNSUPPORTED, "set_precision: no fp16 kernel for H=%d L=%d", m->dims.hidden_size,
                     m->dims.num_layers);
     m->precision = precision;
@@ -1200,7 +1205,7 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
-        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, m->c32_ok && m->c32_on) > B) return m->kernel_name.c_str();
+        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, m->c32_ok && m->c32_on, m->wide_cluster) > B) return m->kernel_name.c_str();
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
     return m->cluster_name.c_str();

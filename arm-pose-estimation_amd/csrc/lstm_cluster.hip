@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     constexpr int SO = 20;                // own-slice staging row stride
     constexpr int QX = KX / 16, QH = H / 16;
     constexpr int NW0 = (KX + H) / 4;     // weight registers per lane, layer 0
+    constexpr bool ACC_V = NW0 + (L - 1) * (2 * H / 4) + 4 * NMT > 256;    // weights fill the accumulator file: accumulators in VGPRs
     constexpr int NW1 = (2 * H) / 4;      //                            layers >= 1
     constexpr int TPS = 4 * MR;           // threads that move one member slice (16 B each)
     constexpr int SPP = 256 / TPS;        // slices per gather pass
@@ -434,13 +435,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = bias_r[l];
             const float* rec_src = hbuf + (l * MR + r) * SH + 4 * g;
             if (l == 0) {
-                layer_mfma<NMT, QX, QX + QH, NW0>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0, hook);
+                layer_mfma<NMT, QX, QX + QH, NW0, ACC_V>(acc, xin + r * SX + 4 * g, SX, rec_src, SH, w0, t > 0, hook);
             } else {
                 const float* in_src = (DROP ? dbuf : hbuf) + ((l - 1) * MR + r) * SH + 4 * g;
                 if (l == 1) {
-                    if constexpr (L > 1) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w1, t > 0, hook);
+                    if constexpr (L > 1) layer_mfma<NMT, QH, 2 * QH, NW1, ACC_V>(acc, in_src, SH, rec_src, SH, w1, t > 0, hook);
                 } else {
-                    if constexpr (L > 2) layer_mfma<NMT, QH, 2 * QH, NW1>(acc, in_src, SH, rec_src, SH, w2, t > 0, hook);
+                    if constexpr (L > 2) layer_mfma<NMT, QH, 2 * QH, NW1, ACC_V>(acc, in_src, SH, rec_src, SH, w2, t > 0, hook);
                 }
             }
             mfma_drain();
@@ -653,14 +654,21 @@ hipError_t prepare() {
 }  // namespace
 
 // shapes the cluster kernel is built for: the deployed pocket / watch-only (H=256, L=2, I<=32) and
-// upper-arm (H=128, L=3, 32<I<=64) regressors
-bool ape_cluster_supported(int H, int L, int KX) { return (H == 256 && L == 2 && KX == 32) || (H == 128 && L == 3 && KX == 64); }
+// upper-arm (H=128, L=3, 32<I<=64) regressors, and ImuPoseLSTM's 2 x 256 LSTM behind its 256-wide input layer (KX = 256:
+// 128 + 128 weight registers per lane = the whole accumulator file, one or two row tiles, no dropout -- its Monte-Carlo
+// mode is the plain forward, nn_models.py:246-251)
+bool ape_cluster_supported(int H, int L, int KX) {
+    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && L == 3 && KX == 64);
+}
 
 #define APE_CL_DISPATCH(FN, ...)                                                     \
     if (H == 256 && L == 2 && KX == 32) {                                            \
         if (nmt == 1) return dropout ? FN<256, 2, 32, 1, true>(__VA_ARGS__) : FN<256, 2, 32, 1, false>(__VA_ARGS__); \
         if (nmt == 2) return dropout ? FN<256, 2, 32, 2, true>(__VA_ARGS__) : FN<256, 2, 32, 2, false>(__VA_ARGS__); \
         if (nmt == 4 && !dropout) return FN<256, 2, 32, 4, false>(__VA_ARGS__);      \
+    } else if (H == 256 && L == 2 && KX == 256) {                                    \
+        if (nmt == 1 && !dropout) return FN<256, 2, 256, 1, false>(__VA_ARGS__);     \
+        if (nmt == 2 && !dropout) return FN<256, 2, 256, 2, false>(__VA_ARGS__);     \
     } else if (H == 128 && L == 3 && KX == 64) {                                     \
         if (nmt == 1) return dropout ? FN<128, 3, 64, 1, true>(__VA_ARGS__) : FN<128, 3, 64, 1, false>(__VA_ARGS__); \
         if (nmt == 2) return dropout ? FN<128, 3, 64, 2, true>(__VA_ARGS__) : FN<128, 3, 64, 2, false>(__VA_ARGS__); \
@@ -672,6 +680,7 @@ hipError_t ape_prepare_lstm_cluster(int H, int L, int KX) {
     for (int nmt : {1, 2, 4})
         for (bool dropout : {false, true}) {
             if (dropout && nmt == 4) continue;
+            if (KX == 256 && (dropout || nmt == 4)) continue;       // not built (LDS: 64 rows x 264 columns of x alone)
             hipError_t e = [&]() -> hipError_t { APE_CL_DISPATCH(prepare) }();
             if (e != hipSuccess) return e;
         }

@@ -56,8 +56,13 @@ __device__ __forceinline__ float row_rot_up(float x) {
 // (column j = lane&15 = batch row).  The result tile D[gate column][batch row] then puts, on every lane, the
 // four gates i,f,g,o of ONE unit (lane>>4) for ONE batch row (lane&15) into its four accumulator registers:
 // the cell update needs no cross-lane traffic at all.
+// ACC_V: the accumulator in the ARCHITECTURAL file instead -- for an instantiation whose weights alone fill the 256
+// accumulator registers (ImuPoseLSTM's 128 + 128): with "+a" the compiler would have to rotate weights through
+// v_accvgpr_write in front of an MFMA whose hazards it does not model.
+template <bool ACC_V = false>
 __device__ __forceinline__ void mfma_aw(f32x4& acc, float a, float w) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+a"(acc) : "v"(a), "a"(w));
+    if constexpr (ACC_V) asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+v"(acc) : "v"(a), "a"(w));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+a"(acc) : "v"(a), "a"(w));
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 
@@ -68,7 +73,7 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7
 // `hook(q)` runs in front of k-block q -- before the A fragments of block q+1 are fetched, so a barrier placed in
 // hook(QIN-1) precedes every read of `rec_src` -- and q is a constant after unrolling: the caller uses it to put
 // exchange traffic, LDS commits and x staging under this section's matrix work.
-template <int NMT, int QIN, int QTOT, int NW, typename Hook>
+template <int NMT, int QIN, int QTOT, int NW, bool ACC_V = false, typename Hook>
 __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __restrict__ in_src, int in_stride,
                                            const float* __restrict__ rec_src, int rec_stride,
                                            const float (&w)[NW], bool do_rec, Hook&& hook) {
@@ -78,6 +83,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
         a_cur[mt] = *reinterpret_cast<const f32x4*>(in_src + mt * 16 * in_stride);
         a_nxt[mt] = a_cur[mt];
     }
+    if constexpr (ACC_V) asm volatile("s_nop 4" ::: "memory");     // the start values were just written by the VALU
     // input span (both spans fully unrolled: every weight-register index is a compile-time constant)
 #pragma unroll
     for (int q = 0; q < QIN; ++q) {
@@ -96,7 +102,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
-                mfma_aw(acc[mt], a_cur[mt][j], w[4 * q + j]);
+                mfma_aw<ACC_V>(acc[mt], a_cur[mt][j], w[4 * q + j]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -116,7 +122,7 @@ __device__ __forceinline__ void layer_mfma(f32x4 (&acc)[NMT], const float* __res
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt)
-                    mfma_aw(acc[mt], a_cur[mt][j], w[4 * q + j]);
+                    mfma_aw<ACC_V>(acc[mt], a_cur[mt][j], w[4 * q + j]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -163,7 +163,8 @@ def test_imupose_lstm_vs_reference_golden(golden, norm_stats, tmp_path, monkeypa
                 y = m(x).numpy()
                 assert y.shape == g["y_" + key].shape == (B, T, O)
                 assert np.abs(y - g["y_" + key]).max() < TOL_Y_SHORT, (key, float(np.abs(y - g["y_" + key]).max()))
-                assert np.array_equal(m(x, last_step_only=True).numpy()[:, 0], y[:, -1])
+                # (on the cluster kernel the all-steps output takes the head in a second launch: another summation order)
+                assert np.abs(m(x, last_step_only=True).numpy()[:, 0] - y[:, -1]).max() < 1e-6
                 ymc = m.monte_carlo_predictions(5, x[:1]).numpy()          # plain forward: no repeat, no dropout
                 assert ymc.shape == (1, T, O) and np.abs(ymc - g["ymc_" + key]).max() < TOL_Y_SHORT
             m.check()

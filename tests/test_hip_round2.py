@@ -13,7 +13,7 @@ import torch
 
 from oracle import ape_oracle as orc
 from tests import mc_check
-from tests.test_hip_parity import make_model, _synthetic_windows, quat_err
+from tests.test_hip_parity import make_model, _synthetic_windows, quat_err, TOL_Y_SHORT
 
 pytestmark = pytest.mark.gpu
 
@@ -332,3 +332,33 @@ def test_mlp_regressor_large_batches(n_hidden, N):
     assert np.abs(ym - orc.ff_forward(sd, x, mask=mask)).max() < 2e-6
     y_small = m(torch.from_numpy(x[:100]).cuda()).cpu().numpy()              # 16-row workgroups
     assert np.array_equal(y_small, y[:100])
+
+
+# ---------------- ImuPoseLSTM on the weight-stationary cluster kernel (256-wide layer-0 input) ---------------------------
+@pytest.mark.gpu
+def test_imupose_on_the_cluster_kernel():
+    """ImuPoseLSTM's 2 x 256 LSTM behind its input layer on ape_lstm_cluster<256, 2, 256, nmt> (AUTO) against the batch-tile
+    kernel (same arithmetic up to the f32 summation order) and the oracle: one and two row tiles, a ragged last cluster,
+    two launches (1024 rows > 16 clusters x 32), last-step and all-steps output"""
+    from wear_mocap_ape_amd.estimate import nn_models
+    sd = orc.make_imupose_state_dict(22, 14, 11)
+    m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0)
+    m.load_state_dict(sd)
+    rng = np.random.default_rng(5)
+    for B, T in ((5, 6), (16, 6), (40, 9), (300, 6), (1024, 12)):
+        x = rng.normal(size=(B, T, 22)).astype(np.float32)
+        xt = torch.from_numpy(x).cuda()
+        assert "ape_lstm_cluster<256, 2, 256" in m.set_kernel("auto").kernel_name(B, T)
+        y_cl = m.set_kernel("auto")(xt, last_step_only=True).cpu().numpy()[:, 0]
+        y_t16 = m.set_kernel("tile16")(xt, last_step_only=True).cpu().numpy()[:, 0]
+        assert np.abs(y_cl - y_t16).max() < 2e-6, (B, T, float(np.abs(y_cl - y_t16).max()))
+        sub = rng.choice(B, size=min(B, 24), replace=False)
+        assert np.abs(y_cl[sub] - orc.imupose_forward(sd, x[sub])[:, -1]).max() < TOL_Y_SHORT
+        if B <= 40:
+            y_all = m.set_kernel("auto")(xt).cpu().numpy()
+            assert np.abs(y_all - orc.imupose_forward(sd, x)).max() < TOL_Y_SHORT
+            assert np.abs(y_all[:, -1] - y_cl).max() < 1e-6          # the all-steps head is a second launch
+    m.set_kernel("auto")
+    with pytest.raises(UserWarning):
+        m.set_precision("f16")
+    m.check()
