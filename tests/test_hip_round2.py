@@ -362,3 +362,4 @@ def test_imupose_on_the_cluster_kernel():
     with pytest.raises(UserWarning):
         m.set_precision("f16")
     m.check()
+
