@@ -286,6 +286,86 @@ def stream_bank_numbers(model, stats):
     return out
 
 
+def other_paths():
+    """the SURVEY 8 'next' rows beside the headline, each one measurement (HIP events) on synthetic inputs with seeded random
+    weights: the MLP regressor and ImuPoseLSTM (f3) and the ensemble Kalman estimator (f4 tail, parity unpinned)"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import nn_models, kalman_models
+    out = {}
+    rng = np.random.default_rng(9)
+    lib = _hip.lib()
+
+    def timed(fn, n_warm, n):
+        for _ in range(n_warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record(); b.synchronize()
+        return a.elapsed_time(b) / n * 1e3          # us
+
+    try:        # DropoutFF 22 -> 256 -> 256 -> 256 -> 14, 262 144 rows (nn_models.py:313-370)
+        N = 262144
+        m = nn_models.DropoutFF(14, 256, 2, 22, dropout=0.2, device=0)
+        m.load_weight_blob(torch.from_numpy(rng.uniform(-0.06, 0.06, m.weight_blob_floats()).astype(np.float32)).cuda())
+        x = torch.randn(N, 1, 22, device="cuda"); y = torch.empty(N, 14, device="cuda")
+        us = timed(lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), N, 1, 0, None, 0.0, 0,
+                                                           C.c_void_p(y.data_ptr()), None), "fwd"), 10, 50)
+        out["mlp_regressor"] = {"rows": N, "us_per_launch": us, "rows_per_s": N / us * 1e6,
+                                "tflops": m.flops_per_window(1) * N / us / 1e6, "kernel": "ape_mlp_tile16<256, 2>",
+                                "profile": "profiles/r02_mlp_tile16.md"}
+        del m, x, y
+    except Exception as exc:
+        out["mlp_regressor"] = {"error": str(exc)[:200]}
+    try:        # ImuPoseLSTM: Linear(22,256)+ReLU -> 2 x 256 LSTM -> Linear, 1024 windows x 64 frames (nn_models.py:210-249)
+        B, T = 1024, 64
+        m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0)
+        m.load_weight_blob(torch.from_numpy(rng.uniform(-0.06, 0.06, m.weight_blob_floats()).astype(np.float32)).cuda())
+        x = torch.randn(B, T, 22, device="cuda"); y = torch.empty(B, 14, device="cuda")
+        us = timed(lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0, None, 0.0, 0,
+                                                           C.c_void_p(y.data_ptr()), None), "fwd"), 5, 20)
+        m.check()
+        out["imupose_lstm"] = {"windows": B, "frames": T, "us_per_call": us, "windows_per_s": B / us * 1e6,
+                               "tflops": m.flops_per_window(T) * B / us / 1e6, "kernel": m.kernel_name(B, T),
+                               "profile": "profiles/r02_imupose_cluster.md"}
+        del m, x, y
+    except Exception as exc:
+        out["imupose_lstm"] = {"error": str(exc)[:200]}
+    try:        # KalmanSmartwatchModel.forward + the state shift (kalman_models.py:175-220, watch_phone_pocket_kalman.py:160-162)
+        E, W = 48, 10                                   # example_scripts/stream/watch_phone_pocket.py:24-25
+        m = kalman_models.KalmanSmartwatchModel(E, W)
+        shapes = m.layer_shapes()
+        sd = {}
+        for name, flip in kalman_models.LAYERS:
+            n, k = shapes[name]
+            b = 1.0 / np.sqrt(k)
+            if flip:
+                sd[name + ".mu_weight"] = rng.uniform(-b, b, (n, k)).astype(np.float32)
+                sd[name + ".rho_weight"] = np.full((n, k), -3.0, np.float32)
+                sd[name + ".mu_bias"] = rng.uniform(-b, b, n).astype(np.float32)
+                sd[name + ".rho_bias"] = np.full(n, -3.0, np.float32)
+            else:
+                sd[name + ".weight"] = rng.uniform(-b, b, (n, k)).astype(np.float32)
+                sd[name + ".bias"] = rng.uniform(-b, b, n).astype(np.float32)
+        m.load_state_dict(sd)
+        res = {}
+        for S in (1, 256):
+            raw = torch.from_numpy(rng.normal(size=(S, W, 1, 22)).astype(np.float32)).cuda()
+            st = [torch.from_numpy((0.1 * rng.normal(size=(S, E, W, 14))).astype(np.float32)).cuda()]
+
+            def frame():
+                o = m.forward(raw, st[0])
+                st[0] = torch.cat((st[0][:, :, 1:, :], o[0][:, :, None, :]), axis=2)
+            us = timed(frame, 10, 100)
+            res[f"S{S}"] = {"us_per_frame": us, "stream_frames_per_s": S / us * 1e6}
+        m.check()
+        out["kalman_estimator"] = dict(res, num_ensemble=E, win_size=W, parity="unpinned (DESIGN 2.1)")
+    except Exception as exc:
+        out["kalman_estimator"] = {"error": str(exc)[:200]}
+    return out
+
+
 def load_traffic(kernel_name, windows):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (profiles/traffic_latest.json, written by tools/summarize_prof.py from separate counter runs of this very
@@ -560,6 +640,7 @@ def main():
         if world == 1:
             out["batch1"] = batch1_latency(model, stats)
             out["stream_bank_T6"] = stream_bank_numbers(model, stats)
+            out["other_paths"] = other_paths()
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
                                                                          NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:
