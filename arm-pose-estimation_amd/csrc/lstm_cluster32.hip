@@ -341,10 +341,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         //   QJ .. QJ+7  one piece of the next section's gather per block
         constexpr int NBL = (l == 0) ? BX + BH : 2 * BH;
         constexpr int QF = 3, QP = NBL / 2 - 4, QJ = NBL / 2;
+        bool staged = false;
         auto mid = [&](int q) {
             if (q == QF) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
+            }
+            // x of the next layer-0 step: registers -> LDS (layer 0's readers of xin finished before this section's barrier), and
+            // the fetch of the step after it EARLY in the section: issued at its end the loads were the youngest entries but one of
+            // the memory queue, and the counted wait at the top of the next section sat out their whole latency (13 us per launch)
+            if (l == L - 1 && q == QF + 1 && (ST || ph + 1 < T)) {
+                stage_x();
+                if (ST || ph + 2 < T) fetch_x(ph + 2);
+                staged = true;
             }
             if (q == QP && pre && lane < NFL)
                 peek = __hip_atomic_load(flags_of + ln * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -389,10 +398,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         if (go) dg_go[ln] += 1;
 #endif
         if constexpr (l == L - 1) {
-            // x of the next layer-0 step: registers -> LDS (layer 0's readers of xin finished a section ago), next fetch
-            if (ST || (ph + 1 < T)) {
+            // (an idle section, whose hooks did not run: the same here)
+            if (!ST && !staged && ph + 1 < T) {
                 stage_x();
-                if (ST || ph + 2 < T) fetch_x(ph + 2);
+                if (ph + 2 < T) fetch_x(ph + 2);
             }
         }
         // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout ----------------------------
