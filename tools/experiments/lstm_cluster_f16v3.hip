@@ -1,0 +1,541 @@
+// fp16 cluster LSTM kernel, third generation (BASELINE.json configs[4]).  lstm_cluster_f16v2.hip -- 8-member XCD-class
+// clusters, two row sets of 16 windows that take turns, exchange layout = MFMA fragment order, LDS-DMA gathers prefetched by
+// the section in front, steady-state section compiled apart; see there -- with the hand-over of lstm_cluster_small.hip:
+// the data is the flag.  A slice travels as 16-byte pieces {2 halves, tag, 2 halves, tag} (tag = launch number << 12 | phase
+// + 1) and is copied, tags and all, straight into its place in LDS, where the MFMA fragment reads step over the tags
+// (two ds_read2_b32 instead of one ds_read_b128) and every wave checks the tags of the KiBs it copied itself before the
+// section's barrier -- a stale KiB is simply copied again.  No flag word, no store drain in front of a flag, no look at
+// flags before the copy: the section in front always starts the copy, and what v2 spent per section on
+// store -> acknowledge -> flag -> look -> copy (most of its 4.4K cycles) is one L2 hop.
+#include <type_traits>
+
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ float gate_act(float v, bool is_tanh) {
+    const float e = __builtin_amdgcn_exp2f((is_tanh ? -2.885390081777927f : -1.4426950408889634f) * v);
+    const float s = __builtin_amdgcn_rcpf(1.0f + e);
+    return is_tanh ? 2.0f * s - 1.0f : s;
+}
+
+// v_mfma_f32_16x16x32_f16 with the A operand (a weight fragment that lives in AGPRs for the whole launch) pinned to
+// the accumulator register file, so that the 256 architectural VGPRs stay free for a whole section's activation
+// fragments (fetched up front: a single ds_read_b128 feeds only two of these 16-cycle MFMAs, so reads issued one
+// block ahead leave the matrix pipe waiting on LDS latency -- 100 cycles per block instead of 32).  hipcc does not
+// model an asm MFMA's result hazard: the accumulators are read only after mfma_drain().
+__device__ __forceinline__ void mfma_wa(f32x4& acc, const f32x4 w, const f32x4 a) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
+}
+// (the accumulators are in/out operands of the drain: the gate math, which reads them, cannot be scheduled above it)
+template <int NTW>
+__device__ __forceinline__ void mfma_drain(f32x4 (&acc)[NTW]) {
+    static_assert(NTW == 2, "two tiles per wave");
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+}
+
+// NQ 32-deep k-blocks of LDS activations (16 rows x 32 k each) into registers; `stride` halves between k-blocks
+template <int NQ>
+__device__ __forceinline__ void load_frags(f32x4 (&a)[NQ], const _Float16* __restrict__ src, int stride) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(src + stride * q);
+}
+// the same from the TAGGED exchange layout: a lane's 8 halves of k-block q are dwords 0, 2, 4, 6 of its 32-byte piece
+// {2 halves, tag, 2 halves, tag, ...} (two ds_read2_b32); `stride` dwords between k-blocks
+template <int NQ>
+__device__ __forceinline__ void load_frags_t(f32x4 (&a)[NQ], const unsigned* __restrict__ src, int stride) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const unsigned* pq = src + stride * q;
+        const u32x4 v = {pq[0], pq[2], pq[4], pq[6]};
+        a[q] = __builtin_bit_cast(f32x4, v);
+    }
+}
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
+// the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes.  M0 is written in the
+// same statement that reads it (the compiler does not preserve it across statements).
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// acc[t] += W_t (registers) x A over NQ k-blocks
+template <int NTW, int NQ, int NW>
+__device__ __forceinline__ void span(f32x4 (&acc)[NTW], const f32x4 (&a)[NQ], const f32x4 (&w)[NTW][NW], int w_off) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) mfma_wa(acc[t], w[t][w_off + q], a[q]);
+}
+
+// Diagnostic build (make diag: -DAPE_CLUSTER_STAMPS): shader-cycle sums per section kind of one workgroup's wave 0,
+// written to the model's debug words (memory nothing else reads).  The shipped library has none of this code.
+#ifdef APE_CLUSTER_STAMPS
+#define V2_STAMP(k)                                                       \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        st_acc[k] += now_ - st_t0;                                        \
+        st_t0 = now_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define V2_STAMP(k) do {} while (0)
+#endif
+
+template <int H, int L, int KX>
+__global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v3(const ClusterParams p) {
+    constexpr int UPW = 8;                  // hidden units per wave
+    constexpr int NTW = UPW / 4;            // 16-column MFMA tiles per wave (column = unit * 4 + gate)
+    constexpr int GH = H / (4 * UPW);       // members per cluster
+    constexpr int SR = 16, NS = 2;          // rows per set, sets per cluster
+    constexpr int SX = KX + 16;             // LDS row stride of the x slabs in halves (16-byte multiple, conflict-free b128 reads)
+    constexpr int QX = KX / 32, QH = H / 32;
+    constexpr int NB0 = QX + QH, NB1 = 2 * QH;
+    constexpr int PIECES = L * GH * 4 * SR * 2; // 16-byte pieces {2 halves, tag, 2 halves, tag} of one set's gathered slices
+    constexpr int NDMA = PIECES / 256;      // LDS-DMA instructions per wave and gather (8: pieces 0..3 layer 0, 4..7 layer 1)
+    constexpr int HLD = GH * 4 * SR * 8;    // dwords of one (set, layer) block: [member][wave][row][32 bytes]
+    constexpr int HL = 2 * HLD;             // ... in halves
+    static_assert(GH == 8 && QH == GH && L == 2 && PIECES % 256 == 0, "built for 8-member clusters of the 2 x 256 models");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int T = p.T, I = p.I, O = p.O;
+    const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;
+#if defined(APE_CLUSTER_STAMPS) || defined(APE_ABLATE)
+    // timing-only ablations (outputs are wrong): what a part really costs = the launch time with and without it
+    // (`make ablate` builds them without the stamps, whose own waits distort a kernel this short)
+    const bool d_noex = (p.flags & APE_DIAG_NO_EXCHANGE) != 0, d_noact = (p.flags & APE_DIAG_NO_ACT) != 0;
+    const bool d_nomfma = (p.flags & APE_DIAG_NO_MFMA) != 0, d_nox = (p.flags & APE_DIAG_NO_XSTAGE) != 0;
+#else
+    constexpr bool d_noex = false, d_noact = false, d_nomfma = false, d_nox = false;
+#endif
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+    _Float16* hbuf = smem16;                              // [NS][L][member][wave][row][32 B tagged]: gathered h of the set's last phase, in
+                                                          //  the exchange order = MFMA fragment order (k-block = member, k-group = wave)
+    _Float16* xin = hbuf + NS * L * HL;                   // [NS][2 parity][SR][SX]
+    _Float16* own = xin + NS * 2 * SR * SX;               // [wave 4][L][SR][UPW]  fresh slice of this wave (wave-private)
+    f32x4* bias_s = reinterpret_cast<f32x4*>(own + 4 * L * SR * UPW);   // [wave 4][L][NTW][lane 64]: the accumulators' start values
+    int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * NTW * 64);   // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+
+    // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words][done]
+    unsigned* const class_ticket = p.xcc_slots + 64;
+    unsigned* const xcc_words = p.xcc_slots + 64 + 8 * 16;
+    const int cls = blockIdx.x & 7;
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
+    const unsigned tag_base = (__hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu) << 12;
+    // a launch that finds the sticky status word set (an earlier launch on this model aborted) leaves at once
+    if (tid == 0) {
+        ctl[0] = 0;
+        ctl[1] = -1;
+        if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned tk = __hip_atomic_fetch_add(class_ticket + cls * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < gridDim.x / 8) ctl[1] = (int)tk;
+            else __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (ctl[1] < 0) return;
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
+    const int cluster = (ticket / GH) * 8 + cls, member = ticket % GH;
+    const int row0 = cluster * (NS * SR);
+    if (tid == 0)
+        __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- weights: registers (binary16 pairs), for the whole launch; host layout [member16][wave][32-deep block][lane][8]
+    //      with 16 units per "member16": this wave's two tiles are waves (2*wave, 2*wave + 1) of member16 = 2*member + (wave >> 1)
+    f32x4 w0[NTW][NB0];                 // binary16 octets, held as 4-register tuples
+    f32x4 w1[NTW][NB1];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int m16 = 2 * member + (wave >> 1), w16 = 2 * (wave & 1) + t;
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(m16 * 4 + w16) * NB0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NB0; ++i) w0[t][i] = s0[i * 64];
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(m16 * 4 + w16) * NB1) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NB1; ++i) w1[t][i] = s1[i * 64];
+    }
+    // unit of (tile t, lane group g): member*32 + wave*8 + t*4 + g
+    // (b_ih + b_hh, f32) of this lane's four gates per (layer, tile): the accumulators start from it; kept in LDS, not in
+    // 16 registers -- the register file is the weight store
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            f32x4 bv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bv[k] = p.bias[l][k * H + member * 32 + wave * 8 + t * 4 + g];
+            bias_s[((wave * L + l) * NTW + t) * 64 + lane] = bv;
+        }
+    // per-set register state is kept as "this section's set" / "the other set" and swapped at the end of every section,
+    // so the section body exists once per kind (no unrolling over the sets, no dynamically indexed register arrays)
+    float cst[L][NTW], cst_o[L][NTW];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) cst[l][t] = cst_o[l][t] = 0.0f;
+
+    // exchange buffer: descriptor for the compiler's loads / stores, and the same words as a scalar tuple for the DMA asm
+    const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    u32x4 hx_desc;
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[3] = 0x00020000u;
+    constexpr unsigned SET_BYTES = PIECES * 16;                            // one (set, parity): [layer][member][wave][row][32 B]
+    auto hx_base = [&](int s, int par) -> unsigned { return (unsigned)((((size_t)cluster * NS + s) * 2 + par) * SET_BYTES); };
+    const unsigned hbuf_lds = (unsigned)reinterpret_cast<unsigned long long>(hbuf);     // LDS byte address (low half of the flat one)
+
+    // ---- x staging (f64 z-score, then binary16); thread owns NE elements of a set's [SR][KX] step slab ------------
+    constexpr int NE = (SR * KX) / 256;
+    const int xk = tid % KX;
+    const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
+    const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
+    const double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;     // 1 / std, rounded once on the host
+    float xr[NE], xr_o[NE];
+    // loads go through a buffer descriptor over this cluster's rows: rows past the batch and the padded columns k >= I
+    // fall outside it and read as 0 (no predicates, no 64-bit per-lane addresses: one 32-bit offset per element)
+    const int rows_here = bcast_x ? NS * SR : max(0, min(NS * SR, p.B - row0));
+    // (the descriptor's words are forced into scalar registers: left to the compiler they end up in vector registers
+    //  and every load becomes a readfirstlane waterfall loop)
+    const unsigned long long x_addr = reinterpret_cast<unsigned long long>(p.x + (bcast_x ? (size_t)0 : (size_t)row0 * T * I));
+    const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)x_addr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(x_addr >> 32));
+    const int x_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)(bcast_x ? 1 : rows_here) * T * I * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(((unsigned long long)x_hi << 32) | x_lo), 0, x_bytes, 0x00020000);
+    const unsigned x_rowbytes = bcast_x ? 0u : (unsigned)(T * I * sizeof(float));
+    unsigned x_off[NE];                      // byte offset of this thread's elements inside set 0 (set 1: + SR rows)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) x_off[e] = (unsigned)((tid + 256 * e) / KX) * x_rowbytes + (unsigned)(xk * sizeof(float));
+    auto fetch_x = [&](float (&dst)[NE], int s, int t) {
+        const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = s * SR + (tid + 256 * e) / KX;
+            const unsigned off = (xk < I && row < rows_here) ? x_off[e] + (unsigned)(s * SR) * x_rowbytes : 0x80000000u;
+            dst[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (unsigned)(slot * I * sizeof(float)), 0));
+        }
+    };
+    // (x - m) / s in f64, correctly rounded: q0 = d * (1/s), one residual step q0 + (d - q0 s)(1/s) -- the tail of the
+    // hardware division sequence, bit-identical to the division (as in lstm_cluster.hip); (0, 1, 1) passes x through
+    auto stage_x = [&](const float (&src)[NE], int s, int t) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = (tid + 256 * e) / KX;
+            const double d = (double)src[e] - x_mean;
+            const double q0 = d * x_rstd;
+            const double rr = fma(-q0, x_std, d);
+            const double q1 = fma(rr, x_rstd, q0);
+            // f64 -> f32 -> binary16 in two roundings, as the reference path's float32 model input stored as binary16 (kept
+            // apart by the empty asm: fused, the compiler emits a ~45-instruction software f64 -> f16 conversion)
+            float xf = (float)((rr == rr) ? q1 : q0);
+            asm volatile("" : "+v"(xf));
+            xin[((s * 2 + (t & 1)) * SR + row) * SX + xk] = (_Float16)xf;
+        }
+    };
+    fetch_x(xr, 0, 0);
+    fetch_x(xr_o, 1, 0);
+    stage_x(xr, 0, 0);
+    stage_x(xr_o, 1, 0);
+    if (T > 1) { fetch_x(xr, 0, 1); fetch_x(xr_o, 1, 1); }
+
+    // ---- do all members of this cluster really share an XCD? ------------------------------------------------------
+    if (wave == 0) {
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(xcc_words + cluster * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
+    __syncthreads();
+    if (ctl[0] != 0) return;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
+
+    // a set's 32 KB straight from the exchange buffer into its LDS block: wave w copies KiB w, w + 4, ... (8 of them)
+    const unsigned dma_voff = (unsigned)(lane * 16);
+    auto issue_piece = [&](int s, int par, int k) {
+        dma_1k(hbuf_lds + (unsigned)(s * L * HL * 2 + wave * 1024 + k * 4096), dma_voff, hx_desc, hx_base(s, par) + (unsigned)(wave * 1024 + k * 4096));
+    };
+    auto issue_gather = [&](int s, int par) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) issue_piece(s, par, k);
+    };
+    // every wave checks the tags of the KiBs IT copied (caller has waited for the copy): the slices of set s published in
+    // phase `php`; a KiB with a stale tag is copied again.  Layers that were idle in that phase carry nothing to check.
+    auto validate = [&](int s, int php) {
+        const unsigned want = tag_base | (unsigned)(php + 1);
+        const unsigned* mine = reinterpret_cast<const unsigned*>(hbuf) + s * L * HLD + wave * 256 + lane * 4;
+        unsigned spins = 0;
+        while (true) {
+            unsigned stale = 0u;
+#pragma unroll
+            for (int k = 0; k < NDMA; ++k) {
+                const int t = php - (k >> 2);                      // step of layer k >> 2 in that phase
+                const u32x4 v = *reinterpret_cast<const u32x4*>(mine + k * 1024);
+                if (t >= 0 && t < T && (v[1] != want || v[3] != want)) stale |= 1u << k;
+            }
+            if (!__any((int)(stale != 0u))) return;
+            if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            if (spins > 16u) __builtin_amdgcn_s_sleep(1);
+            issue_gather(s, php & 1);                              // (all eight again: a stale KiB is the rare case)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    // has every member wave's slice of set s, published in phase `php`, arrived?  One SENTINEL per member wave is looked at: the tag
+    // of the last piece (row 15, second half, of the last layer that was active) its single publish store wrote -- a cheap look
+    // (one dword per lane < 32) before the 32 KB copy is started; the copy's own tags are still checked afterwards
+    auto sentinel_off = [&](int s, int php) -> unsigned {
+        const int ls = (php >= 1 && php - 1 < T) ? 1 : 0;
+        return hx_base(s, php & 1) + (unsigned)((((ls * GH + (lane >> 2)) * 4 + (lane & 3)) * SR + 15) * 32 + 28);
+    };
+    auto look = [&](int s, int php) -> unsigned {
+        return (lane < 4 * GH) ? __builtin_amdgcn_raw_buffer_load_b32(hx_rsrc, sentinel_off(s, php), 0, 16 /* sc1 */) : (tag_base | (unsigned)(php + 1));
+    };
+    auto wait_sentinels = [&](int s, int php) {
+        const unsigned want = tag_base | (unsigned)(php + 1);
+        unsigned spins = 0;
+        while (true) {
+            if (__all((int)(look(s, php) == want))) return;
+            if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+        }
+    };
+    // workgroup barrier that waits for this wave's LDS traffic only (not for the publish store or a DMA in flight)
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    const int P = T + L - 1;
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Section (ph, s) = row set s in phase ph; the sets alternate.  Per wave the vector-memory queue of a steady-state
+    // section is, in issue order:  [publish store of the section in front]  x fetch (2 loads)  gather DMA of the NEXT
+    // section's set (8)  publish store (1) -- so at the top of a section everything but the youngest entry, the publish
+    // store, is waited for (`vmcnt(1)`: the copy is in LDS); then the tags of the copied KiBs are checked.
+    bool prefetched = false;
+    auto section = [&](auto steady_tag, const int ph, const int s) -> bool {
+        constexpr bool ST = decltype(steady_tag)::value;          // steady state: 2 <= ph <= T - 3, every condition below holds
+        // ---- S0: this set's slices of the last phase into LDS ------------------------------------------------------------
+        if (ST || ph > 0) {
+            if (!prefetched && !d_noex) {                         // first phases, a late peer, the final gathers
+                wait_sentinels(s, ph - 1);
+                issue_gather(s, (ph - 1) & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the prefetched copy; only the publish store is younger
+            }
+            V2_STAMP(0);                                          // 0: wait for the copy
+            if (!d_noex) validate(s, ph - 1);
+        }
+        prefetched = false;
+        V2_STAMP(1);                                              // 1: wait for the gather
+        bar();
+        V2_STAMP(3);                                              // 3: barrier
+        if (!ST && ph == P) return ctl[0] == 0;                   // gather-only tail (no per-set register state is needed any more)
+        const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
+        // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
+        // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
+        f32x4 ax[QX], a0r[QH], a1i[QH], a1r[QH];
+        // this lane's 32-byte piece of k-block 0: [member 0][wave g][row r]; k-block q = member q, 512 dwords on
+        const unsigned* hset = reinterpret_cast<const unsigned*>(hbuf) + s * L * HLD + (g * SR + r) * 8;
+        if (ST || ph < T) {
+            load_frags<QX>(ax, xin + ((s * 2 + (ph & 1)) * SR + r) * SX + 8 * g, 32);
+            if (ST || ph > 0) load_frags_t<QH>(a0r, hset, 512);
+        }
+        V2_STAMP(7);                                              // 7: fragment read issue
+        // the next section: the other set, in this phase (s = 0) or the next (s = 1); it needs epoch `want`
+        const int sn = s ^ 1, phn = ph + s;
+        const unsigned want = (unsigned)phn;
+        unsigned peek = 0u;
+
+        // ---- every active layer of this set, back to back (layer l works on step t = ph - l) -----------------------------
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = ph - l;
+            const bool active = ST || (t >= 0 && t < T);          // uniform over the grid
+            f32x4 acc[NTW];
+            if (active) {
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias_s[((wave * L + l) * NTW + tt) * 64 + lane];
+                if (d_nomfma) {
+                } else if (l == 0) {
+                    span<NTW, QX, NB0>(acc, ax, w0, 0);
+                    if (ST || t > 0) span<NTW, QH, NB0>(acc, a0r, w0, QX);
+                } else {
+                    span<NTW, QH, NB1>(acc, a1i, w1, 0);
+                    if (ST || t > 0) span<NTW, QH, NB1>(acc, a1r, w1, QH);
+                }
+                mfma_drain<NTW>(acc);
+            }
+            V2_STAMP(4);                                          // 4: MFMA spans (incl. the wait for the LDS reads feeding them)
+            if (l == 0) {
+                if (ST || ph >= 1) load_frags_t<QH>(a1i, hset, 512);
+                if (ST || ph > 1) load_frags_t<QH>(a1r, hset + HLD, 512);
+                // x of the next step: registers -> the other parity buffer (its readers are two sections back), next fetch
+                if ((ST || ph + 1 < T) && !d_nox) {
+                    stage_x(xr, s, ph + 1);
+                    if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
+                }
+            } else if ((ST || want > 0u) && !d_noex) {
+                // [B0] look at the sentinels of what the next section needs; the load flies under the gate math below
+                peek = look(sn, phn - 1);
+            }
+            V2_STAMP(2);
+            // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit tt*4 + g, batch row r)
+#pragma unroll
+            for (int tt = 0; active && tt < NTW; ++tt) {
+                float hval;
+                if (d_noact) {
+                    const float c = acc[tt][1] * cst[l][tt] + acc[tt][0] * acc[tt][2];
+                    cst[l][tt] = c;
+                    hval = acc[tt][3] * c;
+                } else {
+                    const float iv = gate_act(acc[tt][0], false), fv = gate_act(acc[tt][1], false);
+                    const float gg = gate_act(acc[tt][2], true), ov = gate_act(acc[tt][3], false);
+                    const float c = fv * cst[l][tt] + iv * gg;
+                    cst[l][tt] = c;
+                    hval = ov * gate_act(c, true);
+                }
+                own[((wave * L + l) * SR + r) * UPW + tt * 4 + g] = (_Float16)hval;
+            }
+            V2_STAMP(5);                                          // 5: gates + cell update + own-slice staging
+        }
+        if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
+        // [B] every peer wave's slice has arrived: the next section's whole copy goes into flight now
+        if ((ST || want > 0u) && !d_noex && __all((int)(peek == (tag_base | (unsigned)phn)))) {
+            issue_gather(sn, (phn - 1) & 1);
+            prefetched = true;
+        }
+        // ---- publish: lane (layer = lane >> 5, row = (lane >> 1) & 15, half = lane & 1) sends 16 bytes {2 halves, tag, 2 halves,
+        //      tag}: four of this wave's 8 units of that row and layer
+        //      (exactly ONE store instruction per wave: the counted wait at the top of the next section relies on it)
+        {
+            const int l = lane >> 5, row = (lane >> 1) & 15, half = lane & 1, t = ph - l;
+            const bool live = ST || (t >= 0 && t < T);
+            const unsigned* src = reinterpret_cast<const unsigned*>(own + ((wave * L + l) * SR + row) * UPW + half * 4);
+            const unsigned tag = tag_base | (unsigned)(ph + 1);
+            const u32x4 hv = {src[0], tag, src[1], tag};
+            // dead lanes aim outside the buffer descriptor: the store instruction is issued by every wave, writes nothing there
+            const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 32 + half * 16) : 0x80000000u;
+            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+        }
+        V2_STAMP(6);                                              // 6: publish (LDS read + store issue)
+        // the other set is next: swap the per-set register state
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) { const float tmp = cst[l][tt]; cst[l][tt] = cst_o[l][tt]; cst_o[l][tt] = tmp; }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const float tmp = xr[e]; xr[e] = xr_o[e]; xr_o[e] = tmp; }
+        return true;
+    };
+#pragma unroll 1
+    for (int sec = 0; sec < NS * (P + 1); ++sec) {     // phase P: only the final gather of both sets (for the head)
+        const int ph = sec >> 1, s = sec & 1;
+        const bool ok = (ph >= 2 && ph <= T - 3) ? section(std::true_type{}, ph, s) : section(std::false_type{}, ph, s);
+        if (!ok) return;
+    }
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && lane == 0 && wave == 0 && cluster == 0 && member == 0) {
+        for (int k = 0; k < 8; ++k) p.dbg_wg[k] = st_acc[k];
+        p.dbg_wg[8] = __builtin_amdgcn_s_memtime() - st_begin;
+        p.dbg_wg[9] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    }
+#endif
+    // ---- head (f32 weights, f16 h): member m finishes rows 4m .. 4m+3 of the cluster's 32 ---------------------------
+    {
+        constexpr int RPM = (NS * SR) / GH;
+        if (tid < RPM * O) {
+            const int rr = tid / O, o = tid - rr * O;
+            const int row = member * RPM + rr;                    // 0..31: set = row / 16
+            const int b = row0 + row;
+            if (b < p.B) {
+                // unit k of the row: piece [k / 8][row] (32 bytes = 16 halves), halves (k % 8 / 2) * 4 + (k & 1) inside it (tags skipped)
+                const _Float16* hv = hbuf + ((row >> 4) * L + (L - 1)) * HL + (row & 15) * 16;
+                const float* wv = p.w_out + (size_t)o * H;
+                float sacc = 0.0f;
+                for (int k = 0; k < H; ++k) sacc = fmaf((float)hv[(k >> 3) * (SR * 16) + ((k & 7) >> 1) * 4 + (k & 1)], wv[k], sacc);
+                p.y[(size_t)b * O + o] = sacc + p.b_out[o];
+            }
+        }
+    }
+    // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        // the next launch's tags differ from every tag of this one; at the 20-bit wrap the exchange buffer goes back to zero
+        if ((tag_base >> 12) == 0xFFFFFu)
+            for (size_t i = tid; i < p.hx_bytes / 4; i += 256)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(p.hx) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.seq, (tag_base >> 12) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int H, int L, int KX>
+constexpr size_t smem_bytes() {
+    return ((size_t)2 * L * 16 * H * 2 + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * 8) * sizeof(_Float16) +
+           (size_t)4 * L * 2 * 64 * 16 + 16;
+}
+
+}  // namespace
+
+bool ape_cluster_f16v3_supported(int H, int L, int KX) { return H == 256 && L == 2 && KX == 32; }
+
+hipError_t ape_prepare_lstm_cluster_f16v3(int H, int L, int KX) {
+    if (!ape_cluster_f16v3_supported(H, L, KX)) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster_f16v3<256, 2, 32>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+}
+
+// `clusters` = 32-row clusters needed; the grid is rounded up to whole block-index classes (8 clusters), the extra
+// clusters own rows past the batch and only take part in the formation
+hipError_t ape_launch_lstm_cluster_f16v3(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream) {
+    if (!ape_cluster_f16v3_supported(H, L, KX)) return hipErrorInvalidValue;
+    const int grid_clusters = (clusters + 7) / 8 * 8;
+    constexpr size_t smem = smem_bytes<256, 2, 32>();
+    hipLaunchKernelGGL((ape_lstm_cluster_f16v3<256, 2, 32>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}
