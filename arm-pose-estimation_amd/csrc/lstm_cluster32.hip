@@ -340,7 +340,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         //   QP  look at the flags the next section needs (one load per lane)    QJ  judge
         //   QJ .. QJ+7  one piece of the next section's gather per block
         constexpr int NBL = (l == 0) ? BX + BH : 2 * BH;
-        constexpr int QF = 3, QP = NBL / 2 - 4, QJ = NBL / 2;
+        // (positions swept on MI355X, 1024 x 64: QF 1 / 2 / 3 / 10 / 16 -> 826 / 833 / 819 / 828 / 858 us -- earlier stalls on the store's
+        //  acknowledgement, later the peers' look finds nothing; look 12 blocks ahead of the judge instead of 4 -> 840: the flags are not up yet)
+        constexpr int QF = 3, QP = NBL / 2 - 2, QJ = NBL / 2 + 2;
         bool staged = false;
         auto mid = [&](int q) {
             if (q == QF) {
