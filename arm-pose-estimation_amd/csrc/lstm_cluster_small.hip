@@ -33,10 +33,10 @@ template <int H, int L, int KX, int NR, int UW>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterParams p) {
     constexpr int GH = H / (4 * UW);
     constexpr int CW = 4 * UW, NG = 64 / CW, KB = 4 * NG;   // columns (unit*4 + gate) per wave; k-groups; k-block depth
-    constexpr int SH = H, SX = KX + 8;       // h rows unpadded: a row (H floats = 1 KiB at H = 256) is what one LDS-DMA instruction delivers
+    constexpr int SH = H, SX = KX + 8;       // LDS row strides: h rows unpadded (broadcast reads: no bank conflicts to pad away)
     constexpr int QX = KX / KB, QH = H / KB;
     constexpr int NW0 = (KX + H) / NG, NW1 = (2 * H) / NG;
-    static_assert(NR <= MR && (H == 128 || H == 256), "a window row of h = one or half an LDS-DMA instruction");
+    static_assert(NR <= MR && (H == 128 || H == 256), "built for the deployed hidden sizes");
     static_assert((UW == 4 || UW == 2) && KX % KB == 0 && GH >= MR && GH <= 64, "cluster shape");
 
     const int tid = threadIdx.x;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     // the 8 XCDs -- those GH workgroups share ONE XCD, hence one L2, and the exchange can stay inside it: plain stores
     // (acknowledged by the L2, not written through to memory) and L1-bypassing loads, ~0.8 us less per phase.  HIP
     // guarantees no placement, so nothing is assumed: every member publishes the XCD it really runs on (a non-zero
-    // word; the last member out zeroes the words again, like the flags), all members read all GH words once the
+    // word; the last member out zeroes the words again), all members read all GH words once the
     // weights are in, and only if they agree is the in-L2 form used; otherwise the write-through form that is valid for any placement.  One cluster, one launch: a member
     // that is dispatched late delays the launch, it cannot deadlock it.
     if (blockIdx.x % 8 != 0) return;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
 
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
     const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
-    u32x4 hx_desc;                                 // the same descriptor as a scalar tuple for the DMA asm
+    u32x4 hx_desc;                                 // the same descriptor as a scalar tuple for the polling loads' asm
     hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
     hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
     hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
