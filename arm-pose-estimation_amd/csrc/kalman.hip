@@ -128,22 +128,35 @@ __global__ __launch_bounds__(256) void kf_linear_kernel(const KfLinearParams p) 
     f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f}, accd = {0.0f, 0.0f, 0.0f, 0.0f};
     const float* wmu = p.Wmu + (size_t)(n_ok ? n : 0) * p.K;
     const float* wd = FLIP ? p.Wd + (size_t)(n_ok ? n : 0) * p.K : nullptr;
-    for (int q = 0; q < Kp / 16; ++q) {
-        const int k = 16 * q + 4 * g;
-        const bool k_ok = n_ok && k < p.K;
-        f32x4v b = {0.0f, 0.0f, 0.0f, 0.0f}, bdv = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (k_ok) b = *reinterpret_cast<const f32x4v*>(wmu + k);
-        const f32x4v a = *reinterpret_cast<const f32x4v*>(xs + col * SX + k);
-        f32x4v af = a;
-        if constexpr (FLIP) {
-            if (k_ok) bdv = *reinterpret_cast<const f32x4v*>(wd + k);
-            af = *reinterpret_cast<const f32x4v*>(xf + col * SX + k);
-        }
-        // MFMA j of the block multiplies k = 16 q + 4 g + j: A lane (row = lane & 15, g) and B lane (col = lane & 15, g) agree
+    // four k-blocks per trip, their weight fragments requested together: one dependent L2 round trip per trip instead of per block
+    // (these layers are 3-24 workgroups: latency, not bandwidth)
+    constexpr int UQ = 4;
+    for (int q0 = 0; q0 < Kp / 16; q0 += UQ) {
+        f32x4v b[UQ], bdv[UQ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-            if constexpr (FLIP) accd = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bdv[j], accd, 0, 0, 0);
+        for (int u = 0; u < UQ; ++u) {
+            const int k = 16 * (q0 + u) + 4 * g;
+            const bool k_ok = n_ok && q0 + u < Kp / 16 && k < p.K;
+            b[u] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+            bdv[u] = b[u];
+            if (k_ok) b[u] = *reinterpret_cast<const f32x4v*>(wmu + k);
+            if constexpr (FLIP) {
+                if (k_ok) bdv[u] = *reinterpret_cast<const f32x4v*>(wd + k);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) {
+            if (q0 + u >= Kp / 16) break;                            // uniform
+            const int k = 16 * (q0 + u) + 4 * g;
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(xs + col * SX + k);
+            f32x4v af = a;
+            if constexpr (FLIP) af = *reinterpret_cast<const f32x4v*>(xf + col * SX + k);
+            // MFMA j of the block multiplies k = 16 q + 4 g + j: A lane (row = lane & 15, g) and B lane (col = lane & 15, g) agree
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[u][j], acc, 0, 0, 0);
+                if constexpr (FLIP) accd = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bdv[u][j], accd, 0, 0, 0);
+            }
         }
     }
     // ---- epilogue: acc[i] = C[row 4 g + i][col]
