@@ -1162,13 +1162,14 @@ int ape_debug_read_wg(ape_model_t* m, unsigned long long out[256 * 8]) {
 }
 
 // internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
-// 2 departure counter -- so that tests can stage the state an aborted launch leaves behind
+// 2 departure counter, 3 launch number of the latency kernel -- so that tests can stage the state an aborted launch leaves behind
 int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
-    if (!m || !m->cluster_ok || which < 0 || which > 2) return APE_ERR_INVALID_ARG;
+    if (!m || !m->cluster_ok || which < 0 || which > 3) return APE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(m->dims.device));
     HIP_TRY(hipDeviceSynchronize());
     unsigned* status = m->xflags + m->xflag_bytes / sizeof(unsigned);
-    unsigned* word = which == 0 ? status : (which == 1 ? status - 4 : status - 3);
+    // (3: the latency kernel's launch number, the upper bits of its granule tags -- to stage the 20-bit wrap)
+    unsigned* word = which == 0 ? status : (which == 1 ? status - 4 : which == 2 ? status - 3 : reinterpret_cast<unsigned*>(m->hxs));
     HIP_TRY(hipMemcpy(word, &value, sizeof(value), hipMemcpyHostToDevice));
     return APE_OK;
 }

@@ -363,3 +363,24 @@ def test_imupose_on_the_cluster_kernel():
         m.set_precision("f16")
     m.check()
 
+
+
+# ---------------- the latency kernel's launch number wraps after 2^20 launches ----------------------------------------------
+@pytest.mark.gpu
+def test_latency_kernel_launch_number_wrap():
+    """the granule tags carry a 20-bit launch number kept on the device; at the wrap the last member out zeroes the granules, so a
+    tag of 2^20 launches ago can never be taken for a fresh one: launches across the wrap give the same bits as before it"""
+    from wear_mocap_ape_amd import _hip
+    model, sd, cfg = make_model("pocket", 14)
+    lib = _hip.lib()
+    lib.ape_debug_poke.restype, lib.ape_debug_poke.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_uint]
+    rng = np.random.default_rng(8)
+    xs = [torch.from_numpy(rng.normal(size=(B, 6, cfg["I"])).astype(np.float32)).cuda() for B in (1, 3, 1, 2, 4, 1)]
+    before = [model(x, last_step_only=True).cpu().numpy() for x in xs]
+    for b, x in zip(before, xs):
+        assert np.abs(b[:, 0] - orc.lstm_forward(sd, x.cpu().numpy())[:, -1]).max() < TOL_Y_SHORT
+    assert lib.ape_debug_poke(model.handle, 3, 0xFFFFD) == 0
+    for rep in range(2):                            # launches 0xFFFFD, E, F (wrap: granules zeroed), 0, 1, 2, ...
+        for b, x in zip(before, xs):
+            assert np.array_equal(model(x, last_step_only=True).cpu().numpy(), b)
+    model.check()
