@@ -169,6 +169,12 @@ struct ape_model {
     unsigned* xflags = nullptr;    // [flag words..., status word]
     size_t xflag_bytes = 0;        // bytes of the flag block (multiple of 16), status word follows
     // MLP regressor (APE_MODEL_FF)
+    float *ffp_wa0 = nullptr, *ffp_wa1 = nullptr, *ffp_wb2 = nullptr, *ffp_wbo = nullptr;   // mlp_pipe.hip: the two stages' register files
+    float* ffp_ring = nullptr;       // ... its ring of tiles between the stages
+    size_t ffp_ring_bytes = 0;
+    unsigned* ffp_ctl = nullptr;     // ... class tickets, status, departure counter, per-pair full / empty words (zero between launches)
+    size_t ffp_ctl_words = 0;
+    bool ffp_ok = false, ffp_on = true;
     f32x4* ff_wpack[APE_MAX_FF_LAYERS] = {};
     float* ff_bias[APE_MAX_FF_LAYERS] = {};
     std::string kernel_name, cluster_name;
@@ -270,6 +276,18 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (e == hipSuccess) e = plan((void**)&m->w_out, (size_t)O * H * sizeof(float));
         if (e == hipSuccess) e = plan((void**)&m->b_out, O * sizeof(float));
         if (e == hipSuccess) e = plan((void**)&m->stats, (3 * I + 2 * O) * sizeof(double));
+        if (e == hipSuccess && ape_mlp_pipe_supported(H, L, m->KX, O) && m->n_cus >= 16) {
+            e = plan((void**)&m->ffp_wa0, (size_t)4 * 2 * 4 * 64 * 4 * sizeof(float));
+            if (e == hipSuccess) e = plan((void**)&m->ffp_wa1, (size_t)4 * 2 * 32 * 64 * 4 * sizeof(float));
+            if (e == hipSuccess) e = plan((void**)&m->ffp_wb2, (size_t)4 * 2 * 32 * 64 * 4 * sizeof(float));
+            if (e == hipSuccess) e = plan((void**)&m->ffp_wbo, (size_t)4 * 8 * 64 * 4 * sizeof(float));
+            m->ffp_ring_bytes = ape_mlp_pipe_ring_bytes(m->n_cus);
+            m->ffp_ctl_words = ape_mlp_pipe_ctl_words(m->n_cus);
+            if (e == hipSuccess) e = plan((void**)&m->ffp_ring, m->ffp_ring_bytes);
+            if (e == hipSuccess) e = plan((void**)&m->ffp_ctl, m->ffp_ctl_words * sizeof(unsigned));
+            if (e == hipSuccess) e = ape_prepare_mlp_pipe();
+            m->ffp_ok = e == hipSuccess;
+        }
         if (e == hipSuccess) e = commit_plan();
         if (e != hipSuccess) {
             ape_model_destroy(m);
@@ -423,6 +441,37 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                         }
             HIP_TRY(hipMemcpy(m->ff_wpack[j], packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(m->ff_bias[j], bj, H * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (!pre_only && m->ffp_ok) {
+            // mlp_pipe.hip: v_mfma_f32_32x32x2_f32 A fragments, register 4 kb + j of lane (unit column = lane & 31, hh = lane >> 5) =
+            // W[64 wave + 32 ct + (lane & 31)][8 kb + 4 hh + j]; [wave][ct][kb][lane][4]
+            const float* wl[3];
+            int inl[3], kbl[3];
+            const float* c2 = host.data();
+            for (int j = 0; j <= 2; ++j) { inl[j] = (j == 0) ? I : H; kbl[j] = (j == 0) ? m->KX / 8 : H / 8; wl[j] = c2; c2 += (size_t)H * inl[j] + H; }
+            const float* w_out_h = c2;
+            float* dst[3] = {m->ffp_wa0, m->ffp_wa1, m->ffp_wb2};
+            for (int j = 0; j <= 2; ++j) {
+                std::vector<float> pk((size_t)4 * 2 * kbl[j] * 64 * 4);
+                for (int w = 0; w < 4; ++w)
+                    for (int ct = 0; ct < 2; ++ct)
+                        for (int kb = 0; kb < kbl[j]; ++kb)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const int unit = 64 * w + 32 * ct + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + jj;
+                                    pk[((((size_t)w * 2 + ct) * kbl[j] + kb) * 64 + lane) * 4 + jj] = (k < inl[j]) ? wl[j][(size_t)unit * inl[j] + k] : 0.0f;
+                                }
+                HIP_TRY(hipMemcpy(dst[j], pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            std::vector<float> po((size_t)4 * 8 * 64 * 4);
+            for (int w = 0; w < 4; ++w)
+                for (int kb = 0; kb < 8; ++kb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int o = lane & 31, k = 64 * w + 8 * kb + 4 * (lane >> 5) + jj;
+                            po[(((size_t)w * 8 + kb) * 64 + lane) * 4 + jj] = (o < O) ? w_out_h[(size_t)o * H + k] : 0.0f;
+                        }
+            HIP_TRY(hipMemcpy(m->ffp_wbo, po.data(), po.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         if (!pre_only) {
             HIP_TRY(hipMemcpy(m->w_out, cur, (size_t)O * H * sizeof(float), hipMemcpyHostToDevice));
@@ -606,6 +655,13 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         q.I = m->dims.input_size; q.O = m->dims.output_size; q.KX = m->KX; q.n_hidden = L;
         q.flags = flags; q.dropout_p = dropout_p; q.seed = seed;
         q.neg_slope = 0.01f;                      // torch's leaky_relu default (nn_models.py:347,349)
+        // chip-filling eval batches: the weight-stationary two-stage pipeline (mlp_pipe.hip)
+        if (m->ffp_ok && m->ffp_on && !drop && q.N >= 64 * m->n_cus) {
+            hipError_t e2 = ape_launch_mlp_pipe(q, m->ffp_wa0, m->ffp_wa1, m->ffp_wb2, m->ffp_wbo, m->ffp_ring, m->ffp_ring_bytes, m->ffp_ctl,
+                                               m->n_cus, (hipStream_t)stream);
+            if (e2 != hipSuccess) return fail(APE_ERR_HIP, "mlp pipeline launch failed: %s", hipGetErrorString(e2));
+            return APE_OK;
+        }
         hipError_t e = ape_launch_mlp_tile16(H, q, (hipStream_t)stream, m->n_cus);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "mlp kernel launch failed: %s", hipGetErrorString(e));
         return APE_OK;
@@ -821,6 +877,7 @@ int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER && choice != APE_KERNEL_CLUSTER_GEN1)
         return fail(APE_ERR_INVALID_ARG, "set_kernel: unknown choice %d", choice);
     m->c32_on = choice != APE_KERNEL_CLUSTER_GEN1;
+    m->ffp_on = choice != APE_KERNEL_TILE16;           // (MLP regressor: TILE16 pins the tile kernel)
     if (choice == APE_KERNEL_CLUSTER_GEN1) choice = APE_KERNEL_CLUSTER;
     if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d on a device with %d CUs (a cluster "
@@ -845,6 +902,18 @@ int ape_model_set_precision(ape_model_t* m, int32_t precision) {
 
 int ape_model_check(ape_model_t* m) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "check: NULL model");
+    if (m->ffp_ok) {                                // the MLP pipeline's status word (bounded spins between its two stages)
+        HIP_TRY(hipSetDevice(m->dims.device));
+        HIP_TRY(hipDeviceSynchronize());
+        unsigned st = 0;
+        HIP_TRY(hipMemcpy(&st, m->ffp_ctl + 8 * 16, sizeof(st), hipMemcpyDeviceToHost));
+        if (st != 0) {
+            HIP_TRY(hipMemset(m->ffp_ctl, 0, m->ffp_ctl_words * sizeof(unsigned)));
+            HIP_TRY(hipDeviceSynchronize());
+            return fail(APE_ERR_HIP, "mlp pipeline launch aborted (status %u); outputs since the last successful check are invalid; the model "
+                        "is usable again", st);
+        }
+    }
     if (!m->cluster_ok) return APE_OK;
     HIP_TRY(hipSetDevice(m->dims.device));
     // every stream of the device, non-blocking ones included: a launch that is still spinning must have ended (its

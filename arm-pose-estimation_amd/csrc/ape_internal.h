@@ -183,6 +183,13 @@ hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size
                                  size_t rep_stride, hipStream_t stream);
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream);
 hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream, int n_cus = 0);
+// two-stage weight-stationary pipeline for chip-filling eval batches of the 2-hidden-layer MLP (mlp_pipe.hip)
+bool ape_mlp_pipe_supported(int H, int n_hidden, int KX, int O);
+size_t ape_mlp_pipe_ring_bytes(int n_cus);
+size_t ape_mlp_pipe_ctl_words(int n_cus);
+hipError_t ape_prepare_mlp_pipe();
+hipError_t ape_launch_mlp_pipe(const MlpParams& q, const float* wa0, const float* wa1, const float* wb2, const float* wbo, float* ring,
+                               size_t ring_bytes, unsigned* ctl, int n_cus, hipStream_t stream);
 hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const float* w_out, const float* b_out, float* y,
                                 hipStream_t stream);
 hipError_t ape_launch_fk(const FkParams& p, int preds_dtype, int est_dtype, hipStream_t stream);

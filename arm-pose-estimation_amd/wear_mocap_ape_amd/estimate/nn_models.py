@@ -382,7 +382,10 @@ class DropoutFF(DropoutLSTM):
         return self.forward(rep, last_step_only=last_step_only)
 
     def set_kernel(self, choice: str = "auto"):
-        return self                              # one kernel serves the MLP
+        """'auto' (the two-stage pipeline for chip-filling eval batches, the tile kernel otherwise) | 'tile16' (tile kernel only)"""
+        code = {"auto": _hip.KERNEL_AUTO, "tile16": _hip.KERNEL_TILE16}[choice]
+        _hip.check(_hip.lib().ape_model_set_kernel(self._handle, code), "ape_model_set_kernel")
+        return self
 
     def set_precision(self, precision: str = "f32"):
         if precision != "f32":
