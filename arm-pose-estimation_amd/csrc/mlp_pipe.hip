@@ -14,6 +14,7 @@
 // I <= 32, O <= 32; everything else stays on mlp_tile16.hip.
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -39,14 +40,17 @@ __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 r
 
 // NB k-blocks of 8 for two column tiles at once: acc0 / acc1 += W (registers w[w0 + ct * NWT + ...]) x activations (LDS, one
 // ds_read_b128 per block feeds the eight MFMAs of both tiles), fragments fetched two blocks ahead
-template <int NB, bool AG, int NW>
-__device__ __forceinline__ void span2(f32x16& acc0, f32x16& acc1, const float* __restrict__ src, int stride, const float (&w)[NW], int w0, int nwt) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int NB, bool AG, int NW, typename Hook = NoHook>
+__device__ __forceinline__ void span2(f32x16& acc0, f32x16& acc1, const float* __restrict__ src, int stride, const float (&w)[NW], int w0, int nwt,
+                                      Hook hook = Hook()) {
     f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
     f32x4 a1 = (NB > 1) ? *reinterpret_cast<const f32x4*>(src + stride) : a0;
     f32x4 a2 = a1;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         if (kb + 2 < NB) a2 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 2));
+        hook(kb);                                          // (memory operations of the hand-over, in the shadow of the MFMAs)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mfma32<AG>(acc0, w[w0 + 4 * kb + j], a0[j]);
@@ -66,6 +70,7 @@ struct PipeParams {
     float* ring;           // [pair][slot 4][HLF]
     size_t ring_bytes;
     unsigned* ctl;         // [8 class tickets x 16][status][done][pad..][pair][full 4 x 4 | empty 4 x 4]
+    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = no ring stores
 };
 
 __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // all 4 words of `f` (one per peer wave) have reached `want`
     auto wait_words = [&](const unsigned* f, unsigned want) {
+        if (pp.diag & 1u) return;
         unsigned spins = 0;
         while (true) {
             unsigned v = want;
@@ -128,13 +134,20 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     };
     auto leaky16 = [&](f32x16& a) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = fmaxf(a[i], slope * a[i]);      // slope < 1: max(y, slope y) = leaky_relu / relu
+        for (int i = 0; i < 16; ++i) {                                      // slope < 1: max(y, slope y) = leaky_relu / relu
+            const float sa = slope * a[i];
+            float r;
+            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a[i]), "v"(sa));             // (fmaxf adds a canonicalising v_max per element)
+            a[i] = r;
+        }
     };
     // this lane's 16 values of column tile ct = units 64 wave + 32 ct + 8 (i >> 2) + 4 hh + (i & 3) of row n: four 16-byte pieces of
     // the tile layout [unit / 8][row][8]
     auto tile_off = [&](int ct, int q) -> int { return ((8 * wave + 4 * ct + q) * TR + n) * 8 + 4 * hh; };
 
-    if (role == 0) {
+    if ((pp.diag & 2u) && role == 1) {
+    } else if ((pp.diag & 4u) && role == 0) {
+    } else if (role == 0) {
         // =========================== stage A: x -> layer 0 -> layer 1 -> ring ==========================================
         float* xin = lds;                                      // [TR][SX]
         float* h0 = xin + TR * SX;                             // [HLF]
@@ -148,6 +161,12 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             const f32x4* s1 = reinterpret_cast<const f32x4*>(pp.wa1) + (size_t)wave * 2 * 32 * 64 + lane;
 #pragma unroll
             for (int i = 0; i < 64; ++i) { const f32x4 v = s1[i * 64]; w1[4 * i] = v[0]; w1[4 * i + 1] = v[1]; w1[4 * i + 2] = v[2]; w1[4 * i + 3] = v[3]; }
+            // every weight register "used" here: the compiler waits for the loads in front of the loop instead of carrying
+            // s_waitcnt vmcnt(n) into its MFMA stream (where they would wait for this tile's ring stores as well)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(w0[i]));
+#pragma unroll
+            for (int i = 0; i < 256; ++i) asm volatile("" : "+a"(w1[i]));
         }
         bias_s[tid] = p.bias[0][tid];                          // (the loop's first barrier publishes them)
         bias_s[H + tid] = p.bias[1][tid];
@@ -201,13 +220,6 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 *reinterpret_cast<f32x4*>(h0 + tile_off(0, q)) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
                 *reinterpret_cast<f32x4*>(h0 + tile_off(1, q)) = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
             }
-            // the flag owed for the tile in front: its ring stores went out a whole layer 0 ago, nothing younger is in the queue
-            // (the x fetch of the tile after next is issued below, behind the flag)
-            if (pend_slot >= 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(full + pend_slot * 4 + wave, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pend_slot = -1;
-            }
             bar();                                             // h0 complete; xin is free
             if (tile + n_pairs < n_tiles) {                    // the next tile's x (fetched a tile ago) into LDS, the one after it on its way
                 stage_x();
@@ -219,11 +231,19 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             if (it >= NSLOT) wait_words(empty + slot * 4, (unsigned)(it / NSLOT));
             load_bias(acc0, 1, 0);
             load_bias(acc1, 1, 1);
-            span2<32, true, 256>(acc0, acc1, h0 + frag, TR * 8, w1, 0, 128);
+            // the flag owed for the tile in front is raised half-way through this layer: its ring stores went out 3.5 us ago and the
+            // x fetch behind them is as old, so the wait costs nothing (at the top of the layer it would: stores take ~1 us)
+            span2<32, true, 256>(acc0, acc1, h0 + frag, TR * 8, w1, 0, 128, [&](int kb) {
+                if (kb == 16 && pend_slot >= 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(full + pend_slot * 4 + wave, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            });
             mfma_drain2(acc0, acc1);
             leaky16(acc0);
             leaky16(acc1);
             const unsigned base = slot_base(slot);
+            if (!(pp.diag & 8u))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // (whole-vector casts: hipcc of ROCm 7.2 folds a vector built from per-element bit casts of an asm result into
@@ -255,6 +275,10 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             const f32x4* so = reinterpret_cast<const f32x4*>(pp.wbo) + (size_t)wave * 8 * 64 + lane;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const f32x4 v = so[i * 64]; wo[4 * i] = v[0]; wo[4 * i + 1] = v[1]; wo[4 * i + 2] = v[2]; wo[4 * i + 3] = v[3]; }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wo[i]));
+#pragma unroll
+            for (int i = 0; i < 256; ++i) asm volatile("" : "+a"(w2[i]));
         }
         bias_s[tid] = p.bias[2][tid];                          // (the loop's first barrier publishes them)
         auto load_bias = [&](f32x16& acc, int ct) {
@@ -277,22 +301,35 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             wait_words(full + 0, 1u);
             issue_copy(0);
         }
+        // y of one tile from its four partial sums; issued a tile late, in front of the next copy, so that the wait for the copy
+        // at the top of the loop finds the y stores long gone
+        auto write_y = [&](int tile) {
+            for (int idx = tid; idx < TR * p.O; idx += 256) {
+                const int row = idx / p.O, o = idx - row * p.O;
+                const long long grow = (long long)tile * TR + row;
+                if (grow < p.N)
+                    p.y[(size_t)grow * p.O + o] = ((pbuf[(0 * 32 + o) * TR + row] + pbuf[(1 * 32 + o) * TR + row]) +
+                                                   (pbuf[(2 * 32 + o) * TR + row] + pbuf[(3 * 32 + o) * TR + row])) + p.b_out[o];
+            }
+        };
         for (int it = 0; it < my_tiles; ++it) {
-            const int tile = pair + it * n_pairs;
             const int slot = it & (NSLOT - 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's KiBs of tile `it` are in LDS (and its y stores are out)
             if (lane == 0) __hip_atomic_store(empty + slot * 4 + wave, (unsigned)(it / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bar();                                             // all KiBs of the tile in LDS; h2 / pbuf of the tile in front are free
+            bar();                                             // all KiBs of the tile in LDS; h2 of the tile in front is free, its partial sums are complete
             if (ctl_s[0] != 0) return;
-            // the next tile's copy into the other buffer (its readers finished before the barrier above)
-            if (it + 1 < my_tiles) {
-                wait_words(full + ((it + 1) & (NSLOT - 1)) * 4, (unsigned)((it + 1) / NSLOT + 1));
-                issue_copy(it + 1);
-            }
+            if (it > 0) write_y(pair + (it - 1) * n_pairs);   // (its partial sums were complete at the barrier above)
             f32x16 acc0, acc1;
             load_bias(acc0, 0);
             load_bias(acc1, 1);
-            span2<32, true, 256>(acc0, acc1, inb + (it & 1) * HLF + frag, TR * 8, w2, 0, 128);
+            // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a quarter into this
+            // layer: the pair's producer raises that tile's flag half-way through the tile behind it
+            span2<32, true, 256>(acc0, acc1, inb + (it & 1) * HLF + frag, TR * 8, w2, 0, 128, [&](int kb) {
+                if (kb == 8 && it + 1 < my_tiles) {
+                    wait_words(full + ((it + 1) & (NSLOT - 1)) * 4, (unsigned)((it + 1) / NSLOT + 1));
+                    issue_copy(it + 1);
+                }
+            });
             mfma_drain2(acc0, acc1);
             leaky16(acc0);
             leaky16(acc1);
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 *reinterpret_cast<f32x4*>(h2 + tile_off(0, q)) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
                 *reinterpret_cast<f32x4*>(h2 + tile_off(1, q)) = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
             }
-            bar();                                             // h2 complete
+            bar();                                             // h2 complete; the partial sums of the tile in front have been read
             // output layer: this wave's K slice (units 64 wave .. +63 = k-blocks 8 wave .. +7) of all 32 (padded) outputs
             f32x16 acco;
 #pragma unroll
@@ -318,14 +355,10 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             mfma_drain1(acco);
 #pragma unroll
             for (int i = 0; i < 16; ++i) pbuf[(wave * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)) * TR + n] = acco[i];
-            bar();                                             // partial sums complete
-            for (int idx = tid; idx < TR * p.O; idx += 256) {
-                const int row = idx / p.O, o = idx - row * p.O;
-                const long long grow = (long long)tile * TR + row;
-                if (grow < p.N)
-                    p.y[(size_t)grow * p.O + o] = ((pbuf[(0 * 32 + o) * TR + row] + pbuf[(1 * 32 + o) * TR + row]) +
-                                                   (pbuf[(2 * 32 + o) * TR + row] + pbuf[(3 * 32 + o) * TR + row])) + p.b_out[o];
-            }
+        }
+        if (my_tiles > 0) {
+            bar();
+            write_y(pair + (my_tiles - 1) * n_pairs);
         }
     }
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
@@ -361,6 +394,8 @@ hipError_t ape_prepare_mlp_pipe() {
 hipError_t ape_launch_mlp_pipe(const MlpParams& q, const float* wa0, const float* wa1, const float* wb2, const float* wbo, float* ring,
                                size_t ring_bytes, unsigned* ctl, int n_cus, hipStream_t stream) {
     PipeParams pp{};
+    static const unsigned diag = getenv("APE_PIPE_DIAG") ? (unsigned)atoi(getenv("APE_PIPE_DIAG")) : 0u;
+    pp.diag = diag;
     pp.m = q; pp.wa0 = wa0; pp.wa1 = wa1; pp.wb2 = wb2; pp.wbo = wbo; pp.ring = ring; pp.ring_bytes = ring_bytes; pp.ctl = ctl;
     const int grid = (n_cus / 16) * 16;
     hipLaunchKernelGGL(ape_mlp_pipe, dim3(grid), dim3(256), pipe_smem(), stream, pp);

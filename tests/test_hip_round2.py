@@ -334,6 +334,49 @@ def test_mlp_regressor_large_batches(n_hidden, N):
     assert np.array_equal(y_small, y[:100])
 
 
+# ---------------- MLP regressor, the two-stage weight-stationary pipeline (eval mode, chip-filling batches) ---------------
+@pytest.mark.gpu
+def test_mlp_pipeline_kernel():
+    """ape_mlp_pipe (AUTO, eval mode, N >= 64 rows per CU) against the tile kernel (same arithmetic up to the float32 summation
+    order) and the oracle's restatement of nn_models.py:340-354: a ragged last tile, fewer tiles than some pairs' share, many
+    tiles per pair (the ring wraps), the fused float64 z-score, a [B,T,I] input read at its last step, back-to-back launches
+    (the kernel leaves its own hand-over words zeroed), and dropout falling back to the tile kernel"""
+    from wear_mocap_ape_amd.estimate import nn_models
+    I, H, O = 22, 256, 14
+    sd = orc.make_ff_state_dict(I, H, 2, O, 9)
+    m = nn_models.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=2, input_size=I, dropout=0.2, device=0)
+    m.load_state_dict(sd)
+    rng = np.random.default_rng(23)
+    st = {"xx_m": 0.1 * np.arange(I) - 1.0, "xx_s": 0.5 + 0.05 * np.arange(I), "yy_m": np.zeros(O), "yy_s": np.ones(O)}
+    m.set_norm_stats(st["xx_m"], st["xx_s"], st["yy_m"], st["yy_s"])
+    for N in (16384, 16384 + 37, 40000, 262144 + 5):
+        x = rng.normal(size=(N, I)).astype(np.float32)
+        xt = torch.from_numpy(x).cuda()
+        y_tile = m.set_kernel("tile16")(xt).cpu().numpy()
+        y_pipe = m.set_kernel("auto")(xt).cpu().numpy()
+        y_again = m(xt).cpu().numpy()
+        m.check()
+        assert np.abs(y_pipe - y_tile).max() < 1e-6
+        assert np.array_equal(y_pipe, y_again)
+        if N <= 40000:
+            assert np.abs(y_pipe - orc.ff_forward(sd, x)).max() < 2e-6
+    # fused z-score (float64, like the tile kernel) and a [B,T,I] input at its last step
+    B, T = 20000, 3
+    raw = (rng.normal(size=(B, T, I)) * st["xx_s"] + st["xx_m"]).astype(np.float32)
+    rt = torch.from_numpy(raw).cuda()
+    y_tile = m.set_kernel("tile16")(rt, last_step_only=True, normalize_input=True).cpu().numpy()
+    y_pipe = m.set_kernel("auto")(rt, last_step_only=True, normalize_input=True).cpu().numpy()
+    m.check()
+    assert y_pipe.shape == (B, 1, O) and np.abs(y_pipe - y_tile).max() < 1e-6
+    z = ((raw[:, -1].astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    assert np.abs(y_pipe[:, 0] - orc.ff_forward(sd, z)).max() < 2e-6
+    # an injected dropout mask is the tile kernel's business
+    x = rng.normal(size=(16384, I)).astype(np.float32)
+    mask = ((rng.random((16384, H)) >= 0.2) / 0.8).astype(np.float32)
+    ym = m(torch.from_numpy(x).cuda(), masks=torch.from_numpy(mask).cuda()).cpu().numpy()
+    assert np.abs(ym - orc.ff_forward(sd, x, mask=mask)).max() < 2e-6
+
+
 # ---------------- ImuPoseLSTM on the weight-stationary cluster kernel (256-wide layer-0 input) ---------------------------
 @pytest.mark.gpu
 def test_imupose_on_the_cluster_kernel():
