@@ -70,7 +70,7 @@ struct PipeParams {
     float* ring;           // [pair][slot 4][HLF]
     size_t ring_bytes;
     unsigned* ctl;         // [8 class tickets x 16][status][done][pad..][pair][full 4 x 4 | empty 4 x 4]
-    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = no ring stores
+    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = no ring stores, 16 = no leaky_relu, 32 = no barriers, 64 = no h0 / h2 writes
 };
 
 __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     ring_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)pp.ring_bytes);
     ring_desc[3] = 0x00020000u;
     auto slot_base = [&](int slot) -> unsigned { return (unsigned)(((size_t)pair * NSLOT + slot) * HLF * sizeof(float)); };
-    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto bar = [&]() { if (pp.diag & 32u) return; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // all 4 words of `f` (one per peer wave) have reached `want`
     auto wait_words = [&](const unsigned* f, unsigned want) {
         if (pp.diag & 1u) return;
@@ -132,7 +132,21 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             __builtin_amdgcn_s_sleep(1);
         }
     };
+    // the same wait in two halves, so that the L2 round trip of the look runs beside the MFMAs: the four words are fetched here ...
+    auto poll_begin = [&](const unsigned* f) -> unsigned {
+        unsigned v;
+        const unsigned* a = f + (lane & 3);
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(a) : "memory");
+        return v;
+    };
+    // ... and looked at here (behind an s_waitcnt vmcnt(0)); only a word that is still behind goes into the polling loop
+    auto poll_end = [&](unsigned v, const unsigned* f, unsigned want) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory");
+        if ((pp.diag & 1u) || __all((int)(v >= want))) return;
+        wait_words(f, want);
+    };
     auto leaky16 = [&](f32x16& a) {
+        if (pp.diag & 16u) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {                                      // slope < 1: max(y, slope y) = leaky_relu / relu
             const float sa = slope * a[i];
@@ -208,6 +222,9 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             const int slot = it & (NSLOT - 1);
             bar();                                             // xin of this tile visible; every wave is done with layer 1 of the tile in front: h0 is free
             if (ctl_s[0] != 0) return;
+            // has the consumer copied this tile's ring slot out (tile it - NSLOT of the pair)?  Asked here, looked at in layer 1
+            unsigned slot_free = 0u;
+            if (it >= NSLOT) slot_free = poll_begin(empty + slot * 4);
             f32x16 acc0, acc1;
             load_bias(acc0, 0, 0);
             load_bias(acc1, 0, 1);
@@ -215,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             mfma_drain2(acc0, acc1);
             leaky16(acc0);
             leaky16(acc1);
+            if (!(pp.diag & 64u))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 *reinterpret_cast<f32x4*>(h0 + tile_off(0, q)) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
@@ -225,18 +243,16 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 stage_x();
                 if (tile + 2 * n_pairs < n_tiles) fetch_x(tile + 2 * n_pairs);
             }
-            // the ring slot must have been copied out by the consumer (tile it - NSLOT of this pair; long done at this depth).  In
-            // front of layer 1, not behind it: hipcc (ROCm 7.2) breaks 16-wide vectors that are live across this loop into
-            // copies of their element 0
-            if (it >= NSLOT) wait_words(empty + slot * 4, (unsigned)(it / NSLOT));
             load_bias(acc0, 1, 0);
             load_bias(acc1, 1, 1);
             // the flag owed for the tile in front is raised half-way through this layer: its ring stores went out 3.5 us ago and the
             // x fetch behind them is as old, so the wait costs nothing (at the top of the layer it would: stores take ~1 us)
             span2<32, true, 256>(acc0, acc1, h0 + frag, TR * 8, w1, 0, 128, [&](int kb) {
-                if (kb == 16 && pend_slot >= 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(full + pend_slot * 4 + wave, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kb == 16) {
+                    if (it >= NSLOT) poll_end(slot_free, empty + slot * 4, (unsigned)(it / NSLOT));
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (pend_slot >= 0 && lane == 0)
+                        __hip_atomic_store(full + pend_slot * 4 + wave, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             });
             mfma_drain2(acc0, acc1);
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         float* inb = lds;                                      // [2][HLF]  h1 tiles, double-buffered
         float* h2 = inb + 2 * HLF;                             // [HLF]
         float* bias_s = h2 + HLF;                              // [2 ct][4 q][lane 64] f32x4
-        float* pbuf = bias_s + H;                              // [wave 4][o 32][row 32] partial outputs
+        float* pbuf = bias_s + H;                              // [wave 4][row 32][O] partial outputs (1024 floats per wave)
         float w2[2 * 32 * 4];
         float wo[8 * 4];
         {
@@ -281,6 +297,12 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             for (int i = 0; i < 256; ++i) asm volatile("" : "+a"(w2[i]));
         }
         bias_s[tid] = p.bias[2][tid];                          // (the loop's first barrier publishes them)
+        float bo[16];                                          // the output bias rides in wave 0's partial sum
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = 8 * (i >> 2) + 4 * hh + (i & 3);
+            bo[i] = (wave == 0 && o < p.O) ? p.b_out[o] : 0.0f;
+        }
         auto load_bias = [&](f32x16& acc, int ct) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -303,14 +325,12 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         }
         // y of one tile from its four partial sums; issued a tile late, in front of the next copy, so that the wait for the copy
         // at the top of the loop finds the y stores long gone
-        auto write_y = [&](int tile) {
-            for (int idx = tid; idx < TR * p.O; idx += 256) {
-                const int row = idx / p.O, o = idx - row * p.O;
-                const long long grow = (long long)tile * TR + row;
-                if (grow < p.N)
-                    p.y[(size_t)grow * p.O + o] = ((pbuf[(0 * 32 + o) * TR + row] + pbuf[(1 * 32 + o) * TR + row]) +
-                                                   (pbuf[(2 * 32 + o) * TR + row] + pbuf[(3 * 32 + o) * TR + row])) + p.b_out[o];
-            }
+        auto write_y = [&](int tile) {                         // (a tile's 32 rows of y are one contiguous run of 32 O floats)
+            const long long left = ((long long)p.N - (long long)tile * TR) * p.O;
+            float* ydst = p.y + (size_t)tile * TR * p.O;
+            for (int idx = tid; idx < TR * p.O; idx += 256)
+                if (idx < left)
+                    ydst[idx] = (pbuf[idx] + pbuf[32 * TR + idx]) + (pbuf[2 * 32 * TR + idx] + pbuf[3 * 32 * TR + idx]);
         };
         for (int it = 0; it < my_tiles; ++it) {
             const int slot = it & (NSLOT - 1);
@@ -319,20 +339,24 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             bar();                                             // all KiBs of the tile in LDS; h2 of the tile in front is free, its partial sums are complete
             if (ctl_s[0] != 0) return;
             if (it > 0) write_y(pair + (it - 1) * n_pairs);   // (its partial sums were complete at the barrier above)
+            unsigned next_full = 0u;
             f32x16 acc0, acc1;
             load_bias(acc0, 0);
             load_bias(acc1, 1);
-            // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a quarter into this
-            // layer: the pair's producer raises that tile's flag half-way through the tile behind it
+            // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a third into this
+            // layer (the pair's producer raises that tile's flag half-way through the tile behind it); the look at the flag is two
+            // k-blocks older
             span2<32, true, 256>(acc0, acc1, inb + (it & 1) * HLF + frag, TR * 8, w2, 0, 128, [&](int kb) {
-                if (kb == 8 && it + 1 < my_tiles) {
-                    wait_words(full + ((it + 1) & (NSLOT - 1)) * 4, (unsigned)((it + 1) / NSLOT + 1));
+                if (kb == 4 && it + 1 < my_tiles) next_full = poll_begin(full + ((it + 1) & (NSLOT - 1)) * 4);
+                if (kb == 12 && it + 1 < my_tiles) {
+                    poll_end(next_full, full + ((it + 1) & (NSLOT - 1)) * 4, (unsigned)((it + 1) / NSLOT + 1));
                     issue_copy(it + 1);
                 }
             });
             mfma_drain2(acc0, acc1);
             leaky16(acc0);
             leaky16(acc1);
+            if (!(pp.diag & 64u))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 *reinterpret_cast<f32x4*>(h2 + tile_off(0, q)) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             // output layer: this wave's K slice (units 64 wave .. +63 = k-blocks 8 wave .. +7) of all 32 (padded) outputs
             f32x16 acco;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acco[i] = 0.0f;
+            for (int i = 0; i < 16; ++i) acco[i] = bo[i];
             {
                 const float* src = h2 + (8 * wave) * TR * 8 + frag;
 #pragma unroll
@@ -354,7 +378,10 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             }
             mfma_drain1(acco);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pbuf[(wave * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)) * TR + n] = acco[i];
+            for (int i = 0; i < 16; ++i) {
+                const int o = 8 * (i >> 2) + 4 * hh + (i & 3);
+                if (o < p.O) pbuf[wave * (32 * TR) + n * p.O + o] = acco[i];
+            }
         }
         if (my_tiles > 0) {
             bar();
