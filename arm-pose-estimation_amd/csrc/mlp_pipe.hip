@@ -31,8 +31,15 @@ __device__ __forceinline__ void mfma32(f32x16& acc, float w, float a) {
     if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
 }
-__device__ __forceinline__ void mfma_drain2(f32x16& a, f32x16& b) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void mfma_drain1(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a)); }
+// The last MFMA of a stream carries its own drain (20 wait states: its 16 passes and a margin) INSIDE its asm statement.  The
+// compiler knows nothing of an asm MFMA's latency and is free to put register copies of the accumulators right behind it (it
+// did: a v_mov_b64 of the result two instructions after the MFMA read the lanes of the last passes too early); nothing can
+// come between the instructions of one statement.  The accumulator of the other chain finished 16 passes earlier.
+template <bool AG>
+__device__ __forceinline__ void mfma32_last(f32x16& acc, f32x16& other, float w, float a) {
+    if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc), "+v"(other) : "a"(w), "v"(a));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc), "+v"(other) : "v"(w), "v"(a));
+}
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -54,7 +61,8 @@ __device__ __forceinline__ void span2(f32x16& acc0, f32x16& acc1, const float* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mfma32<AG>(acc0, w[w0 + 4 * kb + j], a0[j]);
-            mfma32<AG>(acc1, w[w0 + nwt + 4 * kb + j], a0[j]);
+            if (kb == NB - 1 && j == 3) mfma32_last<AG>(acc1, acc0, w[w0 + nwt + 4 * kb + j], a0[j]);
+            else mfma32<AG>(acc1, w[w0 + nwt + 4 * kb + j], a0[j]);
         }
         a0 = a1;
         a1 = a2;
@@ -70,7 +78,7 @@ struct PipeParams {
     float* ring;           // [pair][slot 4][HLF]
     size_t ring_bytes;
     unsigned* ctl;         // [8 class tickets x 16][status][done][pad..][pair][full 4 x 4 | empty 4 x 4]
-    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = no ring stores, 16 = no leaky_relu, 32 = no barriers, 64 = no h0 / h2 writes
+    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only
 };
 
 __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
@@ -105,7 +113,6 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     const int n_tiles = (p.N + TR - 1) / TR;
     unsigned* const full = pp.ctl + 256 + pair * 32;            // [slot][producer wave] = tiles of that slot written
     unsigned* const empty = full + 16;                          // [slot][consumer wave] = tiles of that slot copied out
-    const __amdgpu_buffer_rsrc_t ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(pp.ring, 0, (int)pp.ring_bytes, 0x00020000);
     const unsigned long long ring_addr = reinterpret_cast<unsigned long long>(pp.ring);
     u32x4 ring_desc;
     ring_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)ring_addr);
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     ring_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)pp.ring_bytes);
     ring_desc[3] = 0x00020000u;
     auto slot_base = [&](int slot) -> unsigned { return (unsigned)(((size_t)pair * NSLOT + slot) * HLF * sizeof(float)); };
-    auto bar = [&]() { if (pp.diag & 32u) return; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // all 4 words of `f` (one per peer wave) have reached `want`
     auto wait_words = [&](const unsigned* f, unsigned want) {
         if (pp.diag & 1u) return;
@@ -145,27 +152,80 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         if ((pp.diag & 1u) || __all((int)(v >= want))) return;
         wait_words(f, want);
     };
-    auto leaky16 = [&](f32x16& a) {
-        if (pp.diag & 16u) return;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {                                      // slope < 1: max(y, slope y) = leaky_relu / relu
-            const float sa = slope * a[i];
-            float r;
-            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a[i]), "v"(sa));             // (fmaxf adds a canonicalising v_max per element)
-            a[i] = r;
-        }
-    };
     // this lane's 16 values of column tile ct = units 64 wave + 32 ct + 8 (i >> 2) + 4 hh + (i & 3) of row n: four 16-byte pieces of
     // the tile layout [unit / 8][row][8]
     auto tile_off = [&](int ct, int q) -> int { return ((8 * wave + 4 * ct + q) * TR + n) * 8 + 4 * hh; };
+
+    const unsigned lds_base = (unsigned)reinterpret_cast<unsigned long long>(lds);       // LDS byte address of `lds`
+    // Everything that rides in an MFMA stream is volatile asm (or fenced), so that it stays where it is written: the compiler
+    // knows neither the MFMAs' latencies nor that memory instructions are free beside them.
+    auto lrelu = [&](float& a) {                                // slope < 1: max(y, slope y) = leaky_relu / relu
+        float t;
+        asm volatile("v_mul_f32 %1, %2, %0\n\tv_max_f32 %0, %0, %1" : "+v"(a), "=&v"(t) : "v"(slope));
+    };
+    // leaky_relu of a wave's 64 x 32 block in one burst BEHIND its MFMA stream: a VALU instruction between MFMAs costs 5-12
+    // cycles (tools/ubench/chain32_valu.hip), about 2 on its own
+    auto lrelu32 = [&](f32x16& c0, f32x16& c1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float e0 = c0[e], e1 = c1[e];
+            lrelu(e0);
+            lrelu(e1);
+            c0[e] = e0;
+            c1[e] = e1;
+        }
+    };
+    // quarter q of the block into an LDS tile / a ring slot: memory instructions only, they ride in the next MFMA stream for
+    // free.  lane_off = this lane's 16 bytes in k-block 8 wave of a tile; k-block 8 wave + 4 ct + q is (4 ct + q) KiB further.
+    // (The ring stores name their slot in the SGPR offset: a buffer store of more than 8 bytes WITHOUT one must not be followed
+    // directly by a write of its data registers -- the compiler pads its own such stores, it cannot see these.)
+    const unsigned lane_off = (unsigned)(tile_off(0, 0) * 4);
+#define APE_LDS_ST(OFF) asm volatile("ds_write_b128 %0, %1 offset:" #OFF :: "v"(addr), "v"(v) : "memory")
+    auto lds_st = [&](unsigned addr, f32x4 v, int blk) {
+        switch (blk) {
+            case 0: APE_LDS_ST(0); break;
+            case 1: APE_LDS_ST(1024); break;
+            case 2: APE_LDS_ST(2048); break;
+            case 3: APE_LDS_ST(3072); break;
+            case 4: APE_LDS_ST(4096); break;
+            case 5: APE_LDS_ST(5120); break;
+            case 6: APE_LDS_ST(6144); break;
+            default: APE_LDS_ST(7168); break;
+        }
+    };
+#define APE_RING_ST(OFF) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #OFF :: "v"(v), "v"(voff), "s"(ring_desc), "s"(base) : "memory")
+    auto ring_st = [&](unsigned voff, f32x4 v, unsigned base, int q) {
+        switch (q) {
+            case 0: APE_RING_ST(0); break;
+            case 1: APE_RING_ST(1024); break;
+            case 2: APE_RING_ST(2048); break;
+            default: APE_RING_ST(3072); break;
+        }
+    };
+    auto put_lds = [&](const f32x16& c0, const f32x16& c1, int q, unsigned tile_addr) {
+        lds_st(tile_addr + lane_off, f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, q);
+        lds_st(tile_addr + lane_off, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, 4 + q);
+    };
+    const unsigned lane_off_hi = lane_off + 4096u;
+    auto put_ring = [&](const f32x16& c0, const f32x16& c1, int q, unsigned base) {
+        ring_st(lane_off, f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, base, q);
+        ring_st(lane_off_hi, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, base, q);
+    };
+    const int my_tiles = (pair < n_tiles) ? (n_tiles - pair + n_pairs - 1) / n_pairs : 0;
+    auto tile_of = [&](int j) -> int { return pair + j * n_pairs; };
 
     if ((pp.diag & 2u) && role == 1) {
     } else if ((pp.diag & 4u) && role == 0) {
     } else if (role == 0) {
         // =========================== stage A: x -> layer 0 -> layer 1 -> ring ==========================================
-        float* xin = lds;                                      // [TR][SX]
-        float* h0 = xin + TR * SX;                             // [HLF]
-        float* bias_s = h0 + HLF;                              // [2 layers][H]
+        // Software-pipelined: per iteration i ONE barrier, then layer 1 of tile i (256 MFMAs per wave) and layer 0 of tile i + 2
+        // (32).  The leaky_relu + LDS commit of layer 0's result (tile i + 1) ride in the next layer-1 stream, the leaky_relu +
+        // ring stores of layer 1's result in the layer-0 stream behind it: no MFMA drain, no exposed store, and every dependency
+        // has a barrier and most of an iteration between its two ends.  h0 and the x tile are double-buffered by tile parity.
+        float* xin = lds;                                      // [2][TR][SX]
+        float* h0 = xin + 2 * TR * SX;                         // [2][HLF]
+        float* bias_s = h0 + 2 * HLF;                          // [2 layers][H]
+        const unsigned h0_lds = lds_base + (unsigned)(2 * TR * SX * 4);
         float w0[2 * 4 * 4];                                   // input layer: 16 registers per column tile
         float w1[2 * 32 * 4];                                  // hidden layer 1: 128 per column tile (accumulator file)
         {
@@ -182,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
 #pragma unroll
             for (int i = 0; i < 256; ++i) asm volatile("" : "+a"(w1[i]));
         }
-        bias_s[tid] = p.bias[0][tid];                          // (the loop's first barrier publishes them)
+        bias_s[tid] = p.bias[0][tid];                          // (the first barrier publishes them)
         bias_s[H + tid] = p.bias[1][tid];
         auto load_bias = [&](f32x16& acc, int l, int ct) {     // unit 64 wave + 32 ct + 8 q + 4 hh + j of accumulator register 4 q + j
 #pragma unroll
@@ -204,84 +264,95 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 xr[e] = (xk < p.I && row < p.N) ? p.x[(size_t)row * p.row_stride + p.row_offset + xk] : 0.0f;
             }
         };
-        auto stage_x = [&]() {
+        auto stage_x = [&](int buf) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                xin[(xrow + 8 * e) * SX + xk] = normalize ? (float)(((double)xr[e] - x_mean) / x_std) : xr[e];
+                xin[buf * TR * SX + (xrow + 8 * e) * SX + xk] = normalize ? (float)(((double)xr[e] - x_mean) / x_std) : xr[e];
         };
-        int pend_slot = -1;
-        unsigned pend_epoch = 0u;
-        // x of this pair's first tile into LDS, the second tile's on its way
-        if (pair < n_tiles) {
-            fetch_x(pair);
-            stage_x();
-            if (pair + n_pairs < n_tiles) fetch_x(pair + n_pairs);
-        }
-        int it = 0;
-        for (int tile = pair; tile < n_tiles; tile += n_pairs, ++it) {
-            const int slot = it & (NSLOT - 1);
-            bar();                                             // xin of this tile visible; every wave is done with layer 1 of the tile in front: h0 is free
-            if (ctl_s[0] != 0) return;
-            // has the consumer copied this tile's ring slot out (tile it - NSLOT of the pair)?  Asked here, looked at in layer 1
-            unsigned slot_free = 0u;
-            if (it >= NSLOT) slot_free = poll_begin(empty + slot * 4);
-            f32x16 acc0, acc1;
-            load_bias(acc0, 0, 0);
-            load_bias(acc1, 0, 1);
-            span2<4, false, 32>(acc0, acc1, xin + n * SX + hh * 4, 8, w0, 0, 16);
-            mfma_drain2(acc0, acc1);
-            leaky16(acc0);
-            leaky16(acc1);
-            if (!(pp.diag & 64u))
+        auto layer0 = [&](f32x16& c0, f32x16& c1, int buf, auto hook) {
+            load_bias(c0, 0, 0);
+            load_bias(c1, 0, 1);
+            span2<4, false, 32>(c0, c1, xin + buf * TR * SX + n * SX + hh * 4, 8, w0, 0, 16, hook);
+        };
+        f32x16 a0, a1, b0, b1;                                 // layer 0's / layer 1's accumulators (two 32-unit column tiles each)
+        if (my_tiles > 0) {
+            // prologue: layer 0 of tiles 0 and 1 (the second one's epilogue rides in the first layer-1 stream), x of tile 2 staged
+            fetch_x(tile_of(0));
+            stage_x(0);
+            if (my_tiles > 1) { fetch_x(tile_of(1)); stage_x(1); }
+            if (my_tiles > 2) fetch_x(tile_of(2));
+            bar();
+            layer0(a0, a1, 0, NoHook());
+            lrelu32(a0, a1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<f32x4*>(h0 + tile_off(0, q)) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
-                *reinterpret_cast<f32x4*>(h0 + tile_off(1, q)) = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+            for (int q = 0; q < 4; ++q) put_lds(a0, a1, q, h0_lds);
+            if (my_tiles > 1) {
+                layer0(a0, a1, 1, NoHook());
+                lrelu32(a0, a1);
             }
-            bar();                                             // h0 complete; xin is free
-            if (tile + n_pairs < n_tiles) {                    // the next tile's x (fetched a tile ago) into LDS, the one after it on its way
-                stage_x();
-                if (tile + 2 * n_pairs < n_tiles) fetch_x(tile + 2 * n_pairs);
+            bar();                                             // every wave is done with the x tiles
+            if (my_tiles > 2) {
+                stage_x(0);
+                if (my_tiles > 3) fetch_x(tile_of(3));
             }
-            load_bias(acc0, 1, 0);
-            load_bias(acc1, 1, 1);
-            // the flag owed for the tile in front is raised half-way through this layer: its ring stores went out 3.5 us ago and the
-            // x fetch behind them is as old, so the wait costs nothing (at the top of the layer it would: stores take ~1 us)
-            span2<32, true, 256>(acc0, acc1, h0 + frag, TR * 8, w1, 0, 128, [&](int kb) {
+        }
+        for (int i = 0; i < my_tiles; ++i) {
+            const int slot = i & (NSLOT - 1);
+            bar();                                             // h0 of tile i and x of tile i + 2 complete; h0 / x buffers of the other parity free
+            if (ctl_s[0] != 0) return;
+            unsigned slot_free = 0u;
+            // x of tile i + 3 (fetched an iteration ago) into the buffer layer 0 read an iteration ago; tile i + 4 on its way
+            if (i + 3 < my_tiles) {
+                stage_x((i + 3) & 1);
+                if (i + 4 < my_tiles) fetch_x(tile_of(i + 4));
+            }
+            asm volatile("" ::: "memory");
+            load_bias(b0, 1, 0);
+            load_bias(b1, 1, 1);
+            span2<32, true, 256>(b0, b1, h0 + (i & 1) * HLF + frag, TR * 8, w1, 0, 128, [&](int kb) {
+                // layer 0's result of tile i + 1 into the other h0 buffer
+                if (kb >= 1 && kb <= 4 && i + 1 < my_tiles) put_lds(a0, a1, kb - 1, h0_lds + (unsigned)(((i + 1) & 1) * HLF * 4));
                 if (kb == 16) {
-                    if (it >= NSLOT) poll_end(slot_free, empty + slot * 4, (unsigned)(it / NSLOT));
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (pend_slot >= 0 && lane == 0)
-                        __hip_atomic_store(full + pend_slot * 4 + wave, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the flag owed for the tile in front: its ring stores went out 3.5 us ago, the x fetch behind them is as old
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (i > 0 && lane == 0)
+                        __hip_atomic_store(full + ((i - 1) & (NSLOT - 1)) * 4 + wave, (unsigned)((i - 1) / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // has the consumer copied this tile's ring slot out (tile i - NSLOT)?  Asked here, looked at behind the layer
+                    if (i >= NSLOT) slot_free = poll_begin(empty + slot * 4);
                 }
             });
-            mfma_drain2(acc0, acc1);
-            leaky16(acc0);
-            leaky16(acc1);
-            const unsigned base = slot_base(slot);
-            if (!(pp.diag & 8u))
+            lrelu32(b0, b1);
+            if (i >= NSLOT) poll_end(slot_free, empty + slot * 4, (unsigned)(i / NSLOT));
+            const unsigned base = __builtin_amdgcn_readfirstlane(slot_base(slot));
+            if (i + 2 < my_tiles) {
+                // layer 0 of tile i + 2; layer 1's result of tile i goes into the ring beside it
+                layer0(a0, a1, i & 1, [&](int kb) {
+                    if (kb == 0) { put_ring(b0, b1, 0, base); put_ring(b0, b1, 1, base); }
+                    if (kb == 1) { put_ring(b0, b1, 2, base); put_ring(b0, b1, 3, base); }
+                });
+                lrelu32(a0, a1);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // (whole-vector casts: hipcc of ROCm 7.2 folds a vector built from per-element bit casts of an asm result into
-                // four copies of its element 0)
-                const u32x4 v0 = __builtin_bit_cast(u32x4, f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]});
-                const u32x4 v1 = __builtin_bit_cast(u32x4, f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]});
-                __builtin_amdgcn_raw_buffer_store_b128(v0, ring_rsrc, base + (unsigned)(tile_off(0, q) * 4), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(v1, ring_rsrc, base + (unsigned)(tile_off(1, q) * 4), 0, 0);
+                for (int q = 0; q < 4; ++q) put_ring(b0, b1, q, base);
             }
-            pend_slot = slot;
-            pend_epoch = (unsigned)(it / NSLOT + 1);
         }
-        if (pend_slot >= 0) {
+        if (my_tiles > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(full + pend_slot * 4 + wave, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0)
+                __hip_atomic_store(full + ((my_tiles - 1) & (NSLOT - 1)) * 4 + wave, (unsigned)((my_tiles - 1) / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // =========================== stage B: ring -> layer 2 -> output layer -> y ======================================
-        float* inb = lds;                                      // [2][HLF]  h1 tiles, double-buffered
-        float* h2 = inb + 2 * HLF;                             // [HLF]
-        float* bias_s = h2 + HLF;                              // [2 ct][4 q][lane 64] f32x4
-        float* pbuf = bias_s + H;                              // [wave 4][row 32][O] partial outputs (1024 floats per wave)
+        // Software-pipelined like stage A: per iteration i one barrier, layer 2 of tile i (256 MFMAs) and the output layer of
+        // tile i - 1 (32, this wave's K slice); layer 2's leaky_relu + LDS commit ride in the output layer's stream, the output
+        // layer's partial sums go to LDS in the next layer-2 stream and y (the sum of the four waves' partials) leaves in the
+        // one after that.  h2 and the partial sums are double-buffered by tile parity.
+        float* inb = lds;                                      // [2][HLF]  h1 tiles (LDS-DMA target)
+        float* h2 = inb + 2 * HLF;                             // [2][HLF]
+        float* bias_s = h2 + 2 * HLF;                          // [H]
+        float* pbuf = bias_s + H;                              // [2][wave 4][row 32][O] partial outputs
+        const int PW = TR * p.O;
+        const unsigned h2_lds = lds_base + (unsigned)(2 * HLF * 4);
         float w2[2 * 32 * 4];
         float wo[8 * 4];
         {
@@ -310,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 acc[4 * q] = bv[0]; acc[4 * q + 1] = bv[1]; acc[4 * q + 2] = bv[2]; acc[4 * q + 3] = bv[3];
             }
         };
-        const unsigned inb_lds = (unsigned)reinterpret_cast<unsigned long long>(inb);
+        const unsigned inb_lds = lds_base;
         const unsigned dma_voff = (unsigned)(lane * 16);
         auto issue_copy = [&](int it_) {                       // tile it_ of this pair: ring slot -> inb[it_ & 1]; wave w copies KiB w, w + 4, ...
             const unsigned src = slot_base(it_ & (NSLOT - 1)) + (unsigned)(wave * 1024);
@@ -318,74 +389,81 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) dma_1k(dst + (unsigned)(k * 4096), dma_voff, ring_desc, src + (unsigned)(k * 4096));
         };
-        const int my_tiles = (pair < n_tiles) ? (n_tiles - pair + n_pairs - 1) / n_pairs : 0;
+        f32x16 c0, c1, acco;                                   // layer 2's accumulators; the output layer's
+        // the output layer's partial sums of tile j (held in acco) into their LDS buffer, in y order: [wave][row * O + o]
+        auto write_partials = [&](int j) {
+            asm volatile("" ::: "memory");
+            float* pb = pbuf + (j & 1) * 4 * PW + wave * PW + n * p.O;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int o = 8 * (i >> 2) + 4 * hh + (i & 3);
+                if (o < p.O) pb[o] = acco[i];
+            }
+            asm volatile("" ::: "memory");
+        };
+        // y of tile j from its four partial sums (a tile's 32 rows of y are one contiguous run of 32 O floats)
+        auto write_y = [&](int j) {
+            asm volatile("" ::: "memory");
+            const float* pb = pbuf + (j & 1) * 4 * PW;
+            const long long left = ((long long)p.N - (long long)tile_of(j) * TR) * p.O;
+            float* ydst = p.y + (size_t)tile_of(j) * PW;
+            for (int idx = tid; idx < PW; idx += 256)
+                if (idx < left) ydst[idx] = (pb[idx] + pb[PW + idx]) + (pb[2 * PW + idx] + pb[3 * PW + idx]);
+            asm volatile("" ::: "memory");
+        };
         if (my_tiles > 0) {
             wait_words(full + 0, 1u);
             issue_copy(0);
         }
-        // y of one tile from its four partial sums; issued a tile late, in front of the next copy, so that the wait for the copy
-        // at the top of the loop finds the y stores long gone
-        auto write_y = [&](int tile) {                         // (a tile's 32 rows of y are one contiguous run of 32 O floats)
-            const long long left = ((long long)p.N - (long long)tile * TR) * p.O;
-            float* ydst = p.y + (size_t)tile * TR * p.O;
-            for (int idx = tid; idx < TR * p.O; idx += 256)
-                if (idx < left)
-                    ydst[idx] = (pbuf[idx] + pbuf[32 * TR + idx]) + (pbuf[2 * 32 * TR + idx] + pbuf[3 * 32 * TR + idx]);
-        };
-        for (int it = 0; it < my_tiles; ++it) {
-            const int slot = it & (NSLOT - 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's KiBs of tile `it` are in LDS (and its y stores are out)
-            if (lane == 0) __hip_atomic_store(empty + slot * 4 + wave, (unsigned)(it / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bar();                                             // all KiBs of the tile in LDS; h2 of the tile in front is free, its partial sums are complete
+        const int n_iter = (my_tiles > 0) ? my_tiles + 3 : 0;
+        for (int i = 0; i < n_iter; ++i) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's KiBs of tile i are in LDS (and older y stores are out)
+            if (i < my_tiles && lane == 0)
+                __hip_atomic_store(empty + (i & (NSLOT - 1)) * 4 + wave, (unsigned)(i / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bar();                                             // tile i in LDS; h2 of tile i - 1 and the partial sums of tile i - 3 complete
             if (ctl_s[0] != 0) return;
-            if (it > 0) write_y(pair + (it - 1) * n_pairs);   // (its partial sums were complete at the barrier above)
             unsigned next_full = 0u;
-            f32x16 acc0, acc1;
-            load_bias(acc0, 0);
-            load_bias(acc1, 1);
-            // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a third into this
-            // layer (the pair's producer raises that tile's flag half-way through the tile behind it); the look at the flag is two
-            // k-blocks older
-            span2<32, true, 256>(acc0, acc1, inb + (it & 1) * HLF + frag, TR * 8, w2, 0, 128, [&](int kb) {
-                if (kb == 4 && it + 1 < my_tiles) next_full = poll_begin(full + ((it + 1) & (NSLOT - 1)) * 4);
-                if (kb == 12 && it + 1 < my_tiles) {
-                    poll_end(next_full, full + ((it + 1) & (NSLOT - 1)) * 4, (unsigned)((it + 1) / NSLOT + 1));
-                    issue_copy(it + 1);
-                }
-            });
-            mfma_drain2(acc0, acc1);
-            leaky16(acc0);
-            leaky16(acc1);
-            if (!(pp.diag & 64u))
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<f32x4*>(h2 + tile_off(0, q)) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
-                *reinterpret_cast<f32x4*>(h2 + tile_off(1, q)) = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+            if (i >= 3) write_y(i - 3);                        // (VALU work: in front of the stream, not in it)
+            auto side = [&](int kb) {
+                if (kb == 1 && i >= 2 && i - 2 < my_tiles) write_partials(i - 2);
+            };
+            if (i < my_tiles) {
+                load_bias(c0, 0);
+                load_bias(c1, 1);
+                span2<32, true, 256>(c0, c1, inb + (i & 1) * HLF + frag, TR * 8, w2, 0, 128, [&](int kb) {
+                    side(kb);
+                    // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a third
+                    // into this layer; the look at its flag is eight k-blocks older
+                    if (kb == 4 && i + 1 < my_tiles) next_full = poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
+                    if (kb == 12 && i + 1 < my_tiles) {
+                        poll_end(next_full, full + ((i + 1) & (NSLOT - 1)) * 4, (unsigned)((i + 1) / NSLOT + 1));
+                        issue_copy(i + 1);
+                    }
+                });
+                lrelu32(c0, c1);
+            } else {
+                side(1);
             }
-            bar();                                             // h2 complete; the partial sums of the tile in front have been read
-            // output layer: this wave's K slice (units 64 wave .. +63 = k-blocks 8 wave .. +7) of all 32 (padded) outputs
-            f32x16 acco;
+            if (i >= 1 && i - 1 < my_tiles) {
+                // output layer of tile i - 1: this wave's K slice (units 64 wave .. +63) of all 32 (padded) outputs; layer 2's result
+                // of tile i goes into the other h2 buffer beside it
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acco[i] = bo[i];
-            {
-                const float* src = h2 + (8 * wave) * TR * 8 + frag;
+                for (int e = 0; e < 16; ++e) acco[e] = bo[e];
+                const float* src = h2 + ((i - 1) & 1) * HLF + (8 * wave) * TR * 8 + frag;
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(src + kb * TR * 8);
+                    if (kb >= 1 && kb <= 4 && i < my_tiles) put_lds(c0, c1, kb - 1, h2_lds + (unsigned)((i & 1) * HLF * 4));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mfma32<false>(acco, wo[4 * kb + j], a[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (kb == 7 && j == 3) mfma32_last<false>(acco, c0, wo[4 * kb + j], a[j]);
+                        else mfma32<false>(acco, wo[4 * kb + j], a[j]);
+                    }
                 }
-            }
-            mfma_drain1(acco);
+            } else if (i < my_tiles) {                         // the first tile: no output layer to hide behind
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int o = 8 * (i >> 2) + 4 * hh + (i & 3);
-                if (o < p.O) pbuf[wave * (32 * TR) + n * p.O + o] = acco[i];
+                for (int q = 0; q < 4; ++q) put_lds(c0, c1, q, h2_lds);
             }
-        }
-        if (my_tiles > 0) {
-            bar();
-            write_y(pair + (my_tiles - 1) * n_pairs);
         }
     }
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
@@ -400,19 +478,19 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     }
 }
 
-constexpr size_t pipe_smem() {
-    // stage B is the larger one: 2 in-buffers + h2 + bias + partial sums (stage A: x tile + h0 + 2 biases)
-    return (16 + (size_t)3 * HLF + H + 4 * 32 * TR) * sizeof(float);
-}
+// stage B is the larger one: 2 in-buffers + 2 h2 buffers + bias + 2 x 4 partial sums (stage A: 2 x tiles + 2 h0 buffers + 2 biases)
+constexpr size_t pipe_smem(int O) { return (16 + (size_t)4 * HLF + H + 2 * 4 * TR * O) * sizeof(float); }
+constexpr int PIPE_MAX_O = 30;
 
 }  // namespace
 
 size_t ape_mlp_pipe_ring_bytes(int n_cus) { return (size_t)(n_cus / 2) * NSLOT * HLF * sizeof(float); }
 size_t ape_mlp_pipe_ctl_words(int n_cus) { return 256 + (size_t)(n_cus / 2) * 32; }
-bool ape_mlp_pipe_supported(int Hd, int n_hidden, int KXd, int O) { return Hd == H && n_hidden == 2 && KXd == KX && O <= 32; }
+bool ape_mlp_pipe_supported(int Hd, int n_hidden, int KXd, int O) { return Hd == H && n_hidden == 2 && KXd == KX && O <= PIPE_MAX_O; }
 
 hipError_t ape_prepare_mlp_pipe() {
-    static_assert(pipe_smem() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
+    static_assert(pipe_smem(PIPE_MAX_O) <= APE_LDS_BYTES, "LDS layout exceeds a CU");
+    static_assert((size_t)(16 + 2 * TR * SX + 2 * HLF + 2 * H) * sizeof(float) <= pipe_smem(1), "stage A's layout exceeds stage B's");
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
 }
 
@@ -425,6 +503,6 @@ hipError_t ape_launch_mlp_pipe(const MlpParams& q, const float* wa0, const float
     pp.diag = diag;
     pp.m = q; pp.wa0 = wa0; pp.wa1 = wa1; pp.wb2 = wb2; pp.wbo = wbo; pp.ring = ring; pp.ring_bytes = ring_bytes; pp.ctl = ctl;
     const int grid = (n_cus / 16) * 16;
-    hipLaunchKernelGGL(ape_mlp_pipe, dim3(grid), dim3(256), pipe_smem(), stream, pp);
+    hipLaunchKernelGGL(ape_mlp_pipe, dim3(grid), dim3(256), pipe_smem(q.O), stream, pp);
     return hipGetLastError();
 }
