@@ -1269,6 +1269,8 @@ int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, i
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m) return "";
+    if (m->dims.model_kind == APE_MODEL_FF)        // (B rows of the last step, eval mode)
+        return (m->ffp_ok && m->ffp_on && B >= 64 * m->n_cus) ? "ape_mlp_pipe" : m->kernel_name.c_str();
     if (m->precision == APE_PRECISION_F16)
         return (m->f16_v2 && ape_cluster_f16v2_supported(m->dims.hidden_size, m->dims.num_layers, m->KX) &&
                 f16v2_capacity(m->n_cus) > 0 && B > 256) ? "ape_lstm_cluster_f16v2" : "ape_lstm_cluster_f16";

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 if (kb == 16) {
                     // the flag owed for the tile in front: its ring stores went out 3.5 us ago, the x fetch behind them is as old
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (i > 0 && lane == 0)
+                    if (i > 1 && lane == 0)                  // (tile 0's flag went up right behind its stores, below)
                         __hip_atomic_store(full + ((i - 1) & (NSLOT - 1)) * 4 + wave, (unsigned)((i - 1) / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // has the consumer copied this tile's ring slot out (tile i - NSLOT)?  Asked here, looked at behind the layer
                     if (i >= NSLOT) slot_free = poll_begin(empty + slot * 4);
@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) put_ring(b0, b1, q, base);
+            }
+            if (i == 0 && my_tiles > 1) {                      // the pair's consumer is waiting for its first tile: pay the store latency once
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(full + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (my_tiles > 0) {

@@ -313,8 +313,9 @@ def other_paths():
         us = timed(lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), N, 1, 0, None, 0.0, 0,
                                                            C.c_void_p(y.data_ptr()), None), "fwd"), 10, 50)
         out["mlp_regressor"] = {"rows": N, "us_per_launch": us, "rows_per_s": N / us * 1e6,
-                                "tflops": m.flops_per_window(1) * N / us / 1e6, "kernel": "ape_mlp_tile16<256, 2>",
-                                "profile": "profiles/r02_mlp_tile16.md"}
+                                "tflops": m.flops_per_window(1) * N / us / 1e6, "kernel": m.kernel_name(N, 1),
+                                "profile": "profiles/r02_mlp_pipe.md"}
+        m.check()
         del m, x, y
     except Exception as exc:
         out["mlp_regressor"] = {"error": str(exc)[:200]}

@@ -323,6 +323,7 @@ def test_mlp_regressor_large_batches(n_hidden, N):
     sd = orc.make_ff_state_dict(I, H, n_hidden, O, 5)
     m = nn_models.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=n_hidden, input_size=I, dropout=0.2, device=0)
     m.load_state_dict(sd)
+    m.set_kernel("tile16")                                  # (AUTO hands eval batches of this size to the pipeline kernel, below)
     rng = np.random.default_rng(17)
     x = rng.normal(size=(N, I)).astype(np.float32)
     mask = ((rng.random((N, H)) >= 0.2) / 0.8).astype(np.float32)

@@ -1,4 +1,4 @@
-"""Launch time of the MLP regressor kernel (DropoutFF), HIP events: python tests/tools/time_mlp.py [B] [hidden_layers]"""
+"""Launch time of the MLP regressor kernel (DropoutFF), HIP events: python tests/tools/time_mlp.py [B] [hidden_layers] [auto|tile16]"""
 import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
@@ -8,6 +8,7 @@ from wear_mocap_ape_amd.estimate import nn_models
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_hidden = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 m = nn_models.DropoutFF(14, 256, n_hidden, 22, dropout=0.2, device=0)      # (output, hidden, count, input): the reference's order
+if len(sys.argv) > 3: m.set_kernel(sys.argv[3])
 rng = np.random.default_rng(0)
 m.load_weight_blob(torch.from_numpy(rng.uniform(-0.06, 0.06, m.weight_blob_floats()).astype(np.float32)).cuda())
 x = torch.randn(B, 1, 22, device="cuda"); y = torch.empty(B, 14, device="cuda"); lib = _hip.lib()
