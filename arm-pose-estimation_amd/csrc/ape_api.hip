@@ -1231,8 +1231,15 @@ int ape_debug_read_wg(ape_model_t* m, unsigned long long out[256 * 8]) {
 }
 
 // internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
-// 2 departure counter, 3 launch number of the latency kernel -- so that tests can stage the state an aborted launch leaves behind
+// 2 departure counter, 3 launch number of the latency kernel, 4 / 5 status word / a class ticket of the MLP pipeline -- so that tests
+// can stage the state an aborted launch leaves behind
 int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
+    if (m && m->ffp_ok && (which == 4 || which == 5)) {          // the MLP pipeline's status word / first class ticket
+        HIP_TRY(hipSetDevice(m->dims.device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(m->ffp_ctl + (which == 4 ? 8 * 16 : 0), &value, sizeof(value), hipMemcpyHostToDevice));
+        return APE_OK;
+    }
     if (!m || !m->cluster_ok || which < 0 || which > 3) return APE_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(m->dims.device));
     HIP_TRY(hipDeviceSynchronize());

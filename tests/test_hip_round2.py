@@ -378,6 +378,61 @@ def test_mlp_pipeline_kernel():
     assert np.abs(ym - orc.ff_forward(sd, x, mask=mask)).max() < 2e-6
 
 
+@pytest.mark.gpu
+def test_mlp_pipeline_abort_and_graph_replay():
+    """the pipeline kernel is loud and recoverable like the cluster kernels (a sticky status word / class tickets an aborted launch
+    left behind: host results raise, `check()` raises once, then the handle works again bit for bit), and a captured launch replays
+    on new data (the kernel re-zeroes its own hand-over words)"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import nn_models
+    I, H, O, N = 22, 256, 14, 20000
+    m = nn_models.DropoutFF(output_size=O, hidden_layer_size=H, hidden_layer_count=2, input_size=I, dropout=0.2, device=0)
+    m.load_state_dict(orc.make_ff_state_dict(I, H, 2, O, 4))
+    lib = _hip.lib()
+    lib.ape_debug_poke.restype, lib.ape_debug_poke.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_uint]
+    assert m.kernel_name(N, 1) == "ape_mlp_pipe"
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(N, I)).astype(np.float32)
+    good = m(x).numpy().copy()
+    for which, value in ((4, 1), (5, 100000)):
+        assert lib.ape_debug_poke(m.handle, which, value) == 0
+        with pytest.raises(UserWarning, match="aborted"):
+            m(x)                                            # host output: checked before it is handed out
+        assert np.array_equal(m(x).numpy(), good)
+        assert lib.ape_debug_poke(m.handle, which, value) == 0
+        m(torch.from_numpy(x).cuda())                       # device output: the caller checks
+        with pytest.raises(UserWarning, match="aborted"):
+            m.check()
+        m.check()
+        assert np.array_equal(m(x).numpy(), good)
+    # graph capture and replay
+    xin = torch.from_numpy(x).cuda()[:, None, :].contiguous()
+    x2 = torch.from_numpy(rng.normal(size=(N, 1, I)).astype(np.float32)).cuda()
+    y_graph = torch.zeros((N, O), device="cuda")
+    y_eager = torch.zeros((N, O), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call = lambda src, out, stream: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(src.data_ptr()), N, 1, 0, None, 0.0, 0,
+                                                                        C.c_void_p(out.data_ptr()), stream), "fwd")
+        call(xin, y_graph, C.c_void_p(side.cuda_stream))
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            call(xin, y_graph, C.c_void_p(side.cuda_stream))
+    torch.cuda.current_stream().wait_stream(side)
+    first = xin.clone()
+    for data in (first, x2, first):
+        xin.copy_(data)
+        graph.replay()
+        torch.cuda.synchronize()
+        call(data, y_eager, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(y_graph, y_eager)
+    m.check()
+    assert np.array_equal(y_eager.cpu().numpy(), good)
+
+
 # ---------------- ImuPoseLSTM on the weight-stationary cluster kernel (256-wide layer-0 input) ---------------------------
 @pytest.mark.gpu
 def test_imupose_on_the_cluster_kernel():
