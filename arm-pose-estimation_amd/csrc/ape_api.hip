@@ -656,7 +656,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         q.flags = flags; q.dropout_p = dropout_p; q.seed = seed;
         q.neg_slope = 0.01f;                      // torch's leaky_relu default (nn_models.py:347,349)
         // chip-filling eval batches: the weight-stationary two-stage pipeline (mlp_pipe.hip)
-        if (m->ffp_ok && m->ffp_on && !drop && q.N >= 64 * m->n_cus) {
+        // (x and y each behind one 32-bit buffer descriptor)
+        const bool one_descriptor = ((size_t)(q.N - 1) * q.row_stride + q.row_offset + q.I) * sizeof(float) < 0xFFFFFFFFull &&
+                                    (size_t)q.N * q.O * sizeof(float) < 0xFFFFFFFFull;
+        if (m->ffp_ok && m->ffp_on && !drop && q.hidden_out == nullptr && q.mask == nullptr && one_descriptor && q.N >= 64 * m->n_cus) {
             hipError_t e2 = ape_launch_mlp_pipe(q, m->ffp_wa0, m->ffp_wa1, m->ffp_wb2, m->ffp_wbo, m->ffp_ring, m->ffp_ring_bytes, m->ffp_ctl,
                                                m->n_cus, (hipStream_t)stream);
             if (e2 != hipSuccess) return fail(APE_ERR_HIP, "mlp pipeline launch failed: %s", hipGetErrorString(e2));
@@ -1247,6 +1250,15 @@ int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
     // (3: the latency kernel's launch number, the upper bits of its granule tags -- to stage the 20-bit wrap)
     unsigned* word = which == 0 ? status : (which == 1 ? status - 4 : which == 2 ? status - 3 : reinterpret_cast<unsigned*>(m->hxs));
     HIP_TRY(hipMemcpy(word, &value, sizeof(value), hipMemcpyHostToDevice));
+    return APE_OK;
+}
+
+// internal: read `n` control words of the MLP pipeline from word `first` on (its segment stamps, tests/tools/pipe_stamps.py)
+int ape_debug_peek_pipe(ape_model_t* m, int first, unsigned* out, int n) {
+    if (!m || !m->ffp_ok || !out || first < 0 || n < 1 || (size_t)(first + n) > m->ffp_ctl_words) return APE_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(m->dims.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, m->ffp_ctl + first, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost));
     return APE_OK;
 }
 

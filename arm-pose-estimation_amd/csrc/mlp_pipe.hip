@@ -19,6 +19,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int H = 256, KX = 32, TR = 32;            // hidden width, padded input width, rows per tile
@@ -77,8 +78,9 @@ struct PipeParams {
     const float* wbo;      // stage B, output layer:   [wave 4][kb 8][lane 64][4]  (W_out[o = lane & 31][64 w + 8 kb + 4 hh + j], 0 for o >= O)
     float* ring;           // [pair][slot 4][HLF]
     size_t ring_bytes;
+    size_t x_bytes;        // bytes of x the batch spans (< 4 GiB: one buffer descriptor)
     unsigned* ctl;         // [8 class tickets x 16][status][done][pad..][pair][full 4 x 4 | empty 4 x 4]
-    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only
+    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = segment stamps
 };
 
 __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
@@ -159,21 +161,25 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     const unsigned lds_base = (unsigned)reinterpret_cast<unsigned long long>(lds);       // LDS byte address of `lds`
     // Everything that rides in an MFMA stream is volatile asm (or fenced), so that it stays where it is written: the compiler
     // knows neither the MFMAs' latencies nor that memory instructions are free beside them.
-    auto lrelu = [&](float& a) {                                // slope < 1: max(y, slope y) = leaky_relu / relu
-        float t;
-        asm volatile("v_mul_f32 %1, %2, %0\n\tv_max_f32 %0, %0, %1" : "+v"(a), "=&v"(t) : "v"(slope));
-    };
     // leaky_relu of a wave's 64 x 32 block in one burst BEHIND its MFMA stream: a VALU instruction between MFMAs costs 5-12
     // cycles (tools/ubench/chain32_valu.hip), about 2 on its own
-    auto lrelu32 = [&](f32x16& c0, f32x16& c1) {
+    const f32x2 slope2 = {slope, slope};
+    auto lrelu16 = [&](f32x16& c) {                             // (v_pk_mul_f32: two products per instruction; there is no packed f32 max)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float e0 = c0[e], e1 = c1[e];
-            lrelu(e0);
-            lrelu(e1);
-            c0[e] = e0;
-            c1[e] = e1;
+        for (int e = 0; e < 16; e += 2) {
+            const f32x2 v = {c[e], c[e + 1]};
+            f32x2 t;
+            float lo = c[e], hi = c[e + 1];
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(slope2));
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(lo) : "v"(t[0]));
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(hi) : "v"(t[1]));
+            c[e] = lo;
+            c[e + 1] = hi;
         }
+    };
+    auto lrelu32 = [&](f32x16& c0, f32x16& c1) {
+        lrelu16(c0);
+        lrelu16(c1);
     };
     // quarter q of the block into an LDS tile / a ring slot: memory instructions only, they ride in the next MFMA stream for
     // free.  lane_off = this lane's 16 bytes in k-block 8 wave of a tile; k-block 8 wave + 4 ct + q is (4 ct + q) KiB further.
@@ -210,6 +216,21 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     auto put_ring = [&](const f32x16& c0, const f32x16& c1, int q, unsigned base) {
         ring_st(lane_off, f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, base, q);
         ring_st(lane_off_hi, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, base, q);
+    };
+    // timing experiment (APE_PIPE_DIAG & 8): wave 0 of pair 0 sums s_memtime (shader clocks) over the segments of its loop into
+    // ctl[160 + 24 role + 2 k] (tests/tools/pipe_stamps.py)
+    const bool stamping = (pp.diag & 8u) != 0u && pair == 0 && wave == 0;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) {
+        if (!stamping) return;
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        if (k >= 0) seg[k] += t - t_prev;
+        t_prev = t;
+    };
+    auto stamps_out = [&]() {
+        if (stamping && lane == 0)
+            for (int k = 0; k < 8; ++k) { pp.ctl[160 + 24 * role + 2 * k] = (unsigned)seg[k]; pp.ctl[160 + 24 * role + 2 * k + 1] = (unsigned)(seg[k] >> 32); }
     };
     const int my_tiles = (pair < n_tiles) ? (n_tiles - pair + n_pairs - 1) / n_pairs : 0;
     auto tile_of = [&](int j) -> int { return pair + j * n_pairs; };
@@ -257,11 +278,25 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         const double x_mean = (normalize && xk < p.I) ? p.xx_m[xk] : 0.0;
         const double x_std = (normalize && xk < p.I) ? p.xx_s[xk] : 1.0;
         float xr[4];
-        auto fetch_x = [&](int tile) {
+        // a full tile is four loads at per-lane constant offsets from a per-tile SGPR offset (no address arithmetic on the VALU; the
+        // padded columns k >= I lie outside the descriptor and read as 0); only the batch's ragged last tile looks at its row numbers
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)pp.x_bytes, 0x00020000);
+        unsigned x_voff[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const long long row = (long long)tile * TR + xrow + 8 * e;
-                xr[e] = (xk < p.I && row < p.N) ? p.x[(size_t)row * p.row_stride + p.row_offset + xk] : 0.0f;
+        for (int e = 0; e < 4; ++e)
+            x_voff[e] = (xk < p.I) ? (unsigned)((((size_t)(xrow + 8 * e)) * p.row_stride + p.row_offset + xk) * sizeof(float)) : 0x80000000u;
+        const unsigned x_tile_bytes = (unsigned)(TR * p.row_stride * sizeof(float));
+        auto fetch_x = [&](int tile) {
+            const unsigned soff = (unsigned)tile * x_tile_bytes;
+            if ((long long)(tile + 1) * TR <= (long long)p.N) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff[e], soff, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned off = ((long long)tile * TR + xrow + 8 * e < (long long)p.N) ? x_voff[e] : 0x80000000u;
+                    xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, soff, 0));
+                }
             }
         };
         auto stage_x = [&](int buf) {
@@ -296,33 +331,42 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 if (my_tiles > 3) fetch_x(tile_of(3));
             }
         }
+        stamp(-1);
         for (int i = 0; i < my_tiles; ++i) {
             const int slot = i & (NSLOT - 1);
             bar();                                             // h0 of tile i and x of tile i + 2 complete; h0 / x buffers of the other parity free
+            stamp(0);
             if (ctl_s[0] != 0) return;
             unsigned slot_free = 0u;
-            // x of tile i + 3 (fetched an iteration ago) into the buffer layer 0 read an iteration ago; tile i + 4 on its way
-            if (i + 3 < my_tiles) {
-                stage_x((i + 3) & 1);
-                if (i + 4 < my_tiles) fetch_x(tile_of(i + 4));
-            }
-            asm volatile("" ::: "memory");
+            stamp(1);
             load_bias(b0, 1, 0);
             load_bias(b1, 1, 1);
             span2<32, true, 256>(b0, b1, h0 + (i & 1) * HLF + frag, TR * 8, w1, 0, 128, [&](int kb) {
-                // layer 0's result of tile i + 1 into the other h0 buffer
-                if (kb >= 1 && kb <= 4 && i + 1 < my_tiles) put_lds(a0, a1, kb - 1, h0_lds + (unsigned)(((i + 1) & 1) * HLF * 4));
+                // layer 0's result of tile i + 1 into the other h0 buffer (behind the last tile: stale values nobody reads -- a branch in
+                // the stream costs more than the stores)
+                if (kb >= 1 && kb <= 4) put_lds(a0, a1, kb - 1, h0_lds + (unsigned)(((i + 1) & 1) * HLF * 4));
                 if (kb == 16) {
                     // the flag owed for the tile in front: its ring stores went out 3.5 us ago, the x fetch behind them is as old
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (i > 1 && lane == 0)                  // (tile 0's flag went up right behind its stores, below)
                         __hip_atomic_store(full + ((i - 1) & (NSLOT - 1)) * 4 + wave, (unsigned)((i - 1) / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // has the consumer copied this tile's ring slot out (tile i - NSLOT)?  Asked here, looked at behind the layer
-                    if (i >= NSLOT) slot_free = poll_begin(empty + slot * 4);
+                    slot_free = poll_begin(empty + slot * 4);
                 }
             });
+            stamp(2);
             lrelu32(b0, b1);
             if (i >= NSLOT) poll_end(slot_free, empty + slot * 4, (unsigned)(i / NSLOT));
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot_free) :: "memory");
+            // x of tile i + 3 (fetched an iteration ago) into the buffer layer 0 read an iteration ago, tile i + 4 on its way: VALU work
+            // (the f64 z-score), so here between the streams; at the top of the iteration its wait would sit out the ring stores
+            // just issued, here they are a whole layer 1 old
+            if (i + 3 < my_tiles) {
+                stage_x((i + 3) & 1);
+                if (i + 4 < my_tiles) fetch_x(tile_of(i + 4));
+            }
+            asm volatile("" ::: "memory");
+            stamp(3);
             const unsigned base = __builtin_amdgcn_readfirstlane(slot_base(slot));
             if (i + 2 < my_tiles) {
                 // layer 0 of tile i + 2; layer 1's result of tile i goes into the ring beside it
@@ -330,7 +374,9 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                     if (kb == 0) { put_ring(b0, b1, 0, base); put_ring(b0, b1, 1, base); }
                     if (kb == 1) { put_ring(b0, b1, 2, base); put_ring(b0, b1, 3, base); }
                 });
+                stamp(4);
                 lrelu32(a0, a1);
+                stamp(5);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) put_ring(b0, b1, q, base);
@@ -354,8 +400,10 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         float* inb = lds;                                      // [2][HLF]  h1 tiles (LDS-DMA target)
         float* h2 = inb + 2 * HLF;                             // [2][HLF]
         float* bias_s = h2 + 2 * HLF;                          // [H]
-        float* pbuf = bias_s + H;                              // [2][wave 4][row 32][O] partial outputs
-        const int PW = TR * p.O;
+        float* pbuf = bias_s + H;                              // [2][wave 4][row 32][16] partial outputs
+        constexpr int PS = 16, PB = TR * PS;                   // floats per row / per wave
+        const int PW = TR * p.O;                               // floats of y per tile
+        const unsigned pbuf_lds = lds_base + (unsigned)((4 * HLF + H) * 4);
         const unsigned h2_lds = lds_base + (unsigned)(2 * HLF * 4);
         float w2[2 * 32 * 4];
         float wo[8 * 4];
@@ -394,25 +442,37 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             for (int k = 0; k < 8; ++k) dma_1k(dst + (unsigned)(k * 4096), dma_voff, ring_desc, src + (unsigned)(k * 4096));
         };
         f32x16 c0, c1, acco;                                   // layer 2's accumulators; the output layer's
-        // the output layer's partial sums of tile j (held in acco) into their LDS buffer, in y order: [wave][row * O + o]
-        auto write_partials = [&](int j) {
-            asm volatile("" ::: "memory");
-            float* pb = pbuf + (j & 1) * 4 * PW + wave * PW + n * p.O;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int o = 8 * (i >> 2) + 4 * hh + (i & 3);
-                if (o < p.O) pb[o] = acco[i];
-            }
-            asm volatile("" ::: "memory");
+        for (int e = 0; e < 16; ++e) { c0[e] = 0.0f; c1[e] = 0.0f; acco[e] = 0.0f; }
+        // the output layer's partial sums of tile j (held in acco) into their LDS buffer, in y order: [wave][row * O + o]
+        // the output layer's partial sums of tile j (held in acco: outputs 8 q + 4 hh + j2 of row n in registers 4 q + j2) into their LDS
+        // buffer: outputs 0 .. 15 as two 16-byte stores per lane
+        auto write_partials = [&](int j) {
+            const unsigned addr = pbuf_lds + (unsigned)((((j & 1) * 4 + wave) * PB + n * PS + 4 * hh) * 4);
+            lds_st(addr, f32x4{acco[0], acco[1], acco[2], acco[3]}, 0);
+            asm volatile("ds_write_b128 %0, %1 offset:32" :: "v"(addr), "v"(f32x4{acco[4], acco[5], acco[6], acco[7]}) : "memory");
         };
-        // y of tile j from its four partial sums (a tile's 32 rows of y are one contiguous run of 32 O floats)
+        // y of tile j from its four partial sums.  A tile's 32 rows of y are one contiguous run of 32 O floats; a thread owns
+        // elements tid and tid + 256 of it, whose places in the partial sums and in y are per-thread constants (a full tile is LDS
+        // reads, six adds and two bounds-checked stores at an SGPR offset)
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.N * p.O * sizeof(float)), 0x00020000);
+        int y_src[2];
+        unsigned y_voff[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + 256 * k;
+            y_src[k] = (idx < PW) ? (idx / p.O) * PS + (idx % p.O) : 0;
+            y_voff[k] = (idx < PW) ? (unsigned)(idx * sizeof(float)) : 0x80000000u;
+        }
         auto write_y = [&](int j) {
             asm volatile("" ::: "memory");
-            const float* pb = pbuf + (j & 1) * 4 * PW;
-            const long long left = ((long long)p.N - (long long)tile_of(j) * TR) * p.O;
-            float* ydst = p.y + (size_t)tile_of(j) * PW;
-            for (int idx = tid; idx < PW; idx += 256)
-                if (idx < left) ydst[idx] = (pb[idx] + pb[PW + idx]) + (pb[2 * PW + idx] + pb[3 * PW + idx]);
+            const float* pb = pbuf + (j & 1) * 4 * PB;
+            const unsigned soff = (unsigned)tile_of(j) * (unsigned)(PW * sizeof(float));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float v = (pb[y_src[k]] + pb[PB + y_src[k]]) + (pb[2 * PB + y_src[k]] + pb[3 * PB + y_src[k]]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, y_voff[k], soff, 0);
+            }
             asm volatile("" ::: "memory");
         };
         if (my_tiles > 0) {
@@ -420,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             issue_copy(0);
         }
         const int n_iter = (my_tiles > 0) ? my_tiles + 3 : 0;
+        stamp(-1);
         for (int i = 0; i < n_iter; ++i) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's KiBs of tile i are in LDS (and older y stores are out)
             if (i < my_tiles && lane == 0)
@@ -427,9 +488,11 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             bar();                                             // tile i in LDS; h2 of tile i - 1 and the partial sums of tile i - 3 complete
             if (ctl_s[0] != 0) return;
             unsigned next_full = 0u;
+            stamp(0);
             if (i >= 3) write_y(i - 3);                        // (VALU work: in front of the stream, not in it)
+            stamp(1);
             auto side = [&](int kb) {
-                if (kb == 1 && i >= 2 && i - 2 < my_tiles) write_partials(i - 2);
+                if (kb == 1) write_partials(i - 2);            // (i < 2: nothing yet, overwritten before anybody reads it)
             };
             if (i < my_tiles) {
                 load_bias(c0, 0);
@@ -438,14 +501,18 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                     side(kb);
                     // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a third
                     // into this layer; the look at its flag is eight k-blocks older
-                    if (kb == 4 && i + 1 < my_tiles) next_full = poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
+                    if (kb == 4) next_full = poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
                     if (kb == 12 && i + 1 < my_tiles) {
                         poll_end(next_full, full + ((i + 1) & (NSLOT - 1)) * 4, (unsigned)((i + 1) / NSLOT + 1));
                         issue_copy(i + 1);
+                    } else if (kb == 12) {
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_full) :: "memory");      // (the look nobody needs has landed)
                     }
                 });
+                stamp(2);
                 lrelu32(c0, c1);
-            } else {
+                stamp(3);
+            } else if (i - 2 < my_tiles) {
                 side(1);
             }
             if (i >= 1 && i - 1 < my_tiles) {
@@ -457,19 +524,21 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(src + kb * TR * 8);
-                    if (kb >= 1 && kb <= 4 && i < my_tiles) put_lds(c0, c1, kb - 1, h2_lds + (unsigned)((i & 1) * HLF * 4));
+                    if (kb >= 1 && kb <= 4) put_lds(c0, c1, kb - 1, h2_lds + (unsigned)((i & 1) * HLF * 4));   // (i >= my_tiles: stale values nobody reads)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (kb == 7 && j == 3) mfma32_last<false>(acco, c0, wo[4 * kb + j], a[j]);
                         else mfma32<false>(acco, wo[4 * kb + j], a[j]);
                     }
                 }
+                stamp(4);
             } else if (i < my_tiles) {                         // the first tile: no output layer to hide behind
 #pragma unroll
                 for (int q = 0; q < 4; ++q) put_lds(c0, c1, q, h2_lds);
             }
         }
     }
+    stamps_out();
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
     __syncthreads();
     if (tid == 0)
@@ -483,8 +552,8 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
 }
 
 // stage B is the larger one: 2 in-buffers + 2 h2 buffers + bias + 2 x 4 partial sums (stage A: 2 x tiles + 2 h0 buffers + 2 biases)
-constexpr size_t pipe_smem(int O) { return (16 + (size_t)4 * HLF + H + 2 * 4 * TR * O) * sizeof(float); }
-constexpr int PIPE_MAX_O = 30;
+constexpr size_t pipe_smem(int) { return (16 + (size_t)4 * HLF + H + 2 * 4 * TR * 16) * sizeof(float); }
+constexpr int PIPE_MAX_O = 16;           // (two rows of y per 32 bytes ... the partial sums are kept 16 wide)
 
 }  // namespace
 
@@ -505,6 +574,7 @@ hipError_t ape_launch_mlp_pipe(const MlpParams& q, const float* wa0, const float
     PipeParams pp{};
     static const unsigned diag = getenv("APE_PIPE_DIAG") ? (unsigned)atoi(getenv("APE_PIPE_DIAG")) : 0u;
     pp.diag = diag;
+    pp.x_bytes = ((size_t)(q.N - 1) * q.row_stride + q.row_offset + q.I) * sizeof(float);
     pp.m = q; pp.wa0 = wa0; pp.wa1 = wa1; pp.wb2 = wb2; pp.wbo = wbo; pp.ring = ring; pp.ring_bytes = ring_bytes; pp.ctl = ctl;
     const int grid = (n_cus / 16) * 16;
     hipLaunchKernelGGL(ape_mlp_pipe, dim3(grid), dim3(256), pipe_smem(q.O), stream, pp);
