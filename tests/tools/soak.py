@@ -17,8 +17,29 @@ for name in ("pocket", "uarm", "watch"):
     sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5)
     m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0); m.load_state_dict(sd)
     models[name] = (m, cfg)
+ff = nn_models.DropoutFF(14, 256, 2, 22, dropout=0.2, device=0)
+ff.load_state_dict(orc.make_ff_state_dict(22, 256, 2, 14, 6))
+ff.set_norm_stats(0.1 * np.arange(22) - 1.0, 0.5 + 0.05 * np.arange(22), np.zeros(14), np.ones(14))
 t0 = time.time(); n = 0; worst = 0.0; kinds = {}
+t_say = t0
 while time.time() - t0 < budget:
+    if time.time() - t_say > 60:          # (a silent run is taken to be hung)
+        t_say = time.time()
+        print(f"  ... {n} calls in {t_say - t0:.0f} s", flush=True)
+    if rng.integers(6) == 0:          # the MLP regressor: the two-stage pipeline (AUTO, N >= 64 rows per CU) against the tile kernel
+        N = int(rng.choice([1, 100, 5000, 16383, 16384, 16385, 20000, 40001, 65536, 100000]))
+        norm = bool(rng.integers(2))
+        x = torch.randn(N, 22, device="cuda")
+        ya = ff.set_kernel("auto")(x, normalize_input=norm)
+        yb = ff.set_kernel("tile16")(x, normalize_input=norm)
+        torch.cuda.synchronize()
+        ff.check()
+        err = float((ya - yb).abs().max())
+        assert np.isfinite(err) and err < 2e-6, ("ff", N, norm, err)
+        worst = max(worst, err)
+        n += 1
+        kinds[("ff", "f32", norm)] = kinds.get(("ff", "f32", norm), 0) + 1
+        continue
     name = ("pocket", "uarm", "watch")[rng.integers(3)]
     m, cfg = models[name]
     B = int(rng.choice([1, 1, 1, 2, 2, 3, 4, 4, 5, 16, 17, 25, 60, 64, 100, 333, 512, 1000, 1024, 1025, 1500, 2049, 4096, 4500]))
