@@ -142,6 +142,81 @@ __global__ __launch_bounds__(FK_BLOCK) void ape_fk_kernel(const FkParams p) {
         if (c < p.W) dst[c] = (TOut)e[c];
 }
 
+// The same arithmetic with a row's three independent chains side by side (batches from 256 rows on): a workgroup of two waves
+// owns 32 rows.  Wave 0, lane 2 r + s: the 6D -> quaternion chain of row r's lower (s = 0) / upper (s = 1) arm and the rotated
+// bone vector -- one instruction stream for both, no divergence; wave 1, lane r: the hips chain (atan2, cos, sin) and the rotated
+// shoulder origin, lanes 32 + r the columns that pass through.  The two sums that join the chains (estimate_joints.py:60-62,
+// 84-85) follow a barrier, in the reference's order.  Bit-identical to the one-thread-per-row form, whose per-thread chain of
+// ~1400 f64 instructions was the 7 us of a 1024-row call.
+constexpr int FK3_ROWS = 32;
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(128) void ape_fk3_kernel(const FkParams p) {
+    __shared__ double rot[FK3_ROWS][3][3];                 // [row][lower arm, upper arm, shoulder origin][xyz]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+    const bool full = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM_HIPS && hips;      // the 20-column layout (estimate_joints.py:20-45)
+    // column of the first 6D value of the lower / upper arm, of the hips' sine; est columns of the quaternions
+    const int c_l = full ? 3 : 0, c_u = full ? 12 : 6, c_h = full ? 18 : 12;
+    const int e_lq = hips ? 9 : 6, e_uq = hips ? 13 : 10, e_hq = 17;
+    auto load = [&](const TIn* src, int c) -> double {
+        double v = (double)src[c];
+        if (p.yy_m) v = v * p.yy_s[c] + p.yy_m[c];         // de-normalisation in f64: estimator.py:108-109
+        return v;
+    };
+    if (wave == 0) {
+        const int r = lane >> 1, sub = lane & 1;
+        const size_t row = (size_t)blockIdx.x * FK3_ROWS + r;
+        if (row < (size_t)p.N) {
+            const TIn* src = static_cast<const TIn*>(p.preds) + row * p.O;
+            TOut* dst = static_cast<TOut*>(p.est) + row * p.W;
+            double s6[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s6[c] = load(src, (sub ? c_u : c_l) + c);
+            const Quat q = six_drr_to_quat(s6);
+            const Vec3 bone = sub ? Vec3{p.body[3], p.body[4], p.body[5]} : Vec3{p.body[0], p.body[1], p.body[2]};
+            const Vec3 v = qrot(q, bone);
+            rot[r][sub][0] = v.x; rot[r][sub][1] = v.y; rot[r][sub][2] = v.z;
+            const int eq = sub ? e_uq : e_lq;
+            dst[eq] = (TOut)q.w; dst[eq + 1] = (TOut)q.x; dst[eq + 2] = (TOut)q.y; dst[eq + 3] = (TOut)q.z;
+        }
+    } else {
+        const int r = lane & 31;
+        const size_t row = (size_t)blockIdx.x * FK3_ROWS + r;
+        if (row < (size_t)p.N) {
+            const TIn* src = static_cast<const TIn*>(p.preds) + row * p.O;
+            TOut* dst = static_cast<TOut*>(p.est) + row * p.W;
+            if (lane < 32) {
+                Vec3 uo{p.body[6], p.body[7], p.body[8]};
+                if (hips) {
+                    const Quat hq = hips_quat(load(src, c_h), load(src, c_h + 1));
+                    uo = qrot(hq, uo);
+                    dst[e_hq] = (TOut)hq.w; dst[e_hq + 1] = (TOut)hq.x; dst[e_hq + 2] = (TOut)hq.y; dst[e_hq + 3] = (TOut)hq.z;
+                    dst[6] = (TOut)uo.x; dst[7] = (TOut)uo.y; dst[8] = (TOut)uo.z;
+                }
+                rot[r][2][0] = uo.x; rot[r][2][1] = uo.y; rot[r][2][2] = uo.z;
+            } else if (full) {                               // hand and lower-arm positions are network outputs here
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { dst[c] = (TOut)load(src, c); dst[3 + c] = (TOut)load(src, 9 + c); }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && !full) {
+        const int r = lane >> 1, c = lane & 1;             // two lanes per row: the lower-arm origin / the hand origin
+        const size_t row = (size_t)blockIdx.x * FK3_ROWS + r;
+        if (row < (size_t)p.N) {
+            TOut* dst = static_cast<TOut*>(p.est) + row * p.W;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double lo = rot[r][1][k] + rot[r][2][k];                 // qrot(uq, uarm_vec) + uo
+                if (c == 0) dst[3 + k] = (TOut)lo;
+                else dst[k] = (TOut)(rot[r][0][k] + lo);                       // qrot(lq, larm_vec) + lo
+            }
+        }
+    }
+}
+
 // Few rows (the latency path: 1 row per frame): the whole workgroup moves the row(s) through an LDS slab, so the O
 // loads and the W stores of a row are spread over as many threads -- 0.9 us less than one thread doing all of them.
 constexpr int FK_SLAB_BLOCK = 256;
@@ -396,6 +471,10 @@ template <typename TIn, typename TOut>
 hipError_t launch_fk(const FkParams& p, hipStream_t stream) {
     if (p.N <= 64) {
         hipLaunchKernelGGL((ape_fk_slab_kernel<TIn, TOut>), dim3(1), dim3(FK_SLAB_BLOCK), 0, stream, p);
+        return hipGetLastError();
+    }
+    if (p.N >= 256) {
+        hipLaunchKernelGGL((ape_fk3_kernel<TIn, TOut>), dim3((p.N + FK3_ROWS - 1) / FK3_ROWS), dim3(128), 0, stream, p);
         return hipGetLastError();
     }
     const int grid = (p.N + FK_BLOCK - 1) / FK_BLOCK;
