@@ -11,7 +11,6 @@
 //
 // The reference does this arithmetic in float64 (numpy), so both kernels compute in float64
 // whatever the storage type: the work is a few hundred flops per row and HBM/latency bound.
-// One thread per row, the row in registers.
 //
 // rot_mat_to_quat: the reference takes the dominant eigenvector of a symmetric 4x4 matrix
 // (numpy.linalg.eigh, ~70 % of its frame time).  For the orthonormal matrices Gram-Schmidt
@@ -115,39 +114,11 @@ __device__ void fk_row(const double* pr, const double* body, int layout, double*
     }
 }
 
-constexpr int FK_BLOCK = 64;       // one wave per workgroup: 1024 rows spread over 16 CUs
-
-// One thread per row, the row held in registers: its O inputs are O independent scalar loads in flight together and
-// its W outputs W independent stores -- the per-thread chain is the f64 arithmetic, nothing else.  (The first version
-// moved rows through an LDS slab with a division-indexed copy loop on either side: 10.8 us for 1024 rows, of which
-// the arithmetic is under half.)
-template <typename TIn, typename TOut>
-__global__ __launch_bounds__(FK_BLOCK) void ape_fk_kernel(const FkParams p) {
-    const size_t row = (size_t)blockIdx.x * FK_BLOCK + threadIdx.x;
-    if (row >= (size_t)p.N) return;
-    const TIn* src = static_cast<const TIn*>(p.preds) + row * p.O;
-    double pr[20];
-#pragma unroll
-    for (int c = 0; c < 20; ++c) pr[c] = (c < p.O) ? (double)src[c] : 0.0;
-    if (p.yy_m) {                                    // de-normalisation in f64: estimator.py:108-109
-#pragma unroll
-        for (int c = 0; c < 20; ++c)
-            if (c < p.O) pr[c] = pr[c] * p.yy_s[c] + p.yy_m[c];
-    }
-    double e[21];
-    fk_row(pr, p.body, p.layout, e);
-    TOut* dst = static_cast<TOut*>(p.est) + row * p.W;
-#pragma unroll
-    for (int c = 0; c < 21; ++c)
-        if (c < p.W) dst[c] = (TOut)e[c];
-}
-
-// The same arithmetic with a row's three independent chains side by side (batches from 256 rows on): a workgroup of two waves
-// owns 32 rows.  Wave 0, lane 2 r + s: the 6D -> quaternion chain of row r's lower (s = 0) / upper (s = 1) arm and the rotated
+// A row's three independent chains side by side: a workgroup of two waves owns 32 rows.  Wave 0, lane 2 r + s: the 6D -> quaternion chain of row r's lower (s = 0) / upper (s = 1) arm and the rotated
 // bone vector -- one instruction stream for both, no divergence; wave 1, lane r: the hips chain (atan2, cos, sin) and the rotated
 // shoulder origin, lanes 32 + r the columns that pass through.  The two sums that join the chains (estimate_joints.py:60-62,
-// 84-85) follow a barrier, in the reference's order.  Bit-identical to the one-thread-per-row form, whose per-thread chain of
-// ~1400 f64 instructions was the 7 us of a 1024-row call.
+// 84-85) follow a barrier, in the reference's order.  (One thread per row, the first form, is a chain of ~1400 f64 instructions:
+// 7.1 us for 1024 rows against 2-3 here, 4.2 us for the one row of the latency path -- through an LDS slab -- against ~3.)
 constexpr int FK3_ROWS = 32;
 
 template <typename TIn, typename TOut>
@@ -214,42 +185,6 @@ __global__ __launch_bounds__(128) void ape_fk3_kernel(const FkParams p) {
                 else dst[k] = (TOut)(rot[r][0][k] + lo);                       // qrot(lq, larm_vec) + lo
             }
         }
-    }
-}
-
-// Few rows (the latency path: 1 row per frame): the whole workgroup moves the row(s) through an LDS slab, so the O
-// loads and the W stores of a row are spread over as many threads -- 0.9 us less than one thread doing all of them.
-constexpr int FK_SLAB_BLOCK = 256;
-constexpr int FK_STRIDE = 23;      // >= max(O=20, W=21), odd -> per-thread rows hit distinct LDS banks
-
-template <typename TIn, typename TOut>
-__global__ __launch_bounds__(FK_SLAB_BLOCK) void ape_fk_slab_kernel(const FkParams p) {
-    __shared__ double slab[64 * FK_STRIDE];          // launched for N <= 64 rows only
-    const int tid = threadIdx.x;
-    const size_t row0 = (size_t)blockIdx.x * FK_SLAB_BLOCK;
-    const int rows = (int)min((size_t)FK_SLAB_BLOCK, (size_t)p.N - row0);
-    const TIn* src = static_cast<const TIn*>(p.preds) + row0 * p.O;
-    // coalesced slab load (+ de-normalisation in f64: estimator.py:108-109)
-    for (int idx = tid; idx < rows * p.O; idx += FK_SLAB_BLOCK) {
-        const int rr = idx / p.O, c = idx - rr * p.O;
-        double v = (double)src[idx];
-        if (p.yy_m) v = v * p.yy_s[c] + p.yy_m[c];
-        slab[rr * FK_STRIDE + c] = v;
-    }
-    __syncthreads();
-    if (tid < rows) {
-        double* rowp = slab + tid * FK_STRIDE;     // this thread's row: read in place, then overwritten
-        double e[21];
-        fk_row(rowp, p.body, p.layout, e);
-#pragma unroll
-        for (int c = 0; c < 21; ++c)
-            if (c < p.W) rowp[c] = e[c];
-    }
-    __syncthreads();
-    TOut* dst = static_cast<TOut*>(p.est) + row0 * p.W;
-    for (int idx = tid; idx < rows * p.W; idx += FK_SLAB_BLOCK) {
-        const int rr = idx / p.W, c = idx - rr * p.W;
-        dst[idx] = (TOut)slab[rr * FK_STRIDE + c];
     }
 }
 
@@ -367,100 +302,151 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __shfl(v, 0, 64);
 }
 
+// One workgroup per stream, a wave per chain (as ape_fk3_kernel: one wave computing a whole row is a chain of ~1400 f64
+// instructions): wave 0 the lower arm's 6D -> quaternion chain, its rotated bone and its quaternion mean, wave 1 the upper arm's,
+// wave 2 the hips' and the shoulder origin, wave 3 the copy into the ring, the columns that pass through and -- behind a barrier
+// -- the two sums that join the chains (hand / elbow origins: the 6-float tail of every row).  Sums over rows stay what they
+// were: a lane's rows in order, then the wave shuffle tree.
 template <typename TMsg>
 __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostParams p) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= p.S) return;                                   // whole wave
+    __shared__ double rot[64][3][3];                        // per row of a 64-row chunk: rotated lower-arm bone, upper-arm bone, shoulder origin
+    __shared__ double e0_s[21];                             // row 0 of the stack (the N == 1 message)
+    __shared__ double outq_s[3][4];
+    __shared__ double omean_s[9];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int s = blockIdx.x;
     const int M = p.n_mc, N = p.smooth * M, O = p.O;
     const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+    const bool full = p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS;
     const int nq = hips ? 3 : 2;
     const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
+    const int c_in[3] = {full ? 3 : 0, full ? 12 : 6, full ? 18 : 12};     // first input column of the role's chain
     const double wgt = 1.0 / (double)N;
-    double e0[21];                                          // lane 0: row 0 of the stack (the N == 1 message)
-    double ref[3][4];                                       // row 0's quaternions: the sign reference of the mean
-    double acc[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    double osum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double ref[4] = {0, 0, 0, 0};                           // row 0's quaternion of this role: the sign reference of the mean
+    double acc[4] = {0, 0, 0, 0};
+    double osum[6] = {0, 0, 0, 0, 0, 0};
+    if (threadIdx.x < 21) e0_s[threadIdx.x] = 0.0;
+    if (threadIdx.x < 12) outq_s[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;
+    if (threadIdx.x < 9) omean_s[threadIdx.x] = 0.0;
+    __syncthreads();
     // stacked row i = (prediction j of the last `smooth`, oldest first; Monte-Carlo sample k of it): lanes take
-    // rows lane, lane + 64, ... (trip count uniform over the wave)
+    // rows lane, lane + 64, ... (trip count uniform over the workgroup)
     for (int base = 0; base < N; base += 64) {
         const int i = base + lane;
         const bool act = i < N;
-        double pr[20], e[21];
-#pragma unroll
-        for (int c = 0; c < 21; ++c) e[c] = 0.0;
+        const float* src = nullptr;
+        bool fresh = false;
+        int j = 0, k = 0;
         if (act) {
-            const int j = i / M, k = i - j * M;
+            j = i / M; k = i - j * M;
             // the newest prediction sits in ring slot `pos`, the oldest one slot further
-            const bool fresh = p.cold || j == p.smooth - 1;
+            fresh = p.cold || j == p.smooth - 1;
             const int slot = (p.pos + 1 + j) % p.smooth;
-            const float* src = fresh ? p.y_new + ((size_t)s * M + k) * O
-                                     : p.yring + (((size_t)s * p.smooth + slot) * M + k) * O;
-            float raw[20];
+            src = fresh ? p.y_new + ((size_t)s * M + k) * O : p.yring + (((size_t)s * p.smooth + slot) * M + k) * O;
+        }
+        auto load = [&](int c) -> double {
+            double v = (double)src[c];
+            if (p.yy_m) v = v * p.yy_s[c] + p.yy_m[c];      // estimator.py:108-109
+            return v;
+        };
+        double q[4] = {0, 0, 0, 0};
+        if (role < 2) {
+            if (act) {
+                double s6[6];
 #pragma unroll
-            for (int c = 0; c < 20; ++c) raw[c] = (c < O) ? src[c] : 0.0f;
-            if (fresh) {                                    // keep it for the next frames
-                float* dst = p.yring + (((size_t)s * p.smooth + (p.cold ? j : p.pos)) * M + k) * O;
-#pragma unroll
-                for (int c = 0; c < 20; ++c)
-                    if (c < O) dst[c] = raw[c];
+                for (int c = 0; c < 6; ++c) s6[c] = load(c_in[role] + c);
+                const Quat qq = six_drr_to_quat(s6);
+                const Vec3 bone = role ? Vec3{p.body[3], p.body[4], p.body[5]} : Vec3{p.body[0], p.body[1], p.body[2]};
+                const Vec3 v = qrot(qq, bone);
+                rot[lane][role][0] = v.x; rot[lane][role][1] = v.y; rot[lane][role][2] = v.z;
+                q[0] = qq.w; q[1] = qq.x; q[2] = qq.y; q[3] = qq.z;
             }
-#pragma unroll
-            for (int c = 0; c < 20; ++c) {
-                double v = (double)raw[c];
-                if (p.yy_m && c < O) v = v * p.yy_s[c] + p.yy_m[c];      // estimator.py:108-109
-                pr[c] = v;
+        } else if (role == 2) {
+            if (act) {
+                Vec3 uo{p.body[6], p.body[7], p.body[8]};
+                if (hips) {
+                    const Quat hq = hips_quat(load(c_in[2]), load(c_in[2] + 1));
+                    uo = qrot(hq, uo);
+                    q[0] = hq.w; q[1] = hq.x; q[2] = hq.y; q[3] = hq.z;
+                }
+                rot[lane][2][0] = uo.x; rot[lane][2][1] = uo.y; rot[lane][2][2] = uo.z;
+                if (full) { osum[0] += uo.x; osum[1] += uo.y; osum[2] += uo.z; }
+                if (i == 0 && hips) { e0_s[6] = uo.x; e0_s[7] = uo.y; e0_s[8] = uo.z; }
             }
-            fk_row(pr, p.body, p.layout, e);
+        } else if (act && fresh) {                          // keep the prediction for the next frames
+            float* dst = p.yring + (((size_t)s * p.smooth + (p.cold ? j : p.pos)) * M + k) * O;
+#pragma unroll
+            for (int c = 0; c < 20; ++c)
+                if (c < O) dst[c] = src[c];
+        }
+        if (role < nq) {
+            if (base == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ref[c] = __shfl(q[c], 0, 64);
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e0_s[qc[role] + c] = q[c];
+                }
+            }
+            if (N > 1) {
+                const double d = fma(q[3], ref[3], fma(q[2], ref[2], fma(q[1], ref[1], q[0] * ref[0])));   // the sign rule of ape_msg_kernel
+                const double sg = !act ? 0.0 : ((i > 0 && d < 0.0) ? -wgt : wgt);
+                acc[0] += q[0] * sg; acc[1] += q[1] * sg; acc[2] += q[2] * sg; acc[3] += q[3] * sg;
+            }
+        }
+        __syncthreads();                                    // the chunk's rotated vectors are in LDS
+        if (role == 3 && act) {
+            double e6[6];
+            if (full) {                                     // hand and lower-arm positions are network outputs (estimate_joints.py:20-45)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { e6[c] = load(c); e6[3 + c] = load(9 + c); }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) osum[c] += e6[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    e6[3 + c] = rot[lane][1][c] + rot[lane][2][c];          // qrot(uq, uarm_vec) + uo
+                    e6[c] = rot[lane][0][c] + e6[3 + c];                    // qrot(lq, larm_vec) + lo
+                }
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) e0_s[c] = e6[c];
+            }
             if (p.tail || p.packed) {                       // estimator.py:131-137: est[i, :6] of every row
                 TMsg* t = p.packed ? static_cast<TMsg*>(p.msg) + (size_t)s * (25 + 6 * N) + 25 + (size_t)i * 6
                                    : static_cast<TMsg*>(p.tail) + ((size_t)s * N + i) * 6;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) t[c] = (TMsg)e[c];
+                for (int c = 0; c < 6; ++c) t[c] = (TMsg)e6[c];
             }
         }
-        if (base == 0) {
-#pragma unroll
-            for (int c = 0; c < 21; ++c) e0[c] = e[c];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ref[k][c] = (k < nq) ? __shfl(e[qc[k] + c], 0, 64) : 0.0;
-        }
-        if (N > 1) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (k < nq) {
-                    const double q0 = e[qc[k]], q1 = e[qc[k] + 1], q2 = e[qc[k] + 2], q3 = e[qc[k] + 3];
-                    const double d = fma(q3, ref[k][3], fma(q2, ref[k][2], fma(q1, ref[k][1], q0 * ref[k][0])));   // the sign rule of ape_msg_kernel
-                    const double sg = !act ? 0.0 : ((i > 0 && d < 0.0) ? -wgt : wgt);
-                    acc[k][0] += q0 * sg; acc[k][1] += q1 * sg; acc[k][2] += q2 * sg; acc[k][3] += q3 * sg;
-                }
-            }
-            if (p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) osum[c] += act ? e[c] : 0.0;
-            }
-        }
+        __syncthreads();                                    // ... and read: the next chunk may overwrite them
     }
-    double out_q[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    double orig_mean[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (N > 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < nq) {
-                const double a0 = wave_sum(acc[k][0]), a1 = wave_sum(acc[k][1]), a2 = wave_sum(acc[k][2]), a3 = wave_sum(acc[k][3]);
-                const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
-                out_q[k][0] = a0 / nrm; out_q[k][1] = a1 / nrm; out_q[k][2] = a2 / nrm; out_q[k][3] = a3 / nrm;
+        if (role < nq) {
+            const double a0 = wave_sum(acc[0]), a1 = wave_sum(acc[1]), a2 = wave_sum(acc[2]), a3 = wave_sum(acc[3]);
+            const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+            if (lane == 0) { outq_s[role][0] = a0 / nrm; outq_s[role][1] = a1 / nrm; outq_s[role][2] = a2 / nrm; outq_s[role][3] = a3 / nrm; }
+        }
+        if (full && role >= 2) {                            // compose_msg.py:26-29: plain means of the three origins
+            const int n_o = (role == 2) ? 3 : 6, o0 = (role == 2) ? 6 : 0;
+            for (int c = 0; c < n_o; ++c) {
+                const double m_c = wave_sum(osum[c]) / (double)N;
+                if (lane == 0) omean_s[o0 + c] = m_c;
             }
         }
-        if (p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) orig_mean[c] = wave_sum(osum[c]) / (double)N;
-        }
     }
-    if (lane != 0) return;
-    double m[25];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double out_q[3][4], orig_mean[9], e0[21], m[25];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out_q[k][c] = outq_s[k][c];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) orig_mean[c] = omean_s[c];
+#pragma unroll
+    for (int c = 0; c < 21; ++c) e0[c] = e0_s[c];
     finish_msg(p.layout, N, out_q, orig_mean, e0, p.body, m);
     TMsg* dst = static_cast<TMsg*>(p.msg) + (size_t)s * (p.packed ? 25 + 6 * N : 25);
 #pragma unroll
@@ -469,16 +455,7 @@ __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostPa
 
 template <typename TIn, typename TOut>
 hipError_t launch_fk(const FkParams& p, hipStream_t stream) {
-    if (p.N <= 64) {
-        hipLaunchKernelGGL((ape_fk_slab_kernel<TIn, TOut>), dim3(1), dim3(FK_SLAB_BLOCK), 0, stream, p);
-        return hipGetLastError();
-    }
-    if (p.N >= 256) {
-        hipLaunchKernelGGL((ape_fk3_kernel<TIn, TOut>), dim3((p.N + FK3_ROWS - 1) / FK3_ROWS), dim3(128), 0, stream, p);
-        return hipGetLastError();
-    }
-    const int grid = (p.N + FK_BLOCK - 1) / FK_BLOCK;
-    hipLaunchKernelGGL((ape_fk_kernel<TIn, TOut>), dim3(grid), dim3(FK_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL((ape_fk3_kernel<TIn, TOut>), dim3((p.N + FK3_ROWS - 1) / FK3_ROWS), dim3(128), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -498,7 +475,7 @@ hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream) {
 }
 
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream) {
-    const int grid = (p.S + 3) / 4;
+    const int grid = p.S;                                  // one workgroup (four role waves) per stream
     if (p.msg_dtype == APE_F32) hipLaunchKernelGGL(ape_stream_post_kernel<float>, dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(ape_stream_post_kernel<double>, dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
