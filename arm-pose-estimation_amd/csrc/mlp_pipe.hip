@@ -26,6 +26,16 @@ constexpr int H = 256, KX = 32, TR = 32;            // hidden width, padded inpu
 constexpr int NSLOT = 4;                            // ring slots per pair
 constexpr int HLF = (H / 8) * TR * 8;               // floats of one tile of activations [k-block 32][row 32][8] = 32 KB
 constexpr int SX = KX + 4;
+#ifndef APE_PIPE_KB_LOOK
+#define APE_PIPE_KB_LOOK 28
+#endif
+#ifndef APE_PIPE_KB_FLAG
+#define APE_PIPE_KB_FLAG 8
+#endif
+constexpr int KB_FLAG = APE_PIPE_KB_FLAG;   // k-block of layer 1 at which the flag of the tile in front goes up
+// (swept at 262 144 rows, flag / look: 16 / 12 595 us, 16 / 28 591, 12 / 24 591.5, 8 / 24 589.7, 8 / 28 588.6, 4 / 28 588.6.  The consumer looks for tile i + 1's
+//  flag during its tile i and the producer raises it during its tile i + 2: early flag + late look is the slack the consumer starts with)
+constexpr int KB_LOOK = APE_PIPE_KB_LOOK;   // k-block of layer 2 at which the next tile's flag is looked at and its copy starts
 
 template <bool AG>
 __device__ __forceinline__ void mfma32(f32x16& acc, float w, float a) {
@@ -345,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 // layer 0's result of tile i + 1 into the other h0 buffer (behind the last tile: stale values nobody reads -- a branch in
                 // the stream costs more than the stores)
                 if (kb >= 1 && kb <= 4) put_lds(a0, a1, kb - 1, h0_lds + (unsigned)(((i + 1) & 1) * HLF * 4));
-                if (kb == 16) {
-                    // the flag owed for the tile in front: its ring stores went out 3.5 us ago, the x fetch behind them is as old
+                if (kb == KB_FLAG) {
+                    // the flag owed for the tile in front: its ring stores went out ~3 us ago, the x fetch behind them is as old
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (i > 1 && lane == 0)                  // (tile 0's flag went up right behind its stores, below)
                         __hip_atomic_store(full + ((i - 1) & (NSLOT - 1)) * 4 + wave, (unsigned)((i - 1) / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -499,13 +509,13 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 load_bias(c1, 1);
                 span2<32, true, 256>(c0, c1, inb + (i & 1) * HLF + frag, TR * 8, w2, 0, 128, [&](int kb) {
                     side(kb);
-                    // the next tile's copy into the other buffer (its readers finished before the barrier above) starts a third
-                    // into this layer; the look at its flag is eight k-blocks older
-                    if (kb == 4) next_full = poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
-                    if (kb == 12 && i + 1 < my_tiles) {
+                    // the next tile's copy into the other buffer (its readers finished before the barrier above) starts late
+                    // in this layer (KB_LOOK); the look at its flag is eight k-blocks older
+                    if (kb == KB_LOOK - 8) next_full = poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
+                    if (kb == KB_LOOK && i + 1 < my_tiles) {
                         poll_end(next_full, full + ((i + 1) & (NSLOT - 1)) * 4, (unsigned)((i + 1) / NSLOT + 1));
                         issue_copy(i + 1);
-                    } else if (kb == 12) {
+                    } else if (kb == KB_LOOK) {
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_full) :: "memory");      // (the look nobody needs has landed)
                     }
                 });
