@@ -89,8 +89,8 @@ struct PipeParams {
     float* ring;           // [pair][slot 4][HLF]
     size_t ring_bytes;
     size_t x_bytes;        // bytes of x the batch spans (< 4 GiB: one buffer descriptor)
-    unsigned* ctl;         // [8 class tickets x 16][status][done][pad..][pair][full 4 x 4 | empty 4 x 4]
-    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = segment stamps
+    unsigned* ctl;         // [8 class tickets x 16][status][done][pad..][pair][full 4 x 4 | empty 4 x 4] [pair][2 XCC ids]
+    unsigned diag;         // timing experiments (APE_PIPE_DIAG; results are garbage): 1 = never wait for the peer, 2 = stage A only, 4 = stage B only, 8 = segment stamps, 32 = ring stores write through
 };
 
 __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
@@ -122,6 +122,37 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     const int ticket = __builtin_amdgcn_readfirstlane(ctl_s[1]);
     const int pair = (ticket >> 1) * 8 + cls, role = ticket & 1;
     const int n_pairs = gridDim.x / 2;
+    // do the pair's two workgroups share an XCD (one L2)?  Block-index classes are XCDs where the dispatcher deals workgroups round
+    // robin; verified here, as lstm_cluster32.hip does: each writes its XCC id, the producer reads its consumer's
+    unsigned* const xcc_words = pp.ctl + 256 + (size_t)n_pairs * 32;
+    unsigned my_xcc = 0u;
+    if (tid == 0) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        my_xcc = 0x10u | (my_xcc & 0xFu);
+        __hip_atomic_store(xcc_words + pair * 2 + role, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (the producer reads its consumer's id behind its prologue, when it has long been written: stage A below)
+    auto same_xcd_as_peer = [&]() -> bool {
+        if (tid == 0) {
+            unsigned peer = my_xcc;
+            if (!(pp.diag & 1u)) {
+                unsigned spins = 0;
+                while ((peer = __hip_atomic_load(xcc_words + pair * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                    if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        ctl_s[0] = 1;
+                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            ctl_s[3] = (peer == my_xcc) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool same = ctl_s[3] != 0 && !(pp.diag & 32u);     // (APE_PIPE_DIAG & 32: take the write-through path anyway)
+        if ((pp.diag & 8u) && tid == 0 && pair < 8) pp.ctl[240 + pair * 2 + role] = 0x100u | (same ? 1u : 0u);      // (stamps: the first pairs' verdict)
+        return same;
+    };
     const int n_tiles = (p.N + TR - 1) / TR;
     unsigned* const full = pp.ctl + 256 + pair * 32;            // [slot][producer wave] = tiles of that slot written
     unsigned* const empty = full + 16;                          // [slot][consumer wave] = tiles of that slot copied out
@@ -209,8 +240,13 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             default: APE_LDS_ST(7168); break;
         }
     };
-#define APE_RING_ST(OFF) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #OFF :: "v"(v), "v"(voff), "s"(ring_desc), "s"(base) : "memory")
-    auto ring_st = [&](unsigned voff, f32x4 v, unsigned base, int q) {
+#define APE_RING_ST(OFF)                                                                                                              \
+    do {                                                                                                                              \
+        if (wt) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #OFF " sc1" :: "v"(v), "v"(voff), "s"(ring_desc), "s"(base) : "memory"); \
+        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #OFF :: "v"(v), "v"(voff), "s"(ring_desc), "s"(base) : "memory");          \
+    } while (0)
+    auto ring_st = [&](unsigned voff, f32x4 v, unsigned base, int q, auto wt_tag) {
+        constexpr bool wt = decltype(wt_tag)::value;
         switch (q) {
             case 0: APE_RING_ST(0); break;
             case 1: APE_RING_ST(1024); break;
@@ -223,9 +259,10 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         lds_st(tile_addr + lane_off, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, 4 + q);
     };
     const unsigned lane_off_hi = lane_off + 4096u;
-    auto put_ring = [&](const f32x16& c0, const f32x16& c1, int q, unsigned base) {
-        ring_st(lane_off, f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, base, q);
-        ring_st(lane_off_hi, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, base, q);
+    // (wt_tag: the pair's two workgroups do NOT share an XCD -- the stores then write through to memory, `sc1`, 1 % slower)
+    auto put_ring = [&](const f32x16& c0, const f32x16& c1, int q, unsigned base, auto wt_tag) {
+        ring_st(lane_off, f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, base, q, wt_tag);
+        ring_st(lane_off_hi, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, base, q, wt_tag);
     };
     // timing experiment (APE_PIPE_DIAG & 8): wave 0 of pair 0 sums s_memtime (shader clocks) over the segments of its loop into
     // ctl[160 + 24 role + 2 k] (tests/tools/pipe_stamps.py)
@@ -341,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 if (my_tiles > 3) fetch_x(tile_of(3));
             }
         }
+        const bool same_xcd = same_xcd_as_peer();
         stamp(-1);
         for (int i = 0; i < my_tiles; ++i) {
             const int slot = i & (NSLOT - 1);
@@ -378,19 +416,23 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             asm volatile("" ::: "memory");
             stamp(3);
             const unsigned base = __builtin_amdgcn_readfirstlane(slot_base(slot));
-            if (i + 2 < my_tiles) {
-                // layer 0 of tile i + 2; layer 1's result of tile i goes into the ring beside it
-                layer0(a0, a1, i & 1, [&](int kb) {
-                    if (kb == 0) { put_ring(b0, b1, 0, base); put_ring(b0, b1, 1, base); }
-                    if (kb == 1) { put_ring(b0, b1, 2, base); put_ring(b0, b1, 3, base); }
-                });
-                stamp(4);
-                lrelu32(a0, a1);
-                stamp(5);
-            } else {
+            auto tail = [&](auto wt_tag) {
+                if (i + 2 < my_tiles) {
+                    // layer 0 of tile i + 2; layer 1's result of tile i goes into the ring beside it
+                    layer0(a0, a1, i & 1, [&](int kb) {
+                        if (kb == 0) { put_ring(b0, b1, 0, base, wt_tag); put_ring(b0, b1, 1, base, wt_tag); }
+                        if (kb == 1) { put_ring(b0, b1, 2, base, wt_tag); put_ring(b0, b1, 3, base, wt_tag); }
+                    });
+                    stamp(4);
+                    lrelu32(a0, a1);
+                    stamp(5);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) put_ring(b0, b1, q, base);
-            }
+                    for (int q = 0; q < 4; ++q) put_ring(b0, b1, q, base, wt_tag);
+                }
+            };
+            if (same_xcd) tail(std::false_type{});
+            else tail(std::true_type{});
             if (i == 0 && my_tiles > 1) {                      // the pair's consumer is waiting for its first tile: pay the store latency once
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(full + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -555,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         ctl_s[2] = (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (ctl_s[2] != 0) {
-        for (int i = tid; i < (int)(gridDim.x / 2) * 32; i += 256) __hip_atomic_store(pp.ctl + 256 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)(gridDim.x / 2) * 34; i += 256) __hip_atomic_store(pp.ctl + 256 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -568,7 +610,7 @@ constexpr int PIPE_MAX_O = 16;           // (two rows of y per 32 bytes ... the 
 }  // namespace
 
 size_t ape_mlp_pipe_ring_bytes(int n_cus) { return (size_t)(n_cus / 2) * NSLOT * HLF * sizeof(float); }
-size_t ape_mlp_pipe_ctl_words(int n_cus) { return 256 + (size_t)(n_cus / 2) * 32; }
+size_t ape_mlp_pipe_ctl_words(int n_cus) { return 256 + (size_t)(n_cus / 2) * 34; }     // + 2 XCC ids per pair
 bool ape_mlp_pipe_supported(int Hd, int n_hidden, int KXd, int O) { return Hd == H && n_hidden == 2 && KXd == KX && O <= PIPE_MAX_O; }
 
 hipError_t ape_prepare_mlp_pipe() {

@@ -21,6 +21,9 @@ w = np.frombuffer(buf, dtype=np.uint32).astype(np.uint64)
 tiles = (N + 31) // 32 // 128
 names = {0: ["barrier", "(top of the iteration)", "layer 1 stream (256 MFMAs)", "leaky_relu + slot look + x staging", "layer 0 stream (32 MFMAs)", "leaky_relu"],
          1: ["copy wait + flag + barrier", "y of tile i - 3", "layer 2 stream (256 MFMAs)", "leaky_relu", "output layer stream (32 MFMAs)"]}
+vb = (C.c_uint * 16)()
+assert lib.ape_debug_peek_pipe(m.handle, 240, vb, 16) == 0
+print("pairs 0..7 share an XCD (producer's verdict):", [int(vb[2 * k]) & 1 for k in range(8)])
 for role in (0, 1):
     print(f"stage {'AB'[role]} (pair 0, wave 0; {tiles} tiles):")
     tot = 0
