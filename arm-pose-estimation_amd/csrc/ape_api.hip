@@ -617,10 +617,19 @@ int ape_model_set_body(ape_model_t* m, const double body9[9]) {
     return APE_OK;
 }
 
+// the post-filter ape_infer wants behind the regressor: the latency kernel runs it in its own launch (fk_done = true), every other
+// kernel leaves it to the caller
+struct FkTail {
+    void* est;
+    int est_dtype;
+    bool denormalize;
+    bool done;
+};
+
 // x_ring: time step t of every window lives in slot (t + x_ring) mod T (0 = the linear layout of the public entry)
 static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                              const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream,
-                             int x_ring, const float* h0_dev = nullptr, const float* c0_dev = nullptr) {
+                             int x_ring, const float* h0_dev = nullptr, const float* c0_dev = nullptr, FkTail* fk = nullptr) {
     if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
     if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
@@ -843,6 +852,16 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             c.masks = masks_dev; c.dropout_p = dropout_p; c.seed = seed;
             c.dbg_wg = m->dbg_wg;
             c.xcc_slots = m->xcc_slots;
+            if (small && fk != nullptr) {             // (B <= 4: one launch)
+                c.fk_est = fk->est; c.fk_est_dtype = fk->est_dtype;
+                if (fk->denormalize) {
+                    c.fk_yy_m = m->stats + 2 * m->dims.input_size;
+                    c.fk_yy_s = c.fk_yy_m + m->dims.output_size;
+                }
+                memcpy(c.fk_body, m->body, sizeof(c.fk_body));
+                c.fk_layout = m->dims.target_layout; c.fk_W = layout_est_width(c.fk_layout);
+                fk->done = true;
+            }
             if ((flags & APE_FLAG_DROPOUT_MASKS) && b0 + nb < B && cdrop)
                 return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
@@ -1004,9 +1023,15 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
         }
         y = m->y_ws;
     }
-    if (int rc = ape_lstm_forward(m, x_dev, B, T, flags, nullptr, 0.0f, 0, y, stream)) return rc;
     // de-normalise exactly when the inputs were normalised (estimator.py:103-109: one switch)
-    return ape_fk(m, y, APE_F32, B, (flags & APE_FLAG_NORMALIZE_INPUT) ? 1 : 0, est_dev, est_dtype, stream);
+    const bool denorm = (flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    if (est_dtype != APE_F32 && est_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "fk: unknown dtype selector");
+    if (m->dims.target_layout == APE_LAYOUT_NONE) return fail(APE_ERR_INVALID_ARG, "fk: model has no target layout");
+    if (denorm && !m->has_stats) return fail(APE_ERR_NOT_READY, "fk: denormalize without norm stats");
+    FkTail tail{est_dev, est_dtype, denorm, false};
+    if (int rc = lstm_forward_impl(m, x_dev, B, T, flags, nullptr, 0.0f, 0, y, stream, 0, nullptr, nullptr, &tail)) return rc;
+    if (tail.done) return APE_OK;                          // (the latency kernel finished the rows itself)
+    return ape_fk(m, y, APE_F32, B, denorm ? 1 : 0, est_dev, est_dtype, stream);
 }
 
 

@@ -78,6 +78,13 @@ struct ClusterParams {
     float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
     unsigned* seq;                      // latency kernel: [1] launch number of this model (the upper bits of its granule tags)
+    // latency kernel only: the post-filter in the same launch (ape_infer at B <= 4).  est row b = FK of y row b, de-normalised when
+    // fk_yy_m is set; nullptr: no tail
+    void* fk_est;                       // [B,W] of fk_est_dtype
+    const double* fk_yy_m;
+    const double* fk_yy_s;
+    double fk_body[9];                  // larm_vec, uarm_vec, uarm_orig_rh
+    int fk_layout, fk_W, fk_est_dtype;
     unsigned* xcc_slots;                // APE_XCC_WORDS words, zero between launches.  [0,64): small-batch kernel, (0x10 | XCC id) of
                                         // its members; [64,192): fp16 v2 kernel's 8 class tickets, one per 64-byte line;
                                         // [192, ...): its per-workgroup XCD words

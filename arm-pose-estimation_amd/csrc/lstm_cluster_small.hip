@@ -22,6 +22,7 @@
 #include <type_traits>
 #include "ape_internal.h"
 #include "lstm_latency_common.h"
+#include "fk_device.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -383,6 +384,62 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
         s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x141, 0xF, 0xF, false));
         s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x140, 0xF, 0xF, false));
         if (hw_live && hw_part == 0 && b < p.B) p.y[(size_t)b * O + hw_o] = s_acc + hw_b;
+        // ---- the post-filter of this row in the same launch (ape_infer): de-normalise in f64 (estimator.py:108-109), then the row's
+        //      three chains side by side as fk.hip's ape_fk3_kernel has them -- wave 0, lanes 0 / 1 the lower / upper arm's 6D ->
+        //      quaternion and rotated bone, wave 1 the hips quaternion and shoulder origin, the two joining sums behind a barrier.
+        //      The same arithmetic on the same float32 targets: bit-identical to the two-launch form, one launch gap shorter.
+        if (p.fk_est != nullptr) {                  // (uniform over the launch; `member < MR` is uniform over the workgroup)
+            using namespace ape_fkdev;
+            __shared__ double fk_y[20];
+            __shared__ double fk_rot[3][3];
+            if (hw_live && hw_part == 0) {
+                double v = (double)(s_acc + hw_b);
+                if (p.fk_yy_m) {
+#pragma clang fp contract(off)
+                    v = v * p.fk_yy_s[hw_o] + p.fk_yy_m[hw_o];
+                }
+                fk_y[hw_o] = v;
+            }
+            __syncthreads();
+            const bool hips = p.fk_layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+            const bool full = p.fk_layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS;
+            const int c_l = full ? 3 : 0, c_u = full ? 12 : 6, c_h = full ? 18 : 12;
+            const int e_lq = hips ? 9 : 6, e_uq = hips ? 13 : 10, e_hq = 17;
+            auto put = [&](int c, double v) {
+                if (p.fk_est_dtype == APE_F32) static_cast<float*>(p.fk_est)[(size_t)b * p.fk_W + c] = (float)v;
+                else static_cast<double*>(p.fk_est)[(size_t)b * p.fk_W + c] = v;
+            };
+            const int fw = tid >> 6, fl = tid & 63;
+            if (b < p.B) {
+                if (fw == 0 && fl < 2) {
+                    const Quat q = six_drr_to_quat(fk_y + (fl ? c_u : c_l));
+                    const Vec3 bone = fl ? Vec3{p.fk_body[3], p.fk_body[4], p.fk_body[5]} : Vec3{p.fk_body[0], p.fk_body[1], p.fk_body[2]};
+                    const Vec3 v = qrot(q, bone);
+                    fk_rot[fl][0] = v.x; fk_rot[fl][1] = v.y; fk_rot[fl][2] = v.z;
+                    const int eq = fl ? e_uq : e_lq;
+                    put(eq, q.w); put(eq + 1, q.x); put(eq + 2, q.y); put(eq + 3, q.z);
+                } else if (fw == 1 && fl == 0) {
+                    Vec3 uo{p.fk_body[6], p.fk_body[7], p.fk_body[8]};
+                    if (hips) {
+                        const Quat hq = hips_quat(fk_y[c_h], fk_y[c_h + 1]);
+                        uo = qrot(hq, uo);
+                        put(e_hq, hq.w); put(e_hq + 1, hq.x); put(e_hq + 2, hq.y); put(e_hq + 3, hq.z);
+                        put(6, uo.x); put(7, uo.y); put(8, uo.z);
+                    }
+                    fk_rot[2][0] = uo.x; fk_rot[2][1] = uo.y; fk_rot[2][2] = uo.z;
+                } else if (fw == 2 && fl < 6 && full) {      // hand and lower-arm positions are network outputs (estimate_joints.py:20-45)
+                    put(fl, fk_y[fl < 3 ? fl : 6 + fl]);
+                }
+            }
+            __syncthreads();
+            if (b < p.B && !full && fw == 0 && fl < 6) {
+#pragma clang fp contract(off)
+                const int k = fl % 3;
+                const double lo = fk_rot[1][k] + fk_rot[2][k];                  // qrot(uq, uarm_vec) + uo
+                if (fl >= 3) put(3 + k, lo);
+                else put(k, fk_rot[0][k] + lo);                                 // qrot(lq, larm_vec) + lo
+            }
+        }
     }
     SM_STAMP(6);                                    // 6: head
 #ifdef APE_CLUSTER_STAMPS
