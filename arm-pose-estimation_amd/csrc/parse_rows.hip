@@ -64,7 +64,10 @@ __device__ __forceinline__ int sw_sensor_col(int i) { return i == 0 ? 0 : (i <= 
 // ph gyro, lvel, lacc at 33..41; grav at 43..45
 __device__ __forceinline__ int ph_sensor_col(int i) { return i < 9 ? 33 + i : 34 + i; }
 
-constexpr int PR_BLOCK = 64;
+constexpr int PR_BLOCK = 64;                    // threads per workgroup
+constexpr int PR_ROWS = 16;                     // rows per workgroup: a row is one dependent f64 chain (atan2 -> sin / cos -> quaternion
+                                                // products -> atan2, ~5 us) whatever the block shape, so few rows per block = short copy
+                                                // loops either side of it and more CUs busy (1024 rows: 11.7 -> 7.0 us)
 constexpr int XW = 39;                          // feature row stride in LDS (odd: conflict-free per-thread rows)
 
 // Output row n goes to out[n * out_stride + j * rep_stride + 0..I) for j < rep: rep = 1 and out_stride = I is the
@@ -76,17 +79,17 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
                                                                   int kind, TOut* __restrict__ out, int I,
                                                                   size_t out_stride, int rep, size_t rep_stride,
                                                                   int big_endian) {
-    __shared__ float slab[PR_BLOCK * 57];       // row stride 57: odd -> conflict-free per-thread rows
+    __shared__ float slab[PR_ROWS * 57];        // row stride 57: odd -> conflict-free per-thread rows
     const int tid = threadIdx.x;
-    const size_t r0 = (size_t)blockIdx.x * PR_BLOCK;
-    const int n = (int)min((size_t)PR_BLOCK, (size_t)N - r0);
+    const size_t r0 = (size_t)blockIdx.x * PR_ROWS;
+    const int n = (int)min((size_t)PR_ROWS, (size_t)N - r0);
     for (int idx = tid; idx < n * width; idx += PR_BLOCK) {
         const int rr = idx / width, c = idx - rr * width;
         float v = rows[r0 * width + idx];
         if (big_endian) v = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, v)));
         slab[rr * 57 + c] = v;
     }
-    __shared__ double xout[PR_BLOCK * XW];
+    __shared__ double xout[PR_ROWS * XW];
     __syncthreads();
     if (tid < n) {
     const float* row = slab + tid * 57;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
 
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
                                  size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream) {
-    const int grid = (N + PR_BLOCK - 1) / PR_BLOCK;
+    const int grid = (N + PR_ROWS - 1) / PR_ROWS;
     if (out_dtype == APE_F32)
         hipLaunchKernelGGL(ape_parse_rows_kernel<float>, dim3(grid), dim3(PR_BLOCK), 0, stream, rows, N, width, kind,
                            static_cast<float*>(out), I, out_stride, rep, rep_stride, big_endian);
