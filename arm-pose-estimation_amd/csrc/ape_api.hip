@@ -249,7 +249,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
     memcpy(m->body, def_body, sizeof(def_body));
     const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, I = dims->input_size;
     const int NT = 4 * (H / 64);
-    hipError_t e = hipSuccess;
+    // per-device kernel attributes of the MLP / head-rows kernels (every model kind can reach one of them)
+    hipError_t e = ape_prepare_mlp_tile16(H);
     // every fixed-size device buffer of the model comes out of ONE allocation (planned first, carved after at
     // 256-byte boundaries, zero-filled): one driver call to create, one to free, and the flag / ticket words start
     // at zero without separate memsets
@@ -665,9 +666,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         q.flags = flags; q.dropout_p = dropout_p; q.seed = seed;
         q.neg_slope = 0.01f;                      // torch's leaky_relu default (nn_models.py:347,349)
         // chip-filling eval batches: the weight-stationary two-stage pipeline (mlp_pipe.hip)
-        // (x and y each behind one 32-bit buffer descriptor)
-        const bool one_descriptor = ((size_t)(q.N - 1) * q.row_stride + q.row_offset + q.I) * sizeof(float) < 0xFFFFFFFFull &&
-                                    (size_t)q.N * q.O * sizeof(float) < 0xFFFFFFFFull;
+        // (x and y each behind one 32-bit buffer descriptor whose span stays UNDER 2 GiB: the kernel's out-of-range
+        //  sentinel for padded columns and spare lanes is the offset 0x80000000, which must lie outside num_records)
+        const bool one_descriptor = ((size_t)(q.N - 1) * q.row_stride + q.row_offset + q.I) * sizeof(float) < 0x80000000ull &&
+                                    (size_t)q.N * q.O * sizeof(float) < 0x80000000ull;
         if (m->ffp_ok && m->ffp_on && !drop && q.hidden_out == nullptr && q.mask == nullptr && one_descriptor && q.N >= 64 * m->n_cus) {
             hipError_t e2 = ape_launch_mlp_pipe(q, m->ffp_wa0, m->ffp_wa1, m->ffp_wb2, m->ffp_wbo, m->ffp_ring, m->ffp_ring_bytes, m->ffp_ctl,
                                                m->n_cus, (hipStream_t)stream);

@@ -190,6 +190,7 @@ hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size
                                  size_t rep_stride, hipStream_t stream);
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream);
 hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream, int n_cus = 0);
+hipError_t ape_prepare_mlp_tile16(int H);     // per device: dynamic-LDS limits of the MLP and head-rows kernels (from ape_model_create)
 // two-stage weight-stationary pipeline for chip-filling eval batches of the 2-hidden-layer MLP (mlp_pipe.hip)
 bool ape_mlp_pipe_supported(int H, int n_hidden, int KX, int O);
 size_t ape_mlp_pipe_ring_bytes(int n_cus);

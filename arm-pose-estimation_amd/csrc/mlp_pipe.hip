@@ -624,8 +624,14 @@ hipError_t ape_prepare_mlp_pipe() {
 hipError_t ape_launch_mlp_pipe(const MlpParams& q, const float* wa0, const float* wa1, const float* wb2, const float* wbo, float* ring,
                                size_t ring_bytes, unsigned* ctl, int n_cus, hipStream_t stream) {
     PipeParams pp{};
+#if defined(APE_CLUSTER_STAMPS) || defined(APE_ABLATE)
+    // timing experiments: only the diagnostic libraries (make diag / make ablate) read the switch -- several of its bits make the
+    // kernel skip waits or a whole stage (results are garbage), so the product library has no way to turn them on
     static const unsigned diag = getenv("APE_PIPE_DIAG") ? (unsigned)atoi(getenv("APE_PIPE_DIAG")) : 0u;
     pp.diag = diag;
+#else
+    pp.diag = 0u;
+#endif
     pp.x_bytes = ((size_t)(q.N - 1) * q.row_stride + q.row_offset + q.I) * sizeof(float);
     pp.m = q; pp.wa0 = wa0; pp.wa1 = wa1; pp.wb2 = wb2; pp.wbo = wbo; pp.ring = ring; pp.ring_bytes = ring_bytes; pp.ctl = ctl;
     const int grid = (n_cus / 16) * 16;

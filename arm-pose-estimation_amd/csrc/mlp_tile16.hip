@@ -192,13 +192,7 @@ __global__ __launch_bounds__(256) void ape_head_rows_kernel(const float* __restr
 hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const float* w_out, const float* b_out, float* y,
                                 hipStream_t stream) {
     const size_t smem = ((size_t)HR_ROWS * (H + 4) + (size_t)O * (H + 1)) * sizeof(float);      // <= 64 KB + 33 KB
-    static bool prepared = false;
-    if (!prepared) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_head_rows_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-        if (e != hipSuccess) return e;
-        prepared = true;
-    }
+    // (the dynamic-LDS limit is raised per DEVICE in ape_prepare_mlp_tile16, from ape_model_create)
     hipLaunchKernelGGL(ape_head_rows_kernel, dim3((N + HR_ROWS - 1) / HR_ROWS), dim3(256), smem, stream, hseq, N, H, O, w_out,
                        b_out, y);
     return hipGetLastError();
@@ -206,14 +200,7 @@ hipError_t ape_launch_head_rows(const float* hseq, int N, int H, int O, const fl
 
 template <int H, int NMT>
 static hipError_t launch_mlp(const MlpParams& p, hipStream_t stream) {
-    const size_t smem = smem_of<H, NMT>(p.KX);
-    static bool prepared = false;                   // per instantiation, raised once to the CU's whole LDS
-    if (!prepared && smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_tile16<H, NMT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        prepared = true;
-    }
+    const size_t smem = smem_of<H, NMT>(p.KX);      // (limit raised per device in ape_prepare_mlp_tile16)
     const int rows = APE_TILE_ROWS * NMT;
     hipLaunchKernelGGL((ape_mlp_tile16<H, NMT>), dim3((p.N + rows - 1) / rows), dim3(256), smem, stream, p);
     return hipGetLastError();
@@ -227,4 +214,23 @@ hipError_t ape_launch_mlp_tile16(int H, const MlpParams& p, hipStream_t stream, 
     if (H == 256) return wide ? launch_mlp<256, 2>(p, stream) : launch_mlp<256, 1>(p, stream);
     if (H == 128) return wide ? launch_mlp<128, 2>(p, stream) : launch_mlp<128, 1>(p, stream);
     return hipErrorInvalidValue;
+}
+
+// The dynamic-LDS limit is a per-DEVICE attribute of each kernel instantiation: raised to the CU's whole LDS for the
+// current device, from ape_model_create (after its hipSetDevice) -- never from a process-wide flag in the launch path,
+// which would leave every device but the first at the 64 KB default.
+hipError_t ape_prepare_mlp_tile16(int H) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_head_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    if (e != hipSuccess) return e;
+    if (H == 256) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_tile16<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_tile16<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    } else if (H == 128) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_tile16<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_tile16<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return e;
 }

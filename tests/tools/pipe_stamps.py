@@ -1,8 +1,10 @@
-"""Where a stage of the MLP pipeline kernel spends its time: APE_PIPE_DIAG=8 python tests/tools/pipe_stamps.py [rows]
-(wave 0 of pair 0 sums s_memtime -- shader clocks -- over the segments of its tile loop; the last launch)"""
+"""Where a stage of the MLP pipeline kernel spends its time: python tests/tools/pipe_stamps.py [rows]
+(wave 0 of pair 0 sums s_memtime -- shader clocks -- over the segments of its tile loop; the last launch).
+Runs on the DIAGNOSTIC library (`make -C arm-pose-estimation_amd/csrc diag`): the product library does not read APE_PIPE_DIAG."""
 import ctypes as C, os, sys
 import numpy as np
 os.environ.setdefault("APE_PIPE_DIAG", "8")
+os.environ.setdefault("APE_HIP_LIB", "/root/repo/arm-pose-estimation_amd/lib/diag/libape_hip_diag.so")
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
 import torch
 from wear_mocap_ape_amd import _hip
