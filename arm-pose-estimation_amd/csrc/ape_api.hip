@@ -162,6 +162,7 @@ struct ape_model {
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
     bool f16_v2 = true;             // fp16 precision: batches > 256 rows on the row-set-pipelined kernel (lstm_cluster_f16v2.hip)
     bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
+    bool up32_ok = false;           // ... and on the weight-stationary upper-layer kernel (lstm_upper32.hip: 2 x 256 models)
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
@@ -340,6 +341,9 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         for (int l = 0; l < L && e == hipSuccess; ++l)
             e = plan((void**)&m->wcl[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
         m->hx_bytes = (size_t)max_clusters * L * 2 * GH * 64 * 16 * sizeof(float);
+        // (upper-layer kernel: 32-row clusters x 2 sets x 2 parities x 32 KB)
+        if (ape_upper32_supported(H, L, O) && (size_t)f16v2_capacity(m->n_cus) * 2 * 2 * 32768 > m->hx_bytes)
+            m->hx_bytes = (size_t)f16v2_capacity(m->n_cus) * 2 * 2 * 32768;
         // one flag per (cluster, layer, member, wave) -- or, fp16 v2 kernel, per (32-row cluster, row set, member wave) --
         // + the ticket / departure words
         size_t flag_words = (size_t)max_clusters * L * GH * 4;
@@ -369,6 +373,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
                 e = plan((void**)&m->wcl32[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
             if (e == hipSuccess) e = ape_prepare_lstm_cluster32(H, L, m->KX);
             m->c32_ok = true;
+            if (ape_upper32_supported(H, L, O) && !imupose) {       // shares the layer-1 register image, the exchange buffer and the flags
+                if (e == hipSuccess) e = ape_prepare_lstm_upper32();
+                m->up32_ok = true;
+            }
         }
         if (e != hipSuccess) {
             ape_model_destroy(m);
@@ -898,11 +906,13 @@ int ape_lstm_forward_hs(ape_model_t* m, const float* x_dev, int32_t B, int32_t T
 
 int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "set_kernel: NULL model");
-    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER && choice != APE_KERNEL_CLUSTER_GEN1)
+    if (choice != APE_KERNEL_AUTO && choice != APE_KERNEL_TILE16 && choice != APE_KERNEL_CLUSTER && choice != APE_KERNEL_CLUSTER_GEN1 &&
+        choice != APE_KERNEL_AUTO_GEN1)
         return fail(APE_ERR_INVALID_ARG, "set_kernel: unknown choice %d", choice);
-    m->c32_on = choice != APE_KERNEL_CLUSTER_GEN1;
+    m->c32_on = choice != APE_KERNEL_CLUSTER_GEN1 && choice != APE_KERNEL_AUTO_GEN1;
     m->ffp_on = choice != APE_KERNEL_TILE16;           // (MLP regressor: TILE16 pins the tile kernel)
     if (choice == APE_KERNEL_CLUSTER_GEN1) choice = APE_KERNEL_CLUSTER;
+    if (choice == APE_KERNEL_AUTO_GEN1) choice = APE_KERNEL_AUTO;
     if (choice == APE_KERNEL_CLUSTER && !m->cluster_ok)
         return fail(APE_ERR_UNSUPPORTED, "set_kernel: no cluster kernel for H=%d L=%d on a device with %d CUs (a cluster "
                     "needs %d)", m->dims.hidden_size, m->dims.num_layers, m->n_cus, m->dims.hidden_size / 16);
@@ -1049,6 +1059,12 @@ struct ape_streams {
     float* xring = nullptr;      // [S,n_mc,T,I] feature rows, slot = frame mod T (a stream's n_mc windows are copies)
     float* yring = nullptr;      // [S,smooth,n_mc,O] model outputs, slot = step mod smooth
     float* y_new = nullptr;      // [S,n_mc,O]
+    // shared-layer-0 route on the weight-stationary upper-layer kernel (lstm_upper32.hip): the sample rows go through it in
+    // chunks of `chunk_rows` (a multiple of 32), each expand -> LSTM -> head reduce over the two workspaces below
+    bool up32 = false;
+    int chunk_rows = 0;
+    float* xfrag = nullptr;      // [chunk tiles][T][32 KB] masked layer-0 output in MFMA fragment order
+    float* ypart = nullptr;      // [chunk rows][8][16] head partial sums
     long long frames = 0;        // rows pushed since the last reset
     long long steps = 0;         // predictions made since the last reset
 };
@@ -1112,12 +1128,30 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     ape_model* m = b->model;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
                    dropout_p > 0.0f && n_mc >= 2 && (long long)b->S * n_mc >= 2LL * tile16_wave_rows(m->n_cus);
+    if (b->xfrag) { (void)hipFree(b->xfrag); b->xfrag = nullptr; }
+    if (b->ypart) { (void)hipFree(b->ypart); b->ypart = nullptr; }
+    b->up32 = false;
     if (b->shared_l0) {
         const size_t rows = (size_t)b->S * b->T;
         if (rows > m->hseq_cap) {
             if (m->hseq_ws) { HIP_TRY(hipFree(m->hseq_ws)); m->hseq_ws = nullptr; m->hseq_cap = 0; }
             HIP_TRY(hipMalloc((void**)&m->hseq_ws, rows * m->dims.hidden_size * sizeof(float)));
             m->hseq_cap = rows;
+        }
+        if (m->up32_ok && m->c32_on) {
+            // chunks of equal size whose expanded input (T KiB per sample row) stays under 256 MB -- the size of the Infinity
+            // Cache, and far inside one 32-bit buffer descriptor; whole 1024-row waves of clusters where that costs nothing
+            const long long total = (long long)b->S * n_mc;
+            const long long max_chunk = ((256ll << 20) / ((long long)b->T * 1024)) / 1024 * 1024;
+            if (max_chunk >= 1024) {
+                const long long n_chunks = (total + max_chunk - 1) / max_chunk;
+                long long chunk = ((total + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;
+                if (chunk > total) chunk = (total + 31) / 32 * 32;
+                b->chunk_rows = (int)chunk;
+                HIP_TRY(hipMalloc((void**)&b->xfrag, ape_upper32_xfrag_bytes(b->chunk_rows, b->T)));
+                HIP_TRY(hipMalloc((void**)&b->ypart, ape_upper32_ypart_bytes(b->chunk_rows)));
+                b->up32 = true;
+            }
         }
     }
     return APE_OK;
@@ -1128,6 +1162,8 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->xring) (void)hipFree(b->xring);
     if (b->yring) (void)hipFree(b->yring);
     if (b->y_new) (void)hipFree(b->y_new);
+    if (b->xfrag) (void)hipFree(b->xfrag);
+    if (b->ypart) (void)hipFree(b->ypart);
     delete b;
     return APE_OK;
 }
@@ -1214,6 +1250,27 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 launch failed: %s", hipGetErrorString(e));
         // launch B: the layers above as an LSTM of their own over the S x n_mc sample rows; row r reads stream
         // r / n_mc's sequence under its own Philox mask (the counters of a fused launch over the same rows)
+        if (b->up32) {
+            // weight-stationary form (lstm_upper32.hip): per chunk of sample rows the masked input in fragment order, the
+            // persistent cluster kernel, the head reduce
+            const long long total = (long long)b->S * b->n_mc;
+            for (long long r0 = 0; r0 < total; r0 += b->chunk_rows) {
+                const int rows = (int)((total - r0 < b->chunk_rows) ? total - r0 : b->chunk_rows);
+                ExpandParams xq{};
+                xq.hseq = m->hseq_ws; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
+                xq.layer = 0; xq.dropout_p = b->dropout_p; xq.seed = b->seed + b->mc_calls;
+                UpperParams u{};
+                u.xfrag = b->xfrag; u.xfrag_bytes = ape_upper32_xfrag_bytes(rows, b->T); u.ypart = b->ypart;
+                u.w = m->wcl32[1]; u.bias = m->bias[1]; u.w_out = m->w_out;
+                u.hx = m->hx; u.hx_bytes = m->hx_bytes;
+                u.xflags = m->xflags; u.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u.done = u.status - 3;
+                u.xcc_slots = m->xcc_slots; u.dbg_wg = m->dbg_wg;
+                u.T = b->T; u.O = O; u.n_tiles = (rows + 31) / 32;
+                e = ape_launch_lstm_upper32(u, xq, m->b_out, b->y_new + (size_t)r0 * O, f16v2_capacity(m->n_cus), (hipStream_t)stream);
+                if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
+            }
+            ++b->mc_calls;
+        } else {
         LstmParams q{};
         const int LU = m->dims.num_layers - 1;
         q.x = m->hseq_ws; q.y = b->y_new;
@@ -1225,6 +1282,7 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         e = ape_launch_lstm_tile16(H, LU, q, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
         ++b->mc_calls;
+        }
     } else if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
                                    drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring)) {
         return rc;

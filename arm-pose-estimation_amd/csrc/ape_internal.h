@@ -90,6 +90,38 @@ struct ClusterParams {
                                         // [192, ...): its per-workgroup XCD words
 };
 
+// Kernel arguments of the weight-stationary upper-layer kernel of the Monte-Carlo stream bank (lstm_upper32.hip): one chunk of
+// sample rows, tiles of 32.
+struct UpperParams {
+    const float* xfrag;                 // [n_tiles][T][k-block 32][window 32][8 units] masked input, MFMA fragment order
+    size_t xfrag_bytes;                 // < 4 GiB (one buffer descriptor)
+    float* ypart;                       // [n_tiles * 32][member 8][16] head partial sums
+    const float* w;                     // [member 8][wave 4][64][lane 64][4]: 256 weight registers per lane ([W_ih | W_hh], wcl32 layout)
+    const float* bias;                  // [4H] = b_ih + b_hh
+    const float* w_out;                 // [O,H]
+    float* hx;                          // exchange slices [cluster][set 2][parity 2][member 8][wave 4][window 32][8 units]
+    size_t hx_bytes;
+    unsigned* xflags;                   // [cluster][set 2][32] epoch flags, zero between launches
+    unsigned* done;                     // [1] departure counter
+    unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
+    unsigned* xcc_slots;                // as ClusterParams::xcc_slots (class tickets + per-workgroup XCD words)
+    unsigned long long* dbg_wg;         // diagnostic builds only
+    int T, O, n_tiles;
+    unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
+};
+
+// Kernel arguments of the input builder of that launch (ape_mc_expand_kernel, lstm_upper32.hip).
+struct ExpandParams {
+    const float* hseq;                  // [S,T,H] layer-0 output sequence of every stream (launch A)
+    float* xfrag;                       // as UpperParams::xfrag
+    long long row_base;                 // global index of this chunk's first sample row (a multiple of 32)
+    int rows;                           // sample rows in this chunk
+    int T, n_mc;
+    int layer;                          // model layer whose output hseq is (Philox counter word)
+    float dropout_p;
+    unsigned long long seed;
+};
+
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor
 
 // Kernel arguments of the MLP (DropoutFF) kernel.
@@ -181,6 +213,12 @@ hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int cluste
 bool ape_cluster32_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster32(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);
+bool ape_upper32_supported(int H, int L, int O);
+size_t ape_upper32_xfrag_bytes(int rows, int T);
+size_t ape_upper32_ypart_bytes(int rows);
+hipError_t ape_prepare_lstm_upper32();
+hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
+                                   hipStream_t stream);
 bool ape_cluster_f16v2_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);

@@ -1,0 +1,517 @@
+// Weight-stationary UPPER-layer LSTM kernel for the Monte-Carlo stream bank (the estimators' default mode: n_mc dropout
+// samples per stream and frame, reference estimate/nn_models.py:191-207 + watch_phone_pocket_nn.py:13-19), exact float32.
+//
+// nn.LSTM's dropout sits between the layers (nn_models.py:169-174), so layer 0 is computed once per stream (launch A of
+// ape_streams_step) and the layer above runs over the S x n_mc sample rows as a ONE-layer LSTM whose 256-wide input is that
+// sequence under each sample's own mask.  Until round 3 this launch ran on the batch-tile kernel (weights re-streamed from L2
+// for every 16-row tile: 65 % of the f32 MFMA peak, 94 % of a bank frame).  Here:
+//
+//   * one layer with K = 256 + 256 is exactly the 256 accumulator-file registers per lane of an 8-member cluster of
+//     lstm_cluster32.hip (a member = workgroup = CU owns 32 hidden units, a wave 8 of them x 4 gates = the 32 columns of one
+//     v_mfma_f32_32x32x2_f32 tile; the weights are the A operand and never move after the prologue);
+//   * the kernel is PERSISTENT over row tiles: a cluster owns 32-row tiles c, c + NC, c + 2 NC, ... -- one weight prologue per
+//     launch, not per 1024 rows;
+//   * two tiles are in flight per cluster ("sets" 0 / 1, their steps alternate): while set s computes, the slices set s^1
+//     published at the end of its step travel (store -> acknowledged -> flag -> look -> LDS-DMA gather), and so does s^1's next
+//     input tile -- the exchange of a recurrence step has a whole section (16.4K MFMA cycles) to hide in, and the sets share
+//     nothing (no second dependent round trip, as in lstm_cluster_f16v2.hip);
+//   * the masked input arrives pre-laid in MFMA fragment order [tile][step][k-block 32][window 32][8 units] (written by
+//     ape_mc_expand_kernel below with the Philox counters of the fused kernels, so the samples are bit-for-bit the ones the
+//     batch-tile route draws): 32 LDS-DMA instructions per workgroup and step copy it global -> LDS, no register, no VALU
+//     instruction in the MFMA stream (a wave's own VALU work adds its issue time to a dependent MFMA chain on gfx950,
+//     DESIGN.md 4.10);
+//   * h_{-1} = 0: step 0 of a tile is the input span alone (the batch-tile kernel skips it too);
+//   * the head (Linear(H, O) on the last step) needs no exchange: each wave multiplies its own 8 fresh units by its slice of
+//     W_out with four more MFMAs (the fresh h values ARE the activation fragment), the four waves' partial sums meet in LDS,
+//     and every member writes its 32-unit partial [row][member][16]; ape_head_reduce_kernel adds the eight in a fixed order.
+// Exchange protocol, cluster formation (arrival tickets within the block-index class = XCD, verified at run time), bounded
+// spins, sticky status word and self-cleaning are those of lstm_cluster32.hip.
+#include <type_traits>
+
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float tanh_(float v) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390081777927f * v)) - 1.0f; }
+
+// v_mfma_f32_32x32x2_f32, weight operand (A) in the accumulator file (AG) or in an architectural VGPR; the accumulators are read
+// only behind mfma_drain() (hipcc does not model an asm MFMA's result hazard)
+template <bool AG>
+__device__ __forceinline__ void mfma32(f32x16& acc, float w, float a) {
+    if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_drain(f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc)); }
+
+// NB k-blocks of 8: acc += W (registers w[w0 ...]) x activations (LDS, one ds_read_b128 per block, `stride` floats between
+// blocks), fragments fetched two blocks ahead; `mid(kb)` runs after the MFMAs of block kb (a constant after unrolling)
+template <int NB, int NW, typename Mid>
+__device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+    f32x4 a1 = (NB > 1) ? *reinterpret_cast<const f32x4*>(src + stride) : a0;
+    f32x4 a2 = a1;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        if (kb + 2 < NB) a2 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma32<true>(acc, w[w0 + 4 * kb + j], a0[j]);
+        mid(kb);
+        a0 = a1;
+        a1 = a2;
+    }
+}
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
+// the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+constexpr int UH = 256;                  // hidden units = input width of the layer
+constexpr int GH = 8;                    // members per cluster
+constexpr int MR = 32;                   // windows (sample rows) per tile
+constexpr int BH = UH / 8;               // k-blocks of 8 per span
+constexpr int NW = 4 * 2 * BH;           // weight registers per lane: [W_ih | W_hh], all in the accumulator file
+constexpr int NFL = 4 * GH;              // flags per (cluster, set): one per member wave
+constexpr int HL = GH * 4 * MR * 8;      // floats of one slice set / one input tile-step [k-block 32][window 32][8] = 32 KB
+constexpr int NDMA = 8;                  // LDS-DMA instructions per wave and 32 KB copy
+constexpr int PO = 16;                   // width of a head partial row (O <= 16)
+constexpr unsigned SET_BYTES = HL * sizeof(float);
+
+__global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5;     // window of the tile, half (units 4 hh .. 4 hh + 3 of the wave's 8)
+    const int T = p.T, O = p.O;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xb = smem;                            // [set 2][HL]  masked input of the set's current step, fragment order
+    float* hb = xb + 2 * HL;                     // [set 2][HL]  h_{t-1} of the set's tile, all members' slices
+    f32x4* bias_s = reinterpret_cast<f32x4*>(hb + 2 * HL);        // [wave 4][gate 4][hh 2]: accumulator start values (b_ih + b_hh)
+    f32x4* wo_s = bias_s + 4 * 4 * 2;                             // [wave 4][lane 64]: W_out as the head MFMAs' A fragment
+    float* hp = reinterpret_cast<float*>(wo_s + 4 * 64);          // [wave 4][PO][MR]: head partial sums of the four waves
+    int* ctl = reinterpret_cast<int*>(hp + 4 * PO * MR);          // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+
+    // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words]
+    unsigned* const class_ticket = p.xcc_slots + 64;
+    unsigned* const xcc_words = p.xcc_slots + 64 + 8 * 16;
+    const int cls = blockIdx.x & 7;
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
+    if (tid == 0) {
+        ctl[0] = 0;
+        ctl[1] = -1;
+        if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned tk = __hip_atomic_fetch_add(class_ticket + cls * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < gridDim.x / 8) ctl[1] = (int)tk;
+            else __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (ctl[1] < 0) return;
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
+    const int cluster = (ticket / GH) * 8 + cls, member = ticket % GH;
+    const int NC = (int)gridDim.x / GH;          // clusters of this launch
+    if (tid == 0)
+        __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- weights: 256 registers per lane in the accumulator file, for the whole launch.  Host layout (ape_api.hip, wcl32):
+    //      [member][wave][register / 4][lane][4]; register 4 kb + j of lane (column m = lane & 31 = gate * 8 + unit, half hh)
+    //      = [W_ih | W_hh][gate * H + member * 32 + wave * 8 + unit][8 kb + 4 hh + j]
+    float w[NW];
+    {
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.w) + ((size_t)(member * 4 + wave) * (NW / 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NW / 4; ++i) {
+            const f32x4 v = s1[i * 64];
+            w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3];
+        }
+    }
+    // accumulator start values: registers 4 gate + j <-> unit member*32 + wave*8 + 4 hh + j (the same for every window)
+    if (tid < 4 * 4 * 2) {
+        const int wv = tid >> 3, gate = (tid >> 1) & 3, h2 = tid & 1;
+        f32x4 bv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = p.bias[gate * UH + member * 32 + wv * 8 + 4 * h2 + j];
+        bias_s[tid] = bv;
+    }
+    // head: A fragment of the wave's four MFMAs -- column m = lane & 31 is target o = m (zero for m >= O), k = 4 hh + j is the
+    // wave's unit 4 hh + j
+    {
+        f32x4 wv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (n < O) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = p.w_out[(size_t)n * UH + member * 32 + wave * 8 + 4 * hh + j];
+        }
+        wo_s[wave * 64 + lane] = wv;
+    }
+
+    // exchange buffer and input: descriptors as scalar tuples for the DMA asm, and one for the compiler's publish store
+    const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    u32x4 hx_desc;
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[3] = 0x00020000u;
+    const unsigned long long xf_addr = reinterpret_cast<unsigned long long>(p.xfrag);
+    u32x4 xf_desc;
+    xf_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)xf_addr);
+    xf_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xf_addr >> 32) & 0xFFFFu);
+    xf_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.xfrag_bytes);
+    xf_desc[3] = 0x00020000u;
+    unsigned* const flags_of = p.xflags + (size_t)cluster * 2 * NFL;         // [set][member*4 + wave] epoch = slices published
+    auto hx_base = [&](int s, int par) -> unsigned { return (unsigned)((((size_t)cluster * 2 + s) * 2 + par) * SET_BYTES); };
+    const unsigned xb_lds = (unsigned)reinterpret_cast<unsigned long long>(xb);       // LDS byte addresses
+    const unsigned hb_lds = (unsigned)reinterpret_cast<unsigned long long>(hb);
+
+    // ---- do all members of this cluster really share an XCD? ------------------------------------------------------
+    if (wave == 0) {
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(xcc_words + cluster * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
+    __syncthreads();
+    if (ctl[0] != 0) return;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
+
+    // every wave polls for itself: have all member waves published epoch `want` of set s?
+    auto wait_flags = [&](int s, unsigned want) {
+        unsigned spins = 0;
+        while (true) {
+            unsigned v = want;
+            if (lane < NFL) v = __hip_atomic_load(flags_of + s * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v >= want))) return;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    // a 32 KB copy global -> LDS: wave w moves KiB w, w + 4, ... (8 of them); piece k on its own so that a copy can be spread
+    // over the k-blocks of a span
+    const unsigned dma_voff = (unsigned)(lane * 16);
+    auto issue_h_piece = [&](int s, unsigned epoch, int k) {      // the slices published as epoch `epoch` (>= 1) of set s -> hb[s]
+        const unsigned src = hx_base(s, (int)((epoch - 1u) & 1u)) + (unsigned)(wave * 1024 + k * 4096);
+        dma_1k(hb_lds + (unsigned)s * SET_BYTES + (unsigned)(wave * 1024 + k * 4096), dma_voff, hx_desc, src);
+    };
+    auto issue_x_piece = [&](int s, int tile, int t, int k) {     // input of (tile, step t) -> xb[s]
+        const unsigned src = (unsigned)(((size_t)tile * T + t) * SET_BYTES) + (unsigned)(wave * 1024 + k * 4096);
+        dma_1k(xb_lds + (unsigned)s * SET_BYTES + (unsigned)(wave * 1024 + k * 4096), dma_voff, xf_desc, src);
+    };
+    // the flag a wave owes for the slice it stored last: raised once that store has drained
+    int pend_idx = -1;
+    unsigned pend_epoch = 0u;
+    auto raise_pending = [&]() {              // caller has waited vmcnt(0)
+        if (pend_idx < 0) return;
+        if (lane == 0) __hip_atomic_store(flags_of + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_idx = -1;
+    };
+    // workgroup barrier that waits for this wave's LDS traffic only (not for the publish store or a DMA in flight)
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- per-set state (uniform over the workgroup AND over the cluster: every member walks the same tiles) ------------------
+    float cst[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cst[s][j] = 0.0f;
+    int tile_of[2], step_of[2];              // the set's current tile (-1: none left) and step
+    unsigned pub[2] = {0u, 0u};              // slices the set has published so far = epoch of its newest ones
+    bool prex[2] = {false, false};           // the set's input tile / gathered slices for its NEXT section are on their way
+    bool preh[2] = {false, false};           //   (issued by the other set's section)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int tl = cluster + s * NC;
+        tile_of[s] = tl < p.n_tiles ? tl : -1;
+        step_of[s] = 0;
+    }
+    const int frag = n * 8 + hh * 4;                              // this lane's 16 bytes inside a [window][8 units] block
+    const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long dg_block = 0, dg_sections = 0;             // diagnostic counters (cluster 0, member 0)
+#endif
+
+    // One section = one step of one set: S0 the set's operands are in LDS (prefetched by the other set's section, or fetched
+    // here in the blocking form: pipeline fill, a late peer, the other set idle), barrier, input span (+ recurrent span for
+    // t >= 1) with the OTHER set's traffic hung into the MFMA stream, gates, publish (or, last step, the head).
+    // Vector-memory queue of a wave in a steady-state section, in issue order:
+    //   [publish store of the section in front]  x DMA for the other set (8)  flag look (1 load)  h DMA for the other set (8)
+    //   [head partial store, last step only]  publish store (1; a store to nowhere on a last step)
+    // so at the top of a section everything but the youngest entry is waited for (`vmcnt(1)`), and a few k-blocks in the
+    // store itself has drained and its flag goes up.
+    auto section = [&](auto set_tag, auto first_tag) -> bool {
+        constexpr int s = decltype(set_tag)::value, o = s ^ 1;
+        constexpr bool first = decltype(first_tag)::value;          // step 0 of a tile: no recurrent span (h_{-1} = 0)
+        const int t = step_of[s], tile = tile_of[s];
+        const bool last = t == T - 1;
+#ifdef APE_CLUSTER_STAMPS
+        dg_sections += 1;
+#endif
+        // ---- S0 ------------------------------------------------------------------------------------------------------------------
+        if (prex[s] && (first || preh[s])) {
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // the prefetched copies; only the publish store is younger
+        } else {
+#ifdef APE_CLUSTER_STAMPS
+            dg_block += 1;
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            raise_pending();
+            if (!prex[s]) {
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) issue_x_piece(s, tile, t, k);
+            }
+            if (!first) {
+                wait_flags(s, pub[s]);
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) issue_h_piece(s, pub[s], k);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        prex[s] = false;
+        preh[s] = false;
+        bar();
+        const int abort_word = ctl[0];
+        // the other set's next section: (tile_of[o], step_of[o]); it needs its input tile, and from step 1 on the slices it
+        // published last (epoch pub[o])
+        const bool o_act = tile_of[o] >= 0;
+        const bool o_h = o_act && step_of[o] >= 1;
+        unsigned peek = pub[o];
+        bool go = false;
+        // hooks in the MFMA stream (k-block q of the section, a constant after unrolling):
+        //   QF        the flag owed for the publish store of the section in front (drained by now)
+        //   QX .. +7  one piece of the other set's input tile per block
+        //   QP        look at the other set's flags (one load per lane)       QJ  judge
+        //   QJ .. +7  one piece of the other set's gather per block
+        constexpr int QF = 3, QX = 4;
+        constexpr int QP = first ? 16 : 28, QJ = first ? 20 : 32;
+        auto mid = [&](int q) {
+            if (q == QF) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_pending();
+            }
+            if (q >= QX && q < QX + NDMA && o_act) issue_x_piece(o, tile_of[o], step_of[o], q - QX);
+            if (q == QP && o_h && lane < NFL)
+                peek = __hip_atomic_load(flags_of + o * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == QJ) go = o_h && __all((int)(peek >= pub[o])) != 0;
+            if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, pub[o], q - QJ);
+        };
+        // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs ---------------------------------------------------------
+        f32x16 acc;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const f32x4 bv = bias_s[(wave * 4 + gate) * 2 + hh];
+            acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
+        }
+        span32<BH, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
+        if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * BH, [&](int q) { mid(BH + q); });
+        mfma_drain(acc);
+        // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
+        float hnew[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float iv = sigm(acc[j]), fv = sigm(acc[4 + j]), gv = tanh_(acc[8 + j]), ov = sigm(acc[12 + j]);
+            const float c = first ? iv * gv : fv * cst[s][j] + iv * gv;
+            cst[s][j] = c;
+            hnew[j] = ov * tanh_(c);
+        }
+        if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
+        prex[o] = o_act;
+        preh[o] = go;
+        if (last) {
+            // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h values are the activation fragment ----
+            f32x16 ya;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ya[i] = 0.0f;
+            const f32x4 wv = wo_s[wave * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mfma32<false>(ya, wv[j], hnew[j]);
+            mfma_drain(ya);
+            // register 4 g + j of lane (n, hh) = target 8 g + 4 hh + j of window n; O <= 16: g = 0, 1
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hp[(wave * PO + 8 * g + 4 * hh + j) * MR + n] = ya[4 * g + j];
+            bar();
+            if (tid < 128) {
+                const int rn = tid >> 2, oq = tid & 3;
+                f32x4 sum;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = (4 * oq + i) * MR + rn;
+                    sum[i] = ((hp[idx] + hp[PO * MR + idx]) + hp[2 * PO * MR + idx]) + hp[3 * PO * MR + idx];
+                }
+                *reinterpret_cast<f32x4*>(p.ypart + (((size_t)tile * MR + rn) * GH + member) * PO + 4 * oq) = sum;
+            }
+        }
+        // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout; exactly ONE store
+        //      instruction per wave and section ends it (the counted wait at the top of the next section relies on that) --------
+        {
+            const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
+                              __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
+            const unsigned off = last ? 0x80000000u : hx_base(s, (int)(pub[s] & 1u)) + pub_off;
+            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            if (!last) {
+                pub[s] += 1u;
+                pend_idx = s * NFL + member * 4 + wave;
+                pend_epoch = pub[s];
+            }
+        }
+        // ---- next step / next tile of this set -------------------------------------------------------------------------------------
+        if (last) {
+            const int nt = tile + 2 * NC;
+            tile_of[s] = nt < p.n_tiles ? nt : -1;
+            step_of[s] = 0;
+        } else {
+            step_of[s] = t + 1;
+        }
+        return true;
+    };
+
+    bool ok = true;
+#pragma unroll 1
+    while (ok && (tile_of[0] >= 0 || tile_of[1] >= 0)) {
+        if (tile_of[0] >= 0)
+            ok = step_of[0] == 0 ? section(std::integral_constant<int, 0>{}, std::true_type{})
+                                 : section(std::integral_constant<int, 0>{}, std::false_type{});
+        if (ok && tile_of[1] >= 0)
+            ok = step_of[1] == 0 ? section(std::integral_constant<int, 1>{}, std::true_type{})
+                                 : section(std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    if (!ok) return;
+    // (a flag still owed here is awaited by nobody -- the section behind a publish always raises it, and a set's last section
+    //  publishes nothing -- so it is dropped: no flag store may be in flight when the last workgroup out zeroes the words)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) { p.dbg_wg[16] = dg_block; p.dbg_wg[17] = dg_sections; }
+#endif
+    // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        const int n_flags = NC * 2 * NFL;
+        for (int i = tid; i < n_flags; i += 256) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+constexpr size_t smem_upper() {
+    return (size_t)4 * HL * sizeof(float) + (size_t)(4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + 16;
+}
+
+// ---- the masked input of launch B, in the fragment order the kernel above copies ------------------------------------------------
+// Sample row r (row_base + its index in this chunk) is sample r % n_mc of stream r / n_mc; its input at step t is that stream's
+// layer-0 output h0[stream][t][unit] under the inter-layer dropout mask (nn.LSTM dropout, nn_models.py:169-174), drawn with the
+// counters every fused kernel uses for its layer 0 (rows r & ~3, step, unit, layer; value index r & 3 -- lstm_tile16.hip), so
+// the samples are the ones the batch-tile route draws.  One workgroup per (tile, step): thread = unit, one Philox call per four
+// rows; the 32 KB go through LDS so that they leave as whole 1-KiB k-blocks [k-block][window 32][8 units].
+constexpr int XS = 8 * MR + 8;           // LDS stride of a k-block (floats): the 8 k-blocks a wave writes side by side hit 8 bank groups
+
+__global__ __launch_bounds__(256) void ape_mc_expand_kernel(const ExpandParams q) {
+    __shared__ __attribute__((aligned(16))) float sl[BH * XS];
+    const int unit = threadIdx.x;
+    const int tile = blockIdx.x / q.T, t = blockIdx.x - tile * q.T;
+    const long long row0 = (long long)tile * MR;                 // first row of the tile, chunk-local
+    const float keep = 1.0f / (1.0f - q.dropout_p);
+    const bool drop = q.dropout_p > 0.0f;
+#pragma unroll
+    for (int g = 0; g < MR / 4; ++g) {
+        const long long r4 = q.row_base + row0 + 4 * g;           // global index of the row quad (a multiple of 4)
+        uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (drop) philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)q.layer, (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rnd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long r = r4 + i;
+            float v = 0.0f;
+            if (row0 + 4 * g + i < q.rows) {
+                v = q.hseq[((size_t)(r / q.n_mc) * q.T + t) * UH + unit];
+                if (drop) {
+                    const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                    v = (uf >= q.dropout_p) ? v * keep : 0.0f;
+                }
+            }
+            sl[(unit >> 3) * XS + (4 * g + i) * 8 + (unit & 7)] = v;
+        }
+    }
+    __syncthreads();
+    f32x4* dst = reinterpret_cast<f32x4*>(q.xfrag + ((size_t)tile * q.T + t) * HL);
+#pragma unroll
+    for (int e = 0; e < HL / 4 / 256; ++e) {
+        const int idx = threadIdx.x + 256 * e;                    // float4 index: k-block idx / 64, inside it idx % 64
+        dst[idx] = *reinterpret_cast<const f32x4*>(sl + (idx >> 6) * XS + (idx & 63) * 4);
+    }
+}
+
+// y[r][o] = b_out[o] + the eight members' partial sums, member 0 first (a fixed order: run-to-run identical bits)
+__global__ __launch_bounds__(256) void ape_head_reduce_kernel(const float* __restrict__ ypart, const float* __restrict__ b_out,
+                                                              float* __restrict__ y, int rows, int O) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * PO) return;
+    const int r = idx / PO, o = idx - r * PO;
+    if (o >= O) return;
+    const float* src = ypart + (size_t)r * GH * PO + o;
+    float s = src[0];
+#pragma unroll
+    for (int m = 1; m < GH; ++m) s += src[m * PO];
+    y[(size_t)r * O + o] = s + b_out[o];
+}
+
+}  // namespace
+
+bool ape_upper32_supported(int H, int L, int O) { return H == UH && L == 2 && O <= PO; }
+size_t ape_upper32_xfrag_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * SET_BYTES; }
+size_t ape_upper32_ypart_bytes(int rows) { return (size_t)((rows + MR - 1) / MR) * MR * GH * PO * sizeof(float); }
+
+hipError_t ape_prepare_lstm_upper32() {
+    static_assert(smem_upper() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+}
+
+// one chunk of sample rows: expand -> upper layer -> head reduce, all on `stream`.  `max_clusters` = 32-row clusters the device
+// holds at once (a multiple of 8: whole block-index classes); the grid is the smaller of that and the tiles, rounded up to 8.
+hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
+                                   hipStream_t stream) {
+    if (p.n_tiles < 1 || max_clusters < 8 || p.O > PO) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ape_mc_expand_kernel, dim3(p.n_tiles * p.T), dim3(256), 0, stream, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int clusters = (p.n_tiles + 7) / 8 * 8;
+    if (clusters > max_clusters) clusters = max_clusters;
+    hipLaunchKernelGGL(ape_lstm_upper32, dim3(clusters * GH), dim3(256), smem_upper(), stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ape_head_reduce_kernel, dim3((q.rows * PO + 255) / 256), dim3(256), 0, stream, p.ypart, b_out, y, q.rows, p.O);
+    return hipGetLastError();
+}

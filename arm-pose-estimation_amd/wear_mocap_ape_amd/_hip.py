@@ -24,7 +24,7 @@ FLAG_DROPOUT_MASKS = 0x4
 FLAG_DROPOUT_PHILOX = 0x8
 FLAG_PACKED_MSG = 0x20
 FLAG_BROADCAST_X = 0x10
-KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER, KERNEL_CLUSTER_GEN1 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER, KERNEL_CLUSTER_GEN1, KERNEL_AUTO_GEN1 = 0, 1, 2, 3, 4
 PRECISION_F32, PRECISION_F16, PRECISION_F16_GEN1 = 0, 1, 2
 MODEL_LSTM, MODEL_FF, MODEL_IMUPOSE = 0, 1, 2
 PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3

@@ -271,10 +271,10 @@ class DropoutLSTM:
         return self.forward(x, hs, last_step_only=last_step_only, rows=n_samples)
 
     def set_kernel(self, choice: str = "auto"):
-        """'auto' | 'tile16' | 'cluster' | 'cluster_gen1' (cluster kernels of the first generation only): which LSTM
-        kernel ``forward`` launches (A/B runs, tests)"""
+        """'auto' | 'tile16' | 'cluster' | 'cluster_gen1' (cluster kernels of the first generation only) | 'auto_gen1'
+        (auto's dispatch without the second-generation kernels): which LSTM kernel ``forward`` launches (A/B runs, tests)"""
         code = {"auto": _hip.KERNEL_AUTO, "tile16": _hip.KERNEL_TILE16, "cluster": _hip.KERNEL_CLUSTER,
-                "cluster_gen1": _hip.KERNEL_CLUSTER_GEN1}[choice]
+                "cluster_gen1": _hip.KERNEL_CLUSTER_GEN1, "auto_gen1": _hip.KERNEL_AUTO_GEN1}[choice]
         _hip.check(_hip.lib().ape_model_set_kernel(self._handle, code), "ape_model_set_kernel")
         return self
 

@@ -84,7 +84,9 @@ enum { APE_F32 = 0, APE_F64 = 1 };   /* element type selector for preds / est bu
 /* LSTM kernel selection (ape_model_set_kernel).  AUTO = the weight-stationary cluster kernel where it is
  * built (H=256/L=2/I<=32 and H=128/L=3/32<I<=64; dropout up to 32 windows per cluster), else the batch-tile kernel. */
 enum { APE_KERNEL_AUTO = 0, APE_KERNEL_TILE16 = 1, APE_KERNEL_CLUSTER = 2,
-       APE_KERNEL_CLUSTER_GEN1 = 3 /* the cluster kernels, first generation only: A/B runs against lstm_cluster32.hip */ };
+       APE_KERNEL_CLUSTER_GEN1 = 3 /* the cluster kernels, first generation only: A/B runs against lstm_cluster32.hip */,
+       APE_KERNEL_AUTO_GEN1 = 4    /* AUTO's dispatch without the second-generation kernels (lstm_cluster32.hip, and
+                                      lstm_upper32.hip in a Monte-Carlo stream bank): A/B runs, tests */ };
 
 /* Storage precision of W, x and h inside the LSTM (ape_model_set_precision).  F32 (default): exact float32
  * MFMA.  F16: binary16 weights / inputs / hidden state with float32 accumulate, cell state and head
