@@ -1266,6 +1266,10 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
                 u.xflags = m->xflags; u.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u.done = u.status - 3;
                 u.xcc_slots = m->xcc_slots; u.dbg_wg = m->dbg_wg;
                 u.T = b->T; u.O = O; u.n_tiles = (rows + 31) / 32;
+#ifdef APE_ABLATE
+                // timing experiments of the ablation library only (tests/tools/ablate_upper32.py; results are garbage)
+                if (const char* ab = getenv("APE_UP32_ABLATE")) u.flags = (unsigned)strtoul(ab, nullptr, 0);
+#endif
                 e = ape_launch_lstm_upper32(u, xq, m->b_out, b->y_new + (size_t)r0 * O, f16v2_capacity(m->n_cus), (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
             }

@@ -82,6 +82,17 @@ __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 r
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// A flag look that does NOT stall the MFMA stream: hipcc hoists the comparison of a compiler-visible load up to the load and puts
+// `s_waitcnt vmcnt(0)` right behind it -- an L2 round trip exposed in every section (found in round 3 in the disassembly of this
+// kernel as round 2 shipped it).  The load is issued by inline asm (all 64 lanes, no exec juggling, no merge of its result
+// with another value), its value is first touched by peek_wait() four k-blocks later.
+__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
 template <int H, int L, int KX>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams p) {
     constexpr int UPW = 8;                  // hidden units per wave (x 4 gates = the 32 columns of its tile)
@@ -357,9 +368,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
                 if (ST || ph + 2 < T) fetch_x(ph + 2);
                 staged = true;
             }
-            if (q == QP && pre && lane < NFL)
-                peek = __hip_atomic_load(flags_of + ln * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q == QJ) go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
+            if (q == QP) peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));     // (always: no branch around it)
+            if (q == QJ) {
+                peek_wait(peek);
+                go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
+            }
             if (q >= QJ && q < QJ + NDMA && go) issue_piece(ln, tn - 1, q - QJ);
         };
         float hnew[4] = {0.0f, 0.0f, 0.0f, 0.0f};

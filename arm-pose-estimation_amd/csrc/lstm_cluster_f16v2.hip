@@ -100,6 +100,13 @@ __device__ __forceinline__ void span(f32x4 (&acc)[NTW], const f32x4 (&a)[NQ], co
 #define V2_STAMP(k) do {} while (0)
 #endif
 
+__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
 template <int H, int L, int KX>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterParams p) {
     constexpr int UPW = 8;                  // hidden units per wave
@@ -383,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         const int sn = s ^ 1, phn = ph + s;
         const unsigned want = (unsigned)phn;
         unsigned peek = want;
+        bool peeked = false;
 
         // ---- every active layer of this set, back to back (layer l works on step t = ph - l) -----------------------------
 #pragma unroll
@@ -412,9 +420,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
                     stage_x(xr, s, ph + 1);
                     if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
                 }
-            } else if ((ST || want > 0u) && lane < NFL && !d_noex) {
-                // [B0] look at the flags the next section needs; the load flies under the gate math below
-                peek = __hip_atomic_load(flags_of + sn * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // [B0] look at the flags the next section needs; the load flies under the gate math below.  Issued by inline asm and
+                // first touched at [B]: hipcc hoists the comparison of a compiler-visible load up to the load and waits `vmcnt(0)`
+                // right behind it -- the L2 round trip it was meant to hide (round 3, found in the disassembly).  All 64 lanes,
+                // unconditionally: no exec juggling, no merge of its result with another value.
+                peek = peek_issue(flags_of + sn * NFL + (lane & (NFL - 1)));
+                peeked = true;
             }
             V2_STAMP(2);
             // gates + cell update, lane-local: registers 0..3 = i,f,g,o of (unit tt*4 + g, batch row r)
@@ -438,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         }
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         // [B] every peer wave has published what the next section needs: its whole gather goes into flight now
+        if (peeked) peek_wait(peek);
         if ((ST || want > 0u) && !d_noex && __all((int)(peek >= want))) {
             issue_gather(sn, (phn - 1) & 1);
             prefetched = true;

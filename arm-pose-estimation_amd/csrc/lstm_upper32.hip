@@ -67,6 +67,16 @@ __device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ sr
     }
 }
 
+// A flag look that does NOT stall the MFMA stream: hipcc hoists the comparison of a compiler-visible load up to the load and puts
+// `s_waitcnt vmcnt(0)` right behind it (an L2 round trip exposed in every section: found in the disassembly of round 2's kernels).
+// The load is issued by inline asm (all 64 lanes, no exec juggling), its value is first touched by peek_wait() some k-blocks later.
+__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
 // the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
@@ -91,6 +101,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hh = lane >> 5;     // window of the tile, half (units 4 hh .. 4 hh + 3 of the wave's 8)
     const int T = p.T, O = p.O;
+    // timing-only switches of the ablation library (make ablate; results are garbage): what does each part of a section cost?
+#ifdef APE_ABLATE
+    const unsigned ab = p.flags;
+#else
+    constexpr unsigned ab = 0u;
+#endif
+    const bool ab_noex = (ab & APE_DIAG_NO_EXCHANGE) != 0, ab_noact = (ab & APE_DIAG_NO_ACT) != 0, ab_nox = (ab & APE_DIAG_NO_XSTAGE) != 0,
+               ab_nomfma = (ab & APE_DIAG_NO_MFMA) != 0, ab_nobar = (ab & APE_DIAG_SMALL_UW4) != 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xb = smem;                            // [set 2][HL]  masked input of the set's current step, fragment order
@@ -255,7 +273,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     const int frag = n * 8 + hh * 4;                              // this lane's 16 bytes inside a [window][8 units] block
     const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
 #ifdef APE_CLUSTER_STAMPS
-    unsigned long long dg_block = 0, dg_sections = 0;             // diagnostic counters (cluster 0, member 0)
+    // diagnostic counters and shader-clock sums (cluster 0, member 0, wave 0): sections, blocking tops by cause, cycles in the
+    // top of a section (wait + barrier), its MFMA chain, its gates + publish (+ head)
+    unsigned long long dg_block_x = 0, dg_block_h = 0, dg_sections = 0, dg_top = 0, dg_chain = 0, dg_tail = 0, dg_t0 = 0;
+#define UP_STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - dg_t0; dg_t0 = now_; }
+#else
+#define UP_STAMP(acc)
 #endif
 
     // One section = one step of one set: S0 the set's operands are in LDS (prefetched by the other set's section, or fetched
@@ -273,21 +296,23 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         const bool last = t == T - 1;
 #ifdef APE_CLUSTER_STAMPS
         dg_sections += 1;
+        dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- S0 ------------------------------------------------------------------------------------------------------------------
-        if (prex[s] && (first || preh[s])) {
+        if (ab_nobar) {
+        } else if ((prex[s] || ab_nox) && (first || preh[s] || ab_noex)) {
             asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // the prefetched copies; only the publish store is younger
         } else {
 #ifdef APE_CLUSTER_STAMPS
-            dg_block += 1;
+            if (!prex[s]) dg_block_x += 1; else dg_block_h += 1;
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             raise_pending();
-            if (!prex[s]) {
+            if (!prex[s] && !ab_nox) {
 #pragma unroll
                 for (int k = 0; k < NDMA; ++k) issue_x_piece(s, tile, t, k);
             }
-            if (!first) {
+            if (!first && !ab_noex) {
                 wait_flags(s, pub[s]);
 #pragma unroll
                 for (int k = 0; k < NDMA; ++k) issue_h_piece(s, pub[s], k);
@@ -296,12 +321,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         }
         prex[s] = false;
         preh[s] = false;
-        bar();
+        if (!ab_nobar) bar();
         const int abort_word = ctl[0];
         // the other set's next section: (tile_of[o], step_of[o]); it needs its input tile, and from step 1 on the slices it
         // published last (epoch pub[o])
-        const bool o_act = tile_of[o] >= 0;
-        const bool o_h = o_act && step_of[o] >= 1;
+        const bool o_act = tile_of[o] >= 0 && !ab_nox;
+        const bool o_h = tile_of[o] >= 0 && step_of[o] >= 1 && !ab_noex;
         unsigned peek = pub[o];
         bool go = false;
         // hooks in the MFMA stream (k-block q of the section, a constant after unrolling):
@@ -317,11 +342,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
                 raise_pending();
             }
             if (q >= QX && q < QX + NDMA && o_act) issue_x_piece(o, tile_of[o], step_of[o], q - QX);
-            if (q == QP && o_h && lane < NFL)
-                peek = __hip_atomic_load(flags_of + o * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q == QJ) go = o_h && __all((int)(peek >= pub[o])) != 0;
+            if (q == QP) peek = peek_issue(flags_of + o * NFL + (lane & (NFL - 1)));     // (always: no branch, no merge of `peek`)
+            if (q == QJ) {
+                peek_wait(peek);
+                go = o_h && __all((int)(peek >= pub[o])) != 0;
+            }
             if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, pub[o], q - QJ);
         };
+        UP_STAMP(dg_top)
         // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs ---------------------------------------------------------
         f32x16 acc;
 #pragma unroll
@@ -329,13 +357,17 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             const f32x4 bv = bias_s[(wave * 4 + gate) * 2 + hh];
             acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
         }
-        span32<BH, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
-        if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * BH, [&](int q) { mid(BH + q); });
+        if (!ab_nomfma) {
+            span32<BH, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
+            if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * BH, [&](int q) { mid(BH + q); });
+        }
         mfma_drain(acc);
+        UP_STAMP(dg_chain)
         // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
         float hnew[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (ab_noact) { hnew[j] = acc[j] + acc[4 + j] + acc[8 + j] + acc[12 + j]; continue; }
             const float iv = sigm(acc[j]), fv = sigm(acc[4 + j]), gv = tanh_(acc[8 + j]), ov = sigm(acc[12 + j]);
             const float c = first ? iv * gv : fv * cst[s][j] + iv * gv;
             cst[s][j] = c;
@@ -375,15 +407,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         {
             const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
                               __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
-            const unsigned off = last ? 0x80000000u : hx_base(s, (int)(pub[s] & 1u)) + pub_off;
+            const unsigned off = (last || ab_noex) ? 0x80000000u : hx_base(s, (int)(pub[s] & 1u)) + pub_off;
             if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
-            if (!last) {
+            if (!last && !ab_noex) {
                 pub[s] += 1u;
                 pend_idx = s * NFL + member * 4 + wave;
                 pend_epoch = pub[s];
             }
         }
+        UP_STAMP(dg_tail)
         // ---- next step / next tile of this set -------------------------------------------------------------------------------------
         if (last) {
             const int nt = tile + 2 * NC;
@@ -411,7 +444,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 #ifdef APE_CLUSTER_STAMPS
-    if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) { p.dbg_wg[16] = dg_block; p.dbg_wg[17] = dg_sections; }
+    if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) {
+        p.dbg_wg[16] = dg_block_x; p.dbg_wg[17] = dg_block_h; p.dbg_wg[18] = dg_sections;
+        p.dbg_wg[19] = dg_top; p.dbg_wg[20] = dg_chain; p.dbg_wg[21] = dg_tail;
+    }
 #endif
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
     __syncthreads();

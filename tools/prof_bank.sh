@@ -1,6 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+rm -rf /tmp/prof_bank
 rocprofv3 --kernel-trace --stats -d /tmp/prof_bank -- python3 $R/tests/tools/bank_trace.py $1 $2 $3 > $R/gpurun_out/bank_trace.log 2>&1
 cd $R
 python3 - <<'PY'
