@@ -11,6 +11,7 @@
 
 #include "../../include/ape_hip.h"
 #include "ape_internal.h"
+#include "ape_model.h"
 
 namespace {
 
@@ -124,64 +125,16 @@ static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bo
     return best;
 }
 
-struct ape_model {
-    ape_dims_t dims{};
-    void* slab = nullptr;          // the one device allocation every fixed-size buffer below points into
-    size_t slab_bytes = 0;
-    int n_cus = 0;                 // hipDeviceProp_t::multiProcessorCount of the model's device (256 on a whole MI355X)
-    int KX = 0;                    // LSTM layer-0 input width, padded to the kernels' k-blocking
-    int lstm_in = 0;               // LSTM layer-0 input width (input_size; 256 behind ImuPoseLSTM's input layer)
-    int KXpre = 0;                 // ImuPoseLSTM: padded width of the input layer's input
-    float* z_ws = nullptr;         // ImuPoseLSTM: [cap rows, 256] activations of the input layer
-    float* hseq_ws = nullptr;      // all-steps mode of the cluster kernel: [cap rows = B*T, H] top-layer outputs
-    size_t hseq_cap = 0;
-    size_t z_cap = 0;
-    f32x4* wpack[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-    float* bias[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-    float* w_out = nullptr;
-    float* b_out = nullptr;
-    double* stats = nullptr;       // device: xx_m[I] xx_s[I] yy_m[O] yy_s[O] 1/xx_s[I]
-    bool has_weights = false, has_stats = false;
-    double body[9];
-    float* y_ws = nullptr;         // [cap, O] intermediate of ape_infer
-    int y_cap = 0;
-    // weight-stationary cluster kernel (lstm_cluster.hip)
-    bool cluster_ok = false;
-    int kernel_choice = APE_KERNEL_AUTO;
-    float* wcl[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-    void* wcl16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // binary16 fragments of the fp16 variant
-    float* wcl32[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};  // 32x32x2 fragments of the second-generation f32 cluster kernel
-    float* wcls[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // the latency kernel's H/8-member form (two units per wave)
-    char* hxs = nullptr;             // latency kernel: [256 B: launch number][granules {h, tag}: layer, parity, 4 rows, H units]
-    size_t hxs_bytes = 0;
-    int small_uw = 4;                // hidden units per wave of the latency kernel: 2 when one XCD holds H/8 members
-    bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
-    bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
-    int precision = APE_PRECISION_F32;
-    bool wide_cluster = false;      // ImuPoseLSTM: the f32 first-generation cluster kernel with a 256-wide layer-0 input, nothing else
-    bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel
-    bool f16_v2 = true;             // fp16 precision: batches > 256 rows on the row-set-pipelined kernel (lstm_cluster_f16v2.hip)
-    bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
-    bool up32_ok = false;           // ... and on the weight-stationary upper-layer kernel (lstm_upper32.hip: 2 x 256 models)
-    float* hx = nullptr;           // exchange slices
-    size_t hx_bytes = 0;
-    unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
-    unsigned* xcc_slots = nullptr; // small-batch kernel: 64 words its members publish their XCD in (zero between launches)
-    unsigned* xflags = nullptr;    // [flag words..., status word]
-    size_t xflag_bytes = 0;        // bytes of the flag block (multiple of 16), status word follows
-    // MLP regressor (APE_MODEL_FF)
-    float *ffp_wa0 = nullptr, *ffp_wa1 = nullptr, *ffp_wb2 = nullptr, *ffp_wbo = nullptr;   // mlp_pipe.hip: the two stages' register files
-    float* ffp_ring = nullptr;       // ... its ring of tiles between the stages
-    size_t ffp_ring_bytes = 0;
-    unsigned* ffp_ctl = nullptr;     // ... class tickets, status, departure counter, per-pair full / empty words (zero between launches)
-    size_t ffp_ctl_words = 0;
-    bool ffp_ok = false, ffp_on = true;
-    f32x4* ff_wpack[APE_MAX_FF_LAYERS] = {};
-    float* ff_bias[APE_MAX_FF_LAYERS] = {};
-    std::string kernel_name, cluster_name;
-};
 
 int ape_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+
+// every successfully enqueued compute call of a handle is remembered until its next successful check (ape_model_recover)
+static void journal_add(ape_model* m, const ApeJournalEntry& e) {
+    if (!m || m->replaying) return;
+    if (m->journal_n < APE_JOURNAL_CAP) m->journal[m->journal_n++] = e;
+    else m->journal_overflow = true;
+}
+static void journal_clear(ape_model* m) { m->journal_n = 0; m->journal_overflow = false; }
 
 extern "C" {
 
@@ -678,7 +631,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         //  sentinel for padded columns and spare lanes is the offset 0x80000000, which must lie outside num_records)
         const bool one_descriptor = ((size_t)(q.N - 1) * q.row_stride + q.row_offset + q.I) * sizeof(float) < 0x80000000ull &&
                                     (size_t)q.N * q.O * sizeof(float) < 0x80000000ull;
-        if (m->ffp_ok && m->ffp_on && !drop && q.hidden_out == nullptr && q.mask == nullptr && one_descriptor && q.N >= 64 * m->n_cus) {
+        if (m->ffp_ok && m->ffp_on && !m->replaying && !drop && q.hidden_out == nullptr && q.mask == nullptr && one_descriptor && q.N >= 64 * m->n_cus) {
             hipError_t e2 = ape_launch_mlp_pipe(q, m->ffp_wa0, m->ffp_wa1, m->ffp_wb2, m->ffp_wbo, m->ffp_ring, m->ffp_ring_bytes, m->ffp_ctl,
                                                m->n_cus, (hipStream_t)stream);
             if (e2 != hipSuccess) return fail(APE_ERR_HIP, "mlp pipeline launch failed: %s", hipGetErrorString(e2));
@@ -724,7 +677,8 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     // per-launch prologue / head, which decides short windows.  Under APE_KERNEL_AUTO the front of the batch goes to
     // the batch-tile kernel in whole 4096-row waves and the rest to the cluster kernel, by a cost model calibrated
     // on MI355X (tests/tools/time_big_batch.py).
-    const bool f16 = m->precision == APE_PRECISION_F16;
+    // (a re-issue by ape_model_recover runs on the batch-tile kernel, in exact float32 whatever the precision switch)
+    const bool f16 = m->precision == APE_PRECISION_F16 && !m->replaying;
     // all-steps output: the cluster kernel also writes every step's top-layer output to a [B,T,H] workspace and the
     // head runs over those rows in a second, HBM-bound launch
     const bool all_steps = (flags & APE_FLAG_ALL_STEPS) != 0;
@@ -734,13 +688,14 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     const bool masks_fit = !(flags & APE_FLAG_DROPOUT_MASKS) || !cdrop_c || B <= rows_per_cluster_launch ||
                            m->kernel_choice == APE_KERNEL_CLUSTER;
     // a caller-given initial state (h0, c0) is served by the batch-tile kernel, which loads it at step 0
-    bool use_cluster = m->cluster_ok && masks_fit && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16) && !have_hs;
+    bool use_cluster = m->cluster_ok && masks_fit && m->kernel_choice != APE_KERNEL_TILE16 && !(all_steps && f16) && !have_hs &&
+                       !m->replaying;
     if (have_hs && f16) return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant starts from the zero state only");
     if (f16 && (!m->cluster_ok || drop || (flags & APE_FLAG_ALL_STEPS)))
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the fp16 variant covers last-step output without dropout on "
                     "the cluster-kernel shapes only");
     if (f16) use_cluster = true;
-    if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster)
+    if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster && !m->replaying)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
@@ -895,13 +850,30 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
 
 int ape_lstm_forward(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                      const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream) {
-    return lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0);
+    const int rc = lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0);
+    if (rc == APE_OK) {
+        ApeJournalEntry e{};
+        e.kind = ApeJournalEntry::FORWARD; e.in0 = x_dev; e.in1 = masks_dev; e.out0 = y_dev; e.B = B; e.T = T; e.flags = flags;
+        e.dropout_p = dropout_p; e.seed = seed; e.stream = stream;
+        journal_add(m, e);
+    }
+    return rc;
 }
 
 int ape_lstm_forward_hs(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                         const float* masks_dev, float dropout_p, uint64_t seed, const float* h0_dev,
                         const float* c0_dev, float* y_dev, void* stream) {
-    return lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0, h0_dev, c0_dev);
+    // (an initial state is served by the batch-tile kernel, which cannot abort: journaled all the same, a later call may)
+    const int rc = lstm_forward_impl(m, x_dev, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, 0, h0_dev, c0_dev);
+    if (rc == APE_OK && masks_dev == nullptr) {
+        ApeJournalEntry e{};
+        e.kind = ApeJournalEntry::FORWARD_HS; e.in0 = x_dev; e.in1 = h0_dev; e.in2 = c0_dev; e.out0 = y_dev; e.B = B; e.T = T;
+        e.flags = flags; e.dropout_p = dropout_p; e.seed = seed; e.stream = stream;
+        journal_add(m, e);
+    } else if (rc == APE_OK && m) {
+        m->journal_overflow = true;          // (initial state AND injected masks: not representable in an entry)
+    }
+    return rc;
 }
 
 int ape_model_set_kernel(ape_model_t* m, int32_t choice) {
@@ -934,7 +906,67 @@ int ape_model_set_precision(ape_model_t* m, int32_t precision) {
     return APE_OK;
 }
 
+// the blocking part both ape_model_check and ape_model_recover share: 0 = no aborted launch since the last check; else the
+// handle has been reset and g_err describes what happened
+static int check_and_reset(ape_model_t* m);
+
 int ape_model_check(ape_model_t* m) {
+    if (!m) return fail(APE_ERR_INVALID_ARG, "check: NULL model");
+    const int rc = check_and_reset(m);
+    if (rc != APE_OK && rc != APE_ERR_INVALID_ARG) {
+        m->stats_counts.aborted_checks += 1;
+        m->stats_counts.lost_calls += (uint64_t)m->journal_n + (m->journal_overflow ? 1u : 0u);
+    }
+    journal_clear(m);
+    return rc;
+}
+
+int ape_model_stats(const ape_model_t* m, ape_model_stats_t* out) {
+    if (!m || !out) return fail(APE_ERR_INVALID_ARG, "stats: NULL argument");
+    *out = m->stats_counts;
+    return APE_OK;
+}
+
+static int replay_entry(ape_model_t* m, const ApeJournalEntry& e);
+
+int ape_model_recover(ape_model_t* m) {
+    if (!m) return fail(APE_ERR_INVALID_ARG, "recover: NULL model");
+    const int rc = check_and_reset(m);
+    if (rc == APE_OK) { journal_clear(m); return APE_OK; }
+    if (rc == APE_ERR_INVALID_ARG) return rc;
+    const std::string what = g_err;
+    m->stats_counts.aborted_checks += 1;
+    // can every pending call be issued again?  A bank step only while it is that bank's newest step with no row behind it.
+    bool ok = !m->journal_overflow;
+    for (int i = 0; i < m->journal_n && ok; ++i) {
+        const ApeJournalEntry& e = m->journal[i];
+        if (e.kind != ApeJournalEntry::STEP) continue;
+        if (e.bank->frames != e.bank_frames || e.bank->steps != e.bank_steps + 1) ok = false;
+        for (int j = i + 1; j < m->journal_n; ++j)
+            if (m->journal[j].kind == ApeJournalEntry::STEP && m->journal[j].bank == e.bank) ok = false;
+    }
+    if (!ok) {
+        const int n = m->journal_n + (m->journal_overflow ? 1 : 0);
+        m->stats_counts.lost_calls += (uint64_t)n;
+        journal_clear(m);
+        return fail(APE_ERR_HIP, "%s; %d pending call(s) could not be re-issued (%s)", what.c_str(), n,
+                    m->journal_overflow ? "more than 64 calls since the last check" : "a stream bank has moved on since the aborted step");
+    }
+    m->replaying = true;
+    int bad = APE_OK;
+    for (int i = 0; i < m->journal_n && bad == APE_OK; ++i) {
+        bad = replay_entry(m, m->journal[i]);
+        if (bad == APE_OK) m->stats_counts.reissued_calls += 1;
+    }
+    m->replaying = false;
+    const int n = m->journal_n;
+    journal_clear(m);
+    if (bad != APE_OK) { m->stats_counts.lost_calls += (uint64_t)n; return bad; }
+    HIP_TRY(hipDeviceSynchronize());
+    return APE_OK;
+}
+
+static int check_and_reset(ape_model_t* m) {
     if (!m) return fail(APE_ERR_INVALID_ARG, "check: NULL model");
     if (m->ffp_ok) {                                // the MLP pipeline's status word (bounded spins between its two stages)
         HIP_TRY(hipSetDevice(m->dims.device));
@@ -969,8 +1001,23 @@ int ape_model_check(ape_model_t* m) {
     return APE_OK;
 }
 
+static int fk_impl(ape_model_t* m, const void* preds_dev, int32_t preds_dtype, int32_t N, int32_t denormalize, void* est_dev,
+                   int32_t est_dtype, void* stream);
+
 int ape_fk(ape_model_t* m, const void* preds_dev, int32_t preds_dtype, int32_t N, int32_t denormalize, void* est_dev,
            int32_t est_dtype, void* stream) {
+    const int rc = fk_impl(m, preds_dev, preds_dtype, N, denormalize, est_dev, est_dtype, stream);
+    if (rc == APE_OK) {      // (consumes what an aborted launch may have left unwritten: re-issued behind it)
+        ApeJournalEntry e{};
+        e.kind = ApeJournalEntry::FK; e.in0 = preds_dev; e.out0 = est_dev; e.B = N; e.i0 = preds_dtype; e.i1 = denormalize; e.i2 = est_dtype;
+        e.stream = stream;
+        journal_add(m, e);
+    }
+    return rc;
+}
+
+static int fk_impl(ape_model_t* m, const void* preds_dev, int32_t preds_dtype, int32_t N, int32_t denormalize, void* est_dev,
+                   int32_t est_dtype, void* stream) {
     if (!m || !preds_dev || !est_dev) return fail(APE_ERR_INVALID_ARG, "fk: NULL argument");
     if (N < 1) return fail(APE_ERR_INVALID_ARG, "fk: N=%d must be >= 1", N);
     if ((preds_dtype != APE_F32 && preds_dtype != APE_F64) || (est_dtype != APE_F32 && est_dtype != APE_F64))
@@ -1002,6 +1049,9 @@ int ape_msg_reduce(ape_model_t* m, const double* est_dev, int32_t N, double* msg
     p.N = N; p.layout = m->dims.target_layout; p.W = layout_est_width(p.layout);
     hipError_t e = ape_launch_msg_reduce(p, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "msg kernel launch failed: %s", hipGetErrorString(e));
+    ApeJournalEntry je{};
+    je.kind = ApeJournalEntry::MSG; je.in0 = est_dev; je.out0 = msg_dev; je.B = N; je.stream = stream;
+    journal_add(m, je);
     return APE_OK;
 }
 
@@ -1042,32 +1092,17 @@ int ape_infer(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t
     if (denorm && !m->has_stats) return fail(APE_ERR_NOT_READY, "fk: denormalize without norm stats");
     FkTail tail{est_dev, est_dtype, denorm, false};
     if (int rc = lstm_forward_impl(m, x_dev, B, T, flags, nullptr, 0.0f, 0, y, stream, 0, nullptr, nullptr, &tail)) return rc;
-    if (tail.done) return APE_OK;                          // (the latency kernel finished the rows itself)
-    return ape_fk(m, y, APE_F32, B, denorm ? 1 : 0, est_dev, est_dtype, stream);
+    if (!tail.done)                                        // (else the latency kernel finished the rows itself)
+        if (int rc = fk_impl(m, y, APE_F32, B, denorm ? 1 : 0, est_dev, est_dtype, stream)) return rc;
+    ApeJournalEntry e{};
+    e.kind = ApeJournalEntry::INFER; e.in0 = x_dev; e.out0 = y_dev; e.out1 = est_dev; e.B = B; e.T = T; e.flags = flags; e.i2 = est_dtype;
+    e.stream = stream;
+    journal_add(m, e);
+    return APE_OK;
 }
 
 
 // ---- stream bank ------------------------------------------------------------------------------------------
-struct ape_streams {
-    ape_model* model = nullptr;
-    int S = 0, T = 0, smooth = 0;
-    int n_mc = 1;                // Monte-Carlo samples per stream and step
-    bool mc = false;             // dropout on (ape_streams_set_mc was called)
-    bool shared_l0 = false;      // MC mode with layer 0 computed once per stream (two launches per step)
-    float dropout_p = 0.0f;
-    unsigned long long seed = 0, mc_calls = 0;
-    float* xring = nullptr;      // [S,n_mc,T,I] feature rows, slot = frame mod T (a stream's n_mc windows are copies)
-    float* yring = nullptr;      // [S,smooth,n_mc,O] model outputs, slot = step mod smooth
-    float* y_new = nullptr;      // [S,n_mc,O]
-    // shared-layer-0 route on the weight-stationary upper-layer kernel (lstm_upper32.hip): the sample rows go through it in
-    // chunks of `chunk_rows` (a multiple of 32), each expand -> LSTM -> head reduce over the two workspaces below
-    bool up32 = false;
-    int chunk_rows = 0;
-    float* xfrag = nullptr;      // [chunk tiles][T][32 KB] masked layer-0 output in MFMA fragment order
-    float* ypart = nullptr;      // [chunk rows][8][16] head partial sums
-    long long frames = 0;        // rows pushed since the last reset
-    long long steps = 0;         // predictions made since the last reset
-};
 
 // (re)allocates the three rings for the bank's current S, T, smooth, n_mc
 static hipError_t bank_alloc(ape_streams* b) {
@@ -1164,6 +1199,15 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->y_new) (void)hipFree(b->y_new);
     if (b->xfrag) (void)hipFree(b->xfrag);
     if (b->ypart) (void)hipFree(b->ypart);
+    for (auto ev : b->prof_ev) if (ev) (void)hipEventDestroy(ev);
+    if (ape_model* m = b->model) {      // pending steps of this bank can no longer be re-issued
+        int k = 0;
+        for (int i = 0; i < m->journal_n; ++i) {
+            if (m->journal[i].kind == ApeJournalEntry::STEP && m->journal[i].bank == b) { m->journal_overflow = true; continue; }
+            m->journal[k++] = m->journal[i];
+        }
+        m->journal_n = k;
+    }
     delete b;
     return APE_OK;
 }
@@ -1233,6 +1277,16 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     // oldest row of every window: the slot after the newest one
     const int x_ring = (int)(b->frames % b->T);
     const bool drop = b->mc && b->dropout_p > 0.0f && m->dims.num_layers > 1;
+    ApeJournalEntry je{};
+    je.kind = ApeJournalEntry::STEP; je.out0 = msg_dev; je.out1 = tail_dev; je.flags = flags | (packed ? APE_FLAG_PACKED_MSG : 0u);
+    je.i2 = out_dtype; je.stream = stream; je.bank = b; je.bank_frames = b->frames; je.bank_steps = b->steps; je.bank_mc_calls = b->mc_calls;
+    // measurement aid (ape_streams_profile): a pair of events around every launch of the step's dominant kernel
+    auto prof_pair = [&](hipEvent_t* a, hipEvent_t* z) {
+        *a = *z = nullptr;
+        if (!b->prof_on || b->prof_n >= (int)b->prof_ev.size() / 2) return;
+        *a = b->prof_ev[2 * b->prof_n]; *z = b->prof_ev[2 * b->prof_n + 1];
+        b->prof_n += 1;
+    };
     if (b->shared_l0) {
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
         if ((size_t)b->S * b->T > m->hseq_cap) return fail(APE_ERR_CAPACITY, "streams_step: the layer-0 sequence workspace is gone");
@@ -1250,7 +1304,7 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 launch failed: %s", hipGetErrorString(e));
         // launch B: the layers above as an LSTM of their own over the S x n_mc sample rows; row r reads stream
         // r / n_mc's sequence under its own Philox mask (the counters of a fused launch over the same rows)
-        if (b->up32) {
+        if (b->up32 && !m->replaying) {
             // weight-stationary form (lstm_upper32.hip): per chunk of sample rows the masked input in fragment order, the
             // persistent cluster kernel, the head reduce
             const long long total = (long long)b->S * b->n_mc;
@@ -1270,7 +1324,10 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
                 // timing experiments of the ablation library only (tests/tools/ablate_upper32.py; results are garbage)
                 if (const char* ab = getenv("APE_UP32_ABLATE")) u.flags = (unsigned)strtoul(ab, nullptr, 0);
 #endif
-                e = ape_launch_lstm_upper32(u, xq, m->b_out, b->y_new + (size_t)r0 * O, f16v2_capacity(m->n_cus), (hipStream_t)stream);
+                hipEvent_t ev_a, ev_z;
+                prof_pair(&ev_a, &ev_z);
+                e = ape_launch_lstm_upper32(u, xq, m->b_out, b->y_new + (size_t)r0 * O, f16v2_capacity(m->n_cus), (hipStream_t)stream,
+                                            ev_a, ev_z);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
             }
             ++b->mc_calls;
@@ -1283,14 +1340,22 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         q.B = b->S * b->n_mc; q.T = b->T; q.I = H; q.O = O; q.KX = H; q.x_ring = 0;
         q.flags = APE_FLAG_DROPOUT_PHILOX; q.dropout_p = b->dropout_p; q.seed = b->seed + b->mc_calls;
         q.x_group = b->n_mc; q.layer_base = 1;
+        hipEvent_t ev_a, ev_z;
+        prof_pair(&ev_a, &ev_z);
+        if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
         e = ape_launch_lstm_tile16(H, LU, q, (hipStream_t)stream);
+        if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
         ++b->mc_calls;
         }
-    } else if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
-                                   drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring)) {
-        return rc;
     } else {
+        hipEvent_t ev_a, ev_z;
+        prof_pair(&ev_a, &ev_z);
+        if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
+        if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
+                                       drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring))
+            return rc;
+        if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         ++b->mc_calls;
     }
     StreamPostParams q{};
@@ -1306,7 +1371,57 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
     ++b->steps;
+    journal_add(m, je);
     return APE_OK;
+}
+
+int ape_streams_profile(ape_streams_t* b, int32_t enable) {
+    if (!b) return fail(APE_ERR_INVALID_ARG, "streams_profile: NULL bank");
+    HIP_TRY(hipSetDevice(b->model->dims.device));
+    if (enable && b->prof_ev.empty()) {
+        b->prof_ev.resize(512, nullptr);
+        for (auto& ev : b->prof_ev) HIP_TRY(hipEventCreate(&ev));
+    }
+    b->prof_on = enable != 0;
+    b->prof_n = 0;
+    return APE_OK;
+}
+
+int ape_streams_profile_read(ape_streams_t* b, double* kernel_ms_sum, int32_t* launches) {
+    if (!b || !kernel_ms_sum || !launches) return fail(APE_ERR_INVALID_ARG, "streams_profile_read: NULL argument");
+    double sum = 0.0;
+    for (int i = 0; i < b->prof_n; ++i) {
+        HIP_TRY(hipEventSynchronize(b->prof_ev[2 * i + 1]));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->prof_ev[2 * i], b->prof_ev[2 * i + 1]));
+        sum += ms;
+    }
+    *kernel_ms_sum = sum; *launches = b->prof_n;
+    b->prof_n = 0;
+    return APE_OK;
+}
+
+// one journaled call again, on the kernels that need no co-residency (m->replaying is set)
+static int replay_entry(ape_model_t* m, const ApeJournalEntry& e) {
+    switch (e.kind) {
+        case ApeJournalEntry::FORWARD:
+            return ape_lstm_forward(m, (const float*)e.in0, e.B, e.T, e.flags, (const float*)e.in1, e.dropout_p, e.seed, (float*)e.out0, e.stream);
+        case ApeJournalEntry::FORWARD_HS:
+            return ape_lstm_forward_hs(m, (const float*)e.in0, e.B, e.T, e.flags, nullptr, e.dropout_p, e.seed, (const float*)e.in1,
+                                       (const float*)e.in2, (float*)e.out0, e.stream);
+        case ApeJournalEntry::FK:
+            return ape_fk(m, e.in0, e.i0, e.B, e.i1, e.out0, e.i2, e.stream);
+        case ApeJournalEntry::MSG:
+            return ape_msg_reduce(m, (const double*)e.in0, e.B, (double*)e.out0, e.stream);
+        case ApeJournalEntry::INFER:
+            return ape_infer(m, (const float*)e.in0, e.B, e.T, e.flags, (float*)e.out0, e.out1, e.i2, e.stream);
+        case ApeJournalEntry::STEP: {
+            ape_streams* b = e.bank;
+            b->steps = e.bank_steps; b->mc_calls = e.bank_mc_calls;         // (frames unchanged: checked by the caller)
+            return ape_streams_step(b, e.flags, e.out0, e.out1, e.i2, e.stream);
+        }
+    }
+    return fail(APE_ERR_INVALID_ARG, "recover: unknown journal entry");
 }
 
 // internal diagnostic accessor (not part of the public header): copies the 2 stamp words
@@ -1319,26 +1434,6 @@ int ape_debug_read_stamps(ape_model_t* m, unsigned long long out[14]) {
 int ape_debug_read_wg(ape_model_t* m, unsigned long long out[256 * 8]) {
     if (!m || !m->dbg_wg) return APE_ERR_INVALID_ARG;
     HIP_TRY(hipMemcpy(out, m->dbg_wg, 256 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return APE_OK;
-}
-
-// internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
-// 2 departure counter, 3 launch number of the latency kernel, 4 / 5 status word / a class ticket of the MLP pipeline -- so that tests
-// can stage the state an aborted launch leaves behind
-int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
-    if (m && m->ffp_ok && (which == 4 || which == 5)) {          // the MLP pipeline's status word / first class ticket
-        HIP_TRY(hipSetDevice(m->dims.device));
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(m->ffp_ctl + (which == 4 ? 8 * 16 : 0), &value, sizeof(value), hipMemcpyHostToDevice));
-        return APE_OK;
-    }
-    if (!m || !m->cluster_ok || which < 0 || which > 3) return APE_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(m->dims.device));
-    HIP_TRY(hipDeviceSynchronize());
-    unsigned* status = m->xflags + m->xflag_bytes / sizeof(unsigned);
-    // (3: the latency kernel's launch number, the upper bits of its granule tags -- to stage the 20-bit wrap)
-    unsigned* word = which == 0 ? status : (which == 1 ? status - 4 : which == 2 ? status - 3 : reinterpret_cast<unsigned*>(m->hxs));
-    HIP_TRY(hipMemcpy(word, &value, sizeof(value), hipMemcpyHostToDevice));
     return APE_OK;
 }
 

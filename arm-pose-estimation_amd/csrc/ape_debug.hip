@@ -1,0 +1,29 @@
+// Test hooks: linked into lib/diag/libape_hip_testhooks.so only (csrc/Makefile, target `hooks`), never into the product library.
+#include "ape_model.h"
+
+#define APE_DBG_TRY(expr) do { if ((expr) != hipSuccess) return APE_ERR_HIP; } while (0)
+
+extern "C" {
+
+// internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
+// 2 departure counter, 3 launch number of the latency kernel, 4 / 5 status word / a class ticket of the MLP pipeline -- so that tests
+// can stage the state an aborted launch leaves behind
+int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
+    if (m && m->ffp_ok && (which == 4 || which == 5)) {          // the MLP pipeline's status word / first class ticket
+        APE_DBG_TRY(hipSetDevice(m->dims.device));
+        APE_DBG_TRY(hipDeviceSynchronize());
+        APE_DBG_TRY(hipMemcpy(m->ffp_ctl + (which == 4 ? 8 * 16 : 0), &value, sizeof(value), hipMemcpyHostToDevice));
+        return APE_OK;
+    }
+    if (!m || !m->cluster_ok || which < 0 || which > 3) return APE_ERR_INVALID_ARG;
+    APE_DBG_TRY(hipSetDevice(m->dims.device));
+    APE_DBG_TRY(hipDeviceSynchronize());
+    unsigned* status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+    // (3: the latency kernel's launch number, the upper bits of its granule tags -- to stage the 20-bit wrap)
+    unsigned* word = which == 0 ? status : (which == 1 ? status - 4 : which == 2 ? status - 3 : reinterpret_cast<unsigned*>(m->hxs));
+    APE_DBG_TRY(hipMemcpy(word, &value, sizeof(value), hipMemcpyHostToDevice));
+    return APE_OK;
+}
+
+
+}  // extern "C"

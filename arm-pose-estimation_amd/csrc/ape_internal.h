@@ -218,7 +218,7 @@ size_t ape_upper32_xfrag_bytes(int rows, int T);
 size_t ape_upper32_ypart_bytes(int rows);
 hipError_t ape_prepare_lstm_upper32();
 hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
-                                   hipStream_t stream);
+                                   hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 bool ape_cluster_f16v2_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);

@@ -546,15 +546,17 @@ hipError_t ape_prepare_lstm_upper32() {
 // one chunk of sample rows: expand -> upper layer -> head reduce, all on `stream`.  `max_clusters` = 32-row clusters the device
 // holds at once (a multiple of 8: whole block-index classes); the grid is the smaller of that and the tiles, rounded up to 8.
 hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (p.n_tiles < 1 || max_clusters < 8 || p.O > PO) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ape_mc_expand_kernel, dim3(p.n_tiles * p.T), dim3(256), 0, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int clusters = (p.n_tiles + 7) / 8 * 8;
     if (clusters > max_clusters) clusters = max_clusters;
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);          // (measurement aid: ape_streams_profile)
     hipLaunchKernelGGL(ape_lstm_upper32, dim3(clusters * GH), dim3(256), smem_upper(), stream, p);
     e = hipGetLastError();
+    if (ev_end) (void)hipEventRecord(ev_end, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ape_head_reduce_kernel, dim3((q.rows * PO + 255) / 256), dim3(256), 0, stream, p.ypart, b_out, y, q.rows, p.O);
     return hipGetLastError();

@@ -30,7 +30,7 @@ MODEL_LSTM, MODEL_FF, MODEL_IMUPOSE = 0, 1, 2
 PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3
 PARSE_SHAPES = {0: (55, 22), 1: (28, 20), 2: (55, 20), 3: (55, 38)}
 PARSE_BIG_ENDIAN = 0x100          # OR-ed into a kind: rows are big-endian float32 (the UDP payload as received)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EST_WIDTH = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 21, LAYOUT_ORI_CAL_LARM_UARM: 14, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 21}
 NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 20}
@@ -40,6 +40,10 @@ class ApeDims(C.Structure):
     _fields_ = [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
                 ("output_size", C.c_int32), ("target_layout", C.c_int32), ("device", C.c_int32),
                 ("model_kind", C.c_int32)]
+
+
+class ApeModelStats(C.Structure):
+    _fields_ = [("aborted_checks", C.c_uint64), ("reissued_calls", C.c_uint64), ("lost_calls", C.c_uint64)]
 
 
 class ApeKalmanDims(C.Structure):
@@ -77,6 +81,10 @@ SIGNATURES = {
     "ape_model_set_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
     "ape_model_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "ape_model_check": (C.c_int, [C.c_void_p]),
+    "ape_model_recover": (C.c_int, [C.c_void_p]),
+    "ape_model_stats": (C.c_int, [C.c_void_p, C.POINTER(ApeModelStats)]),
+    "ape_streams_profile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ape_streams_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "ape_lstm_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "ape_flops_per_window": (C.c_double, [C.POINTER(ApeDims), C.c_int32]),
     "ape_kalman_create": (C.c_int, [C.POINTER(ApeKalmanDims), C.POINTER(C.c_void_p)]),

@@ -238,9 +238,11 @@ class DropoutLSTM:
                                                        float(dropout_p), int(seed), C.c_void_p(y.data_ptr()), stream),
                            "ape_lstm_forward")
         if on_host:
-            out = y.cpu()            # synchronises: the one place where results reach the host, so the health of the
-            self.check()             # launch is checked here (an aborted cluster launch leaves `y` unwritten)
-            return out
+            # the one place where results reach the host, so the health of the launch is checked here: an aborted
+            # weight-stationary launch leaves `y` unwritten, and ape_model_recover then runs the call again on the
+            # batch-tile kernel (the inputs are still alive here), so the frame is not lost
+            self.recover()
+            return y.cpu()
         return y
 
     def forward(self, x, hs=None, masks=None, last_step_only=False, normalize_input=False, rows=None):
@@ -287,8 +289,22 @@ class DropoutLSTM:
         return self
 
     def check(self):
-        """blocking health check: raises if a cluster-kernel launch gave up waiting for a peer workgroup"""
+        """blocking health check: raises if a cluster-kernel launch gave up waiting for a peer workgroup (the handle is
+        reset; the outputs of the calls since the last check are invalid)"""
         _hip.check(_hip.lib().ape_model_check(self._handle), "ape_model_check")
+
+    def recover(self):
+        """blocking health check that survives an abort (``ape_model_recover``): the calls made since the last check are
+        issued again on the kernels that need no co-residency; raises only if that is impossible.  The device inputs of
+        those calls must still be alive and unchanged."""
+        _hip.check(_hip.lib().ape_model_recover(self._handle), "ape_model_recover")
+
+    def stats(self) -> dict:
+        """{'aborted_checks', 'reissued_calls', 'lost_calls'} of this handle (``ape_model_stats``)"""
+        import ctypes as C
+        st = _hip.ApeModelStats()
+        _hip.check(_hip.lib().ape_model_stats(self._handle, C.byref(st)), "ape_model_stats")
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}
 
     def kernel_name(self, B: int, T: int) -> str:
         return _hip.lib().ape_lstm_kernel_name(self._handle, B, T).decode()

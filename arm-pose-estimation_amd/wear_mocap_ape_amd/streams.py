@@ -117,6 +117,22 @@ class StreamBank:
         datagrams leave the host"""
         self._model.check()
 
+    def recover(self):
+        """like ``check``, but an aborted step is run again on the kernels that need no co-residency (``ape_model_recover``):
+        call it behind a step, before the next row is pushed, wherever the datagrams are about to leave the device"""
+        self._model.recover()
+
+    def profile(self, enable: bool = True):
+        """measurement aid: HIP events around every launch of the step's dominant kernel (``ape_streams_profile``)"""
+        self._hip.check(self._hip.lib().ape_streams_profile(self._handle, 1 if enable else 0), "ape_streams_profile")
+
+    def profile_read(self):
+        """-> (summed kernel ms, launches) since the last read"""
+        ms, n = self._C.c_double(0.0), self._C.c_int32(0)
+        self._hip.check(self._hip.lib().ape_streams_profile_read(self._handle, self._C.byref(ms), self._C.byref(n)),
+                        "ape_streams_profile_read")
+        return float(ms.value), int(n.value)
+
     def push_rows(self, rows: torch.Tensor, kind: int, big_endian: bool = False):
         """rows: float32 [S, 55|28] on the device -- one raw message per stream (data_types/messaging.py layouts)"""
         width = self._hip.PARSE_SHAPES[kind][0]

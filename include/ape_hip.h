@@ -26,8 +26,10 @@
  *   - a launch of the weight-stationary kernels that cannot make progress (its workgroups never all resident, e.g. on
  *     a GPU shared with other long-running kernels) gives up after a bounded wait, sets a sticky status word and
  *     leaves its outputs unwritten; every later launch on that handle then leaves at once, also without writing.
- *     ape_model_check() reports (and clears) that state; call it wherever results are consumed on the host (the
- *     Python mirror does, whenever it copies results to host memory).
+ *     ape_model_check() reports (and clears) that state; ape_model_recover() does the same and then RE-ISSUES every
+ *     call made on the handle since its last successful check on the kernels that need no co-residency (the batch-tile
+ *     LSTM / MLP kernels), on the streams the calls named, so that no frame is lost: call one of them wherever results
+ *     are consumed on the host (the Python mirror calls ape_model_recover whenever it copies results to host memory).
  *   - quaternions are [w,x,y,z]; all joint/column indices are fixed by the layouts below.
  */
 #ifndef APE_HIP_H
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 4
+#define APE_ABI_VERSION 5
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -246,6 +248,13 @@ int ape_streams_set_mc(ape_streams_t* bank, int32_t n_mc, float dropout_p, uint6
 int ape_streams_push_rows(ape_streams_t* bank, int32_t kind, const float* rows_dev, void* stream);
 int ape_streams_push_features(ape_streams_t* bank, const float* xx_dev, void* stream);
 int ape_streams_step(ape_streams_t* bank, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream);
+/* measurement aid (bench.py `stream_bank_T6.*.roofline`): with profiling on, every launch of the step's dominant kernel (the
+ * regressor: ape_lstm_upper32 in a Monte-Carlo bank, else the LSTM launch) is bracketed by a pair of HIP events on the
+ * step's own stream; ape_streams_profile_read synchronises, returns the summed duration and the number of launches since
+ * the last read, and re-arms.  At most 256 launches are recorded between two reads; off by default (two event records
+ * per launch otherwise). */
+int ape_streams_profile(ape_streams_t* bank, int32_t enable);
+int ape_streams_profile_read(ape_streams_t* bank, double* kernel_ms_sum, int32_t* launches);
 
 int ape_infer(ape_model_t* model, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
               float* y_dev, void* est_dev, int32_t est_dtype, void* stream);
@@ -257,6 +266,25 @@ int ape_model_set_precision(ape_model_t* model, int32_t precision);
  * since the last check gave up waiting for a peer workgroup (its bounded spins expired) -- the outputs of that launch
  * and of every later one on this handle are invalid.  A failing check also resets the handle: the next launch works. */
 int ape_model_check(ape_model_t* model);
+/* ape_model_check that survives an abort.  The handle keeps a journal of the compute calls made on it since the last
+ * successful check / recover (ape_lstm_forward[_hs], ape_fk, ape_msg_reduce, ape_infer, ape_streams_step; up to 64).  When
+ * the blocking check finds an aborted weight-stationary launch, the handle is reset as by ape_model_check and every
+ * journaled call is issued again, in order, on its own stream, with the cooperative kernels switched off (batch-tile LSTM
+ * kernel, tile MLP kernel: no workgroup waits for another; same arithmetic up to float32 summation order, so results
+ * agree with the aborted kernels' to ~1e-6 -- an fp16-precision model is re-run in exact float32), then the device is
+ * synchronised: 0 = nothing was aborted, or everything was re-issued and the outputs are valid now.  The CALLER'S PART:
+ * the device buffers those calls read must still hold the same data (recover before re-using them; a Python mirror that
+ * copies outputs to the host right behind a call satisfies this by construction).  A stream-bank step can be re-issued
+ * only while it is the bank's newest step and no row was pushed behind it; otherwise, or when more than 64 calls are
+ * pending, the function returns APE_ERR_HIP like ape_model_check and counts the calls as lost.  Never a CPU path: the
+ * re-issue is a fresh launch of HIP kernels in this process. */
+int ape_model_recover(ape_model_t* model);
+typedef struct ape_model_stats {
+    uint64_t aborted_checks;      /* checks / recovers that found an aborted launch                       */
+    uint64_t reissued_calls;      /* calls ape_model_recover issued again on the non-cooperative kernels  */
+    uint64_t lost_calls;          /* calls pending at an abort that could not be re-issued                */
+} ape_model_stats_t;
+int ape_model_stats(const ape_model_t* model, ape_model_stats_t* out);
 
 /* introspection for benchmarks: name of the dominant kernel for (B,T) and its algorithmic
  * FLOP per window (sum_layers 2*4H*(in_l+H) per step, + 2*O*H head once). */
