@@ -1178,7 +1178,7 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
             // Cache, and far inside one 32-bit buffer descriptor; whole 1024-row waves of clusters where that costs nothing
             const long long total = (long long)b->S * n_mc;
             const long long max_chunk = ((256ll << 20) / ((long long)b->T * 1024)) / 1024 * 1024;
-            if (max_chunk >= 1024) {
+            if (max_chunk >= 1024 && total < (1ll << 31)) {          // (the input builder indexes sample rows with 32 bits)
                 const long long n_chunks = (total + max_chunk - 1) / max_chunk;
                 long long chunk = ((total + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;
                 if (chunk > total) chunk = (total + 31) / 32 * 32;

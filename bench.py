@@ -87,6 +87,7 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=8.0, gpu_y=None, gpu_est=N
                           window/pad/trim, f64 z-score, model, de-normalise, FK, message),
       config1_B1_T6_mc25  the same with the estimators' default 25 Monte-Carlo dropout samples per frame
                           (nn_models.py:191-207: lstm.train() + x.repeat),
+      config1_B1_T6_mc60_smooth5  the reference script's own setting (experimental_applications/watch_phone_pocket_lstm.py:22-25),
       config3_B1024_T64   the benchmark shape, one batched forward + FK over 1024 windows,
     each at 1 thread and at the best thread count of a short probe (torch's default of one thread per core is far from
     the best for 2x256 LSTM GEMMs), each with the reference's FK route (one 4x4 `eigh` per quaternion,
@@ -103,12 +104,12 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=8.0, gpu_y=None, gpu_est=N
     def batch_leg(xb, route):
         return lambda: orc.infer_windows(sd, stats, body, layout, xb, route=route, use_torch=True)
 
-    def stream_leg(n_mc, route):
+    def stream_leg(n_mc, route, smooth=1):
         # the per-frame loop of one estimator from the feature row on (the row -> feature step is the HIP path's
         # ape_parse_rows and is not part of either side's timing here)
         predict = (lambda hist: run_eval(hist[None].astype(np.float32))[:, -1, :]) if n_mc == 1 else \
                   (lambda hist: run_mc(np.repeat(hist[None].astype(np.float32), n_mc, axis=0))[:, -1, :])
-        win = orc.WindowOracle(T6, 1, stats, predict)
+        win = orc.WindowOracle(T6, smooth, stats, predict)
         frames = x[0]                               # 64 feature rows of stream 0, replayed as a 50 Hz sequence
         state = {"i": 0}
 
@@ -120,13 +121,14 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=8.0, gpu_y=None, gpu_est=N
         return one
 
     def timed(fn, units, budget, max_calls=1 << 30):
-        fn()                                        # warm-up call (thread pool, allocator)
+        # one warm-up call (thread pool, allocator), then at least THREE timed repeats and on until the budget is spent
+        fn()
         n, t0 = 0, time.perf_counter()
         while True:
             fn()
             n += 1
             el = time.perf_counter() - t0
-            if el >= budget or n >= max_calls:
+            if n >= 3 and (el >= budget or n >= max_calls):
                 return n * units / el, n * units, el
 
     # thread-count probe on the benchmark shape
@@ -152,6 +154,11 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=8.0, gpu_y=None, gpu_est=N
                 v, n, el = timed(stream_leg(n_mc, route), 1, 0.8)
                 legs[f"config1_B1_T6_mc{n_mc}/{tname}/fk_{route}"] = {"frames_per_s": v, "sample_frames": n, "seconds": el,
                                                                       "sample_windows_per_s": v * n_mc}
+            # the reference script's own setting: 60 samples, smooth 5 (watch_phone_pocket_lstm.py:22-25): 300 rows through the
+            # post-filter per frame -- with the reference's per-row eigh this is the 54 frames/s of BASELINE.md
+            v, n, el = timed(stream_leg(60, route, smooth=5), 1, 1.5)
+            legs[f"config1_B1_T6_mc60_smooth5/{tname}/fk_{route}"] = {"frames_per_s": v, "sample_frames": n, "seconds": el,
+                                                                      "sample_windows_per_s": v * 60}
     # headline leg: config3, best threads, reference FK route; its outputs are the parity reference of the timed GPU run
     torch.set_num_threads(best)
     done, t0 = 0, time.perf_counter()
@@ -183,7 +190,21 @@ def cpu_baseline(sd, stats, body, layout, x, budget_s=8.0, gpu_y=None, gpu_est=N
             "legs": legs}
 
 
-def batch1_latency(model, stats, n_frames=300):
+def _tail_report(us, what):
+    """the tail of a per-frame latency series: p99.9, max, and WHERE the outliers sit (frame indices above 1.5 x the median) --
+    a tail made of the first frames behind the warm-up or of isolated single frames reads differently from a periodic one"""
+    us = np.asarray(us)
+    med = float(np.median(us))
+    idx = np.nonzero(us > 1.5 * med)[0]
+    return {"p999_us": float(np.percentile(us, 99.9)), "max_us": float(us.max()), "frames": int(us.size),
+            "outliers_above_1p5x_median": {"count": int(idx.size), "frame_indices": [int(i) for i in idx[:32]],
+                                           "their_us": [round(float(v), 1) for v in us[idx[:32]]],
+                                           "note": f"{what}: frames above 1.5 x the median; index 0 is the first timed frame behind 20 "
+                                                   "untimed ones; the host synchronises on every frame (a 50 Hz consumer), so a "
+                                                   "late host wake-up shows up here as well as a slow launch"}}
+
+
+def batch1_latency(model, stats, n_frames=1000):
     """configs[1]: batch=1 streaming, T=6 window, one frame per call, HIP-event timed"""
     from wear_mocap_ape_amd import _hip
     x = torch.from_numpy(synthetic_windows(stats, 0, 1, 6, POCKET["I"])).cuda()
@@ -203,6 +224,11 @@ def batch1_latency(model, stats, n_frames=300):
     out = {"workload": "configs[1]: pocket B=1 T=6 streaming, one ape_infer per frame",
            "p50_us": float(np.percentile(us, 50)), "p99_us": float(np.percentile(us, 99)),
            "frames_per_s": float(1e6 / np.mean(us))}
+    out.update(_tail_report(us, "ape_infer"))
+    # ONE launch per frame (the latency kernel carries the post-filter), issued directly: a hipGraph replay of the same frame
+    # is slower on this ROCm (graph_replay_* below; a replay costs ~10-16 us of host time per forward, MI355X guide,
+    # "graph-replay-floor"), so the latency path launches directly
+    out["launch_form"] = "direct launch per frame (graph replay measured slower, see graph_replay_p50_us)"
     # the same frame step captured once into a hipGraph (LSTM + FK kernels, no memset node) and replayed per frame
     try:
         side = torch.cuda.Stream()
@@ -248,6 +274,25 @@ def batch1_latency(model, stats, n_frames=300):
         out["mc25_stream_p99_us"] = float(np.percentile(mus, 99))
         out["mc25_note"] = "one stream, 25 dropout samples per frame (the deployed estimators' default), push_rows + step_datagrams per frame"
         del bank
+        # the reference script's own setting (experimental_applications/watch_phone_pocket_lstm.py:22-25 + :52): 60 samples per
+        # frame, smoothing over the last 5 predictions -> 300 stacked rows per frame
+        bank = StreamBank(model, 1, 6, smooth=5, normalize=True, dtype=torch.float32, monte_carlo_samples=60, dropout=0.2)
+        mus = []
+        for i in range(20 + n_frames):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            bank.push_rows(rows[i % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+            bank.step_datagrams()
+            b.record(); b.synchronize()
+            if i >= 20:
+                mus.append(a.elapsed_time(b) * 1e3)
+        model.check()
+        out["mc60_smooth5_stream_p50_us"] = float(np.percentile(mus, 50))
+        out["mc60_smooth5_stream_p99_us"] = float(np.percentile(mus, 99))
+        out["mc60_smooth5_frames_per_s"] = float(1e6 / np.mean(mus))
+        out["mc60_smooth5_note"] = ("one stream, 60 dropout samples per frame, smooth 5 (the setting of "
+                                    "experimental_applications/watch_phone_pocket_lstm.py:22-25): 300 stacked rows per message")
+        del bank
     except Exception as exc:
         out["mc25_error"] = str(exc)[:200]
     return out
@@ -278,8 +323,38 @@ def stream_bank_numbers(model, stats):
             b.synchronize()
             model.check()
             ms = a.elapsed_time(b) / frames
-            out[f"S{S}_mc{n_mc or 1}"] = {"ms_per_frame_of_all_streams": ms, "stream_frames_per_s": S / (ms * 1e-3),
-                                          "sample_windows_per_s": S * (n_mc or 1) / (ms * 1e-3)}
+            ent = {"ms_per_frame_of_all_streams": ms, "stream_frames_per_s": S / (ms * 1e-3),
+                   "sample_windows_per_s": S * (n_mc or 1) / (ms * 1e-3)}
+            # the frame's dominant kernel, bracketed by HIP events on the step's own stream in a SEPARATE pass of the same
+            # frames (ape_streams_profile: two event records per launch, kept out of the pass timed above)
+            bank.profile(True)
+            for f in range(frames):
+                bank.push_rows(rows[f % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+                bank.step_datagrams()
+            kms, launches = bank.profile_read()
+            bank.profile(False)
+            model.check()
+            rows_total = S * (n_mc or 1)
+            if n_mc:
+                # Monte-Carlo bank: layer 0 once per stream, then ONE layer over the S x n_mc sample rows -- algorithmic work of
+                # that launch = 2 * 4H * (H + H) FLOP per row and step + the head (the reference repeats the window n_mc
+                # times through BOTH layers, nn_models.py:191-207; the shared layer 0 is work the bank does not do)
+                flop = rows_total * (6 * 2.0 * 4 * POCKET["H"] * (POCKET["H"] + POCKET["H"]) + 2.0 * POCKET["O"] * POCKET["H"])
+                kname = "ape_lstm_upper32"
+                alg_bytes = S * 6 * POCKET["H"] * 4 + rows_total * POCKET["O"] * 4      # layer-0 sequence in, NN targets out
+            else:
+                flop = model.flops_per_window(6) * rows_total
+                kname = model.kernel_name(rows_total, 6)
+                alg_bytes = rows_total * (6 * POCKET["I"] * 4 + POCKET["O"] * 4)
+            k_ms = kms / frames                  # all launches of the kernel in one frame (8192 x 25: five chunks)
+            tf = flop / (k_ms * 1e-3) / 1e12
+            traffic, ttag, stale = load_traffic(kname, rows_total)
+            ent["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag, "traffic_stale": stale,
+                               "kernel": kname, "kernel_ms": k_ms, "launches_per_frame": launches / frames,
+                               "flop_per_frame": flop, "hbm_algorithmic_bytes_per_frame": alg_bytes,
+                               "kernel_share_of_frame": k_ms / ms}
+            out[f"S{S}_mc{n_mc or 1}"] = ent
             del bank
     except Exception as exc:                # reported, never fatal for the headline line
         out["error"] = str(exc)[:200]
@@ -314,7 +389,7 @@ def other_paths():
                                                            C.c_void_p(y.data_ptr()), None), "fwd"), 10, 50)
         out["mlp_regressor"] = {"rows": N, "us_per_launch": us, "rows_per_s": N / us * 1e6,
                                 "tflops": m.flops_per_window(1) * N / us / 1e6, "kernel": m.kernel_name(N, 1),
-                                "profile": "profiles/r02_mlp_pipe.md"}
+                                "profile": "profiles/r03_mlp_pipe.md"}
         m.check()
         del m, x, y
     except Exception as exc:
@@ -333,6 +408,23 @@ def other_paths():
         del m, x, y
     except Exception as exc:
         out["imupose_lstm"] = {"error": str(exc)[:200]}
+    try:        # the third deployed regressor: WatchPhoneUarmNN's 3 x 128 LSTM (watch_phone_uarm_nn.py:13-41), eval mode
+        B = 1024
+        m = nn_models.DropoutLSTM(38, 128, 3, 12, device=0)
+        m.load_weight_blob(torch.from_numpy(rng.uniform(-0.088, 0.088, m.weight_blob_floats()).astype(np.float32)).cuda())
+        res = {}
+        for T in (6, 64):
+            x = torch.randn(B, T, 38, device="cuda"); y = torch.empty(B, 12, device="cuda")
+            us = timed(lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0, None, 0.0, 0,
+                                                               C.c_void_p(y.data_ptr()), None), "fwd"), 10, 50)
+            tf = m.flops_per_window(T) * B / us / 1e6
+            res[f"T{T}"] = {"us_per_launch": us, "windows_per_s": B / us * 1e6, "tflops": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
+                            "kernel": m.kernel_name(B, T)}
+        m.check()
+        out["uarm_lstm"] = dict(res, windows=B, profile="profiles/r03_uarm_T64.md")
+        del m, x, y
+    except Exception as exc:
+        out["uarm_lstm"] = {"error": str(exc)[:200]}
     try:        # KalmanSmartwatchModel.forward + the state shift (kalman_models.py:175-220, watch_phone_pocket_kalman.py:160-162)
         E, W = 48, 10                                   # example_scripts/stream/watch_phone_pocket.py:24-25
         m = kalman_models.KalmanSmartwatchModel(E, W)
@@ -374,13 +466,25 @@ def load_traffic(kernel_name, windows):
     tfile = REPO / "profiles" / "traffic_latest.json"
     try:
         tj = json.loads(tfile.read_text())
+        best = None
         for ent in tj.get("kernels", [tj]):
             a = ent.get("kernel", "")
             if a and (a in kernel_name or kernel_name in a) and ent.get("windows") == windows:
-                return ent["hbm_bytes_per_launch"], ent.get("tag")
+                best = ent                                   # the newest matching entry wins (the file is append-ordered)
+        if best is not None:
+            # stale = the entry was measured on another build of the kernel: tools/summarize_prof.py stamps every entry with
+            # the SHA-256 of the kernel's object file (lib/build_info.json, written at link time); an entry without a stamp
+            # (round 1 / 2) cannot be vouched for either
+            stale = True
+            try:
+                cur = json.loads((REPO / "arm-pose-estimation_amd" / "lib" / "build_info.json").read_text())["objects"]
+                stale = not (best.get("object") and cur.get(best["object"]) == best.get("object_sha256"))
+            except Exception:
+                pass
+            return best["hbm_bytes_per_launch"], best.get("tag"), stale
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def fp16_config4(stats_watch, n_iter=20):
@@ -417,14 +521,14 @@ def fp16_config4(stats_watch, n_iter=20):
     m.check()
     flop = m.flops_per_window(T_FRAMES) * WINDOWS_PER_GPU
     tf16 = flop / (out["f16"] * 1e-3) / 1e12
-    traffic, ttag = load_traffic(names["f16"], WINDOWS_PER_GPU)
+    traffic, ttag, tstale = load_traffic(names["f16"], WINDOWS_PER_GPU)
     alg_bytes = WINDOWS_PER_GPU * (T_FRAMES * cfg["I"] * 4 + cfg["O"] * 4)
     return {"workload": "configs[4]: watch-only (I=20,H=256,L=2,O=12), 1024 windows x 64 frames, fp16 W/x/h, fp32 accumulate",
             "kernel_ms_f16": out["f16"], "kernel_ms_f32": out["f32"], "windows_per_s_f16": WINDOWS_PER_GPU / out["f16"] * 1e3,
             "algorithmic_tflops_f16": tf16,
             "max_abs_diff_targets_f16_vs_f32": float((y["f16"] - y["f32"]).abs().max().item()),
             "roofline": {"bound": "mfma", "achieved": tf16, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf16 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag,
+                         "frac": tf16 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag, "traffic_stale": tstale,
                          "kernel": names["f16"], "kernel_ms": out["f16"], "flop_per_launch": flop,
                          "hbm_algorithmic_bytes_per_launch": alg_bytes,
                          "note": "latency-bound, not matrix-bound: per layer-step a wave has 2 x 16 f16 MFMAs (~0.5K cycles) "
@@ -434,15 +538,38 @@ def fp16_config4(stats_watch, n_iter=20):
 PREROLL = 40        # untimed clock-ramp steps in front of the warmup steps
 
 
+def visible_gpus_without_opening_them():
+    """GPUs this process may use, counted WITHOUT a HIP / HSA call (the spawning parent must provably never open the device):
+    the KFD topology in sysfs lists every node with its `simd_count` (0 for a CPU node); HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow it.  None when sysfs has no answer (the children then find out)."""
+    n = 0
+    if not Path("/sys/class/kfd").exists():
+        return 0                                  # no amdgpu compute driver in this kernel: no GPU a HIP process could open
+    try:
+        nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+        for node in nodes.iterdir():
+            for ln in (node / "properties").read_text().splitlines():
+                k, _, v = ln.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except Exception:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no RANK/WORLD_SIZE in the environment: start the N single-GPU ranks as CHILD
     processes (torch.distributed.run, one rank per GPU, RCCL) and relay rank 0's JSON line.  This parent never
-    initialises the GPU (torch.cuda.device_count() does not on this image) and never replaces itself (no exec)."""
+    touches the GPU (the device count comes from sysfs) and never replaces itself (no exec)."""
     import socket
     import subprocess
     share_gpu = os.environ.get("APE_BENCH_SHARE_GPU") == "1"
-    n_dev = torch.cuda.device_count()
-    if not share_gpu and n_dev < args.gpus:
+    n_dev = visible_gpus_without_opening_them()
+    if not share_gpu and n_dev is not None and n_dev < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -510,6 +637,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: the process group formed {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        if not share_gpu and dist.get_backend() != "nccl":
+            raise SystemExit(f"bench.py: the N-rank run must use RCCL (backend nccl), got {dist.get_backend()}")
         world = dist.get_world_size()
     comm_dev = torch.device("cpu") if share_gpu else dev
 
@@ -595,6 +724,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -602,13 +732,20 @@ def main():
     model.check()           # blocking health check of the cluster kernel (bounded spins never expired)
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k]))
+    # every rank's own numbers travel to rank 0 (a straggler GPU must be visible in the one line the driver gets)
+    mine_t = torch.tensor([rank, kernel_ms, own_elapsed / args.steps * 1e3], dtype=torch.float64, device=comm_dev)
+    rank_times = [mine_t]
+    if use_dist:
+        rank_times = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(rank_times, mine_t)
+    rank_times = {int(t_[0].item()): (float(t_[1].item()), float(t_[2].item())) for t_ in rank_times}
     flop_per_launch = model.flops_per_window(T_FRAMES) * B
     achieved_tf = flop_per_launch / (kernel_ms * 1e-3) / 1e12
 
     if rank == 0:
         total_windows = sum(int(s_[2] - s_[1]) for s_ in shards) * args.steps
         kname = model.kernel_name(B, T_FRAMES)
-        traffic, ttag = load_traffic(kname, B)
+        traffic, ttag, tstale = load_traffic(kname, B)
         out = {
             "metric": "IMU windows/sec", "value": total_windows / elapsed, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -621,11 +758,12 @@ def main():
                        "sharding": {"ranks": world, "backend": (dist.get_backend() if use_dist else "none"),
                                     "collectives": "one broadcast of the weight blob + stats at start-up; none per step",
                                     "per_rank": [{"rank": int(s_[0]), "streams": [int(s_[1]), int(s_[2])], "device": int(s_[3]),
-                                                  "weight_blob_sum": s_[4]} for s_ in shards]},
+                                                  "weight_blob_sum": s_[4], "kernel_ms": rank_times[int(s_[0])][0],
+                                                  "ms_per_step": rank_times[int(s_[0])][1]} for s_ in shards]},
                        "preroll_steps": PREROLL},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag,
-                         "kernel": kname, "kernel_ms": kernel_ms,
+                         "traffic_stale": tstale, "kernel": kname, "kernel_ms": kernel_ms,
                          "flop_per_launch": flop_per_launch,
                          "hbm_algorithmic_bytes_per_launch": B * (T_FRAMES * POCKET["I"] * 4 + POCKET["O"] * 4),
                          # the other roofline, stated plainly: ~1.8e4 FLOP per algorithmic byte, so HBM is idle by construction
@@ -654,6 +792,10 @@ def main():
                 if best:
                     out["batch1"]["cpu_frames_per_s"] = cb["legs"][best[0]]["frames_per_s"]
                     out["batch1"]["cpu_leg"] = best[0]
+                best = [k for k in cb["legs"] if k.startswith("config1_B1_T6_mc60_smooth5/") and "best" in k and k.endswith("fk_eigh")]
+                if best:
+                    out["batch1"]["mc60_smooth5_cpu_frames_per_s"] = cb["legs"][best[0]]["frames_per_s"]
+                    out["batch1"]["mc60_smooth5_cpu_leg"] = best[0]
         os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

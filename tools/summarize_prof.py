@@ -132,6 +132,12 @@ lines = [f"# rocprofv3 summary `{args.tag}`", "",
          f"kernel `{args.kname}`, grid {args.grid} threads ({args.grid // 256} workgroups x 256), {args.windows} windows per launch", ""]
 if args.note:
     lines += [args.note, ""]
+try:
+    _info = json.loads((REPO / "arm-pose-estimation_amd" / "lib" / "build_info.json").read_text())
+    _obj = Path(args.source).name.replace(".hip", ".o") if args.source else None
+    lines += [f"Library built from commit `{_info.get('commit')}`" + (f"; object `{_obj}` sha256 `{str(_info['objects'].get(_obj))[:16]}...`" if _obj else ""), ""]
+except Exception:
+    pass
 lines += ["| quantity | value |", "|---|---|", f"| launches in trace | {len(dur)} |"]
 if dur:
     lines.append(f"| mean / min / max duration (us), launches {args.skip_first + 1}.. | {mean_us:.1f} / {min(steady):.1f} / {max(steady):.1f} |")
@@ -181,7 +187,19 @@ if hbm is not None:
     except Exception:
         ents = []
     ents = [e for e in ents if not (e.get("kernel") == args.kname and e.get("windows") == args.windows)]
-    ents.append({"tag": args.tag, "kernel": args.kname, "windows": args.windows, "hbm_bytes_per_launch": hbm,
-                 "fetch_kib_raw": fetch_kib, "write_kib_raw": write_kib, "kernel_us_mean": mean_us})
+    ent = {"tag": args.tag, "kernel": args.kname, "windows": args.windows, "hbm_bytes_per_launch": hbm,
+           "fetch_kib_raw": fetch_kib, "write_kib_raw": write_kib, "kernel_us_mean": mean_us}
+    # which build was measured: the commit the library was built from and the SHA-256 of the kernel's object file
+    # (lib/build_info.json, written by csrc/Makefile at link time); bench.py compares the hash with the library it runs
+    try:
+        info = json.loads((REPO / "arm-pose-estimation_amd" / "lib" / "build_info.json").read_text())
+        ent["commit"] = info.get("commit")
+        if args.source:
+            obj = Path(args.source).name.replace(".hip", ".o")
+            ent["object"] = obj
+            ent["object_sha256"] = info["objects"].get(obj)
+    except Exception:
+        pass
+    ents.append(ent)
     tfile.write_text(json.dumps({"kernels": ents}, indent=1))
 print("\n".join(lines[:40]))
