@@ -281,17 +281,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
 #define UP_STAMP(acc)
 #endif
 
-    // One section = one step of one set: input span (+ recurrent span for t >= 1) with the OTHER set's traffic hung into the
-    // MFMA stream, [E] wait for that traffic + the section's ONE workgroup barrier, gates, publish (or, last step, the head).
-    // The barrier sits at the END of the MFMA chain, in front of the gate math: behind it (a) every wave has finished reading
-    // this set's LDS buffers -- whoever copies into them next (the other set's hooks, or this set's own blocking top when the
-    // other set is idle) comes later -- and (b) the other set's operands, prefetched by this section, are in LDS for every wave,
-    // so the next section starts its chain with no wait and no barrier at all; the skew of the four waves and the latency of the
-    // copies' tail hide under the gate math instead of in front of the first MFMA.  A section whose operands were NOT
-    // prefetched (pipeline fill, a late peer, the other set idle) fetches them itself at its top, with a barrier of its own.
+    // One section = one step of one set: S0 the set's operands are in LDS (prefetched by the other set's section, or fetched
+    // here in the blocking form: pipeline fill, a late peer, the other set idle), barrier, input span (+ recurrent span for
+    // t >= 1) with the OTHER set's traffic hung into the MFMA stream, gates, publish (or, last step, the head).
     // Vector-memory queue of a wave in a steady-state section, in issue order:
     //   [publish store of the section in front]  x DMA for the other set (8)  flag look (1 load)  h DMA for the other set (8)
-    //   -- all waited for at [E] --  [head partial store, last step only]  publish store (not on a last step)
+    //   [head partial store, last step only]  publish store (1; a store to nowhere on a last step)
+    // so at the top of a section everything but the youngest entry is waited for (`vmcnt(1)`), and a few k-blocks in the
+    // store itself has drained and its flag goes up.
     auto section = [&](auto set_tag, auto first_tag) -> bool {
         constexpr int s = decltype(set_tag)::value, o = s ^ 1;
         constexpr bool first = decltype(first_tag)::value;          // step 0 of a tile: no recurrent span (h_{-1} = 0)
@@ -301,11 +298,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         dg_sections += 1;
         dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- S0: operands not prefetched -> fetch them here --------------------------------------------------------------------
-        int abort_word = 0;
+        // ---- S0 ------------------------------------------------------------------------------------------------------------------
         if (ab_nobar) {
         } else if ((prex[s] || ab_nox) && (first || preh[s] || ab_noex)) {
-            // (in LDS since the barrier at [E] of the section in front)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // the prefetched copies; only the publish store is younger
         } else {
 #ifdef APE_CLUSTER_STAMPS
             if (!prex[s]) dg_block_x += 1; else dg_block_h += 1;
@@ -322,11 +318,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
                 for (int k = 0; k < NDMA; ++k) issue_h_piece(s, pub[s], k);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bar();
-            abort_word = ctl[0];
         }
         prex[s] = false;
         preh[s] = false;
+        // (UNCONDITIONAL: each wave judged the peers' flags for itself, so the four waves may take different forms of S0 -- a
+        //  barrier inside the blocking form would pair with the wrong one.  Round 3 tried the barrier at the end of the MFMA
+        //  chain with none here for prefetched operands: no gain, and exactly that mis-pairing under rocprofv3's timing.)
+        if (!ab_nobar) bar();
+        const int abort_word = ctl[0];
         // the other set's next section: (tile_of[o], step_of[o]); it needs its input tile, and from step 1 on the slices it
         // published last (epoch pub[o])
         const bool o_act = tile_of[o] >= 0 && !ab_nox;
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         //   QP        look at the other set's flags (one load per lane)       QJ  judge
         //   QJ .. +7  one piece of the other set's gather per block
         constexpr int QF = 3, QX = 4;
-        constexpr int QP = first ? 12 : 28, QJ = first ? 16 : 32;
+        constexpr int QP = first ? 16 : 28, QJ = first ? 20 : 32;
         auto mid = [&](int q) {
             if (q == QF) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -365,12 +364,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             span32<BH, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
             if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * BH, [&](int q) { mid(BH + q); });
         }
-        // ---- [E] the other set's copies have landed (this wave's share), every wave is through with this set's buffers -------------
-        if (!ab_nobar) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bar();
-            abort_word |= ctl[0];
-        }
+        // (the other set idle: THIS set runs the next section too, and its top copies into the buffers read above -- every wave
+        //  must be through with them first.  `tile_of[o] < 0` is state, not a flag judgement: uniform over the workgroup, so the
+        //  extra barrier pairs up.  With both sets active the copies into this set's buffers are issued from the other set's
+        //  section, behind ITS top barrier.)
+        if (tile_of[o] < 0 && !ab_nobar) bar();
         mfma_drain(acc);
         UP_STAMP(dg_chain)
         // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
@@ -412,17 +410,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
                 *reinterpret_cast<f32x4*>(p.ypart + (((size_t)tile * MR + rn) * GH + member) * PO + 4 * oq) = sum;
             }
         }
-        // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout (a last step publishes
-        //      nothing: its h feeds only the head) -----------------------------------------------------------------------------------
-        if (!last && !ab_noex) {
+        // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout; exactly ONE store
+        //      instruction per wave and section ends it (the counted wait at the top of the next section relies on that) --------
+        {
             const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
                               __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
-            const unsigned off = hx_base(s, (int)(pub[s] & 1u)) + pub_off;
+            const unsigned off = (last || ab_noex) ? 0x80000000u : hx_base(s, (int)(pub[s] & 1u)) + pub_off;
             if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
-            pub[s] += 1u;
-            pend_idx = s * NFL + member * 4 + wave;
-            pend_epoch = pub[s];
+            if (!last && !ab_noex) {
+                pub[s] += 1u;
+                pend_idx = s * NFL + member * 4 + wave;
+                pend_epoch = pub[s];
+            }
         }
         UP_STAMP(dg_tail)
         // ---- next step / next tile of this set -------------------------------------------------------------------------------------
