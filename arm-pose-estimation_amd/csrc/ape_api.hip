@@ -1165,6 +1165,8 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
                    dropout_p > 0.0f && n_mc >= 2 && (long long)b->S * n_mc >= 2LL * tile16_wave_rows(m->n_cus);
     if (b->xfrag) { (void)hipFree(b->xfrag); b->xfrag = nullptr; }
     if (b->ypart) { (void)hipFree(b->ypart); b->ypart = nullptr; }
+    if (b->xfrag0) { (void)hipFree(b->xfrag0); b->xfrag0 = nullptr; }
+    if (b->hfrag) { (void)hipFree(b->hfrag); b->hfrag = nullptr; }
     b->up32 = false;
     if (b->shared_l0) {
         const size_t rows = (size_t)b->S * b->T;
@@ -1185,6 +1187,9 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
                 b->chunk_rows = (int)chunk;
                 HIP_TRY(hipMalloc((void**)&b->xfrag, ape_upper32_xfrag_bytes(b->chunk_rows, b->T)));
                 HIP_TRY(hipMalloc((void**)&b->ypart, ape_upper32_ypart_bytes(b->chunk_rows)));
+                // layer 0 on the same cluster structure (its SEQ form): input tiles and the [tile][step] sequence, fragment order
+                HIP_TRY(hipMalloc((void**)&b->xfrag0, ape_lower32_xfrag_bytes(b->S, b->T)));
+                HIP_TRY(hipMalloc((void**)&b->hfrag, ape_lower32_hseq_bytes(b->S, b->T)));
                 b->up32 = true;
             }
         }
@@ -1199,6 +1204,8 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->y_new) (void)hipFree(b->y_new);
     if (b->xfrag) (void)hipFree(b->xfrag);
     if (b->ypart) (void)hipFree(b->ypart);
+    if (b->xfrag0) (void)hipFree(b->xfrag0);
+    if (b->hfrag) (void)hipFree(b->hfrag);
     for (auto ev : b->prof_ev) if (ev) (void)hipEventDestroy(ev);
     if (ape_model* m = b->model) {      // pending steps of this bank can no longer be re-issued
         int k = 0;
@@ -1291,6 +1298,26 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
         if ((size_t)b->S * b->T > m->hseq_cap) return fail(APE_ERR_CAPACITY, "streams_step: the layer-0 sequence workspace is gone");
         const int H = m->dims.hidden_size, I = m->dims.input_size, O = m->dims.output_size;
+        const bool cluster_route = b->up32 && !m->replaying;
+        hipError_t e = hipSuccess;
+        if (cluster_route) {
+            // launch A on the weight-stationary structure (lstm_upper32.hip, SEQ form): S streams in tiles of 32 on the clusters,
+            // every step's output in the fragment order launch B's input builder reads
+            XFragParams xq{};
+            xq.x = b->xring; xq.xfrag = b->xfrag0; xq.x_row_stride = (size_t)b->n_mc * b->T * I;
+            xq.xx_m = norm ? m->stats : nullptr; xq.xx_s = norm ? m->stats + I : nullptr;
+            xq.S = b->S; xq.T = b->T; xq.I = I; xq.x_ring = x_ring;
+            UpperParams u{};
+            u.xfrag = b->xfrag0; u.xfrag_bytes = ape_lower32_xfrag_bytes(b->S, b->T);
+            u.w = m->wcl32[0]; u.bias = m->bias[0]; u.w_out = m->w_out;
+            u.hx = m->hx; u.hx_bytes = m->hx_bytes;
+            u.xflags = m->xflags; u.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u.done = u.status - 3;
+            u.xcc_slots = m->xcc_slots; u.dbg_wg = m->dbg_wg;
+            u.hseq = b->hfrag; u.hseq_bytes = ape_lower32_hseq_bytes(b->S, b->T);
+            u.T = b->T; u.O = O; u.n_tiles = (b->S + 31) / 32;
+            e = ape_launch_lstm_lower32(u, xq, f16v2_capacity(m->n_cus), (hipStream_t)stream);
+            if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
+        } else {
         // launch A: layer 0 alone over the S windows (first copy of every stream's ring), all steps -> [S,T,H]
         LstmParams a{};
         a.x = b->xring; a.x_row_stride = (size_t)b->n_mc * b->T * I;
@@ -1300,18 +1327,19 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         a.xx_m = m->stats; a.xx_s = m->stats + I;
         a.B = b->S; a.T = b->T; a.I = I; a.O = O; a.KX = m->KX; a.x_ring = x_ring;
         a.flags = flags & APE_FLAG_NORMALIZE_INPUT;
-        hipError_t e = ape_launch_lstm_tile16(H, 1, a, (hipStream_t)stream);
+        e = ape_launch_lstm_tile16(H, 1, a, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 launch failed: %s", hipGetErrorString(e));
+        }
         // launch B: the layers above as an LSTM of their own over the S x n_mc sample rows; row r reads stream
         // r / n_mc's sequence under its own Philox mask (the counters of a fused launch over the same rows)
-        if (b->up32 && !m->replaying) {
+        if (cluster_route) {
             // weight-stationary form (lstm_upper32.hip): per chunk of sample rows the masked input in fragment order, the
             // persistent cluster kernel, the head reduce
             const long long total = (long long)b->S * b->n_mc;
             for (long long r0 = 0; r0 < total; r0 += b->chunk_rows) {
                 const int rows = (int)((total - r0 < b->chunk_rows) ? total - r0 : b->chunk_rows);
                 ExpandParams xq{};
-                xq.hseq = m->hseq_ws; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
+                xq.hseq = b->hfrag; xq.hseq_frag = 1; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
                 xq.layer = 0; xq.dropout_p = b->dropout_p; xq.seed = b->seed + b->mc_calls;
                 UpperParams u{};
                 u.xfrag = b->xfrag; u.xfrag_bytes = ape_upper32_xfrag_bytes(rows, b->T); u.ypart = b->ypart;

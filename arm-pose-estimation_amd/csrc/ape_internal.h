@@ -106,8 +106,20 @@ struct UpperParams {
     unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
     unsigned* xcc_slots;                // as ClusterParams::xcc_slots (class tickets + per-workgroup XCD words)
     unsigned long long* dbg_wg;         // diagnostic builds only
+    float* hseq;                        // layer-0 form only: [n_tiles][T][32 KB] every step's slices (fragment order)
+    size_t hseq_bytes;
     int T, O, n_tiles;
     unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
+};
+
+// Kernel arguments of the input builder of the layer-0 launch (ape_x_frag_kernel, lstm_upper32.hip).
+struct XFragParams {
+    const float* x;                     // window rings: stream s at x + s * x_row_stride, [T][I]
+    float* xfrag;                       // [tiles][T][4 KB]
+    const double* xx_m;                 // [I] or nullptr (no z-score)
+    const double* xx_s;
+    size_t x_row_stride;
+    int S, T, I, x_ring;
 };
 
 // Kernel arguments of the input builder of that launch (ape_mc_expand_kernel, lstm_upper32.hip).
@@ -120,6 +132,7 @@ struct ExpandParams {
     int layer;                          // model layer whose output hseq is (Philox counter word)
     float dropout_p;
     unsigned long long seed;
+    int hseq_frag;                      // 1: hseq is the layer-0 cluster kernel's [S / 32][T][k-block 32][stream 32][8] (fragment order)
 };
 
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor
@@ -216,6 +229,9 @@ hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const C
 bool ape_upper32_supported(int H, int L, int O);
 size_t ape_upper32_xfrag_bytes(int rows, int T);
 size_t ape_upper32_ypart_bytes(int rows);
+size_t ape_lower32_xfrag_bytes(int streams, int T);
+size_t ape_lower32_hseq_bytes(int streams, int T);
+hipError_t ape_launch_lstm_lower32(const UpperParams& p, const XFragParams& xq, int max_clusters, hipStream_t stream);
 hipError_t ape_prepare_lstm_upper32();
 hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
                                    hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);

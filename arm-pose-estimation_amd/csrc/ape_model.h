@@ -109,6 +109,8 @@ struct ape_streams {
     int chunk_rows = 0;
     float* xfrag = nullptr;      // [chunk tiles][T][32 KB] masked layer-0 output in MFMA fragment order
     float* ypart = nullptr;      // [chunk rows][8][16] head partial sums
+    float* xfrag0 = nullptr;     // [S / 32][T][4 KB] layer 0's input tiles, fragment order
+    float* hfrag = nullptr;      // [S / 32][T][32 KB] layer 0's output sequence, fragment order (launch B's input builder reads it)
     bool prof_on = false;        // ape_streams_profile: event pairs around the dominant kernel's launches
     int prof_n = 0;
     std::vector<hipEvent_t> prof_ev;

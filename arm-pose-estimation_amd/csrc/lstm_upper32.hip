@@ -79,6 +79,13 @@ __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
 // the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes
+// the publish store through the SAME scalar descriptor tuple as the gathers (a second, compiler-built copy of it costs four more
+// scalar registers in a kernel that already spills them); `sc1` = write-through form for clusters that span XCDs
+template <bool WT>
+__device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
+    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -88,19 +95,26 @@ constexpr int UH = 256;                  // hidden units = input width of the la
 constexpr int GH = 8;                    // members per cluster
 constexpr int MR = 32;                   // windows (sample rows) per tile
 constexpr int BH = UH / 8;               // k-blocks of 8 per span
-constexpr int NW = 4 * 2 * BH;           // weight registers per lane: [W_ih | W_hh], all in the accumulator file
+// (weight registers per lane: 4 * (KXB + BH) -- [W_ih | W_hh], all in the accumulator file; KXB = k-blocks of the input)
 constexpr int NFL = 4 * GH;              // flags per (cluster, set): one per member wave
 constexpr int HL = GH * 4 * MR * 8;      // floats of one slice set / one input tile-step [k-block 32][window 32][8] = 32 KB
 constexpr int NDMA = 8;                  // LDS-DMA instructions per wave and 32 KB copy
 constexpr int PO = 16;                   // width of a head partial row (O <= 16)
 constexpr unsigned SET_BYTES = HL * sizeof(float);
 
+// KXB = k-blocks of 8 of the layer's input: 32 (the layer above, 256-wide input) or 4 (layer 0 of the 2 x 256 models, I <= 32).
+// SEQ: the layer-0 form -- no head; every step's slices go to p.hseq ([tile][step][32 KB], the fragment order the layer above's
+// input builder reads) instead of the parity buffers, and the gather of step t reads step t - 1 from there.
+template <int KXB, bool SEQ>
 __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) {
+    constexpr int NW = 4 * (KXB + BH);
+    constexpr int NXD = (KXB + 3) / 4;       // LDS-DMA instructions per wave and input tile (1 KiB each, 4 waves)
+    constexpr unsigned XT_BYTES = KXB * 1024u;                   // bytes of one input tile-step
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hh = lane >> 5;     // window of the tile, half (units 4 hh .. 4 hh + 3 of the wave's 8)
-    const int T = p.T, O = p.O;
+    const int T = p.T, O = SEQ ? 0 : p.O;
     // timing-only switches of the ablation library (make ablate; results are garbage): what does each part of a section cost?
 #ifdef APE_ABLATE
     const unsigned ab = p.flags;
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     }
     // head: A fragment of the wave's four MFMAs -- column m = lane & 31 is target o = m (zero for m >= O), k = 4 hh + j is the
     // wave's unit 4 hh + j
-    {
+    if constexpr (!SEQ) {
         f32x4 wv = {0.0f, 0.0f, 0.0f, 0.0f};
         if (n < O) {
 #pragma unroll
@@ -174,12 +188,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     }
 
     // exchange buffer and input: descriptors as scalar tuples for the DMA asm, and one for the compiler's publish store
-    const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
-    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    // (ONE exchange buffer per form: the parity slices p.hx, or -- SEQ -- the sequence p.hseq that is both exchange and output)
+    float* const ex_ptr = SEQ ? p.hseq : p.hx;
+    const size_t ex_bytes = SEQ ? p.hseq_bytes : p.hx_bytes;
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(ex_ptr);
     u32x4 hx_desc;
     hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
     hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
-    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)ex_bytes);
     hx_desc[3] = 0x00020000u;
     const unsigned long long xf_addr = reinterpret_cast<unsigned long long>(p.xfrag);
     u32x4 xf_desc;
@@ -235,13 +251,23 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     // a 32 KB copy global -> LDS: wave w moves KiB w, w + 4, ... (8 of them); piece k on its own so that a copy can be spread
     // over the k-blocks of a span
     const unsigned dma_voff = (unsigned)(lane * 16);
-    auto issue_h_piece = [&](int s, unsigned epoch, int k) {      // the slices published as epoch `epoch` (>= 1) of set s -> hb[s]
-        const unsigned src = hx_base(s, (int)((epoch - 1u) & 1u)) + (unsigned)(wave * 1024 + k * 4096);
-        dma_1k(hb_lds + (unsigned)s * SET_BYTES + (unsigned)(wave * 1024 + k * 4096), dma_voff, hx_desc, src);
+    // the slices published as epoch `epoch` (>= 1) of set s -> hb[s]; SEQ: they are step t - 1 of the set's tile in the sequence buffer
+    // (the LDS base is laundered through an empty asm at every use: hipcc otherwise hoists all sixteen `base + k * 4096` sums of a
+    //  section out of the loop, runs out of scalar registers and parks them in VGPR lanes -- a v_readlane in front of every copy)
+    auto opaque = [](unsigned v) -> unsigned { asm volatile("" : "+s"(v)); return v; };
+    const unsigned wave_kib = (unsigned)(wave * 1024);
+    auto issue_h_piece = [&](int s, unsigned epoch, int tile, int t, int k) {
+        const unsigned dst = opaque(hb_lds + wave_kib) + (unsigned)s * SET_BYTES + (unsigned)(k * 4096);
+        if constexpr (SEQ) {
+            dma_1k(dst, dma_voff, hx_desc, (unsigned)(((size_t)tile * T + (t - 1)) * SET_BYTES) + (unsigned)(wave * 1024 + k * 4096));
+        } else {
+            dma_1k(dst, dma_voff, hx_desc, hx_base(s, (int)((epoch - 1u) & 1u)) + (unsigned)(wave * 1024 + k * 4096));
+        }
     };
-    auto issue_x_piece = [&](int s, int tile, int t, int k) {     // input of (tile, step t) -> xb[s]
-        const unsigned src = (unsigned)(((size_t)tile * T + t) * SET_BYTES) + (unsigned)(wave * 1024 + k * 4096);
-        dma_1k(xb_lds + (unsigned)s * SET_BYTES + (unsigned)(wave * 1024 + k * 4096), dma_voff, xf_desc, src);
+    auto issue_x_piece = [&](int s, int tile, int t, int k) {     // input of (tile, step t) -> xb[s]: KiB wave + 4 k of its KXB
+        if (wave + 4 * k >= KXB) return;
+        const unsigned src = (unsigned)(((size_t)tile * T + t) * XT_BYTES) + (unsigned)(wave * 1024 + k * 4096);
+        dma_1k(opaque(xb_lds + wave_kib) + (unsigned)s * SET_BYTES + (unsigned)(k * 4096), dma_voff, xf_desc, src);
     };
     // the flag a wave owes for the slice it stored last: raised once that store has drained
     int pend_idx = -1;
@@ -310,12 +336,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             raise_pending();
             if (!prex[s] && !ab_nox) {
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_x_piece(s, tile, t, k);
+                for (int k = 0; k < NXD; ++k) issue_x_piece(s, tile, t, k);
             }
             if (!first && !ab_noex) {
                 wait_flags(s, pub[s]);
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_h_piece(s, pub[s], k);
+                for (int k = 0; k < NDMA; ++k) issue_h_piece(s, pub[s], tile, t, k);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -344,13 +370,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
             }
-            if (q >= QX && q < QX + NDMA && o_act) issue_x_piece(o, tile_of[o], step_of[o], q - QX);
+            if (q >= QX && q < QX + NXD && o_act) issue_x_piece(o, tile_of[o], step_of[o], q - QX);
             if (q == QP) peek = peek_issue(flags_of + o * NFL + (lane & (NFL - 1)));     // (always: no branch, no merge of `peek`)
             if (q == QJ) {
                 peek_wait(peek);
                 go = o_h && __all((int)(peek >= pub[o])) != 0;
             }
-            if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, pub[o], q - QJ);
+            if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, pub[o], tile_of[o], step_of[o], q - QJ);
         };
         UP_STAMP(dg_top)
         // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs ---------------------------------------------------------
@@ -361,8 +387,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
         }
         if (!ab_nomfma) {
-            span32<BH, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
-            if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * BH, [&](int q) { mid(BH + q); });
+            span32<KXB, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
+            if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * KXB, [&](int q) { mid(KXB + q); });
+        }
+        // (a section shorter than the hook schedule -- step 0 of the narrow-input form is 4 k-blocks -- runs the rest of it here)
+        {
+            constexpr int NBLK = first ? KXB : KXB + BH;
+#pragma unroll
+            for (int q = NBLK; q < QJ + NDMA; ++q) mid(q);
         }
         // (the other set idle: THIS set runs the next section too, and its top copies into the buffers read above -- every wave
         //  must be through with them first.  `tile_of[o] < 0` is state, not a flag judgement: uniform over the workgroup, so the
@@ -384,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         prex[o] = o_act;
         preh[o] = go;
-        if (last) {
+        if (!SEQ && last) {
             // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h values are the activation fragment ----
             f32x16 ya;
 #pragma unroll
@@ -415,9 +447,17 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         {
             const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
                               __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
-            const unsigned off = (last || ab_noex) ? 0x80000000u : hx_base(s, (int)(pub[s] & 1u)) + pub_off;
-            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            if constexpr (SEQ) {
+                // every step's slices ARE the output: [tile][step][member][wave][window][8 units]; a last step's are awaited by
+                // nobody inside the launch (its flag is raised all the same: one rule)
+                const unsigned off = ab_noex ? 0x80000000u : (unsigned)(((size_t)tile * T + t) * SET_BYTES) + pub_off;
+                if (in_l2) store_16<false>(hv, off, hx_desc);
+                else store_16<true>(hv, off, hx_desc);
+            } else {
+                const unsigned off = (last || ab_noex) ? 0x80000000u : hx_base(s, (int)(pub[s] & 1u)) + pub_off;
+                if (in_l2) store_16<false>(hv, off, hx_desc);
+                else store_16<true>(hv, off, hx_desc);
+            }
             if (!last && !ab_noex) {
                 pub[s] += 1u;
                 pend_idx = s * NFL + member * 4 + wave;
@@ -475,6 +515,27 @@ constexpr size_t smem_upper() {
     return (size_t)4 * HL * sizeof(float) + (size_t)(4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + 16;
 }
 
+// ---- the input of the layer-0 launch in fragment order: [tile][step][k-block 4][stream 32][8 features] ---------------------------
+// One workgroup per (tile of 32 streams, step): ring order undone (step t lives in slot (t + x_ring) mod T), f64 z-score then
+// float32 (estimator.py:103-104 + watch_phone_pocket_nn.py:100, the formula of lstm_tile16.hip), columns I .. 31 and streams
+// past the bank zero.
+__global__ __launch_bounds__(256) void ape_x_frag_kernel(const XFragParams q) {
+    const unsigned tile = blockIdx.x / (unsigned)q.T, t = blockIdx.x - tile * (unsigned)q.T;
+    const int slot = ((int)t + q.x_ring >= q.T) ? (int)t + q.x_ring - q.T : (int)t + q.x_ring;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = threadIdx.x + 256 * e;                    // k-block idx / 256, stream (idx / 8) % 32, feature idx % 8
+        const int kb = idx >> 8, row = (idx >> 3) & 31, k = kb * 8 + (idx & 7);
+        const int stream = (int)tile * MR + row;
+        float v = 0.0f;
+        if (k < q.I && stream < q.S) {
+            v = q.x[(size_t)stream * q.x_row_stride + (size_t)slot * q.I + k];
+            if (q.xx_m != nullptr) v = (float)(((double)v - q.xx_m[k]) / q.xx_s[k]);
+        }
+        q.xfrag[((size_t)tile * q.T + t) * 1024 + idx] = v;
+    }
+}
+
 // ---- the masked input of launch B, in the fragment order the kernel above copies ------------------------------------------------
 // Sample row r (row_base + its index in this chunk) is sample r % n_mc of stream r / n_mc; its input at step t is that stream's
 // layer-0 output h0[stream][t][unit] under the inter-layer dropout mask (nn.LSTM dropout, nn_models.py:169-174), drawn with the
@@ -503,7 +564,8 @@ __global__ __launch_bounds__(256) void ape_mc_expand_kernel(const ExpandParams q
         for (int i = 0; i < 4; ++i) {
             float v = 0.0f;
             if (row0 + 4 * g + i < (unsigned)q.rows) {
-                v = q.hseq[((size_t)stream * q.T + t) * UH + unit];
+                v = q.hseq_frag ? q.hseq[((size_t)(stream >> 5) * q.T + t) * HL + (unit >> 3) * (MR * 8) + (stream & 31) * 8 + (unit & 7)]
+                                : q.hseq[((size_t)stream * q.T + t) * UH + unit];
                 if (drop) {
                     const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
                     v = (uf >= q.dropout_p) ? v * keep : 0.0f;
@@ -540,11 +602,28 @@ __global__ __launch_bounds__(256) void ape_head_reduce_kernel(const float* __res
 
 bool ape_upper32_supported(int H, int L, int O) { return H == UH && L == 2 && O <= PO; }
 size_t ape_upper32_xfrag_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * SET_BYTES; }
+size_t ape_lower32_xfrag_bytes(int streams, int T) { return (size_t)((streams + MR - 1) / MR) * T * 4 * 1024; }
+size_t ape_lower32_hseq_bytes(int streams, int T) { return (size_t)((streams + MR - 1) / MR) * T * SET_BYTES; }
 size_t ape_upper32_ypart_bytes(int rows) { return (size_t)((rows + MR - 1) / MR) * MR * GH * PO * sizeof(float); }
 
 hipError_t ape_prepare_lstm_upper32() {
     static_assert(smem_upper() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+}
+
+// layer 0 of the S streams of a Monte-Carlo bank, every step's output in fragment order (p.hseq): the input tiles first
+// (ape_x_frag_kernel: ring order undone, f64 z-score, zero padding to 32 columns), then the SEQ form of the cluster kernel
+hipError_t ape_launch_lstm_lower32(const UpperParams& p, const XFragParams& xq, int max_clusters, hipStream_t stream) {
+    if (p.n_tiles < 1 || max_clusters < 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ape_x_frag_kernel, dim3(p.n_tiles * p.T), dim3(256), 0, stream, xq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int clusters = (p.n_tiles + 7) / 8 * 8;
+    if (clusters > max_clusters) clusters = max_clusters;
+    hipLaunchKernelGGL((ape_lstm_upper32<4, true>), dim3(clusters * GH), dim3(256), smem_upper(), stream, p);
+    return hipGetLastError();
 }
 
 // one chunk of sample rows: expand -> upper layer -> head reduce, all on `stream`.  `max_clusters` = 32-row clusters the device
@@ -558,7 +637,7 @@ hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, 
     int clusters = (p.n_tiles + 7) / 8 * 8;
     if (clusters > max_clusters) clusters = max_clusters;
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);          // (measurement aid: ape_streams_profile)
-    hipLaunchKernelGGL(ape_lstm_upper32, dim3(clusters * GH), dim3(256), smem_upper(), stream, p);
+    hipLaunchKernelGGL((ape_lstm_upper32<32, false>), dim3(clusters * GH), dim3(256), smem_upper(), stream, p);
     e = hipGetLastError();
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     if (e != hipSuccess) return e;
