@@ -225,6 +225,14 @@ def batch1_latency(model, stats, n_frames=1000):
            "p50_us": float(np.percentile(us, 50)), "p99_us": float(np.percentile(us, 99)),
            "frames_per_s": float(1e6 / np.mean(us))}
     out.update(_tail_report(us, "ape_infer"))
+    # the roofline that binds this configuration is latency, not a throughput peak: T + L - 1 = 7 dependent phases,
+    # each one register-resident GEMV pass + ONE hop through the XCD's L2, behind a weight prologue (profiles/r03_small_stamps.md)
+    floor = 2.82 + 7 * (0.69 + 0.24) + 0.34
+    out["latency_floor_us"] = floor
+    out["frac_of_latency_floor"] = floor / out["p50_us"]
+    out["latency_floor_note"] = ("kernel floor = prologue 2.82 + 7 phases x (compute 0.69 + in-XCD granule hop 0.24) + head 0.34 us, from the "
+                                 "stamps in profiles/r03_small_stamps.md (kernel itself: 11.1 us); p50 is the whole host-synchronised "
+                                 "frame, i.e. it also holds one direct launch + completion (~6 us)")
     # ONE launch per frame (the latency kernel carries the post-filter), issued directly: a hipGraph replay of the same frame
     # is slower on this ROCm (graph_replay_* below; a replay costs ~10-16 us of host time per forward, MI355X guide,
     # "graph-replay-floor"), so the latency path launches directly
@@ -354,6 +362,12 @@ def stream_bank_numbers(model, stats):
                                "kernel": kname, "kernel_ms": k_ms, "launches_per_frame": launches / frames,
                                "flop_per_frame": flop, "hbm_algorithmic_bytes_per_frame": alg_bytes,
                                "kernel_share_of_frame": k_ms / ms}
+            if n_mc:
+                # stated plainly: h_{-1} = 0, so step 0's recurrent span is algorithmic work the kernel does not execute (like
+                # the batch-tile kernel before it): 11/12 of the FLOP above run on the matrix cores at T = 6
+                ex = rows_total * ((6 * 2 - 1) * 2.0 * 4 * POCKET["H"] * POCKET["H"] + 2.0 * POCKET["O"] * POCKET["H"])
+                ent["roofline"]["flop_executed_per_frame"] = ex
+                ent["roofline"]["frac_executed"] = ex / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
             out[f"S{S}_mc{n_mc or 1}"] = ent
             del bank
     except Exception as exc:                # reported, never fatal for the headline line
@@ -531,8 +545,13 @@ def fp16_config4(stats_watch, n_iter=20):
                          "frac": tf16 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag, "traffic_stale": tstale,
                          "kernel": names["f16"], "kernel_ms": out["f16"], "flop_per_launch": flop,
                          "hbm_algorithmic_bytes_per_launch": alg_bytes,
+                         # the bound that binds: 2 (T + 2) = 132 dependent sections, each MFMA spans + gate math + ONE hop
+                         # through the XCD's L2 (cycles from profiles/r03_f16v2_stamps.md / r03_small_stamps.md at 2.31 GHz)
+                         "latency_floor_us": 2 * (T_FRAMES + 2) * (1140 + 898 + 546) / 2310.0,
+                         "frac_of_latency_floor": 2 * (T_FRAMES + 2) * (1140 + 898 + 546) / 2310.0 / (out["f16"] * 1e3),
                          "note": "latency-bound, not matrix-bound: per layer-step a wave has 2 x 16 f16 MFMAs (~0.5K cycles) "
-                                 "between two cluster-wide exchanges of h; the f16 dense MFMA peak is the stated roofline"}}
+                                 "between two cluster-wide exchanges of h; the f16 dense MFMA peak is the stated roofline, "
+                                 "latency_floor_us = sections x (MFMA spans + gates + one in-XCD hop) the one that binds"}}
 
 
 PREROLL = 40        # untimed clock-ramp steps in front of the warmup steps
