@@ -1161,8 +1161,13 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     // stream): worth its extra launch from two batch-tile waves of sample rows on.  The [S,T,H] sequence lives in the
     // model's all-steps workspace, sized here so that the step itself never allocates.
     ape_model* m = b->model;
+    // (on the weight-stationary route -- lstm_upper32.hip, both launches -- the sharing pays from 2048 sample rows on: two
+    //  32-row tiles per cluster, against four 512-row launches of the fused first-generation dropout kernel)
+    const long long sample_rows = (long long)b->S * n_mc;
+    const bool can_up32 = m->up32_ok && m->c32_on && f16v2_capacity(m->n_cus) >= 8;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
-                   dropout_p > 0.0f && n_mc >= 2 && (long long)b->S * n_mc >= 2LL * tile16_wave_rows(m->n_cus);
+                   dropout_p > 0.0f && n_mc >= 2 &&
+                   (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= 2048));
     if (b->xfrag) { (void)hipFree(b->xfrag); b->xfrag = nullptr; }
     if (b->ypart) { (void)hipFree(b->ypart); b->ypart = nullptr; }
     if (b->xfrag0) { (void)hipFree(b->xfrag0); b->xfrag0 = nullptr; }
@@ -1175,7 +1180,7 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
             HIP_TRY(hipMalloc((void**)&m->hseq_ws, rows * m->dims.hidden_size * sizeof(float)));
             m->hseq_cap = rows;
         }
-        if (m->up32_ok && m->c32_on) {
+        if (can_up32) {
             // chunks of equal size whose expanded input (T KiB per sample row) stays under 256 MB -- the size of the Infinity
             // Cache, and far inside one 32-bit buffer descriptor; whole 1024-row waves of clusters where that costs nothing
             const long long total = (long long)b->S * n_mc;

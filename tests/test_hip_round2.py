@@ -440,3 +440,36 @@ def test_two_estimator_threads_on_the_latency_kernel(norm_stats):
             assert np.array_equal(got[k], want[k]), (k, float(d.max()))
         else:
             assert float(d.max()) < 1e-6 and int((d > 0).sum()) <= st["reissued_calls"], (k, st, float(d.max()))
+
+
+# ---------------- Monte-Carlo bank on the weight-stationary route (lstm_upper32.hip), shapes the other tests do not reach -----------
+@pytest.mark.parametrize("name,S,n_mc,T", [("pocket", 83, 25, 1), ("watch", 83, 25, 2), ("pocket", 350, 7, 3), ("pocket", 41, 60, 6),
+                                            ("watch", 1100, 2, 8)])
+def test_mc_bank_cluster_route_against_batch_tile_route(golden, norm_stats, name, S, n_mc, T):
+    """layer 0 once per stream + the layer above over the sample rows, both on the persistent cluster kernels (AUTO), against the
+    same bank on the batch-tile kernels ('auto_gen1': same Philox counters, so the same dropout masks): window lengths 1 .. 8, sample
+    rows from 2048 on (the route's threshold), ragged last tiles, streams that straddle tiles, n_mc = 2 .. 60, several frames so
+    that the window rings wrap.  Every stacked row's hand / elbow position to 5e-6 (float32 summation order), messages to 5e-5."""
+    from wear_mocap_ape_amd.streams import StreamBank
+    assert S * n_mc >= 2048
+    stats = norm_stats[name]
+    cfg = orc.MODEL_CONFIGS[name]
+    feats = _synthetic_windows(stats, S, T + 3, cfg["I"], 77)
+    outs = {}
+    for kern in ("auto", "auto_gen1"):
+        m, sd, _ = make_model(name, 21, stats)
+        m.set_body(orc.DEFAULT_BODY)
+        m.set_kernel(kern)
+        bank = StreamBank(m, S, T, smooth=2, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=4242)
+        res = []
+        for f in range(T + 3):
+            bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+            msg, tail = bank.step(with_tail=True)
+            res.append((msg.cpu().numpy().copy(), tail.cpu().numpy().copy()))
+        m.check()
+        outs[kern] = res
+        del bank
+    worst_tail = max(float(np.abs(a[1] - b[1]).max()) for a, b in zip(outs["auto"], outs["auto_gen1"]))
+    worst_msg = max(float(np.abs(a[0] - b[0]).max()) for a, b in zip(outs["auto"], outs["auto_gen1"]))
+    assert worst_tail < 5e-6 and worst_msg < 5e-5, (worst_tail, worst_msg)
+    assert worst_tail > 0.0          # (two different kernels: not the same launch twice)
