@@ -107,16 +107,26 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // dropout variant) however few of its rows are used.  Both rates scale with the CU count of the device.
 // `wide` (ImuPoseLSTM, 256-wide layer-0 input): a full batch-tile wave sustains 123 TFLOP/s, the two-tile cluster launch
 // (512 rows) costs 20 + 11 T -- 95 TFLOP/s when full, so whole waves go to the batch-tile kernel and the rest to the cluster.
+// which cluster kernel serves `rest` rows behind the batch-tile waves (the ONE rule lstm_forward_impl, the cost model and
+// ape_debug_plan share): the second-generation f32 kernel from 513 rows on where the model and the call allow it (`c32`:
+// a 2 x 256 model, eval mode, last-step output), else the first-generation kernel
+enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3 };
+static int rest_kernel(int rest, bool c32) { return rest <= 0 ? PLAN_NONE : (c32 && rest > 512) ? PLAN_C32 : PLAN_GEN1; }
+
 static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, bool c32 = false, bool wide = false) {
     const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop || wide);
     if (rpl == 0) return (B + wave - 1) / wave;          // no cluster fits on this device
     const double rate = (wide ? 1.23e14 : dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
     const double t16 = (double)wave * ape_flops_per_window(dims, T) / rate * 1e6;
-    // (second-generation f32 cluster kernel, eval mode: 16 + 12.4 T per launch of up to 1024 rows, round 2)
-    const double tcl = wide ? 20.0 + 11.0 * T : cdrop ? 22.0 + 8.4 * T : (c32 ? 16.0 + 12.4 * T : 25.0 + 13.7 * T);
+    // first-generation launches: 25 + 13.7 T (22 + 8.4 T with dropout, 20 + 11 T wide); second-generation f32 kernel, eval mode:
+    // 16 + 12.4 T per launch of up to 32 x f16v2_capacity rows -- priced only where rest_kernel() really picks it
+    const double tcl1 = wide ? 20.0 + 11.0 * T : cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
+    const int rpl2 = 32 * f16v2_capacity(n_cus);
     auto cost = [&](int w) {
         const int rest = B - wave * w;
-        return w * t16 + (rest > 0 ? (double)((rest + rpl - 1) / rpl) * tcl : 0.0);
+        if (rest <= 0) return w * t16;
+        if (rest_kernel(rest, c32 && !cdrop && !wide && rpl2 > 0) == PLAN_C32) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (16.0 + 12.4 * T);
+        return w * t16 + (double)((rest + rpl - 1) / rpl) * tcl1;
     };
     int best = 0;
     double best_cost = cost(0);
@@ -730,7 +740,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path && !m->wide_cluster;   // latency path: VALU GEMV, one exchange per phase
         const int small_uw = (flags & APE_DIAG_SMALL_UW4) ? 4 : m->small_uw;
-        if (!f16 && !cdrop && !drop && !all_steps && !small && m->c32_ok && m->c32_on && B - n16 > 512) {
+        if (!f16 && !small && rest_kernel(B - n16, !cdrop && !drop && !all_steps && m->c32_ok && m->c32_on) == PLAN_C32) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
             const int rpl2 = 32 * f16v2_capacity(m->n_cus);
             for (int b0 = n16; b0 < B; b0 += rpl2) {
@@ -1481,26 +1491,44 @@ int ape_debug_peek_pipe(ape_model_t* m, int first, unsigned* out, int n) {
 
 // internal: the batch split of lstm_forward for a device with `n_cus` CUs, no GPU needed.
 // out = {rows to the batch-tile kernel, row tiles per cluster, clusters per launch, cluster launches, cluster capacity}
-int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, int out[5]) {
+// `c32`: the model / call is eligible for the second-generation f32 kernel (what lstm_forward_impl passes for an eval-mode,
+// last-step call on a 2 x 256 model); out[5] = the kernel that serves the rest (PLAN_*), with the second-generation kernel out[1]
+// (row tiles) is 2 = its 32-row clusters
+int ape_debug_plan2(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, int c32, int out[6]) {
     if (!dims || !out || n_cus < 1 || B < 1 || T < 1) return APE_ERR_INVALID_ARG;
     const int H = dims->hidden_size;
     const int cap = cluster_capacity(n_cus, H);
-    out[4] = cap;
+    out[4] = cap; out[5] = PLAN_NONE;
     if (cap < 1) { out[0] = B; out[1] = out[2] = out[3] = 0; return APE_OK; }
+    const bool c32_ok = c32 != 0 && !cdrop && ape_cluster32_supported(H, dims->num_layers, padded_input(dims->input_size)) && f16v2_capacity(n_cus) > 0;
     long long n16 = 0;
-    if (B > 4) n16 = (long long)tile16_wave_rows(n_cus) * auto_tile16_waves(dims, n_cus, B, T, cdrop != 0);
+    if (B > 4) n16 = (long long)tile16_wave_rows(n_cus) * auto_tile16_waves(dims, n_cus, B, T, cdrop != 0, c32_ok);
     if (n16 > B) n16 = B;
     out[0] = (int)n16;
     const int rest = B - (int)n16;
     out[1] = out[2] = out[3] = 0;
     if (rest > 0) {
-        const int nmt = cluster_nmt(n_cus, H, rest, cdrop != 0), rpl = 16 * nmt * cap;
-        out[1] = nmt;
-        out[3] = (rest + rpl - 1) / rpl;
-        const int first = rest < rpl ? rest : rpl;
-        out[2] = (first + 16 * nmt - 1) / (16 * nmt);
+        out[5] = (B <= 4 && !cdrop) ? PLAN_SMALL : rest_kernel(rest, c32_ok);
+        if (out[5] == PLAN_C32) {
+            const int rpl2 = 32 * f16v2_capacity(n_cus);
+            out[1] = 2;
+            out[3] = (rest + rpl2 - 1) / rpl2;
+            out[2] = ((rest < rpl2 ? rest : rpl2) + 31) / 32;
+        } else {
+            const int nmt = cluster_nmt(n_cus, H, rest, cdrop != 0), rpl = 16 * nmt * cap;
+            out[1] = nmt;
+            out[3] = (rest + rpl - 1) / rpl;
+            const int first = rest < rpl ? rest : rpl;
+            out[2] = (first + 16 * nmt - 1) / (16 * nmt);
+        }
     }
     return APE_OK;
+}
+int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, int out[5]) {
+    int o6[6];
+    const int rc = ape_debug_plan2(dims, n_cus, B, T, cdrop, 0, o6);
+    if (rc == APE_OK) for (int i = 0; i < 5; ++i) out[i] = o6[i];
+    return rc;
 }
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {

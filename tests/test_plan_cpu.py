@@ -49,3 +49,38 @@ def test_batch_split_follows_the_cu_count():
                     per_launch = 16 * p["nmt"] * p["capacity"]
                     assert (p["launches"] - 1) * per_launch < rest <= p["launches"] * per_launch
                     assert p["clusters"] <= p["capacity"]
+
+
+def _plan2(dims, n_cus, B, T, cdrop=0, c32=1):
+    from wear_mocap_ape_amd import _hip
+    lib = _hip.lib()
+    lib.ape_debug_plan2.restype = C.c_int
+    lib.ape_debug_plan2.argtypes = [C.POINTER(_hip.ApeDims), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 6)]
+    out = (C.c_int * 6)()
+    assert lib.ape_debug_plan2(C.byref(dims), n_cus, B, T, cdrop, c32, C.byref(out)) == 0
+    return dict(n16=out[0], nmt=out[1], clusters=out[2], launches=out[3], capacity=out[4], kernel=out[5])
+
+
+def test_split_with_the_second_generation_kernel():
+    """the same rule as the real dispatch (`rest_kernel`): eval-mode calls on a 2 x 256 model go to the second-generation f32
+    kernel from 513 rows on, in launches of 32 clusters x 32 rows; smaller rests, dropout calls and other shapes stay on the
+    first generation -- and the cost model prices a rest on the kernel that will really run it"""
+    from wear_mocap_ape_amd import _hip
+    GEN1, C32, SMALL = 1, 2, 3
+    pocket = _hip.ApeDims(22, 256, 2, 14, 0, 0, _hip.MODEL_LSTM)
+    uarm = _hip.ApeDims(38, 128, 3, 12, 1, 0, _hip.MODEL_LSTM)
+    assert _plan2(pocket, 256, 1024, 64) == dict(n16=0, nmt=2, clusters=32, launches=1, capacity=16, kernel=C32)
+    assert _plan2(pocket, 256, 513, 6)["kernel"] == C32 and _plan2(pocket, 256, 512, 6)["kernel"] == GEN1
+    assert _plan2(pocket, 256, 1, 6)["kernel"] == SMALL and _plan2(pocket, 256, 5, 6)["kernel"] == GEN1
+    assert _plan2(pocket, 256, 1024, 64, cdrop=1)["kernel"] == GEN1
+    assert _plan2(uarm, 256, 1024, 64)["kernel"] == GEN1
+    # round 2's test case: 4396 rows x 64 frames stay on the cluster kernel altogether (five launches of it are priced below a
+    # batch-tile wave + one more launch) ...
+    p = _plan2(pocket, 256, 4396, 64)
+    assert p["n16"] == 0 and p["kernel"] == C32 and p["launches"] == 5
+    # ... while at T = 6 the front wave goes to the batch-tile kernel and the 300-row rest to the FIRST generation
+    p = _plan2(pocket, 256, 4396, 6)
+    assert p["n16"] == 4096 and p["kernel"] == GEN1
+    # a device with 64 CUs holds 8 second-generation clusters: 256 rows per launch
+    p = _plan2(pocket, 64, 1024, 64)
+    assert p["kernel"] == C32 and p["launches"] == 4 and p["clusters"] == 8
