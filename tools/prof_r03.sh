@@ -26,9 +26,12 @@ cluster32)
   ;;
 bank_mc)
   passes python3 tests/tools/bank_trace.py 1024 25 40
-  python3 tools/summarize_prof.py r03_bank_mc $P/trace $P/fetch $P/write ape_lstm_upper32 65536 25600 --pmc-dir $P/mfma --pmc-dir $P/wave \
-    --source csrc/lstm_upper32.hip --lds 143888 --flop-per-launch 1.61244774400e11 --peak-tflops 157.3 --skip-first 6 \
-    --note "Command (MI355X, one GPU): \`rocprofv3 --kernel-trace --stats -- python3 tests/tools/bank_trace.py 1024 25 40\` = a stream bank of 1024 streams x 25 Monte-Carlo dropout samples (the deployed estimators' default, watch_phone_pocket_nn.py:13-19), T = 6, 6 + 40 frames; one frame = feature builder, layer 0 once per stream (\`ape_lstm_tile16<256, 1, 4>\`), input builder (\`ape_mc_expand_kernel\`), THIS kernel over the 25 600 sample rows (800 tiles of 32 rows on 32 clusters of 8 workgroups), head reduce, post kernel.  Algorithmic FLOP of the launch = 25 600 rows x (6 steps x 2 x 4H x (H + H) + 2 O H) = 161.2 GFLOP (the reference runs the repeated window through both layers, nn_models.py:191-207; layer 0 is shared here).  Recipe \`tools/prof_r03.sh bank_mc\`."
+  python3 tools/summarize_prof.py r03_bank_l0 $P/trace $P/fetch $P/write "ape_lstm_upper32<4, true>" 65536 1024 --pmc-dir $P/mfma --pmc-dir $P/wave \
+    --source csrc/lstm_upper32.hip --lds 143920 --flop-per-launch 3.498049536e9 --peak-tflops 157.3 --skip-first 6 \
+    --note "Launch A of the same frames (see r03_bank_mc.md): layer 0 once per stream, 1024 streams = 32 tiles of 32 on 32 clusters (ONE tile per cluster: every exchange is exposed), T = 6; algorithmic FLOP = 1024 x 6 x 2 x 4H x (I + H) with I = 22.  Latency-bound by construction at this size (3.8 us of MFMAs + one exposed exchange per step); it replaces 124 us of the batch-tile kernel on 64 CUs."
+  python3 tools/summarize_prof.py r03_bank_mc $P/trace $P/fetch $P/write "ape_lstm_upper32<32, false>" 65536 25600 --pmc-dir $P/mfma --pmc-dir $P/wave \
+    --source csrc/lstm_upper32.hip --lds 143920 --flop-per-launch 1.61244774400e11 --peak-tflops 157.3 --skip-first 6 \
+    --note "Command (MI355X, one GPU): \`rocprofv3 --kernel-trace --stats -- python3 tests/tools/bank_trace.py 1024 25 40\` = a stream bank of 1024 streams x 25 Monte-Carlo dropout samples (the deployed estimators' default, watch_phone_pocket_nn.py:13-19), T = 6, 6 + 40 frames; one frame = feature builder, input tiles (\`ape_x_frag_kernel\`), layer 0 once per stream (\`ape_lstm_upper32<4, true>\`, r03_bank_l0.md), input builder (\`ape_mc_expand_kernel\`), THIS kernel over the 25 600 sample rows (800 tiles of 32 rows on 32 clusters of 8 workgroups), head reduce, post kernel.  Algorithmic FLOP of the launch = 25 600 rows x (6 steps x 2 x 4H x (H + H) + 2 O H) = 161.2 GFLOP (the reference runs the repeated window through both layers, nn_models.py:191-207; layer 0 is shared here).  Recipe \`tools/prof_r03.sh bank_mc\`."
   ;;
 pipe)
   passes python3 tests/tools/time_mlp.py 262144
