@@ -150,10 +150,24 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 
     // every wave polls for itself (no barrier on the way): all members published epoch `want` of layer l?
     // bounded; on give-up raises the sticky status word and the workgroup abort flag
-    auto peek_flags = [&](int l, unsigned want) -> unsigned {      // non-blocking: the load only
-        if (diag_noex || lane >= NFL) return want;
-        return __hip_atomic_load(myflags + l * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // non-blocking look: the load only.  Eval-mode instantiations issue it by inline asm and first touch it at the judge
+    // (peek_wait): hipcc hoists the comparison of a compiler-visible load up to the load and waits `vmcnt(0)` right behind it, an
+    // L2 round trip exposed in every section (round 3, found in the disassembly; lstm_cluster32.hip).  Measured on this kernel:
+    // upper-arm model 1024 x 64 530 -> 513 us, ImuPoseLSTM neutral -- but the dropout instantiations (the estimators' 25-sample
+    // Monte-Carlo launch, T = 6) LOSE 1 us of 43 with it (there the exposed wait gives late flags time to arrive), so they keep
+    // the compiler-visible form.
+    auto peek_flags = [&](int l, unsigned want) -> unsigned {
+        if constexpr (DROP) {
+            if (diag_noex || lane >= NFL) return want;
+            return __hip_atomic_load(myflags + l * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned v;
+            const unsigned* addr = myflags + l * NFL + (lane & (NFL - 1));
+            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
+            return v;
+        }
     };
+    auto peek_wait = [&](unsigned& v) { if constexpr (!DROP) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); };
     auto wait_flags = [&](int l, unsigned want, unsigned peeked) {
         if (diag_noex) return;
         if (__all((int)(peeked >= want))) return;                  // the prefetched look was enough
@@ -395,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             static_assert(CBLK <= QH - 1 && APE_QP + APE_QJ + GBLK <= 2 * QH - CBLK && CBLK <= APE_QP + APE_QJ - 1 + 1,
                           "k-block schedule does not fit");
             unsigned peeked = 0u;
+            bool peek_pending = false;                   // (eval-mode form) a look is in flight and has not been waited for
             bool ready = false, new_done = false;
             unsigned goff = g_thread_off + 0x80000000u;
             auto hook = [&](int q) {
@@ -404,9 +419,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                         if (q * CPB + j < NGH) commit_piece(l, q * CPB + j, gv);
                 }
                 if (q == QF) raise_pending();
-                if (q == QP) peeked = peek_flags(ln, (unsigned)tn);
+                if (q == QP) { peeked = peek_flags(ln, (unsigned)tn); peek_pending = true; }
                 if (q == Q0) {
-                    ready = pre && __all((int)(peeked >= (unsigned)tn)) != 0;
+                    if (peek_pending) { peek_wait(peeked); peek_pending = false; }
+                    ready = pre && (diag_noex || __all((int)(peeked >= (unsigned)tn)) != 0);
                     goff = g_thread_off + (ready ? 0u : 0x80000000u);
                 }
                 if (q >= Q0 && q < Q0 + GBLK) {
@@ -461,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 #ifdef APE_CLUSTER_STAMPS
             if (pre && !ready) st_acc[l == 0 ? 0 : 11] += 1;    // diagnostic: how often the blocking path runs
 #endif
+            if (peek_pending) { peek_wait(peeked); peek_pending = false; }     // (a short section: looked, never judged)
             if (pre && !ready) {                         // first step of a layer, or a peer was late: blocking path
                 wait_flags(ln, (unsigned)tn, peeked);
                 issue_gather(ln, (tn - 1) & 1, gv);
