@@ -562,8 +562,10 @@ def visible_gpus_without_opening_them():
     the KFD topology in sysfs lists every node with its `simd_count` (0 for a CPU node); HIP_VISIBLE_DEVICES /
     ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow it.  None when sysfs has no answer (the children then find out)."""
     n = 0
+    if not Path("/dev/kfd").exists():
+        return 0                                  # no compute device node: nothing a HIP process could open
     if not Path("/sys/class/kfd").exists():
-        return 0                                  # no amdgpu compute driver in this kernel: no GPU a HIP process could open
+        return None                               # (a container without the sysfs view: the children will find out)
     try:
         nodes = Path("/sys/class/kfd/kfd/topology/nodes")
         for node in nodes.iterdir():
@@ -573,6 +575,8 @@ def visible_gpus_without_opening_them():
                     n += 1
     except Exception:
         return None
+    if n == 0:
+        return None                               # /dev/kfd is there but sysfs lists no compute node: do not guess
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None and v.strip() != "":
