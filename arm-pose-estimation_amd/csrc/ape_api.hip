@@ -1191,10 +1191,13 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
             m->hseq_cap = rows;
         }
         if (can_up32) {
-            // chunks of equal size whose expanded input (T KiB per sample row) stays under 256 MB -- the size of the Infinity
-            // Cache, and far inside one 32-bit buffer descriptor; whole 1024-row waves of clusters where that costs nothing
+            // chunks of equal size whose expanded input (T KiB per sample row) stays under 2 GiB -- inside one 32-bit buffer
+            // descriptor with offsets to spare; whole 1024-row waves of clusters where that costs nothing.  (Measured at
+            // 8192 x 25, T = 6: one 1.26 GB chunk 9.30 ms per frame, five 256 MB chunks -- the Infinity Cache's size -- 9.38 ms: a
+            // launch's prologue and tail cost more than the cache residency of the tiles buys; 288 GB of HBM make the footprint
+            // a non-issue.)
             const long long total = (long long)b->S * n_mc;
-            const long long max_chunk = ((256ll << 20) / ((long long)b->T * 1024)) / 1024 * 1024;
+            const long long max_chunk = ((2047ll << 20) / ((long long)b->T * 1024)) / 1024 * 1024;
             if (max_chunk >= 1024 && total < (1ll << 31)) {          // (the input builder indexes sample rows with 32 bits)
                 const long long n_chunks = (total + max_chunk - 1) / max_chunk;
                 long long chunk = ((total + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;

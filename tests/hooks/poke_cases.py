@@ -203,3 +203,34 @@ def test_latency_kernel_launch_number_wrap():
         for b, x in zip(before, xs):
             assert np.array_equal(model(x, last_step_only=True).cpu().numpy(), b)
     model.check()
+
+
+def test_mc_bank_in_several_chunks(norm_stats):
+    """the weight-stationary route handles the sample rows in chunks (one launch each, <= 2 GiB of pre-laid input): a bank cut
+    into chunks of 2048 rows by the test hook must give the bits of the same bank in one chunk (Philox counters and tile
+    contents are functions of the GLOBAL row index)"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    name, S, n_mc = "pocket", 330, 25                      # 8250 sample rows: 4 chunks of 2048 + one of 58
+    stats = norm_stats[name]
+    cfg = orc.MODEL_CONFIGS[name]
+    lib = _hip.lib()
+    lib.ape_debug_set_chunk_rows.restype, lib.ape_debug_set_chunk_rows.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    feats = _synthetic_windows(stats, S, 8, cfg["I"], 91)
+    outs = []
+    for chunk in (None, 2048):
+        m, sd, _ = make_model(name, 3, stats)
+        m.set_body(orc.DEFAULT_BODY)
+        bank = StreamBank(m, S, cfg["T"], smooth=1, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=7)
+        if chunk:
+            assert lib.ape_debug_set_chunk_rows(bank._handle, chunk) == 0
+        res = []
+        for f in range(8):
+            bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+            msg, tail = bank.step(with_tail=True)
+            res.append((msg.cpu().numpy().copy(), tail.cpu().numpy().copy()))
+        m.check()
+        outs.append(res)
+        del bank
+    for (a, b), (c, d) in zip(*outs):
+        assert np.array_equal(a, c) and np.array_equal(b, d)
