@@ -16,7 +16,10 @@ try:
     old = json.loads((lib / "build_info.json").read_text())
 except Exception:
     pass
-# an unchanged set of objects keeps the commit it was first built from (a re-link on a box without git must not say "unknown")
-if old.get("objects") == objs and (commit == "unknown" or old.get("commit", "unknown") != "unknown"):
-    commit = old.get("commit", commit)
+# an unchanged set of objects keeps the commit it was first built from -- a re-link on a box without git must not say
+# "unknown" -- unless the tree has been committed since: a clean describe replaces a "-dirty" one
+if old.get("objects") == objs:
+    prev = old.get("commit", "unknown")
+    if commit == "unknown" or (prev != "unknown" and not prev.endswith("-dirty")) or commit.endswith("-dirty"):
+        commit = prev if prev != "unknown" else commit
 (lib / "build_info.json").write_text(json.dumps({"commit": commit, "objects": objs}, indent=1) + "\n")
