@@ -1289,6 +1289,9 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     if (!b->xring || !b->yring || !b->y_new)
         return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
     if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
+    // (APE_DIAG_WRITE_THROUGH: internal, tests only -- the cluster kernels take their any-placement exchange form, same bits)
+    const uint32_t diag_wt = flags & APE_DIAG_WRITE_THROUGH;
+    flags &= ~(uint32_t)APE_DIAG_WRITE_THROUGH;
     if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_PACKED_MSG))
         return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT and PACKED_MSG are accepted");
     if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_step: unknown dtype selector");
@@ -1333,6 +1336,7 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
             u.xcc_slots = m->xcc_slots; u.dbg_wg = m->dbg_wg;
             u.hseq = b->hfrag; u.hseq_bytes = ape_lower32_hseq_bytes(b->S, b->T);
             u.T = b->T; u.O = O; u.n_tiles = (b->S + 31) / 32;
+            u.flags = diag_wt;
             e = ape_launch_lstm_lower32(u, xq, f16v2_capacity(m->n_cus), (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
         } else {
@@ -1366,6 +1370,7 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
                 u.xflags = m->xflags; u.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u.done = u.status - 3;
                 u.xcc_slots = m->xcc_slots; u.dbg_wg = m->dbg_wg;
                 u.T = b->T; u.O = O; u.n_tiles = (rows + 31) / 32;
+                u.flags = diag_wt;
 #ifdef APE_ABLATE
                 // timing experiments of the ablation library only (tests/tools/ablate_upper32.py; results are garbage)
                 if (const char* ab = getenv("APE_UP32_ABLATE")) u.flags = (unsigned)strtoul(ab, nullptr, 0);
@@ -1398,7 +1403,7 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         hipEvent_t ev_a, ev_z;
         prof_pair(&ev_a, &ev_z);
         if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
-        if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
+        if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | diag_wt | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
                                        drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring))
             return rc;
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);

@@ -469,6 +469,18 @@ def test_mc_bank_cluster_route_against_batch_tile_route(golden, norm_stats, name
         m.check()
         outs[kern] = res
         del bank
+    # the any-placement exchange form of the cluster kernels (write-through stores: what a cluster whose members do not share an
+    # XCD runs), forced by the internal flag: the same bits as the in-L2 form
+    m, sd, _ = make_model(name, 21, stats)
+    m.set_body(orc.DEFAULT_BODY)
+    bank = StreamBank(m, S, T, smooth=2, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=4242)
+    bank._flags |= 0x08000000                      # APE_DIAG_WRITE_THROUGH (csrc/ape_internal.h)
+    for f in range(T + 3):
+        bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+        msg, tail = bank.step(with_tail=True)
+        assert np.array_equal(msg.cpu().numpy(), outs["auto"][f][0]) and np.array_equal(tail.cpu().numpy(), outs["auto"][f][1])
+    m.check()
+    del bank
     worst_tail = max(float(np.abs(a[1] - b[1]).max()) for a, b in zip(outs["auto"], outs["auto_gen1"]))
     worst_msg = max(float(np.abs(a[0] - b[0]).max()) for a, b in zip(outs["auto"], outs["auto_gen1"]))
     assert worst_tail < 5e-6 and worst_msg < 5e-5, (worst_tail, worst_msg)
