@@ -958,9 +958,11 @@ int ape_model_recover(ape_model_t* m) {
     if (!ok) {
         const int n = m->journal_n + (m->journal_overflow ? 1 : 0);
         m->stats_counts.lost_calls += (uint64_t)n;
+        const bool over = m->journal_overflow;
         journal_clear(m);
-        return fail(APE_ERR_HIP, "%s; %d pending call(s) could not be re-issued (%s)", what.c_str(), n,
-                    m->journal_overflow ? "more than 64 calls since the last check" : "a stream bank has moved on since the aborted step");
+        return fail(APE_ERR_HIP, "%d pending call(s) could not be re-issued (%s) behind an aborted launch: %s", n,
+                    over ? "more than 64 calls since the last check, or a call the journal cannot hold"
+                         : "a stream bank has moved on since the aborted step", what.c_str());
     }
     m->replaying = true;
     int bad = APE_OK;

@@ -234,3 +234,59 @@ def test_mc_bank_in_several_chunks(norm_stats):
         del bank
     for (a, b), (c, d) in zip(*outs):
         assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+def test_recover_reissues_a_chain_and_reports_what_it_cannot(norm_stats):
+    """the journal of a handle: (1) a chain forward -> fk -> msg_reduce behind an aborted launch is re-issued in order and ends
+    with the good results; (2) more than 64 pending calls cannot be replayed: loud, counted as lost, handle usable; (3) a bank
+    destroyed with a pending step takes the step out of the journal (lost, not a dangling pointer)."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    name = "pocket"
+    m, sd, cfg = make_model(name, 9, norm_stats[name])
+    m.set_body(orc.DEFAULT_BODY)
+    lib = _hip.lib()
+    poke = _poke(lib)
+    B, T, O = 300, cfg["T"], cfg["O"]
+    x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 12)).cuda()
+    y = torch.empty((B, O), dtype=torch.float32, device="cuda")
+    est = torch.empty((B, 21), dtype=torch.float64, device="cuda")
+    msg = torch.empty((25,), dtype=torch.float64, device="cuda")
+
+    def chain():
+        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT, None, 0.0, 0,
+                                        C.c_void_p(y.data_ptr()), None), "fwd")
+        _hip.check(lib.ape_fk(m.handle, C.c_void_p(y.data_ptr()), _hip.F32, B, 1, C.c_void_p(est.data_ptr()), _hip.F64, None), "fk")
+        _hip.check(lib.ape_msg_reduce(m.handle, C.c_void_p(est.data_ptr()), B, C.c_void_p(msg.data_ptr()), None), "msg")
+    chain(); m.check()
+    good = (y.cpu().numpy().copy(), est.cpu().numpy().copy(), msg.cpu().numpy().copy())
+    assert poke(m.handle, 0, 1) == 0
+    y.zero_(); est.zero_(); msg.zero_()
+    chain()
+    m.recover()
+    assert m.stats() == {"aborted_checks": 1, "reissued_calls": 3, "lost_calls": 0}
+    assert np.abs(y.cpu().numpy() - good[0]).max() < 1e-6
+    assert np.abs(est.cpu().numpy() - good[1]).max() < 5e-5 and np.abs(msg.cpu().numpy() - good[2]).max() < 5e-5
+    # (2) journal overflow
+    assert poke(m.handle, 0, 1) == 0
+    for _ in range(70):
+        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT, None, 0.0, 0,
+                                        C.c_void_p(y.data_ptr()), None), "fwd")
+    with pytest.raises(UserWarning, match="more than 64 calls"):
+        m.recover()
+    st = m.stats()
+    assert st["aborted_checks"] == 2 and st["reissued_calls"] == 3 and st["lost_calls"] == 65, st
+    chain(); m.recover()
+    assert np.array_equal(y.cpu().numpy(), good[0])
+    # (3) a bank that is gone
+    S, n_mc = 100, 25
+    bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc, dropout=0.2, seed=5)
+    bank.push_features(torch.from_numpy(_synthetic_windows(norm_stats[name], S, 1, cfg["I"], 13)[:, 0].copy()).cuda())
+    assert poke(m.handle, 0, 1) == 0
+    bank.step()
+    del bank
+    with pytest.raises(UserWarning, match="could not be re-issued"):
+        m.recover()
+    m.check()
+    chain(); m.recover()
+    assert np.array_equal(y.cpu().numpy(), good[0])
