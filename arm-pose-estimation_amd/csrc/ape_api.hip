@@ -341,6 +341,10 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
                 m->up32_ok = true;
             }
         }
+        if (ape_cluster16_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0 && !imupose) {
+            if (e == hipSuccess) e = ape_prepare_lstm_cluster16(H, L, m->KX);
+            m->c16_ok = true;
+        }
         if (e != hipSuccess) {
             ape_model_destroy(m);
             return fail(APE_ERR_HIP, "cluster kernel set-up failed: %s", hipGetErrorString(e));
@@ -761,6 +765,30 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.dbg_wg = m->dbg_wg;
                 hipError_t e = ape_launch_lstm_cluster32(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster32 lstm launch failed: %s", hipGetErrorString(e));
+            }
+            return APE_OK;
+        }
+        if (!f16 && !small && !cdrop && !drop && !all_steps && m->c16_ok && m->c32_on && B - n16 > 256) {
+            // second-generation kernel of the 3 x 128 model: 8-member clusters of 32 windows (lstm_cluster16.hip)
+            const int rpl2 = 32 * f16v2_capacity(m->n_cus);
+            for (int b0 = n16; b0 < B; b0 += rpl2) {
+                const int nb = (B - b0 < rpl2) ? B - b0 : rpl2;
+                ClusterParams c{};
+                c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
+                c.y = y_dev + (size_t)b0 * m->dims.output_size;
+                for (int l = 0; l < L; ++l) { c.wcl[l] = m->wcl[l]; c.bias[l] = m->bias[l]; }
+                c.w_out = m->w_out; c.b_out = m->b_out;
+                c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
+                c.xx_r = m->stats + 2 * m->dims.input_size + 2 * m->dims.output_size;
+                c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+                c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+                c.ticket = c.status - 4; c.done = c.status - 3;
+                c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
+                c.flags = flags; c.x_ring = x_ring;
+                c.xcc_slots = m->xcc_slots;
+                c.dbg_wg = m->dbg_wg;
+                hipError_t e = ape_launch_lstm_cluster16(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
+                if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster16 lstm launch failed: %s", hipGetErrorString(e));
             }
             return APE_OK;
         }
@@ -1554,6 +1582,7 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
         if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, m->c32_ok && m->c32_on, m->wide_cluster) > B) return m->kernel_name.c_str();
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
+    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 256) return "ape_lstm_cluster16<128, 3, 64>";
     return m->cluster_name.c_str();
 }
 

@@ -1,0 +1,495 @@
+// Weight-stationary cluster LSTM kernel, second generation, for the shapes whose members own 16 hidden units: the third deployed
+// regressor (WatchPhoneUarmNN: I = 38, H = 128, L = 3; reference estimate/watch_phone_uarm_nn.py:13-41, nn_models.py:160-189),
+// exact float32, eval mode, last-step output.
+//
+// lstm_cluster32.hip needs 32 hidden units per member (a wave = 8 units x 4 gates = the 32 columns of a 32x32x2 tile), i.e. four
+// members per cluster at H = 128 -- half the chip at 1024 windows.  Here a member owns 16 units, a wave 4 of them: 16 columns
+// ordered unit * 4 + gate on v_mfma_f32_16x16x4_f32, two 16-window row tiles per cluster (two independent accumulator chains per
+// wave, so the 32-cycle issue rate is met), 8 members x 32 clusters = 256 CUs at 1024 windows -- the decomposition of the
+// first-generation kernel (lstm_cluster.hip), with the second generation's exchange:
+//   * exchange layout = LDS layout = fragment order [member][wave][window 32][4 units]: a lane (window n, k-group g) reads the 16
+//     bytes of member q's wave g for its window -- units 16 q + 4 g + j, j = 0..3 -- and feeds four MFMAs (the weights are packed
+//     with the same k permutation: the first generation's register image, wcl); gathered slices never pass through registers, a
+//     layer-step's slice set (GH x 2 KB) is copied global -> LDS by LDS-DMA, prefetched by the section in front;
+//   * layers software-pipelined (phase p: layer l on step p - l): with three layers every section's hand-over has two other
+//     sections to hide in;
+//   * XCD-class clusters (arrival tickets within blockIdx % 8, verified at run time: plain stores in one XCD's L2, else
+//     write-through), asynchronous flag look (inline-asm load, judged blocks later), bounded spins, sticky status, self-cleaning
+//     -- all as lstm_cluster32.hip;
+//   * the four gates of a (unit, window) cell land in one lane's four accumulator registers: lane-local cell update; the fresh
+//     h values (one per lane and row tile) are transposed through a wave-private LDS patch into 16-byte pieces for the publish.
+#include <type_traits>
+
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float tanh_(float v) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390081777927f * v)) - 1.0f; }
+
+// v_mfma_f32_16x16x4_f32: A = a weight register (row lane & 15 = unit * 4 + gate), B = an activation (column lane & 15 = window of
+// the row tile), k = lane >> 4.  hipcc does not model an asm MFMA's result hazard: accumulators are read only behind mfma_drain16().
+__device__ __forceinline__ void mfma16(f32x4& acc, float w, float a) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_drain16(f32x4& a0, f32x4& a1) { asm volatile("s_nop 15" : "+v"(a0), "+v"(a1)); }
+
+// NB k-blocks of 16: acc[rt] += W (registers w[w0 + 4 kb + j]) x activations (LDS: block kb at src + kb * stride, this lane's 16
+// bytes per row tile, the second row tile 16 windows = 64 floats further), fragments fetched one block ahead; mid(kb) behind block kb
+template <int NB, int NW, typename Mid>
+__device__ __forceinline__ void span16(f32x4 (&acc)[2], const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src), b0 = *reinterpret_cast<const f32x4*>(src + 64);
+    f32x4 a1 = a0, b1 = b0;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        if (kb + 1 < NB) {
+            a1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1));
+            b1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1) + 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mfma16(acc[0], w[w0 + 4 * kb + j], a0[j]);
+            mfma16(acc[1], w[w0 + 4 * kb + j], b0[j]);
+        }
+        mid(kb);
+        a0 = a1;
+        b0 = b1;
+    }
+}
+
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <bool WT>
+__device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
+    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
+template <int H, int L, int KX>
+__global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams p) {
+    constexpr int GH = H / 16;              // members per cluster (16 units each, 4 per wave)
+    constexpr int MR = 32;                  // windows per cluster: two 16-row tiles
+    constexpr int BX = KX / 16, BH = H / 16;// k-blocks of 16 (one block = one member's units, or 16 input columns)
+    constexpr int NWX = 4 * BX, NWH = 4 * BH;               // weight registers per lane: input part of layer 0 / an H-wide part
+    constexpr int NW0 = NWX + NWH, NWU = 2 * NWH;           // layer 0 / a layer above
+    constexpr int NFL = 4 * GH;             // flags per (cluster, layer): one per member wave
+    constexpr int BLK = 4 * MR * 4;         // floats of one k-block in LDS: [wave / k-group 4][window 32][4] = 2 KB
+    constexpr int HL = GH * BLK;            // floats of one slice set
+    constexpr int XL = BX * BLK;            // floats of the x slab (the same fragment order)
+    constexpr int NDMA = HL * 4 / 1024 / 4; // LDS-DMA instructions per wave and gather
+    constexpr unsigned SET_BYTES = HL * sizeof(float);
+    static_assert(L >= 2 && L <= 3 && GH * 4 <= 64 && (GH & (GH - 1)) == 0 && NDMA >= 1, "shape");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;         // window of a row tile; k-group of the operands = hidden unit of the results
+    const int T = p.T, I = p.I, O = p.O;
+    const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool bcast_x = (p.flags & APE_FLAG_BROADCAST_X) != 0;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // h of layer l < L-1: two parity buffers (read by the layer's recurrence AND as the next layer's input); top layer: one
+    float* hbase = smem;                                  // [2 (L-1) + 1][HL]
+    float* xin = hbase + (2 * (L - 1) + 1) * HL;          // [XL]
+    float* patch = xin + XL;                              // [wave 4][window 32][4]: the publish transpose
+    f32x4* bias_s = reinterpret_cast<f32x4*>(patch + 4 * MR * 4);     // [wave 4][L][g 4]: start values of unit g's four gates
+    int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * 4);            // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    auto hb = [&](int l, int par) -> float* { return hbase + (l < L - 1 ? 2 * l + par : 2 * (L - 1)) * HL; };
+
+    unsigned* const class_ticket = p.xcc_slots + 64;
+    unsigned* const xcc_words = p.xcc_slots + 64 + 8 * 16;
+    const int cls = blockIdx.x & 7;
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
+    if (tid == 0) {
+        ctl[0] = 0;
+        ctl[1] = -1;
+        if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned tk = __hip_atomic_fetch_add(class_ticket + cls * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < gridDim.x / 8) ctl[1] = (int)tk;
+            else __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (ctl[1] < 0) return;
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
+    const int cluster = (ticket / GH) * 8 + cls, member = ticket % GH;
+    const int row0 = cluster * MR;
+    if (tid == 0)
+        __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- x: thread -> NE (window, column) elements of the step slab, all with the same column ---------------------------------
+    constexpr int NE = (MR * KX) / 256;
+    const int xk = tid % KX, xrow = tid / KX;
+    const int rows_here = bcast_x ? MR : max(0, min(MR, p.B - row0));
+    const unsigned long long x_addr = reinterpret_cast<unsigned long long>(p.x + (bcast_x ? (size_t)0 : (size_t)row0 * T * I));
+    const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)x_addr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(x_addr >> 32));
+    const int x_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)(bcast_x ? 1 : rows_here) * T * I * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(((unsigned long long)x_hi << 32) | x_lo), 0, x_bytes, 0x00020000);
+    const unsigned x_rowbytes = bcast_x ? 0u : (unsigned)(T * I * sizeof(float));
+    const unsigned x_off0 = (xk < I) ? (unsigned)xrow * x_rowbytes + (unsigned)(xk * sizeof(float)) : 0x80000000u;
+    const unsigned x_estride = (unsigned)(256 / KX) * x_rowbytes;
+    float xr[NE];
+    auto fetch_x = [&](int t) {
+        const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const unsigned off = (xrow + e * (256 / KX) < rows_here) ? x_off0 + (unsigned)e * x_estride : 0x80000000u;
+            xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (unsigned)(slot * I * sizeof(float)), 0));
+        }
+    };
+    const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
+    const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
+    const double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;
+    // column k of window w lives at [k-block k / 16][k-group (k % 16) / 4][window w][k % 4]
+    const int x_slot = ((xk >> 4) * 4 + ((xk & 15) >> 2)) * (MR * 4) + (xk & 3);
+    auto stage_x = [&]() {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const double d = (double)xr[e] - x_mean;
+            const double q0 = d * x_rstd;
+            const double rr = fma(-q0, x_std, d);
+            const double q1 = fma(rr, x_rstd, q0);
+            xin[x_slot + (xrow + e * (256 / KX)) * 4] = (float)((rr == rr) ? q1 : q0);
+        }
+    };
+    fetch_x(0);
+
+    // ---- weights: registers for the whole launch; host layout of the first generation (ape_api.hip, wcl):
+    //      [member][wave][register / 4][lane][4], register 4 q + j of lane (row c = lane & 15 = unit * 4 + gate, k-group g) =
+    //      [W_ih | W_hh][gate * H + member * 16 + wave * 4 + unit][16 q + 4 g + j]
+    float w0[NW0];
+    float wu[L - 1][NWU];
+    {
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NW0 / 4; ++i) {
+            const f32x4 v = s0[i * 64];
+            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
+        }
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[l]) + ((size_t)(member * 4 + wave) * (NWU / 4)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NWU / 4; ++i) {
+                const f32x4 v = s1[i * 64];
+                wu[l - 1][4 * i] = v[0]; wu[l - 1][4 * i + 1] = v[1]; wu[l - 1][4 * i + 2] = v[2]; wu[l - 1][4 * i + 3] = v[3];
+            }
+        }
+    }
+    if (tid < 4 * L * 4) {                  // start values (b_ih + b_hh): [wave][layer][unit g] -> the four gates
+        const int wv = tid / (L * 4), l = (tid / 4) % L, gg = tid & 3;
+        f32x4 bv;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) bv[gate] = p.bias[l][gate * H + member * 16 + wv * 4 + gg];
+        bias_s[tid] = bv;
+    }
+    float cst[L][2];
+#pragma unroll
+    for (int l = 0; l < L; ++l) { cst[l][0] = 0.0f; cst[l][1] = 0.0f; }
+
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    u32x4 hx_desc;
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[3] = 0x00020000u;
+    unsigned* const flags_of = p.xflags + (size_t)cluster * L * NFL;
+    auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SET_BYTES); };
+    const unsigned hbase_lds = (unsigned)reinterpret_cast<unsigned long long>(hbase);
+
+    stage_x();
+    if (T > 1) fetch_x(1);
+
+    if (wave == 0) {                        // do all members of this cluster share an XCD?
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(xcc_words + cluster * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
+    __syncthreads();
+    if (ctl[0] != 0) return;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
+
+    auto wait_flags = [&](int l, unsigned want) {
+        unsigned spins = 0;
+        while (true) {
+            unsigned v = want;
+            if (lane < NFL) v = __hip_atomic_load(flags_of + l * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v >= want))) return;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto opaque = [](unsigned v) -> unsigned { asm volatile("" : "+s"(v)); return v; };
+    const unsigned dma_voff = (unsigned)(lane * 16);
+    const unsigned wave_kib = (unsigned)(wave * 1024);
+    // slices of layer l, step `step` -> its LDS buffer; wave w copies KiB w, w + 4, ...
+    auto issue_piece = [&](int l, int step, int k) {
+        const unsigned src = hx_base(l, step & 1) + wave_kib + (unsigned)(k * 4096);
+        const unsigned buf = (unsigned)(l < L - 1 ? 2 * l + (step & 1) : 2 * (L - 1));
+        dma_1k(opaque(hbase_lds + wave_kib) + buf * SET_BYTES + (unsigned)(k * 4096), dma_voff, hx_desc, src);
+    };
+    int pend_idx = -1;
+    unsigned pend_epoch = 0u;
+    auto raise_pending = [&]() {
+        if (pend_idx < 0) return;
+        if (lane == 0) __hip_atomic_store(flags_of + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_idx = -1;
+    };
+#ifdef APE_C16_V2
+    auto bar = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#else
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#endif
+
+    // Section (ph, l) = layer l on step t = ph - l.  It reads x_t / h^{l-1}_t (in LDS since layer l-1's section of this phase
+    // gathered it as ITS recurrent input) and h^l_{t-1}: the ONE slice set it still misses, prefetched by the section in front.
+    // Vector-memory queue of a wave in a steady-state section: [publish store of the section in front]  flag look (1)
+    // [x fetch, top layer only]  gather DMA for the next section (NDMA)  publish store (1) -- `vmcnt(1)` at the top.
+    const int P = T + L - 1;
+    bool prefetched = false;
+    const int frag = (g * MR + n) * 4;                            // this lane's 16 bytes inside a k-block, row tile 0
+    float* const my_patch = patch + wave * (MR * 4);
+    auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
+        constexpr bool ST = decltype(steady_tag)::value;
+        constexpr int l = decltype(layer_tag)::value;
+        const int t = ph - l;
+        const bool active = ST || (t >= 0 && t < T);
+        const bool need = ST || (t >= 1 && t <= T);
+        if (need) {
+            if (!prefetched) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_pending();
+                wait_flags(l, (unsigned)t);
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) issue_piece(l, t - 1, k);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            }
+        }
+        prefetched = false;
+        bar();
+        const int abort_word = ctl[0];
+        constexpr int ln = (l + 1 < L) ? l + 1 : 0;
+        const int tn = (l + 1 < L) ? t - 1 : t + L;
+        const bool pre = ST || (tn >= 1 && tn <= T);
+        unsigned peek = (unsigned)tn;
+        bool go = false;
+        constexpr int NBL = (l == 0) ? BX + BH : 2 * BH;
+        // (block = 8 MFMAs = 256 cycles, as in lstm_cluster32.hip a block = 4 x 64)
+        constexpr int QF = 2, QP = NBL / 2 - 1, QJ = NBL / 2 + 1;
+        static_assert(QJ + NDMA <= NBL && QF + 1 < QP, "hook schedule");
+        bool staged = false;
+        auto mid = [&](int q) {
+            if (q == QF) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_pending();
+            }
+            if (l == L - 1 && q == QF + 1 && (ST || ph + 1 < T)) {
+                stage_x();
+                if (ST || ph + 2 < T) fetch_x(ph + 2);
+                staged = true;
+            }
+            if (q == QP) peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));
+            if (q == QJ) {
+                peek_wait(peek);
+                go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
+            }
+            if (q >= QJ && q < QJ + NDMA && go) issue_piece(ln, tn - 1, q - QJ);
+        };
+        float hnew[2] = {0.0f, 0.0f};
+        if (active) {
+            f32x4 acc[2];
+            acc[0] = bias_s[(wave * L + l) * 4 + g];
+            acc[1] = acc[0];
+#ifdef APE_C16_V1
+            asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+#endif
+            if constexpr (l == 0) {
+                span16<BX, NW0>(acc, xin + frag, BLK, w0, 0, [&](int q) { mid(q); });
+                if (ST || t > 0) span16<BH, NW0>(acc, hb(0, (t - 1) & 1) + frag, BLK, w0, NWX, [&](int q) { mid(BX + q); });
+            } else {
+                span16<BH, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, [&](int q) { mid(q); });
+                if (ST || t > 0) span16<BH, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, [&](int q) { mid(BH + q); });
+            }
+            mfma_drain16(acc[0], acc[1]);
+            // gates + cell update, lane-local: registers 0..3 = i, f, g, o of unit g, window rt * 16 + n
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float iv = sigm(acc[rt][0]), fv = sigm(acc[rt][1]), gv = tanh_(acc[rt][2]), ov = sigm(acc[rt][3]);
+                const float c = fv * cst[l][rt] + iv * gv;
+                cst[l][rt] = c;
+                hnew[rt] = ov * tanh_(c);
+            }
+        }
+#ifdef APE_C16_DUMP
+        if (active && t < 2 && cluster == 0 && member == 0 && p.dbg_wg != nullptr) {
+            float* dump = reinterpret_cast<float*>(p.dbg_wg) + ((l * 2 + t) * 4 + wave) * 128 + lane;
+            dump[0] = hnew[0];
+            dump[64] = hnew[1];
+        }
+#endif
+        if (abort_word != 0) return false;
+        if (!ST && pend_idx >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            raise_pending();
+        }
+        if (go) prefetched = true;
+        if constexpr (l == L - 1) {
+            if (!ST && !staged && ph + 1 < T) {
+                stage_x();
+                if (ph + 2 < T) fetch_x(ph + 2);
+            }
+        }
+        // ---- publish: transpose through the wave's LDS patch ([window][4 units]); lanes 0..31 send one window's 16 bytes each
+        //      (exactly ONE store instruction per wave and section: the counted wait at the top of the next section relies on it)
+        {
+            my_patch[n * 4 + g] = hnew[0];
+            my_patch[(16 + n) * 4 + g] = hnew[1];
+#ifdef APE_C16_V3
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
+#endif
+            const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);     // (same wave: LDS operations are in order)
+            // (whole-vector cast: hipcc 7.2 folds a per-element cast of a loaded vector into a one-dword load + splat)
+            const u32x4 hv = __builtin_bit_cast(u32x4, hf);
+            const unsigned off = (active && lane < 32) ? hx_base(l, t & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
+            if (in_l2) store_16<false>(hv, off, hx_desc);
+            else store_16<true>(hv, off, hx_desc);
+            if (active) {
+                pend_idx = l * NFL + member * 4 + wave;
+                pend_epoch = (unsigned)(t + 1);
+            }
+        }
+        return true;
+    };
+    bool ok = true;
+#pragma unroll 1
+    for (int ph = 0; ph < P && ok; ++ph) {
+        const bool st = ph >= L && ph <= T - 3;
+        ok = st ? section(std::true_type{}, std::integral_constant<int, 0>{}, ph) : section(std::false_type{}, std::integral_constant<int, 0>{}, ph);
+        if (!ok) break;
+        ok = st ? section(std::true_type{}, std::integral_constant<int, 1>{}, ph) : section(std::false_type{}, std::integral_constant<int, 1>{}, ph);
+        if constexpr (L == 3) {
+            if (!ok) break;
+            ok = st ? section(std::true_type{}, std::integral_constant<int, 2>{}, ph) : section(std::false_type{}, std::integral_constant<int, 2>{}, ph);
+        }
+    }
+    if (!ok) return;
+    // ---- final gather: h^{L-1}_{T-1} of every member ----------------------------------------------------------------------------
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raise_pending();
+        if (!prefetched) {
+            wait_flags(L - 1, (unsigned)T);
+#pragma unroll
+            for (int k = 0; k < NDMA; ++k) issue_piece(L - 1, T - 1, k);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bar();
+        if (ctl[0] != 0) return;
+    }
+    // ---- head: member m finishes windows (MR / GH) m .. of the cluster's 32; 4 lanes per (window, target) ----------------------------
+    {
+        constexpr int RPM = MR / GH;
+        const float* htop = hb(L - 1, 0);
+#ifdef APE_C16_DUMP
+        if (cluster == 0 && (member == 0 || member == 7) && tid < 64 && p.dbg_wg != nullptr) {
+            float sum = 0.0f;
+            for (int i = 0; i < 64; ++i) sum += htop[(tid >> 1) * 128 + (tid & 1) * 64 + i];
+            reinterpret_cast<float*>(p.dbg_wg)[3072 + (member ? 64 : 0) + tid] = sum;
+        }
+#endif
+        const int part = tid & 3;
+        for (int oi = tid >> 2; oi < ((RPM * O + 63) / 64) * 64; oi += 64) {
+            const bool live = oi < RPM * O;
+            const int rr = live ? oi / O : 0, o = live ? oi - rr * O : 0;
+            const int row = member * RPM + rr, b = row0 + row;
+            float s_acc = 0.0f;
+            if (live) {
+                const float* wv = p.w_out + (size_t)o * H;
+                // units 4 q .. 4 q + 3 (q = k / 4) of window `row` live at htop[(q * MR + row) * 4]
+                for (int q = part; q < H / 4; q += 4) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(htop + (q * MR + row) * 4);
+                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(wv + q * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s_acc = fmaf(a0[j], u0[j], s_acc);
+                }
+            }
+            s_acc += __shfl_xor(s_acc, 1, 64);
+            s_acc += __shfl_xor(s_acc, 2, 64);
+            if (p.y != nullptr && live && part == 0 && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
+        }
+    }
+    // ---- self-cleaning -----------------------------------------------------------------------------------------------------------------
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        const int n_flags = (int)(gridDim.x / GH) * L * NFL;
+        for (int i = tid; i < n_flags; i += 256) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int H, int L, int KX>
+constexpr size_t smem16() {
+    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 512 + (size_t)(KX / 16) * 512 + 4 * 32 * 4) * sizeof(float) + (size_t)4 * L * 4 * 16 + 16;
+}
+
+}  // namespace
+
+bool ape_cluster16_supported(int H, int L, int KX) { return H == 128 && L == 3 && KX == 64; }
+
+hipError_t ape_prepare_lstm_cluster16(int H, int L, int KX) {
+    if (!ape_cluster16_supported(H, L, KX)) return hipSuccess;
+    static_assert(smem16<128, 3, 64>() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster16<128, 3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               APE_LDS_BYTES);
+}
+
+// `clusters` = 32-window clusters needed; the grid is rounded up to whole block-index classes (8 clusters x GH members)
+hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream) {
+    if (!ape_cluster16_supported(H, L, KX)) return hipErrorInvalidValue;
+    const int grid_clusters = (clusters + 7) / 8 * 8;
+    constexpr size_t smem = smem16<128, 3, 64>();
+    hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}

@@ -1,0 +1,55 @@
+"""GPU parity tests added in round 3 (all through the C ABI of libape_hip.so):
+  * the second-generation cluster kernel of the 3 x 128 upper-arm regressor (lstm_cluster16.hip).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ape_oracle as orc
+from tests.test_hip_parity import make_model, _synthetic_windows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as entry
+    entry.build()
+
+
+@pytest.mark.parametrize("B,T", [(1024, 64), (257, 1), (300, 2), (700, 3), (290, 4), (2100, 5), (1000, 6), (333, 31)])
+def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
+    """lstm_cluster16.hip (eval-mode batches above 256 rows of WatchPhoneUarmNN's 3 x 128 LSTM, watch_phone_uarm_nn.py:13-41)
+    against the float32 oracle (module tolerance 1e-6), the first-generation cluster kernel and the batch-tile kernel (other
+    summation orders only); window lengths around the depth of its three-layer software pipeline (fill and drain sections),
+    ragged and multi-launch batches, the forced any-placement (write-through) exchange and run-to-run determinism."""
+    from wear_mocap_ape_amd import _hip
+    name = "uarm"
+    st = norm_stats[name]
+    model, sd, cfg = make_model(name, 5, st)
+    x = _synthetic_windows(st, B, T, cfg["I"], 17)
+    xd = torch.from_numpy(x).cuda()
+    xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    model.set_kernel("cluster")
+    assert model.kernel_name(B, T) == "ape_lstm_cluster16<128, 3, 64>"
+    y2 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    model.check()
+    y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    assert np.array_equal(y2, y2b)
+    y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | 0x08000000,
+                                           None, 0.0, 0, C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
+    torch.cuda.synchronize()
+    model.check()
+    assert np.array_equal(y_wt.cpu().numpy(), y2)
+    model.set_kernel("cluster_gen1")
+    assert "ape_lstm_cluster<" in model.kernel_name(B, T)
+    y1 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    y0 = model.set_kernel("tile16")(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
+    model.set_kernel("auto")
+    y_ref = orc.lstm_forward(sd, xn)[:, -1]
+    e_ref, e_gen, e_t16 = float(np.abs(y2 - y_ref).max()), float(np.abs(y2 - y1).max()), float(np.abs(y2 - y0).max())
+    print(f"\n[uarm B={B} T={T} cluster16] vs oracle {e_ref:.2e}, vs gen-1 kernel {e_gen:.2e}, vs batch-tile kernel {e_t16:.2e}")
+    assert e_ref < 1e-6 and e_gen < 1e-6 and e_t16 < 1e-6

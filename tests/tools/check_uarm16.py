@@ -1,0 +1,27 @@
+"""Second-generation kernel of the 3 x 128 model (lstm_cluster16.hip) against the batch-tile kernel and the first-generation cluster kernel,
+over window lengths that exercise the pipeline fill / drain: python tests/tools/check_uarm16.py"""
+import sys
+import numpy as np
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
+import torch
+from oracle import ape_oracle as orc
+from wear_mocap_ape_amd.estimate import nn_models
+cfg = orc.MODEL_CONFIGS["uarm"]
+m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0)
+m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 3))
+worst = 0.0
+for B, T in [(257, 1), (300, 2), (300, 3), (290, 4), (512, 5), (700, 6), (1024, 7), (1000, 8), (1024, 64), (2100, 9), (1024, 200), (333, 31)]:
+    x = torch.randn(B, T, cfg["I"], device="cuda")
+    y2 = m.set_kernel("cluster")(x, last_step_only=True).cpu().numpy()[:, 0]
+    name = m.kernel_name(B, T)
+    m.check()
+    y2b = m.set_kernel("cluster")(x, last_step_only=True).cpu().numpy()[:, 0]
+    m.check()
+    y1 = m.set_kernel("cluster_gen1")(x, last_step_only=True).cpu().numpy()[:, 0]
+    y0 = m.set_kernel("tile16")(x, last_step_only=True).cpu().numpy()[:, 0]
+    m.check()
+    d0, d1 = float(np.abs(y2 - y0).max()), float(np.abs(y2 - y1).max())
+    worst = max(worst, d0)
+    print(f"B={B} T={T}: |c16 - tile16| {d0:.2e}  |c16 - gen1| {d1:.2e}  repeat identical {np.array_equal(y2, y2b)}  ({name})", flush=True)
+print("worst", worst)
+assert worst < 2e-5
