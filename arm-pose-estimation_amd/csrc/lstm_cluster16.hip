@@ -32,15 +32,26 @@ __device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.
 __device__ __forceinline__ float tanh_(float v) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390081777927f * v)) - 1.0f; }
 
 // v_mfma_f32_16x16x4_f32: A = a weight register (row lane & 15 = unit * 4 + gate), B = an activation (column lane & 15 = window of
-// the row tile), k = lane >> 4.  hipcc does not model an asm MFMA's result hazard: accumulators are read only behind mfma_drain16().
+// the row tile), k = lane >> 4.  hipcc does not model an asm MFMA's result hazard: accumulators are read only behind mfma16_last().
+// (AG: the weight lives in an accumulation register, read by the matrix core directly.  Never let the compiler park an operand of
+//  these there by itself: its v_accvgpr_read right in front of the MFMA is a VALU write -> SrcA read without the wait states the
+//  hardware needs, which hipcc cannot insert around inline asm -- seen as the first row tile of the top layer off by 2e-3.)
+template <bool AG>
 __device__ __forceinline__ void mfma16(f32x4& acc, float w, float a) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
 }
-__device__ __forceinline__ void mfma_drain16(f32x4& a0, f32x4& a1) { asm volatile("s_nop 15" : "+v"(a0), "+v"(a1)); }
+// the last MFMA of a span that ends a section, with the drain in the SAME statement: the compiler, which takes an asm's result for ready,
+// puts the phi copies of a branch merge right behind the MFMA otherwise (seen: the second row tile one k-step short, 1e-4)
+template <bool AG>
+__device__ __forceinline__ void mfma16_last(f32x4& a0, f32x4& a1, float w, float a) {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %1, %2, %3, %1\n\ts_nop 15" : "+v"(a0), "+v"(a1) : "a"(w), "v"(a));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %1, %2, %3, %1\n\ts_nop 15" : "+v"(a0), "+v"(a1) : "v"(w), "v"(a));
+}
 
 // NB k-blocks of 16: acc[rt] += W (registers w[w0 + 4 kb + j]) x activations (LDS: block kb at src + kb * stride, this lane's 16
 // bytes per row tile, the second row tile 16 windows = 64 floats further), fragments fetched one block ahead; mid(kb) behind block kb
-template <int NB, int NW, typename Mid>
+template <int NB, bool AG, bool DR, int NW, typename Mid>
 __device__ __forceinline__ void span16(f32x4 (&acc)[2], const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid) {
     f32x4 a0 = *reinterpret_cast<const f32x4*>(src), b0 = *reinterpret_cast<const f32x4*>(src + 64);
     f32x4 a1 = a0, b1 = b0;
@@ -52,8 +63,9 @@ __device__ __forceinline__ void span16(f32x4 (&acc)[2], const float* __restrict_
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mfma16(acc[0], w[w0 + 4 * kb + j], a0[j]);
-            mfma16(acc[1], w[w0 + 4 * kb + j], b0[j]);
+            mfma16<AG>(acc[0], w[w0 + 4 * kb + j], a0[j]);
+            if (DR && kb == NB - 1 && j == 3) mfma16_last<AG>(acc[0], acc[1], w[w0 + 4 * kb + j], b0[j]);
+            else mfma16<AG>(acc[1], w[w0 + 4 * kb + j], b0[j]);
         }
         mid(kb);
         a0 = a1;
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     constexpr int XL = BX * BLK;            // floats of the x slab (the same fragment order)
     constexpr int NDMA = HL * 4 / 1024 / 4; // LDS-DMA instructions per wave and gather
     constexpr unsigned SET_BYTES = HL * sizeof(float);
-    static_assert(L >= 2 && L <= 3 && GH * 4 <= 64 && (GH & (GH - 1)) == 0 && NDMA >= 1, "shape");
+    static_assert(L == 3 && GH * 4 <= 64 && (GH & (GH - 1)) == 0 && NDMA >= 1, "shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -270,26 +282,128 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         if (lane == 0) __hip_atomic_store(flags_of + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_idx = -1;
     };
-#ifdef APE_C16_V2
-    auto bar = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#else
     auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#endif
 
-    // Section (ph, l) = layer l on step t = ph - l.  It reads x_t / h^{l-1}_t (in LDS since layer l-1's section of this phase
-    // gathered it as ITS recurrent input) and h^l_{t-1}: the ONE slice set it still misses, prefetched by the section in front.
-    // Vector-memory queue of a wave in a steady-state section: [publish store of the section in front]  flag look (1)
-    // [x fetch, top layer only]  gather DMA for the next section (NDMA)  publish store (1) -- `vmcnt(1)` at the top.
+    // Section (ph, l) = layer l on step t = ph - l, in two spans with the workgroup barrier BETWEEN them:
+    //   span A  x_t / h^{l-1}_t: in LDS since before the barrier of the section in front (layer l-1 gathered h^{l-1}_t as ITS recurrent
+    //           input; x was staged two sections ago), so it starts without waiting for anybody -- and carries, in its first blocks,
+    //           the cell update and the publish of the section in front, whose accumulators were only drained at its end: the gate
+    //           arithmetic (20 transcendentals per lane) and the exchange store run under this section's matrix work;
+    //   ------  the slice set prefetched by the section in front (h^l_{t-1}) has landed: counted wait, barrier;
+    //   span B  h^l_{t-1}; in its blocks: flag of the store above, the look at the next section's flags, its gather.
+    // Vector-memory queue of a wave at the barrier of a steady-state section: [x fetch, section 1 only] [gather DMA (NDMA)] | publish
+    // store (1) -- `vmcnt(1)`.
     const int P = T + L - 1;
     bool prefetched = false;
     const int frag = (g * MR + n) * 4;                            // this lane's 16 bytes inside a k-block, row tile 0
     float* const my_patch = patch + wave * (MR * 4);
+    f32x4 pa[2];                                                  // drained accumulators of the section in front
+    pa[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    pa[1] = pa[0];
     auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;
         constexpr int l = decltype(layer_tag)::value;
         const int t = ph - l;
         const bool active = ST || (t >= 0 && t < T);
         const bool need = ST || (t >= 1 && t <= T);
+        // the section in front: layer lp on step tp
+        constexpr int lp = (l + L - 1) % L;
+        const int tp = (l == 0) ? t - L : t + 1;
+        const bool pactive = ST || (tp >= 0 && tp < T);
+        // the next section: layer ln on step tn; the slice set it is missing is h^{ln}_{tn-1}, epoch tn
+        constexpr int ln = (l + 1 < L) ? l + 1 : 0;
+        const int tn = (l + 1 < L) ? t - 1 : t + L;
+        const bool pre_ok = ST || (tn >= 1 && tn <= T);
+        unsigned peek = (unsigned)tn;
+        bool go = false;
+        float hn[2] = {0.0f, 0.0f};
+        // ---- work in front of the barrier, item k: 0, 1 cell update of row tile k of the section in front; 2 its publish; 3 flag look
+        auto pre = [&](int k) {
+            if (k < 2) {
+                if (pactive) {
+                    // registers 0..3 = i, f, g, o of unit g, window k * 16 + n
+                    const float iv = sigm(pa[k][0]), fv = sigm(pa[k][1]), gv = tanh_(pa[k][2]), ov = sigm(pa[k][3]);
+                    const float c = fv * cst[lp][k] + iv * gv;
+                    cst[lp][k] = c;
+                    hn[k] = ov * tanh_(c);
+                }
+            } else if (k == 2) {
+                // transpose through the wave's LDS patch ([window][4 units]); lanes 0..31 send one window's 16 bytes each
+                // (exactly ONE store instruction per wave and section: the counted wait at the barrier relies on it)
+#ifdef APE_C16_DUMP
+                if (pactive && tp < 2 && cluster == 0 && member == 0 && p.dbg_wg != nullptr) {
+                    float* dump = reinterpret_cast<float*>(p.dbg_wg) + ((lp * 2 + tp) * 4 + wave) * 128 + lane;
+                    dump[0] = hn[0];
+                    dump[64] = hn[1];
+                }
+#endif
+                my_patch[n * 4 + g] = hn[0];
+                my_patch[(16 + n) * 4 + g] = hn[1];
+                const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);     // (same wave: LDS operations are in order)
+                // (whole-vector cast: hipcc 7.2 folds a per-element cast of a loaded vector into a one-dword load + splat)
+                const u32x4 hv = __builtin_bit_cast(u32x4, hf);
+                const unsigned off = (pactive && lane < 32) ? hx_base(lp, tp & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
+                if (in_l2) store_16<false>(hv, off, hx_desc);
+                else store_16<true>(hv, off, hx_desc);
+                if (pactive) {
+                    pend_idx = lp * NFL + member * 4 + wave;
+                    pend_epoch = (unsigned)(tp + 1);
+                }
+            }
+        };
+        // ---- work behind the barrier, item k: 0 flag of the store above, x; 1 look at the next section's flags; 2 judge;
+        //      3 .. 2 + NDMA the next section's gather.  (The look and its judgement stay in one straight run of code: the register the
+        //      load lands in must not be copied by the compiler in between.)
+        auto post = [&](int k) {
+            if (k == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the publish store has drained
+                raise_pending();
+                if constexpr (l == 1) {
+                    // x of the next layer-0 step: registers -> LDS (its readers, span A of this phase's layer-0 section, finished
+                    // before this section's barrier; the next ones start behind the barrier of section 2)
+                    if (ST || ph + 1 < T) stage_x();
+                }
+            } else if (k == 1) {
+                peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));                     // (always: no branch around it)
+            } else if (k == 2) {
+                peek_wait(peek);
+                go = pre_ok && __all((int)(peek >= (unsigned)tn)) != 0;
+#ifdef APE_C16_X1
+                go = false;
+#endif
+                if constexpr (l == 1) {
+                    // the fetch of the step after it: the oldest entries of the memory queue when the next counted wait comes
+                    if (ST || ph + 2 < T) fetch_x(ph + 2);
+                }
+            } else if (go) {
+                issue_piece(ln, tn - 1, k - 3);
+            }
+        };
+        constexpr int QF = 0, QP = 1, QJ = 4;
+        static_assert(QJ + NDMA <= BH && QF < QP && QP < QJ && BX >= 3, "hook schedule");
+        f32x4 acc[2];
+#if defined(APE_C16_Y2)
+        pre(0); pre(1); pre(2);
+        auto hook_a = [&](int q) {};
+#elif defined(APE_C16_Y1)
+        auto hook_a = [&](int q) { if (q == 2) { pre(0); pre(1); pre(2); } };
+#else
+        auto hook_a = [&](int q) { if (q < 3) pre(q); };
+#endif
+        if (active) {
+            acc[0] = bias_s[(wave * L + l) * 4 + g];
+            acc[1] = acc[0];
+            if constexpr (l == 0) span16<BX, false, !ST, NW0>(acc, xin + frag, BLK, w0, 0, hook_a);
+            else span16<BH, (l == L - 1), !ST, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, hook_a);
+#if defined(APE_C16_Y2)
+        } else if (false) {
+#else
+        } else {
+#endif
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pre(k);
+        }
+        // ---- this layer's slices of its last step into LDS ------------------------------------------------------------------------
         if (need) {
             if (!prefetched) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -305,96 +419,27 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         prefetched = false;
         bar();
         const int abort_word = ctl[0];
-        constexpr int ln = (l + 1 < L) ? l + 1 : 0;
-        const int tn = (l + 1 < L) ? t - 1 : t + L;
-        const bool pre = ST || (tn >= 1 && tn <= T);
-        unsigned peek = (unsigned)tn;
-        bool go = false;
-        constexpr int NBL = (l == 0) ? BX + BH : 2 * BH;
-        // (block = 8 MFMAs = 256 cycles, as in lstm_cluster32.hip a block = 4 x 64)
-        constexpr int QF = 2, QP = NBL / 2 - 1, QJ = NBL / 2 + 1;
-        static_assert(QJ + NDMA <= NBL && QF + 1 < QP, "hook schedule");
-        bool staged = false;
-        auto mid = [&](int q) {
-            if (q == QF) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                raise_pending();
-            }
-            if (l == L - 1 && q == QF + 1 && (ST || ph + 1 < T)) {
-                stage_x();
-                if (ST || ph + 2 < T) fetch_x(ph + 2);
-                staged = true;
-            }
-            if (q == QP) peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));
-            if (q == QJ) {
-                peek_wait(peek);
-                go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
-            }
-            if (q >= QJ && q < QJ + NDMA && go) issue_piece(ln, tn - 1, q - QJ);
-        };
-        float hnew[2] = {0.0f, 0.0f};
-        if (active) {
-            f32x4 acc[2];
-            acc[0] = bias_s[(wave * L + l) * 4 + g];
-            acc[1] = acc[0];
-#ifdef APE_C16_V1
-            asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
-#endif
-            if constexpr (l == 0) {
-                span16<BX, NW0>(acc, xin + frag, BLK, w0, 0, [&](int q) { mid(q); });
-                if (ST || t > 0) span16<BH, NW0>(acc, hb(0, (t - 1) & 1) + frag, BLK, w0, NWX, [&](int q) { mid(BX + q); });
-            } else {
-                span16<BH, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, [&](int q) { mid(q); });
-                if (ST || t > 0) span16<BH, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, [&](int q) { mid(BH + q); });
-            }
-            mfma_drain16(acc[0], acc[1]);
-            // gates + cell update, lane-local: registers 0..3 = i, f, g, o of unit g, window rt * 16 + n
+        if (active && (ST || t > 0)) {
+            auto hook = [&](int q) {
+                if (q == QF) post(0);
+                if (q == QP) post(1);
+                if (q >= QJ && q < QJ + NDMA) {
+                    if (q == QJ) post(2);
+                    post(3 + q - QJ);
+                }
+            };
+            if constexpr (l == 0) span16<BH, false, true, NW0>(acc, hb(0, (t - 1) & 1) + frag, BLK, w0, NWX, hook);
+            else span16<BH, (l == L - 1), true, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, hook);
+        } else {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const float iv = sigm(acc[rt][0]), fv = sigm(acc[rt][1]), gv = tanh_(acc[rt][2]), ov = sigm(acc[rt][3]);
-                const float c = fv * cst[l][rt] + iv * gv;
-                cst[l][rt] = c;
-                hnew[rt] = ov * tanh_(c);
-            }
+            for (int k = 0; k < 3 + NDMA; ++k) post(k);
         }
-#ifdef APE_C16_DUMP
-        if (active && t < 2 && cluster == 0 && member == 0 && p.dbg_wg != nullptr) {
-            float* dump = reinterpret_cast<float*>(p.dbg_wg) + ((l * 2 + t) * 4 + wave) * 128 + lane;
-            dump[0] = hnew[0];
-            dump[64] = hnew[1];
+        if (active) {
+            pa[0] = acc[0];
+            pa[1] = acc[1];
         }
-#endif
         if (abort_word != 0) return false;
-        if (!ST && pend_idx >= 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            raise_pending();
-        }
         if (go) prefetched = true;
-        if constexpr (l == L - 1) {
-            if (!ST && !staged && ph + 1 < T) {
-                stage_x();
-                if (ph + 2 < T) fetch_x(ph + 2);
-            }
-        }
-        // ---- publish: transpose through the wave's LDS patch ([window][4 units]); lanes 0..31 send one window's 16 bytes each
-        //      (exactly ONE store instruction per wave and section: the counted wait at the top of the next section relies on it)
-        {
-            my_patch[n * 4 + g] = hnew[0];
-            my_patch[(16 + n) * 4 + g] = hnew[1];
-#ifdef APE_C16_V3
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
-#endif
-            const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);     // (same wave: LDS operations are in order)
-            // (whole-vector cast: hipcc 7.2 folds a per-element cast of a loaded vector into a one-dword load + splat)
-            const u32x4 hv = __builtin_bit_cast(u32x4, hf);
-            const unsigned off = (active && lane < 32) ? hx_base(l, t & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
-            if (in_l2) store_16<false>(hv, off, hx_desc);
-            else store_16<true>(hv, off, hx_desc);
-            if (active) {
-                pend_idx = l * NFL + member * 4 + wave;
-                pend_epoch = (unsigned)(t + 1);
-            }
-        }
         return true;
     };
     bool ok = true;
@@ -404,10 +449,36 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         ok = st ? section(std::true_type{}, std::integral_constant<int, 0>{}, ph) : section(std::false_type{}, std::integral_constant<int, 0>{}, ph);
         if (!ok) break;
         ok = st ? section(std::true_type{}, std::integral_constant<int, 1>{}, ph) : section(std::false_type{}, std::integral_constant<int, 1>{}, ph);
-        if constexpr (L == 3) {
-            if (!ok) break;
-            ok = st ? section(std::true_type{}, std::integral_constant<int, 2>{}, ph) : section(std::false_type{}, std::integral_constant<int, 2>{}, ph);
+        if (!ok) break;
+        ok = st ? section(std::true_type{}, std::integral_constant<int, 2>{}, ph) : section(std::false_type{}, std::integral_constant<int, 2>{}, ph);
+    }
+    if (!ok) return;
+    // ---- the last section's cell update and publish (layer L-1, step T-1) ----------------------------------------------------------------
+    {
+        float hn[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float iv = sigm(pa[k][0]), fv = sigm(pa[k][1]), gv = tanh_(pa[k][2]), ov = sigm(pa[k][3]);
+            hn[k] = ov * tanh_(fv * cst[L - 1][k] + iv * gv);
         }
+#ifdef APE_C16_DUMP
+        if (T - 1 < 2 && cluster == 0 && member == 0 && p.dbg_wg != nullptr) {
+            float* dump = reinterpret_cast<float*>(p.dbg_wg) + (((L - 1) * 2 + T - 1) * 4 + wave) * 128 + lane;
+            dump[0] = hn[0];
+            dump[64] = hn[1];
+        }
+#endif
+        my_patch[n * 4 + g] = hn[0];
+        my_patch[(16 + n) * 4 + g] = hn[1];
+        const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);
+        const u32x4 hv = __builtin_bit_cast(u32x4, hf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raise_pending();
+        const unsigned off = (lane < 32) ? hx_base(L - 1, (T - 1) & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
+        if (in_l2) store_16<false>(hv, off, hx_desc);
+        else store_16<true>(hv, off, hx_desc);
+        pend_idx = (L - 1) * NFL + member * 4 + wave;
+        pend_epoch = (unsigned)T;
     }
     if (!ok) return;
     // ---- final gather: h^{L-1}_{T-1} of every member ----------------------------------------------------------------------------
@@ -427,13 +498,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     {
         constexpr int RPM = MR / GH;
         const float* htop = hb(L - 1, 0);
-#ifdef APE_C16_DUMP
-        if (cluster == 0 && (member == 0 || member == 7) && tid < 64 && p.dbg_wg != nullptr) {
-            float sum = 0.0f;
-            for (int i = 0; i < 64; ++i) sum += htop[(tid >> 1) * 128 + (tid & 1) * 64 + i];
-            reinterpret_cast<float*>(p.dbg_wg)[3072 + (member ? 64 : 0) + tid] = sum;
-        }
-#endif
         const int part = tid & 3;
         for (int oi = tid >> 2; oi < ((RPM * O + 63) / 64) * 64; oi += 64) {
             const bool live = oi < RPM * O;
