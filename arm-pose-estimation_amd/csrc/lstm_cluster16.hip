@@ -51,21 +51,27 @@ __device__ __forceinline__ void mfma16_last(f32x4& a0, f32x4& a1, float w, float
 
 // NB k-blocks of 16: acc[rt] += W (registers w[w0 + 4 kb + j]) x activations (LDS: block kb at src + kb * stride, this lane's 16
 // bytes per row tile, the second row tile 16 windows = 64 floats further), fragments fetched one block ahead; mid(kb) behind block kb
-template <int NB, bool AG, bool DR, int NW, typename Mid>
-__device__ __forceinline__ void span16(f32x4 (&acc)[2], const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid) {
+// ... and fine(8 kb + 2 j + r) behind every single MFMA: one slot of scalar work (a transcendental and its operand preparation fit under the
+// 32 cycles the matrix core is busy)
+template <int NB, bool AG, bool DR, int NW, typename Mid, typename Fine>
+__device__ __forceinline__ void span16(f32x4 (&acc)[2], const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid, Fine&& fine) {
     f32x4 a0 = *reinterpret_cast<const f32x4*>(src), b0 = *reinterpret_cast<const f32x4*>(src + 64);
     f32x4 a1 = a0, b1 = b0;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
+#ifndef APE_ABL_NOLDS
         if (kb + 1 < NB) {
             a1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1));
             b1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1) + 64);
         }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mfma16<AG>(acc[0], w[w0 + 4 * kb + j], a0[j]);
+            fine(8 * kb + 2 * j);
             if (DR && kb == NB - 1 && j == 3) mfma16_last<AG>(acc[0], acc[1], w[w0 + 4 * kb + j], b0[j]);
             else mfma16<AG>(acc[1], w[w0 + 4 * kb + j], b0[j]);
+            if (!(DR && kb == NB - 1 && j == 3)) fine(8 * kb + 2 * j + 1);
         }
         mid(kb);
         a0 = a1;
@@ -170,15 +176,21 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     const double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;
     // column k of window w lives at [k-block k / 16][k-group (k % 16) / 4][window w][k % 4]
     const int x_slot = ((xk >> 4) * 4 + ((xk & 15) >> 2)) * (MR * 4) + (xk & 3);
-    auto stage_x = [&]() {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
+    // (x - mean) / std in float64 like the reference (numpy), rounded to float32 once: q1 is the correctly rounded quotient
+    auto stage_x1 = [&](int e) {
+        float v = xr[e];
+        if (normalize) {
             const double d = (double)xr[e] - x_mean;
             const double q0 = d * x_rstd;
             const double rr = fma(-q0, x_std, d);
             const double q1 = fma(rr, x_rstd, q0);
-            xin[x_slot + (xrow + e * (256 / KX)) * 4] = (float)((rr == rr) ? q1 : q0);
+            v = (float)((rr == rr) ? q1 : q0);
         }
+        xin[x_slot + (xrow + e * (256 / KX)) * 4] = v;
+    };
+    auto stage_x = [&]() {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) stage_x1(e);
     };
     fetch_x(0);
 
@@ -297,6 +309,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     bool prefetched = false;
     const int frag = (g * MR + n) * 4;                            // this lane's 16 bytes inside a k-block, row tile 0
     float* const my_patch = patch + wave * (MR * 4);
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long dg[L][5] = {};                             // steady-state sections: cycles in span A, counted wait, barrier, span B; count
+    auto now = [&]() -> unsigned long long {
+        const unsigned long long c = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return c;
+    };
+#endif
     f32x4 pa[2];                                                  // drained accumulators of the section in front
     pa[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     pa[1] = pa[0];
@@ -330,13 +350,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             } else if (k == 2) {
                 // transpose through the wave's LDS patch ([window][4 units]); lanes 0..31 send one window's 16 bytes each
                 // (exactly ONE store instruction per wave and section: the counted wait at the barrier relies on it)
-#ifdef APE_C16_DUMP
-                if (pactive && tp < 2 && cluster == 0 && member == 0 && p.dbg_wg != nullptr) {
-                    float* dump = reinterpret_cast<float*>(p.dbg_wg) + ((lp * 2 + tp) * 4 + wave) * 128 + lane;
-                    dump[0] = hn[0];
-                    dump[64] = hn[1];
-                }
-#endif
                 my_patch[n * 4 + g] = hn[0];
                 my_patch[(16 + n) * 4 + g] = hn[1];
                 const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);     // (same wave: LDS operations are in order)
@@ -351,6 +364,43 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
                 }
             }
         };
+        // the same work in the steady state, one slot behind every MFMA of span A: slot i < 20: step i % 10 of row tile i / 10's cell update
+        // (four exponentials, four reciprocals, the cell, its hyperbolic tangent), slot 20 the patch, slot 24 the store; every result is pinned
+        // by an empty volatile asm so that the compiler leaves the step in its slot
+        float ge[2][4], gc[2];
+        auto pin = [](float& v) { asm volatile("" : "+v"(v)); };
+        auto gate_slot = [&](int i) {
+            if (i < 20) {
+                const int k = i / 10, st = i % 10;
+                if (st < 4) {
+                    ge[k][st] = __builtin_amdgcn_exp2f((st == 2 ? -2.885390081777927f : -1.4426950408889634f) * pa[k][st]);
+                    pin(ge[k][st]);
+                } else if (st < 8) {
+                    const float r = __builtin_amdgcn_rcpf(1.0f + ge[k][st - 4]);
+                    ge[k][st - 4] = (st == 6) ? 2.0f * r - 1.0f : r;
+                    pin(ge[k][st - 4]);
+                } else if (st == 8) {
+                    const float c = ge[k][1] * cst[lp][k] + ge[k][0] * ge[k][2];
+                    cst[lp][k] = c;
+                    gc[k] = __builtin_amdgcn_exp2f(-2.885390081777927f * c);
+                    pin(gc[k]);
+                } else {
+                    hn[k] = ge[k][3] * (2.0f * __builtin_amdgcn_rcpf(1.0f + gc[k]) - 1.0f);
+                    pin(hn[k]);
+                }
+            } else if (i == 20) {
+                my_patch[n * 4 + g] = hn[0];
+                my_patch[(16 + n) * 4 + g] = hn[1];
+            } else if (i == 24) {
+                const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);
+                const u32x4 hv = __builtin_bit_cast(u32x4, hf);
+                const unsigned off = (lane < 32) ? hx_base(lp, tp & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
+                if (in_l2) store_16<false>(hv, off, hx_desc);
+                else store_16<true>(hv, off, hx_desc);
+                pend_idx = lp * NFL + member * 4 + wave;
+                pend_epoch = (unsigned)(tp + 1);
+            }
+        };
         // ---- work behind the barrier, item k: 0 flag of the store above, x; 1 look at the next section's flags; 2 judge;
         //      3 .. 2 + NDMA the next section's gather.  (The look and its judgement stay in one straight run of code: the register the
         //      load lands in must not be copied by the compiler in between.)
@@ -358,19 +408,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             if (k == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the publish store has drained
                 raise_pending();
-                if constexpr (l == 1) {
+                if constexpr (l == 1 && !ST) {
                     // x of the next layer-0 step: registers -> LDS (its readers, span A of this phase's layer-0 section, finished
-                    // before this section's barrier; the next ones start behind the barrier of section 2)
-                    if (ST || ph + 1 < T) stage_x();
+                    // before this section's barrier; the next ones start behind the barrier of section 2); steady state: in slots
+                    if (ph + 1 < T) stage_x();
                 }
             } else if (k == 1) {
                 peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));                     // (always: no branch around it)
             } else if (k == 2) {
                 peek_wait(peek);
                 go = pre_ok && __all((int)(peek >= (unsigned)tn)) != 0;
-#ifdef APE_C16_X1
-                go = false;
-#endif
                 if constexpr (l == 1) {
                     // the fetch of the step after it: the oldest entries of the memory queue when the next counted wait comes
                     if (ST || ph + 2 < T) fetch_x(ph + 2);
@@ -381,28 +428,28 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         };
         constexpr int QF = 0, QP = 1, QJ = 4;
         static_assert(QJ + NDMA <= BH && QF < QP && QP < QJ && BX >= 3, "hook schedule");
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c0 = ST ? now() : 0ull;
+#endif
         f32x4 acc[2];
-#if defined(APE_C16_Y2)
-        pre(0); pre(1); pre(2);
-        auto hook_a = [&](int q) {};
-#elif defined(APE_C16_Y1)
-        auto hook_a = [&](int q) { if (q == 2) { pre(0); pre(1); pre(2); } };
+        auto hook_a = [&](int q) { if (!ST && q < 3) pre(q); };
+#ifdef APE_ABL_NOGATES
+        auto fine_a = [&](int i) { if (ST && i == 24) gate_slot(i); };
 #else
-        auto hook_a = [&](int q) { if (q < 3) pre(q); };
+        auto fine_a = [&](int i) { if (ST && i <= 24) gate_slot(i); };
 #endif
         if (active) {
             acc[0] = bias_s[(wave * L + l) * 4 + g];
             acc[1] = acc[0];
-            if constexpr (l == 0) span16<BX, false, !ST, NW0>(acc, xin + frag, BLK, w0, 0, hook_a);
-            else span16<BH, (l == L - 1), !ST, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, hook_a);
-#if defined(APE_C16_Y2)
-        } else if (false) {
-#else
+            if constexpr (l == 0) span16<BX, false, !ST, NW0>(acc, xin + frag, BLK, w0, 0, hook_a, fine_a);
+            else span16<BH, (l == L - 1), !ST, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, hook_a, fine_a);
         } else {
-#endif
 #pragma unroll
             for (int k = 0; k < 3; ++k) pre(k);
         }
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c1 = ST ? now() : 0ull;
+#endif
         // ---- this layer's slices of its last step into LDS ------------------------------------------------------------------------
         if (need) {
             if (!prefetched) {
@@ -417,7 +464,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             }
         }
         prefetched = false;
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c2 = ST ? now() : 0ull;
+#endif
         bar();
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c3 = ST ? now() : 0ull;
+#endif
         const int abort_word = ctl[0];
         if (active && (ST || t > 0)) {
             auto hook = [&](int q) {
@@ -428,8 +481,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
                     post(3 + q - QJ);
                 }
             };
-            if constexpr (l == 0) span16<BH, false, true, NW0>(acc, hb(0, (t - 1) & 1) + frag, BLK, w0, NWX, hook);
-            else span16<BH, (l == L - 1), true, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, hook);
+            // (steady state, section 1: one element of the next x slab every other slot of blocks 1 .. 2, behind the store's drain)
+            auto fine_b = [&](int i) {
+                if constexpr (ST && l == 1) {
+                    if (i >= 8 && i < 8 + 2 * NE && ((i - 8) & 1) == 0) stage_x1((i - 8) >> 1);
+                }
+            };
+            if constexpr (l == 0) span16<BH, false, true, NW0>(acc, hb(0, (t - 1) & 1) + frag, BLK, w0, NWX, hook, fine_b);
+            else span16<BH, (l == L - 1), true, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, hook, fine_b);
         } else {
 #pragma unroll
             for (int k = 0; k < 3 + NDMA; ++k) post(k);
@@ -438,6 +497,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             pa[0] = acc[0];
             pa[1] = acc[1];
         }
+#ifdef APE_CLUSTER_STAMPS
+        if (ST) {
+            const unsigned long long c4 = now();
+            dg[l][0] += c1 - c0; dg[l][1] += c2 - c1; dg[l][2] += c3 - c2; dg[l][3] += c4 - c3; dg[l][4] += 1;
+        }
+#endif
         if (abort_word != 0) return false;
         if (go) prefetched = true;
         return true;
@@ -453,6 +518,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         ok = st ? section(std::true_type{}, std::integral_constant<int, 2>{}, ph) : section(std::false_type{}, std::integral_constant<int, 2>{}, ph);
     }
     if (!ok) return;
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && lane == 0 && cluster == 0 && member == 0)
+        for (int l = 0; l < L; ++l)
+            for (int k = 0; k < 5; ++k) p.dbg_wg[wave * 16 + l * 5 + k] = dg[l][k];
+#endif
     // ---- the last section's cell update and publish (layer L-1, step T-1) ----------------------------------------------------------------
     {
         float hn[2];
@@ -461,13 +531,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             const float iv = sigm(pa[k][0]), fv = sigm(pa[k][1]), gv = tanh_(pa[k][2]), ov = sigm(pa[k][3]);
             hn[k] = ov * tanh_(fv * cst[L - 1][k] + iv * gv);
         }
-#ifdef APE_C16_DUMP
-        if (T - 1 < 2 && cluster == 0 && member == 0 && p.dbg_wg != nullptr) {
-            float* dump = reinterpret_cast<float*>(p.dbg_wg) + (((L - 1) * 2 + T - 1) * 4 + wave) * 128 + lane;
-            dump[0] = hn[0];
-            dump[64] = hn[1];
-        }
-#endif
         my_patch[n * 4 + g] = hn[0];
         my_patch[(16 + n) * 4 + g] = hn[1];
         const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);

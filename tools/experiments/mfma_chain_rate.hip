@@ -1,0 +1,81 @@
+// How many independent accumulator chains does a wave need to keep the matrix core of its SIMD busy?  One wave per SIMD (4 per
+// workgroup, 1 workgroup per CU), N MFMAs round-robin over C chains, cycles per MFMA from s_memtime.
+//   hipcc -O3 --offload-arch=gfx950 tools/experiments/mfma_chain_rate.hip -o /tmp/mfma_chain_rate && /tmp/mfma_chain_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void k16(unsigned long long* out, float a, float b, int iters) {
+    f32x4 acc[C];
+    for (int c = 0; c < C; ++c) acc[c] = f32x4{0, 0, 0, 0};
+    float wa = a + threadIdx.x, wb = b;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 32 / C; ++r)
+#pragma unroll
+            for (int c = 0; c < C; ++c) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(wa), "v"(wb));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int c = 0; c < C; ++c) s += acc[c][0];
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)s; }
+}
+template <int C>
+__global__ __launch_bounds__(256, 1) void k32(unsigned long long* out, float a, float b, int iters) {
+    f32x16 acc[C];
+    for (int c = 0; c < C; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+    float wa = a + threadIdx.x, wb = b;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 32 / C; ++r)
+#pragma unroll
+            for (int c = 0; c < C; ++c) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(wa), "v"(wb));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int c = 0; c < C; ++c) s += acc[c][0];
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)s; }
+}
+// two chains, and between every two MFMAs V plain VALU instructions (v_fma_f32) and X transcendentals (v_exp_f32) on other registers
+template <int V, int X>
+__global__ __launch_bounds__(256, 1) void k16v(unsigned long long* out, float a, float b, int iters) {
+    f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    float wa = a + threadIdx.x, wb = b, v0 = a, v1 = b;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[r & 1]) : "v"(wa), "v"(wb));
+#pragma unroll
+            for (int i = 0; i < V; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v0) : "v"(wb));
+#pragma unroll
+            for (int i = 0; i < X; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v1));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0][0] + acc[1][0] + v0 + v1); }
+}
+template <typename K>
+void run(const char* name, K kern, int chains) {
+    unsigned long long* d; (void)hipMalloc(&d, 16);
+    const int iters = 2000;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, d, 1.0f, 0.5f, iters);
+    unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    printf("%s, %d chain(s): %.2f cycles per MFMA\n", name, chains, (double)h[0] / (iters * 32.0));
+    (void)hipFree(d);
+}
+int main() {
+    run("v_mfma_f32_16x16x4_f32", k16<1>, 1); run("v_mfma_f32_16x16x4_f32", k16<2>, 2); run("v_mfma_f32_16x16x4_f32", k16<4>, 4);
+    run("v_mfma_f32_32x32x2_f32", k32<1>, 1); run("v_mfma_f32_32x32x2_f32", k32<2>, 2); run("v_mfma_f32_32x32x2_f32", k32<4>, 4);
+    run("16x16x4 x 2 chains + 1 v_fma between", k16v<1, 0>, 2); run("16x16x4 x 2 chains + 4 v_fma between", k16v<4, 0>, 2);
+    run("16x16x4 x 2 chains + 6 v_fma between", k16v<6, 0>, 2); run("16x16x4 x 2 chains + 1 v_exp between", k16v<0, 1>, 2);
+    run("16x16x4 x 2 chains + 2 v_exp between", k16v<0, 2>, 2); run("16x16x4 x 2 chains + 1 v_exp + 2 v_fma between", k16v<2, 1>, 2);
+    return 0;
+}
