@@ -312,6 +312,9 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         size_t flag_words = (size_t)max_clusters * L * GH * 4;
         if (ape_cluster_f16v2_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * 2 * 32 > flag_words)
             flag_words = (size_t)f16v2_capacity(m->n_cus) * 2 * 32;
+        // (second-generation kernel of the 3 x 128 model: one flag per (32-row cluster, layer, member, one of eight waves))
+        if (ape_cluster16_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * L * 64 > flag_words)
+            flag_words = (size_t)f16v2_capacity(m->n_cus) * L * 64;
         m->xflag_bytes = ((flag_words * sizeof(unsigned)) + 15) / 16 * 16 + 16;
         if (e == hipSuccess) e = plan((void**)&m->hx, m->hx_bytes);
         if (e == hipSuccess) e = plan((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));

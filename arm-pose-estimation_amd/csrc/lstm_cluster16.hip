@@ -44,38 +44,30 @@ __device__ __forceinline__ void mfma16(f32x4& acc, float w, float a) {
 // the last MFMA of a span that ends a section, with the drain in the SAME statement: the compiler, which takes an asm's result for ready,
 // puts the phi copies of a branch merge right behind the MFMA otherwise (seen: the second row tile one k-step short, 1e-4)
 template <bool AG>
-__device__ __forceinline__ void mfma16_last(f32x4& a0, f32x4& a1, float w, float a) {
-    if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %1, %2, %3, %1\n\ts_nop 15" : "+v"(a0), "+v"(a1) : "a"(w), "v"(a));
-    else asm volatile("v_mfma_f32_16x16x4_f32 %1, %2, %3, %1\n\ts_nop 15" : "+v"(a0), "+v"(a1) : "v"(w), "v"(a));
+__device__ __forceinline__ void mfma16_last(f32x4& acc, float w, float a) {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 15" : "+v"(acc) : "a"(w), "v"(a));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 15" : "+v"(acc) : "v"(w), "v"(a));
 }
 
-// NB k-blocks of 16: acc[rt] += W (registers w[w0 + 4 kb + j]) x activations (LDS: block kb at src + kb * stride, this lane's 16
-// bytes per row tile, the second row tile 16 windows = 64 floats further), fragments fetched one block ahead; mid(kb) behind block kb
-// ... and fine(8 kb + 2 j + r) behind every single MFMA: one slot of scalar work (a transcendental and its operand preparation fit under the
-// 32 cycles the matrix core is busy)
+// NB k-blocks of 16: acc += W (registers w[w0 + 4 kb + j]) x activations (LDS: block kb at src + kb * stride, this lane's 16 bytes),
+// fragments fetched one block ahead; mid(kb) behind block kb, fine(4 kb + j) behind every single MFMA
 template <int NB, bool AG, bool DR, int NW, typename Mid, typename Fine>
-__device__ __forceinline__ void span16(f32x4 (&acc)[2], const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid, Fine&& fine) {
-    f32x4 a0 = *reinterpret_cast<const f32x4*>(src), b0 = *reinterpret_cast<const f32x4*>(src + 64);
-    f32x4 a1 = a0, b1 = b0;
+__device__ __forceinline__ void span16(f32x4& acc, const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid, Fine&& fine) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+    f32x4 a1 = a0;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-#ifndef APE_ABL_NOLDS
-        if (kb + 1 < NB) {
-            a1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1));
-            b1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1) + 64);
-        }
-#endif
+        if (kb + 1 < NB) a1 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 1));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mfma16<AG>(acc[0], w[w0 + 4 * kb + j], a0[j]);
-            fine(8 * kb + 2 * j);
-            if (DR && kb == NB - 1 && j == 3) mfma16_last<AG>(acc[0], acc[1], w[w0 + 4 * kb + j], b0[j]);
-            else mfma16<AG>(acc[1], w[w0 + 4 * kb + j], b0[j]);
-            if (!(DR && kb == NB - 1 && j == 3)) fine(8 * kb + 2 * j + 1);
+            if (DR && kb == NB - 1 && j == 3) mfma16_last<AG>(acc, w[w0 + 4 * kb + j], a0[j]);
+            else {
+                mfma16<AG>(acc, w[w0 + 4 * kb + j], a0[j]);
+                fine(4 * kb + j);
+            }
         }
         mid(kb);
         a0 = a1;
-        b0 = b1;
     }
 }
 
@@ -96,23 +88,28 @@ __device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
 __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 
 template <int H, int L, int KX>
-__global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams p) {
+__global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams p) {
     constexpr int GH = H / 16;              // members per cluster (16 units each, 4 per wave)
     constexpr int MR = 32;                  // windows per cluster: two 16-row tiles
     constexpr int BX = KX / 16, BH = H / 16;// k-blocks of 16 (one block = one member's units, or 16 input columns)
     constexpr int NWX = 4 * BX, NWH = 4 * BH;               // weight registers per lane: input part of layer 0 / an H-wide part
     constexpr int NW0 = NWX + NWH, NWU = 2 * NWH;           // layer 0 / a layer above
-    constexpr int NFL = 4 * GH;             // flags per (cluster, layer): one per member wave
+    constexpr int NFL = 8 * GH;             // flags per (cluster, layer): one per member wave
     constexpr int BLK = 4 * MR * 4;         // floats of one k-block in LDS: [wave / k-group 4][window 32][4] = 2 KB
     constexpr int HL = GH * BLK;            // floats of one slice set
     constexpr int XL = BX * BLK;            // floats of the x slab (the same fragment order)
-    constexpr int NDMA = HL * 4 / 1024 / 4; // LDS-DMA instructions per wave and gather
+    constexpr int NDMA = HL * 4 / 1024 / 8; // LDS-DMA instructions per wave and gather
     constexpr unsigned SET_BYTES = HL * sizeof(float);
-    static_assert(L == 3 && GH * 4 <= 64 && (GH & (GH - 1)) == 0 && NDMA >= 1, "shape");
+    static_assert(L == 3 && NFL <= 64 && (GH & (GH - 1)) == 0 && NDMA >= 1, "shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // eight waves, two per SIMD: unit group ug (4 hidden units = 16 tile columns) x row tile rt (16 windows).  A wave cannot issue anything
+    // while its own MFMA occupies the matrix core (tools/experiments/mfma_chain_rate.hip: one v_fma between two MFMAs costs 12 cycles), so
+    // the waves (ug, 0) and (ug, 1), which hold the same weights, take turns there: one's cell update, exchange and operand fetches run
+    // under the other's matrix work
+    const int ug = wave & 3, rt = wave >> 2;
     const int n = lane & 15, g = lane >> 4;         // window of a row tile; k-group of the operands = hidden unit of the results
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
@@ -122,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     // h of layer l < L-1: two parity buffers (read by the layer's recurrence AND as the next layer's input); top layer: one
     float* hbase = smem;                                  // [2 (L-1) + 1][HL]
     float* xin = hbase + (2 * (L - 1) + 1) * HL;          // [XL]
-    float* patch = xin + XL;                              // [wave 4][window 32][4]: the publish transpose
+    float* patch = xin + XL;                              // [wave 8][window 16][4]: the publish transpose
     f32x4* bias_s = reinterpret_cast<f32x4*>(patch + 4 * MR * 4);     // [wave 4][L][g 4]: start values of unit g's four gates
     int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * 4);            // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
     auto hb = [&](int l, int par) -> float* { return hbase + (l < L - 1 ? 2 * l + par : 2 * (L - 1)) * HL; };
@@ -151,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- x: thread -> NE (window, column) elements of the step slab, all with the same column ---------------------------------
-    constexpr int NE = (MR * KX) / 256;
+    constexpr int NE = (MR * KX) / 512;
     const int xk = tid % KX, xrow = tid / KX;
     const int rows_here = bcast_x ? MR : max(0, min(MR, p.B - row0));
     const unsigned long long x_addr = reinterpret_cast<unsigned long long>(p.x + (bcast_x ? (size_t)0 : (size_t)row0 * T * I));
@@ -161,13 +158,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         reinterpret_cast<float*>(((unsigned long long)x_hi << 32) | x_lo), 0, x_bytes, 0x00020000);
     const unsigned x_rowbytes = bcast_x ? 0u : (unsigned)(T * I * sizeof(float));
     const unsigned x_off0 = (xk < I) ? (unsigned)xrow * x_rowbytes + (unsigned)(xk * sizeof(float)) : 0x80000000u;
-    const unsigned x_estride = (unsigned)(256 / KX) * x_rowbytes;
+    const unsigned x_estride = (unsigned)(512 / KX) * x_rowbytes;
     float xr[NE];
     auto fetch_x = [&](int t) {
         const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const unsigned off = (xrow + e * (256 / KX) < rows_here) ? x_off0 + (unsigned)e * x_estride : 0x80000000u;
+            const unsigned off = (xrow + e * (512 / KX) < rows_here) ? x_off0 + (unsigned)e * x_estride : 0x80000000u;
             xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (unsigned)(slot * I * sizeof(float)), 0));
         }
     };
@@ -186,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             const double q1 = fma(rr, x_rstd, q0);
             v = (float)((rr == rr) ? q1 : q0);
         }
-        xin[x_slot + (xrow + e * (256 / KX)) * 4] = v;
+        xin[x_slot + (xrow + e * (512 / KX)) * 4] = v;
     };
     auto stage_x = [&]() {
 #pragma unroll
@@ -200,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     float w0[NW0];
     float wu[L - 1][NWU];
     {
-        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + ug) * (NW0 / 4)) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NW0 / 4; ++i) {
             const f32x4 v = s0[i * 64];
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         }
 #pragma unroll
         for (int l = 1; l < L; ++l) {
-            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[l]) + ((size_t)(member * 4 + wave) * (NWU / 4)) * 64 + lane;
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[l]) + ((size_t)(member * 4 + ug) * (NWU / 4)) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < NWU / 4; ++i) {
                 const f32x4 v = s1[i * 64];
@@ -223,9 +220,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         for (int gate = 0; gate < 4; ++gate) bv[gate] = p.bias[l][gate * H + member * 16 + wv * 4 + gg];
         bias_s[tid] = bv;
     }
-    float cst[L][2];
+    float cst[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) { cst[l][0] = 0.0f; cst[l][1] = 0.0f; }
+    for (int l = 0; l < L; ++l) cst[l] = 0.0f;
 
     const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
     u32x4 hx_desc;
@@ -283,9 +280,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     const unsigned wave_kib = (unsigned)(wave * 1024);
     // slices of layer l, step `step` -> its LDS buffer; wave w copies KiB w, w + 4, ...
     auto issue_piece = [&](int l, int step, int k) {
-        const unsigned src = hx_base(l, step & 1) + wave_kib + (unsigned)(k * 4096);
+        const unsigned src = hx_base(l, step & 1) + wave_kib + (unsigned)(k * 8192);
         const unsigned buf = (unsigned)(l < L - 1 ? 2 * l + (step & 1) : 2 * (L - 1));
-        dma_1k(opaque(hbase_lds + wave_kib) + buf * SET_BYTES + (unsigned)(k * 4096), dma_voff, hx_desc, src);
+        dma_1k(opaque(hbase_lds + wave_kib) + buf * SET_BYTES + (unsigned)(k * 8192), dma_voff, hx_desc, src);
     };
     int pend_idx = -1;
     unsigned pend_epoch = 0u;
@@ -307,8 +304,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     // store (1) -- `vmcnt(1)`.
     const int P = T + L - 1;
     bool prefetched = false;
-    const int frag = (g * MR + n) * 4;                            // this lane's 16 bytes inside a k-block, row tile 0
-    float* const my_patch = patch + wave * (MR * 4);
+    const int frag = (g * MR + rt * 16 + n) * 4;                  // this lane's 16 bytes inside a k-block
+    float* const my_patch = patch + wave * 64;
 #ifdef APE_CLUSTER_STAMPS
     unsigned long long dg[L][5] = {};                             // steady-state sections: cycles in span A, counted wait, barrier, span B; count
     auto now = [&]() -> unsigned long long {
@@ -317,9 +314,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         return c;
     };
 #endif
-    f32x4 pa[2];                                                  // drained accumulators of the section in front
-    pa[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    pa[1] = pa[0];
+    f32x4 pa = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                    // drained accumulator of the section in front
     auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;
         constexpr int l = decltype(layer_tag)::value;
@@ -336,69 +331,58 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         const bool pre_ok = ST || (tn >= 1 && tn <= T);
         unsigned peek = (unsigned)tn;
         bool go = false;
-        float hn[2] = {0.0f, 0.0f};
-        // ---- work in front of the barrier, item k: 0, 1 cell update of row tile k of the section in front; 2 its publish; 3 flag look
-        auto pre = [&](int k) {
-            if (k < 2) {
-                if (pactive) {
-                    // registers 0..3 = i, f, g, o of unit g, window k * 16 + n
-                    const float iv = sigm(pa[k][0]), fv = sigm(pa[k][1]), gv = tanh_(pa[k][2]), ov = sigm(pa[k][3]);
-                    const float c = fv * cst[lp][k] + iv * gv;
-                    cst[lp][k] = c;
-                    hn[k] = ov * tanh_(c);
-                }
-            } else if (k == 2) {
-                // transpose through the wave's LDS patch ([window][4 units]); lanes 0..31 send one window's 16 bytes each
-                // (exactly ONE store instruction per wave and section: the counted wait at the barrier relies on it)
-                my_patch[n * 4 + g] = hn[0];
-                my_patch[(16 + n) * 4 + g] = hn[1];
-                const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);     // (same wave: LDS operations are in order)
-                // (whole-vector cast: hipcc 7.2 folds a per-element cast of a loaded vector into a one-dword load + splat)
-                const u32x4 hv = __builtin_bit_cast(u32x4, hf);
-                const unsigned off = (pactive && lane < 32) ? hx_base(lp, tp & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
-                if (in_l2) store_16<false>(hv, off, hx_desc);
-                else store_16<true>(hv, off, hx_desc);
-                if (pactive) {
-                    pend_idx = lp * NFL + member * 4 + wave;
-                    pend_epoch = (unsigned)(tp + 1);
-                }
+        float hn = 0.0f;
+        // the publish: transpose through the wave's LDS patch ([window 16][4 units]); lanes 0..15 send one window's 16 bytes each
+        // (exactly ONE store instruction per wave and section: the counted wait at the barrier relies on it)
+        auto publish = [&]() {
+            const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 15) * 4);     // (same wave: LDS operations are in order)
+            // (whole-vector cast: hipcc 7.2 folds a per-element cast of a loaded vector into a one-dword load + splat)
+            const u32x4 hv = __builtin_bit_cast(u32x4, hf);
+            const unsigned off = (pactive && lane < 16) ? hx_base(lp, tp & 1) + (unsigned)(((member * 4 + ug) * MR + rt * 16 + lane) * 16) : 0x80000000u;
+            if (in_l2) store_16<false>(hv, off, hx_desc);
+            else store_16<true>(hv, off, hx_desc);
+            if (pactive) {
+                pend_idx = lp * NFL + member * 8 + wave;
+                pend_epoch = (unsigned)(tp + 1);
             }
         };
-        // the same work in the steady state, one slot behind every MFMA of span A: slot i < 20: step i % 10 of row tile i / 10's cell update
-        // (four exponentials, four reciprocals, the cell, its hyperbolic tangent), slot 20 the patch, slot 24 the store; every result is pinned
-        // by an empty volatile asm so that the compiler leaves the step in its slot
-        float ge[2][4], gc[2];
+        // ---- work in front of the barrier (fill and drain sections, in one piece): cell update of the section in front, its publish
+        auto pre = [&]() {
+            if (pactive) {
+                // registers 0..3 = i, f, g, o of unit g, window rt * 16 + n
+                const float iv = sigm(pa[0]), fv = sigm(pa[1]), gv = tanh_(pa[2]), ov = sigm(pa[3]);
+                const float c = fv * cst[lp] + iv * gv;
+                cst[lp] = c;
+                hn = ov * tanh_(c);
+            }
+            my_patch[n * 4 + g] = hn;
+            publish();
+        };
+        // the same work in the steady state, one slot behind every MFMA of span A: slots 0 .. 9 the cell update (four exponentials, four
+        // reciprocals, the cell, its hyperbolic tangent), slot 10 the patch, slot 13 the store; every result is pinned by an empty volatile
+        // asm so that the compiler leaves the step in its slot
+        float ge[4], gc = 0.0f;
         auto pin = [](float& v) { asm volatile("" : "+v"(v)); };
         auto gate_slot = [&](int i) {
-            if (i < 20) {
-                const int k = i / 10, st = i % 10;
-                if (st < 4) {
-                    ge[k][st] = __builtin_amdgcn_exp2f((st == 2 ? -2.885390081777927f : -1.4426950408889634f) * pa[k][st]);
-                    pin(ge[k][st]);
-                } else if (st < 8) {
-                    const float r = __builtin_amdgcn_rcpf(1.0f + ge[k][st - 4]);
-                    ge[k][st - 4] = (st == 6) ? 2.0f * r - 1.0f : r;
-                    pin(ge[k][st - 4]);
-                } else if (st == 8) {
-                    const float c = ge[k][1] * cst[lp][k] + ge[k][0] * ge[k][2];
-                    cst[lp][k] = c;
-                    gc[k] = __builtin_amdgcn_exp2f(-2.885390081777927f * c);
-                    pin(gc[k]);
-                } else {
-                    hn[k] = ge[k][3] * (2.0f * __builtin_amdgcn_rcpf(1.0f + gc[k]) - 1.0f);
-                    pin(hn[k]);
-                }
-            } else if (i == 20) {
-                my_patch[n * 4 + g] = hn[0];
-                my_patch[(16 + n) * 4 + g] = hn[1];
-            } else if (i == 24) {
-                const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);
-                const u32x4 hv = __builtin_bit_cast(u32x4, hf);
-                const unsigned off = (lane < 32) ? hx_base(lp, tp & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
-                if (in_l2) store_16<false>(hv, off, hx_desc);
-                else store_16<true>(hv, off, hx_desc);
-                pend_idx = lp * NFL + member * 4 + wave;
-                pend_epoch = (unsigned)(tp + 1);
+            if (i < 4) {
+                ge[i] = __builtin_amdgcn_exp2f((i == 2 ? -2.885390081777927f : -1.4426950408889634f) * pa[i]);
+                pin(ge[i]);
+            } else if (i < 8) {
+                const float r = __builtin_amdgcn_rcpf(1.0f + ge[i - 4]);
+                ge[i - 4] = (i == 6) ? 2.0f * r - 1.0f : r;
+                pin(ge[i - 4]);
+            } else if (i == 8) {
+                const float c = ge[1] * cst[lp] + ge[0] * ge[2];
+                cst[lp] = c;
+                gc = __builtin_amdgcn_exp2f(-2.885390081777927f * c);
+                pin(gc);
+            } else if (i == 9) {
+                hn = ge[3] * (2.0f * __builtin_amdgcn_rcpf(1.0f + gc) - 1.0f);
+                pin(hn);
+            } else if (i == 10) {
+                my_patch[n * 4 + g] = hn;
+            } else if (i == 13) {
+                publish();
             }
         };
         // ---- work behind the barrier, item k: 0 flag of the store above, x; 1 look at the next section's flags; 2 judge;
@@ -427,25 +411,23 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             }
         };
         constexpr int QF = 0, QP = 1, QJ = 4;
-        static_assert(QJ + NDMA <= BH && QF < QP && QP < QJ && BX >= 3, "hook schedule");
+        static_assert(QJ + NDMA <= BH && QF < QP && QP < QJ && BX >= 4, "hook schedule");
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c0 = ST ? now() : 0ull;
 #endif
-        f32x4 acc[2];
-        auto hook_a = [&](int q) { if (!ST && q < 3) pre(q); };
+        f32x4 acc;
+        auto hook_a = [&](int q) { if (!ST && q == 0) pre(); };
 #ifdef APE_ABL_NOGATES
-        auto fine_a = [&](int i) { if (ST && i == 24) gate_slot(i); };
+        auto fine_a = [&](int i) { if (ST && i == 13) gate_slot(i); };
 #else
-        auto fine_a = [&](int i) { if (ST && i <= 24) gate_slot(i); };
+        auto fine_a = [&](int i) { if (ST && i <= 13) gate_slot(i); };
 #endif
         if (active) {
-            acc[0] = bias_s[(wave * L + l) * 4 + g];
-            acc[1] = acc[0];
+            acc = bias_s[(ug * L + l) * 4 + g];
             if constexpr (l == 0) span16<BX, false, !ST, NW0>(acc, xin + frag, BLK, w0, 0, hook_a, fine_a);
-            else span16<BH, (l == L - 1), !ST, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, hook_a, fine_a);
+            else span16<BH, true, !ST, NWU>(acc, hb(l - 1, t & 1) + frag, BLK, wu[l - 1], 0, hook_a, fine_a);
         } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) pre(k);
+            pre();
         }
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c1 = ST ? now() : 0ull;
@@ -484,19 +466,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
             // (steady state, section 1: one element of the next x slab every other slot of blocks 1 .. 2, behind the store's drain)
             auto fine_b = [&](int i) {
                 if constexpr (ST && l == 1) {
-                    if (i >= 8 && i < 8 + 2 * NE && ((i - 8) & 1) == 0) stage_x1((i - 8) >> 1);
+                    if (i >= 4 && i < 4 + 2 * NE && ((i - 4) & 1) == 0) stage_x1((i - 4) >> 1);
                 }
             };
             if constexpr (l == 0) span16<BH, false, true, NW0>(acc, hb(0, (t - 1) & 1) + frag, BLK, w0, NWX, hook, fine_b);
-            else span16<BH, (l == L - 1), true, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, hook, fine_b);
+            else span16<BH, true, true, NWU>(acc, hb(l, (t - 1) & 1) + frag, BLK, wu[l - 1], NWH, hook, fine_b);
         } else {
 #pragma unroll
             for (int k = 0; k < 3 + NDMA; ++k) post(k);
         }
-        if (active) {
-            pa[0] = acc[0];
-            pa[1] = acc[1];
-        }
+        if (active) pa = acc;
 #ifdef APE_CLUSTER_STAMPS
         if (ST) {
             const unsigned long long c4 = now();
@@ -525,25 +504,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
 #endif
     // ---- the last section's cell update and publish (layer L-1, step T-1) ----------------------------------------------------------------
     {
-        float hn[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float iv = sigm(pa[k][0]), fv = sigm(pa[k][1]), gv = tanh_(pa[k][2]), ov = sigm(pa[k][3]);
-            hn[k] = ov * tanh_(fv * cst[L - 1][k] + iv * gv);
-        }
-        my_patch[n * 4 + g] = hn[0];
-        my_patch[(16 + n) * 4 + g] = hn[1];
-        const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 31) * 4);
+        const float iv = sigm(pa[0]), fv = sigm(pa[1]), gv = tanh_(pa[2]), ov = sigm(pa[3]);
+        my_patch[n * 4 + g] = ov * tanh_(fv * cst[L - 1] + iv * gv);
+        const f32x4 hf = *reinterpret_cast<const f32x4*>(my_patch + (lane & 15) * 4);
         const u32x4 hv = __builtin_bit_cast(u32x4, hf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         raise_pending();
-        const unsigned off = (lane < 32) ? hx_base(L - 1, (T - 1) & 1) + (unsigned)(((member * 4 + wave) * MR + lane) * 16) : 0x80000000u;
+        const unsigned off = (lane < 16) ? hx_base(L - 1, (T - 1) & 1) + (unsigned)(((member * 4 + ug) * MR + rt * 16 + lane) * 16) : 0x80000000u;
         if (in_l2) store_16<false>(hv, off, hx_desc);
         else store_16<true>(hv, off, hx_desc);
-        pend_idx = (L - 1) * NFL + member * 4 + wave;
+        pend_idx = (L - 1) * NFL + member * 8 + wave;
         pend_epoch = (unsigned)T;
     }
-    if (!ok) return;
     // ---- final gather: h^{L-1}_{T-1} of every member ----------------------------------------------------------------------------
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -562,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
         constexpr int RPM = MR / GH;
         const float* htop = hb(L - 1, 0);
         const int part = tid & 3;
-        for (int oi = tid >> 2; oi < ((RPM * O + 63) / 64) * 64; oi += 64) {
+        for (int oi = tid >> 2; oi < ((RPM * O + 127) / 128) * 128; oi += 128) {
             const bool live = oi < RPM * O;
             const int rr = live ? oi / O : 0, o = live ? oi - rr * O : 0;
             const int row = member * RPM + rr, b = row0 + row;
@@ -589,8 +561,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster16(const ClusterParams
     __syncthreads();
     if (ctl[2] != 0) {
         const int n_flags = (int)(gridDim.x / GH) * L * NFL;
-        for (int i = tid; i < n_flags; i += 256) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < n_flags; i += 512) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)gridDim.x; i += 512) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -617,6 +589,6 @@ hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int clusters, const C
     if (!ape_cluster16_supported(H, L, KX)) return hipErrorInvalidValue;
     const int grid_clusters = (clusters + 7) / 8 * 8;
     constexpr size_t smem = smem16<128, 3, 64>();
-    hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64>), dim3(grid_clusters * 8), dim3(512), smem, stream, p);
     return hipGetLastError();
 }

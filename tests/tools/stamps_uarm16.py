@@ -20,9 +20,9 @@ torch.cuda.synchronize(); m.check()
 lib = _hip.lib(); buf = (C.c_ulonglong * 2048)()
 lib.ape_debug_read_wg.argtypes = [C.c_void_p, C.c_void_p]
 lib.ape_debug_read_wg(m.handle, buf)
-d = np.frombuffer(buf, dtype=np.uint64)[:64].reshape(4, 16)[:, :15].reshape(4, 3, 5).astype(np.float64)
+d = np.frombuffer(buf, dtype=np.uint64)[:128].reshape(8, 16)[:, :15].reshape(8, 3, 5).astype(np.float64)
 print(f"{m.kernel_name(B, T)}  B={B} T={T}: cycles per steady-state section (100 MHz counter x 24 -> shader clocks if constant)")
-for w in range(4):
+for w in (0, 4):
     for l in range(3):
         n = max(d[w, l, 4], 1)
         a, wt, bar, b = (d[w, l, k] / n for k in range(4))
