@@ -110,10 +110,19 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // which cluster kernel serves `rest` rows behind the batch-tile waves (the ONE rule lstm_forward_impl, the cost model and
 // ape_debug_plan share): the second-generation f32 kernel from 513 rows on where the model and the call allow it (`c32`:
 // a 2 x 256 model, eval mode, last-step output), else the first-generation kernel
-enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3 };
-static int rest_kernel(int rest, bool c32) { return rest <= 0 ? PLAN_NONE : (c32 && rest > 512) ? PLAN_C32 : PLAN_GEN1; }
+// `gen2`: the second-generation kernel the model and the call are eligible for -- 32: lstm_cluster32.hip (2 x 256), 16:
+// lstm_cluster16.hip (3 x 128: a launch costs 24.6 + 6.6 T against the first generation's 15.1 + 7.75 T at 513 .. 1024 rows, so it
+// serves windows of 10 steps and more), 0: none
+enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3, PLAN_C16 = 4 };
+static int rest_kernel(int rest, int T, int gen2) {
+    if (rest <= 0) return PLAN_NONE;
+    if (gen2 == 32 && rest > 512) return PLAN_C32;
+    if (gen2 == 16 && rest > 512 && T >= 10) return PLAN_C16;
+    return PLAN_GEN1;
+}
+static int gen2_of(const ape_model* m) { return (m->c32_ok && m->c32_on) ? 32 : (m->c16_ok && m->c32_on) ? 16 : 0; }
 
-static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, bool c32 = false, bool wide = false) {
+static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, int gen2 = 0, bool wide = false) {
     const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop || wide);
     if (rpl == 0) return (B + wave - 1) / wave;          // no cluster fits on this device
     const double rate = (wide ? 1.23e14 : dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
@@ -125,7 +134,9 @@ static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bo
     auto cost = [&](int w) {
         const int rest = B - wave * w;
         if (rest <= 0) return w * t16;
-        if (rest_kernel(rest, c32 && !cdrop && !wide && rpl2 > 0) == PLAN_C32) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (16.0 + 12.4 * T);
+        const int k = rest_kernel(rest, T, (!cdrop && !wide && rpl2 > 0) ? gen2 : 0);
+        if (k == PLAN_C32) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (16.0 + 12.4 * T);
+        if (k == PLAN_C16) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (24.6 + 6.6 * T);
         return w * t16 + (double)((rest + rpl - 1) / rpl) * tcl1;
     };
     int best = 0;
@@ -716,7 +727,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
-        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c, m->c32_ok && m->c32_on && !drop, m->wide_cluster);
+        const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c, drop ? 0 : gen2_of(m), m->wide_cluster);
         const long long front = (long long)tile16_wave_rows(m->n_cus) * w;
         n16 = (front < B) ? (int)front : B;
     }
@@ -747,7 +758,8 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path && !m->wide_cluster;   // latency path: VALU GEMV, one exchange per phase
         const int small_uw = (flags & APE_DIAG_SMALL_UW4) ? 4 : m->small_uw;
-        if (!f16 && !small && rest_kernel(B - n16, !cdrop && !drop && !all_steps && m->c32_ok && m->c32_on) == PLAN_C32) {
+        const int rest_plan = (f16 || small) ? PLAN_NONE : rest_kernel(B - n16, T, (!cdrop && !drop && !all_steps) ? gen2_of(m) : 0);
+        if (rest_plan == PLAN_C32) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
             const int rpl2 = 32 * f16v2_capacity(m->n_cus);
             for (int b0 = n16; b0 < B; b0 += rpl2) {
@@ -771,7 +783,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             }
             return APE_OK;
         }
-        if (!f16 && !small && !cdrop && !drop && !all_steps && m->c16_ok && m->c32_on && B - n16 > 256) {
+        if (rest_plan == PLAN_C16) {
             // second-generation kernel of the 3 x 128 model: 8-member clusters of 32 windows (lstm_cluster16.hip)
             const int rpl2 = 32 * f16v2_capacity(m->n_cus);
             for (int b0 = n16; b0 < B; b0 += rpl2) {
@@ -1541,16 +1553,18 @@ int ape_debug_plan2(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, 
     const int cap = cluster_capacity(n_cus, H);
     out[4] = cap; out[5] = PLAN_NONE;
     if (cap < 1) { out[0] = B; out[1] = out[2] = out[3] = 0; return APE_OK; }
-    const bool c32_ok = c32 != 0 && !cdrop && ape_cluster32_supported(H, dims->num_layers, padded_input(dims->input_size)) && f16v2_capacity(n_cus) > 0;
+    const bool g2 = c32 != 0 && !cdrop && f16v2_capacity(n_cus) > 0;
+    const int gen2 = !g2 ? 0 : ape_cluster32_supported(H, dims->num_layers, padded_input(dims->input_size)) ? 32
+                     : ape_cluster16_supported(H, dims->num_layers, padded_input(dims->input_size)) ? 16 : 0;
     long long n16 = 0;
-    if (B > 4) n16 = (long long)tile16_wave_rows(n_cus) * auto_tile16_waves(dims, n_cus, B, T, cdrop != 0, c32_ok);
+    if (B > 4) n16 = (long long)tile16_wave_rows(n_cus) * auto_tile16_waves(dims, n_cus, B, T, cdrop != 0, gen2);
     if (n16 > B) n16 = B;
     out[0] = (int)n16;
     const int rest = B - (int)n16;
     out[1] = out[2] = out[3] = 0;
     if (rest > 0) {
-        out[5] = (B <= 4 && !cdrop) ? PLAN_SMALL : rest_kernel(rest, c32_ok);
-        if (out[5] == PLAN_C32) {
+        out[5] = (B <= 4 && !cdrop) ? PLAN_SMALL : rest_kernel(rest, T, gen2);
+        if (out[5] == PLAN_C32 || out[5] == PLAN_C16) {
             const int rpl2 = 32 * f16v2_capacity(n_cus);
             out[1] = 2;
             out[3] = (rest + rpl2 - 1) / rpl2;
@@ -1582,10 +1596,10 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
-        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, m->c32_ok && m->c32_on, m->wide_cluster) > B) return m->kernel_name.c_str();
+        if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, gen2_of(m), m->wide_cluster) > B) return m->kernel_name.c_str();
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
-    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 256) return "ape_lstm_cluster16<128, 3, 64>";
+    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 10) return "ape_lstm_cluster16<128, 3, 64>";
     return m->cluster_name.c_str();
 }
 

@@ -19,9 +19,10 @@ def _built():
     entry.build()
 
 
-@pytest.mark.parametrize("B,T", [(1024, 64), (257, 1), (300, 2), (700, 3), (290, 4), (2100, 5), (1000, 6), (333, 31)])
+@pytest.mark.parametrize("B,T", [(1024, 64), (513, 10), (700, 11), (2100, 12), (1000, 13), (600, 31), (1024, 200)])
 def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
-    """lstm_cluster16.hip (eval-mode batches above 256 rows of WatchPhoneUarmNN's 3 x 128 LSTM, watch_phone_uarm_nn.py:13-41)
+    """lstm_cluster16.hip (eval-mode batches above 512 rows and windows of 10 steps and more of WatchPhoneUarmNN's 3 x 128 LSTM,
+    watch_phone_uarm_nn.py:13-41)
     against the float32 oracle (module tolerance 1e-6), the first-generation cluster kernel and the batch-tile kernel (other
     summation orders only); window lengths around the depth of its three-layer software pipeline (fill and drain sections),
     ragged and multi-launch batches, the forced any-placement (write-through) exchange and run-to-run determinism."""

@@ -13,7 +13,7 @@ m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, d
 m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0))
 if len(sys.argv) > 2: m.set_kernel(sys.argv[2])
 lib = _hip.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for T in (6, 64):
+for T in (tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else (6, 64)):
     x = torch.randn(B, T, cfg["I"], device="cuda"); y = torch.empty(B, cfg["O"], device="cuda")
     run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0, None, 0.0, 0, C.c_void_p(y.data_ptr()), st), "fwd")
     for _ in range(30): run()

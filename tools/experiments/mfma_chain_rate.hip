@@ -62,6 +62,42 @@ __global__ __launch_bounds__(256, 1) void k16v(unsigned long long* out, float a,
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0][0] + acc[1][0] + v0 + v1); }
 }
+// the steady-state block of lstm_cluster32.hip: four 32x32x2 MFMAs of one chain, MODE 0: nothing else; 1: an s_nop 0 behind each of the
+// first three (what hipcc puts between inline-asm MFMAs); 2: + one ds_read_b128 and a counted wait per block; 3: the ds_read and the wait
+// only; 4: all four MFMAs in ONE asm statement + the ds_read and the wait
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k32blk(unsigned long long* out, float a, float b, int iters) {
+    __shared__ f32x4 lds[1024];
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    lds[threadIdx.x] = f32x4{a, b, a, b};
+    __syncthreads();
+    float wa = a + threadIdx.x;
+    f32x4 f0 = lds[threadIdx.x], f1 = f0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (MODE >= 2) asm volatile("ds_read_b128 %0, %1" : "=v"(f1) : "v"((unsigned)(threadIdx.x * 16 + (r & 3) * 4096)));
+            if (MODE == 4) {
+                asm volatile("s_waitcnt lgkmcnt(1)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\tv_mfma_f32_32x32x2_f32 %0, %1, %3, %0\n\t"
+                             "v_mfma_f32_32x32x2_f32 %0, %1, %4, %0\n\tv_mfma_f32_32x32x2_f32 %0, %1, %5, %0"
+                             : "+v"(acc) : "v"(wa), "v"(f0[0]), "v"(f0[1]), "v"(f0[2]), "v"(f0[3]));
+            } else {
+                if (MODE >= 2) asm volatile("s_waitcnt lgkmcnt(1)");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(f0[j]));
+                    if ((MODE == 1 || MODE == 2) && j < 3) asm volatile("s_nop 0");
+                }
+            }
+            if (MODE >= 2) { asm volatile("" : "+v"(f1)); f0 = f1; }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0] + f0[0]); }
+}
 template <typename K>
 void run(const char* name, K kern, int chains) {
     unsigned long long* d; (void)hipMalloc(&d, 16);
@@ -77,5 +113,8 @@ int main() {
     run("16x16x4 x 2 chains + 1 v_fma between", k16v<1, 0>, 2); run("16x16x4 x 2 chains + 4 v_fma between", k16v<4, 0>, 2);
     run("16x16x4 x 2 chains + 6 v_fma between", k16v<6, 0>, 2); run("16x16x4 x 2 chains + 1 v_exp between", k16v<0, 1>, 2);
     run("16x16x4 x 2 chains + 2 v_exp between", k16v<0, 2>, 2); run("16x16x4 x 2 chains + 1 v_exp + 2 v_fma between", k16v<2, 1>, 2);
+    run("32x32x2 block of 4, bare", k32blk<0>, 1); run("32x32x2 block of 4 + s_nop 0 x 3", k32blk<1>, 1);
+    run("32x32x2 block of 4 + s_nop 0 x 3 + ds_read_b128 + wait", k32blk<2>, 1); run("32x32x2 block of 4 + ds_read_b128 + wait", k32blk<3>, 1);
+    run("32x32x2 block of 4 in one asm + ds_read_b128 + wait", k32blk<4>, 1);
     return 0;
 }
