@@ -38,6 +38,7 @@ ap.add_argument("--lds", type=int)
 ap.add_argument("--flop-per-launch", type=float)
 ap.add_argument("--peak-tflops", type=float)
 ap.add_argument("--note", default="")
+ap.add_argument("--wg-threads", type=int, default=256)
 ap.add_argument("--skip-first", type=int, default=0, help="leave the first N matching launches out of the duration mean (clock ramp)")
 ap.add_argument("--min-us", type=float, default=0.0, help="only launches at least this long (the same instantiation also serves shorter windows)")
 args = ap.parse_args()
@@ -129,7 +130,7 @@ hbm = fetch_kib * 1024 * 2 + write_kib * 1024 if fetch_kib is not None and write
 res = code_object_resources()
 mean_us = statistics.mean(steady) if steady else None
 lines = [f"# rocprofv3 summary `{args.tag}`", "",
-         f"kernel `{args.kname}`, grid {args.grid} threads ({args.grid // 256} workgroups x 256), {args.windows} windows per launch", ""]
+         f"kernel `{args.kname}`, grid {args.grid} threads ({args.grid // args.wg_threads} workgroups x {args.wg_threads}), {args.windows} windows per launch", ""]
 if args.note:
     lines += [args.note, ""]
 try:
