@@ -19,17 +19,17 @@ def _poke(lib):
     return lib.ape_debug_poke
 
 
-@pytest.mark.parametrize("B", [1, 64, 1024])
-def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, B):
+@pytest.mark.parametrize("name,B", [("pocket", 1), ("pocket", 64), ("pocket", 1024), ("uarm", 1024)])
+def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
     """state an aborted launch leaves behind (sticky status word set, tickets consumed): the next call on that handle must never
     return garbage silently.  Host outputs: the Python mirror recovers (ape_model_recover re-issues the call on the batch-tile
     kernel: the frame is NOT lost, the result is within 1e-6 of the cooperative kernel's, ape_model_stats counts it).  Device
     outputs: the strict check raises and resets; `recover()` instead re-issues.  Afterwards the handle works again, bit-equal."""
     from wear_mocap_ape_amd import _hip
-    name = "pocket"
     m, sd, cfg = make_model(name, 0, norm_stats[name])
     poke = _poke(_hip.lib())
     T = cfg["T"] if B < 1024 else 64
+    if B == 1024: assert m.kernel_name(B, T) == {"pocket": "ape_lstm_cluster32<256, 2, 32>", "uarm": "ape_lstm_cluster16<128, 3, 64>"}[name]
     x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 3))
     good = m(x, last_step_only=True, normalize_input=True).numpy().copy()
     m.set_kernel("tile16")
