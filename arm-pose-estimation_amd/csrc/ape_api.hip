@@ -802,7 +802,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.flags = flags; c.x_ring = x_ring;
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
-                hipError_t e = ape_launch_lstm_cluster16(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
+                hipError_t e = ape_launch_lstm_cluster16(H, L, m->KX, nb, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster16 lstm launch failed: %s", hipGetErrorString(e));
             }
             return APE_OK;

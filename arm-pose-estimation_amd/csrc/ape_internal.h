@@ -231,7 +231,7 @@ hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const C
 // second generation for 16-unit members (lstm_cluster16.hip: the 3 x 128 upper-arm model; first-generation register image wcl)
 bool ape_cluster16_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster16(int H, int L, int KX);
-hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);
+hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int rows, const ClusterParams& p, hipStream_t stream);
 bool ape_upper32_supported(int H, int L, int O);
 size_t ape_upper32_xfrag_bytes(int rows, int T);
 size_t ape_upper32_ypart_bytes(int rows);

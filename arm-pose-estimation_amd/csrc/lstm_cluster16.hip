@@ -87,18 +87,20 @@ __device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
 }
 __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 
-template <int H, int L, int KX>
-__global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams p) {
+template <int H, int L, int KX, int RT>
+__global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const ClusterParams p) {
     constexpr int GH = H / 16;              // members per cluster (16 units each, 4 per wave)
-    constexpr int MR = 32;                  // windows per cluster: two 16-row tiles
+    constexpr int MR = 16 * RT;             // windows per cluster: RT tiles of 16 (RT = 2: one workgroup of eight waves per CU; RT = 1: two workgroups
+                                            // of four waves per CU, each its own cluster member with its own barrier)
+    constexpr int NWV = 4 * RT, NT = 64 * NWV;
     constexpr int BX = KX / 16, BH = H / 16;// k-blocks of 16 (one block = one member's units, or 16 input columns)
     constexpr int NWX = 4 * BX, NWH = 4 * BH;               // weight registers per lane: input part of layer 0 / an H-wide part
     constexpr int NW0 = NWX + NWH, NWU = 2 * NWH;           // layer 0 / a layer above
-    constexpr int NFL = 8 * GH;             // flags per (cluster, layer): one per member wave
+    constexpr int NFL = NWV * GH;           // flags per (cluster, layer): one per member wave
     constexpr int BLK = 4 * MR * 4;         // floats of one k-block in LDS: [wave / k-group 4][window 32][4] = 2 KB
     constexpr int HL = GH * BLK;            // floats of one slice set
     constexpr int XL = BX * BLK;            // floats of the x slab (the same fragment order)
-    constexpr int NDMA = HL * 4 / 1024 / 8; // LDS-DMA instructions per wave and gather
+    constexpr int NDMA = HL * 4 / 1024 / NWV; // LDS-DMA instructions per wave and gather
     constexpr unsigned SET_BYTES = HL * sizeof(float);
     static_assert(L == 3 && NFL <= 64 && (GH & (GH - 1)) == 0 && NDMA >= 1, "shape");
 
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
         __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- x: thread -> NE (window, column) elements of the step slab, all with the same column ---------------------------------
-    constexpr int NE = (MR * KX) / 512;
+    constexpr int NE = (MR * KX) / NT;
     const int xk = tid % KX, xrow = tid / KX;
     const int rows_here = bcast_x ? MR : max(0, min(MR, p.B - row0));
     const unsigned long long x_addr = reinterpret_cast<unsigned long long>(p.x + (bcast_x ? (size_t)0 : (size_t)row0 * T * I));
@@ -158,13 +160,13 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
         reinterpret_cast<float*>(((unsigned long long)x_hi << 32) | x_lo), 0, x_bytes, 0x00020000);
     const unsigned x_rowbytes = bcast_x ? 0u : (unsigned)(T * I * sizeof(float));
     const unsigned x_off0 = (xk < I) ? (unsigned)xrow * x_rowbytes + (unsigned)(xk * sizeof(float)) : 0x80000000u;
-    const unsigned x_estride = (unsigned)(512 / KX) * x_rowbytes;
+    const unsigned x_estride = (unsigned)(NT / KX) * x_rowbytes;
     float xr[NE];
     auto fetch_x = [&](int t) {
         const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const unsigned off = (xrow + e * (512 / KX) < rows_here) ? x_off0 + (unsigned)e * x_estride : 0x80000000u;
+            const unsigned off = (xrow + e * (NT / KX) < rows_here) ? x_off0 + (unsigned)e * x_estride : 0x80000000u;
             xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (unsigned)(slot * I * sizeof(float)), 0));
         }
     };
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
             const double q1 = fma(rr, x_rstd, q0);
             v = (float)((rr == rr) ? q1 : q0);
         }
-        xin[x_slot + (xrow + e * (512 / KX)) * 4] = v;
+        xin[x_slot + (xrow + e * (NT / KX)) * 4] = v;
     };
     auto stage_x = [&]() {
 #pragma unroll
@@ -280,9 +282,9 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
     const unsigned wave_kib = (unsigned)(wave * 1024);
     // slices of layer l, step `step` -> its LDS buffer; wave w copies KiB w, w + 4, ...
     auto issue_piece = [&](int l, int step, int k) {
-        const unsigned src = hx_base(l, step & 1) + wave_kib + (unsigned)(k * 8192);
+        const unsigned src = hx_base(l, step & 1) + wave_kib + (unsigned)(k * NWV * 1024);
         const unsigned buf = (unsigned)(l < L - 1 ? 2 * l + (step & 1) : 2 * (L - 1));
-        dma_1k(opaque(hbase_lds + wave_kib) + buf * SET_BYTES + (unsigned)(k * 8192), dma_voff, hx_desc, src);
+        dma_1k(opaque(hbase_lds + wave_kib) + buf * SET_BYTES + (unsigned)(k * NWV * 1024), dma_voff, hx_desc, src);
     };
     int pend_idx = -1;
     unsigned pend_epoch = 0u;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
             if (in_l2) store_16<false>(hv, off, hx_desc);
             else store_16<true>(hv, off, hx_desc);
             if (pactive) {
-                pend_idx = lp * NFL + member * 8 + wave;
+                pend_idx = lp * NFL + member * NWV + wave;
                 pend_epoch = (unsigned)(tp + 1);
             }
         };
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
         const unsigned off = (lane < 16) ? hx_base(L - 1, (T - 1) & 1) + (unsigned)(((member * 4 + ug) * MR + rt * 16 + lane) * 16) : 0x80000000u;
         if (in_l2) store_16<false>(hv, off, hx_desc);
         else store_16<true>(hv, off, hx_desc);
-        pend_idx = (L - 1) * NFL + member * 8 + wave;
+        pend_idx = (L - 1) * NFL + member * NWV + wave;
         pend_epoch = (unsigned)T;
     }
     // ---- final gather: h^{L-1}_{T-1} of every member ----------------------------------------------------------------------------
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
         constexpr int RPM = MR / GH;
         const float* htop = hb(L - 1, 0);
         const int part = tid & 3;
-        for (int oi = tid >> 2; oi < ((RPM * O + 127) / 128) * 128; oi += 128) {
+        for (int oi = tid >> 2; oi < ((RPM * O + NT / 4 - 1) / (NT / 4)) * (NT / 4); oi += NT / 4) {
             const bool live = oi < RPM * O;
             const int rr = live ? oi / O : 0, o = live ? oi - rr * O : 0;
             const int row = member * RPM + rr, b = row0 + row;
@@ -561,16 +563,16 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_cluster16(const ClusterParams
     __syncthreads();
     if (ctl[2] != 0) {
         const int n_flags = (int)(gridDim.x / GH) * L * NFL;
-        for (int i = tid; i < n_flags; i += 512) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = tid; i < (int)gridDim.x; i += 512) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < n_flags; i += NT) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)gridDim.x; i += NT) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int H, int L, int KX>
+template <int H, int L, int KX, int RT>
 constexpr size_t smem16() {
-    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 512 + (size_t)(KX / 16) * 512 + 4 * 32 * 4) * sizeof(float) + (size_t)4 * L * 4 * 16 + 16;
+    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 256 * RT + (size_t)(KX / 16) * 256 * RT + 4 * RT * 64) * sizeof(float) + (size_t)4 * L * 4 * 16 + 16;
 }
 
 }  // namespace
@@ -579,16 +581,28 @@ bool ape_cluster16_supported(int H, int L, int KX) { return H == 128 && L == 3 &
 
 hipError_t ape_prepare_lstm_cluster16(int H, int L, int KX) {
     if (!ape_cluster16_supported(H, L, KX)) return hipSuccess;
-    static_assert(smem16<128, 3, 64>() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster16<128, 3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               APE_LDS_BYTES);
+    static_assert(smem16<128, 3, 64, 2>() <= APE_LDS_BYTES && 2 * smem16<128, 3, 64, 1>() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster16<128, 3, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       APE_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster16<128, 3, 64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               APE_LDS_BYTES / 2);
 }
 
-// `clusters` = 32-window clusters needed; the grid is rounded up to whole block-index classes (8 clusters x GH members)
-hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream) {
+// `rows` windows (at most 1024 on a whole MI355X); the grid is rounded up to whole block-index classes (8 clusters x GH members).
+// Default form: 32-window clusters, one eight-wave workgroup per CU.  APE_DIAG_SMALL_UW4 (diagnostic flag, re-used): 16-window clusters,
+// two four-wave workgroups per CU, each with its own barrier -- built to see whether two cluster members that drift freely on a CU overlap
+// better than two row tiles behind one barrier: they do not (1024 x 64 on one box: 456 vs 450 us)
+hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int rows, const ClusterParams& p, hipStream_t stream) {
     if (!ape_cluster16_supported(H, L, KX)) return hipErrorInvalidValue;
-    const int grid_clusters = (clusters + 7) / 8 * 8;
-    constexpr size_t smem = smem16<128, 3, 64>();
-    hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64>), dim3(grid_clusters * 8), dim3(512), smem, stream, p);
+    if (!(p.flags & APE_DIAG_SMALL_UW4)) {
+        const int grid_clusters = ((rows + 31) / 32 + 7) / 8 * 8;
+        constexpr size_t smem = smem16<128, 3, 64, 2>();
+        hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64, 2>), dim3(grid_clusters * 8), dim3(512), smem, stream, p);
+    } else {
+        const int grid_clusters = ((rows + 15) / 16 + 7) / 8 * 8;
+        constexpr size_t smem = smem16<128, 3, 64, 1>();
+        hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64, 1>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    }
     return hipGetLastError();
 }

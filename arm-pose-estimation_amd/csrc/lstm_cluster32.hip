@@ -310,6 +310,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     bool prefetched = false;
 #ifdef APE_CLUSTER_STAMPS
     unsigned long long dg_block[2] = {0, 0}, dg_go[2] = {0, 0};      // diagnostic counters per layer (cluster 0, member 0)
+    unsigned long long dgc[2][5] = {};       // steady-state sections: cycles in the top wait, the barrier, the MFMA spans, everything behind the barrier; count
+    auto now = [&]() -> unsigned long long {
+        const unsigned long long c = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return c;
+    };
 #endif
     auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 1 <= t <= T - 2 for both layers
@@ -319,6 +325,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         // h^l_{t-1} exists and somebody reads it from here on (layer 0 at t == T: no layer-0 step any more, but layer 1's
         // last step takes h^0_{T-1} as its input)
         const bool need = ST || (t >= 1 && t <= T);
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c0 = ST ? now() : 0ull;
+#endif
         // ---- S0: this layer's slices of its last step into LDS ------------------------------------------------------------
         if (need) {
             if (!prefetched) {                                    // pipeline fill, a late peer, the final gather
@@ -336,7 +345,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             }
         }
         prefetched = false;
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c1 = ST ? now() : 0ull;
+#endif
         bar();
+#ifdef APE_CLUSTER_STAMPS
+        const unsigned long long c2 = ST ? now() : 0ull;
+#endif
         const int abort_word = ctl[0];
         // the next section: layer ln on step tn = its phase - ln; the slice set it is missing is h^{ln}_{tn-1}, epoch tn
         constexpr int ln = (l + 1 < L) ? l + 1 : 0;
@@ -392,6 +407,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
                 span32<BH, true, NW1>(acc, hb0 + (t & 1) * HL + frag, MR * 8, w1, 0, [&](int q) { mid(q); });
                 if (ST || t > 0) span32<BH, true, NW1>(acc, hb1 + frag, MR * 8, w1, 4 * BH, [&](int q) { mid(BH + q); });
             }
+#ifdef APE_CLUSTER_STAMPS
+            const unsigned long long c3 = ST ? now() : 0ull;
+            if (ST) { dgc[l][0] += c1 - c0; dgc[l][1] += c2 - c1; dgc[l][2] += c3 - c2; }
+#endif
             mfma_drain(acc);
             // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
 #pragma unroll
@@ -432,6 +451,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
                 pend_epoch = (unsigned)(t + 1);
             }
         }
+#ifdef APE_CLUSTER_STAMPS
+        if (ST) { dgc[l][3] += now() - c2; dgc[l][4] += 1; }
+#endif
         return true;
     };
     bool ok = true;
@@ -461,6 +483,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
 #ifdef APE_CLUSTER_STAMPS
     if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0)
         for (int k = 0; k < 2; ++k) { p.dbg_wg[16 + k] = dg_block[k]; p.dbg_wg[18 + k] = dg_go[k]; }
+    if (p.dbg_wg != nullptr && lane == 0 && cluster == 0 && member == 0)
+        for (int l = 0; l < 2; ++l)
+            for (int k = 0; k < 5; ++k) p.dbg_wg[32 + wave * 16 + l * 5 + k] = dgc[l][k];
 #endif
     // ---- head: member m finishes windows 4m .. 4m+3 of the cluster's 32 ----------------------------------------------------------------
     {

@@ -1,0 +1,30 @@
+"""Per-section cycle accounting of lstm_cluster32.hip (diagnostic build, make diag): steady-state sections of cluster 0 / member 0, per wave and
+layer: top wait, barrier, MFMA spans (with the exchange hooks), everything behind the barrier (spans + drain + cell update + publish).
+python tests/tools/stamps_c32.py [B] [T]"""
+import ctypes as C, os, sys
+os.environ.setdefault("APE_HIP_LIB", "/root/repo/arm-pose-estimation_amd/lib/diag/libape_hip_diag.so")
+import numpy as np
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
+import torch
+from oracle import ape_oracle as orc
+from wear_mocap_ape_amd import _hip
+from wear_mocap_ape_amd.estimate import nn_models
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+cfg = orc.MODEL_CONFIGS["pocket"]
+m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0)
+m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0))
+m.set_kernel("cluster")
+x = torch.randn(B, T, cfg["I"], device="cuda")
+for _ in range(5): m(x, last_step_only=True)
+torch.cuda.synchronize(); m.check()
+lib = _hip.lib(); buf = (C.c_ulonglong * 2048)()
+lib.ape_debug_read_wg.argtypes = [C.c_void_p, C.c_void_p]
+lib.ape_debug_read_wg(m.handle, buf)
+d = np.frombuffer(buf, dtype=np.uint64)[32:32 + 64].reshape(4, 16)[:, :10].reshape(4, 2, 5).astype(np.float64)
+print(f"{m.kernel_name(B, T)}  B={B} T={T}: shader cycles per steady-state section; MFMA content: layer 0 {(4 + 32) * 4 * 64}, layer 1 {64 * 4 * 64}")
+for w in range(4):
+    for l in range(2):
+        n = max(d[w, l, 4], 1)
+        top, bar, span, behind = (d[w, l, k] / n for k in range(4))
+        print(f"  wave {w} layer {l}: top wait {top:6.1f}  barrier {bar:6.1f}  spans {span:8.1f}  drain + cell update + publish {behind - span:7.1f}  total {top + bar + behind:8.1f}   ({int(n)} sections)")

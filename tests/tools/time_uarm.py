@@ -13,9 +13,10 @@ m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, d
 m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0))
 if len(sys.argv) > 2: m.set_kernel(sys.argv[2])
 lib = _hip.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+FLAGS = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0       # diagnostic bits, e.g. 0x01000000: the one-workgroup-per-CU form of ape_lstm_cluster16
 for T in (tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else (6, 64)):
     x = torch.randn(B, T, cfg["I"], device="cuda"); y = torch.empty(B, cfg["O"], device="cuda")
-    run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0, None, 0.0, 0, C.c_void_p(y.data_ptr()), st), "fwd")
+    run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, FLAGS, None, 0.0, 0, C.c_void_p(y.data_ptr()), st), "fwd")
     for _ in range(30): run()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record()
     for _ in range(100): run()

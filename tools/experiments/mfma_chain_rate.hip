@@ -98,13 +98,53 @@ __global__ __launch_bounds__(256, 1) void k32blk(unsigned long long* out, float 
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0] + f0[0]); }
 }
+// the same with TWO waves per SIMD (512 threads): cycles per MFMA of ONE wave; 64 = the matrix core never idles (2 x 32)
+template <int V, int X>
+__global__ __launch_bounds__(512, 1) void k16v2(unsigned long long* out, float a, float b, int iters) {
+    f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    float wa = a + threadIdx.x, wb = b, v0 = a, v1 = b;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[r & 1]) : "v"(wa), "v"(wb));
+#pragma unroll
+            for (int i = 0; i < V; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v0) : "v"(wb));
+#pragma unroll
+            for (int i = 0; i < X; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v1));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0][0] + acc[1][0] + v0 + v1); }
+}
+template <typename K>
+void run2(const char* name, K kern) {
+    unsigned long long* d; (void)hipMalloc(&d, 16);
+    const int iters = 2000;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, d, 1.0f, 0.5f, iters);
+    unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, d, 1.0f, 0.5f, iters);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("two waves per SIMD, %s: %.2f cycles per MFMA of one wave; wall clock %.3f ms = %.1f TFLOP/s over 256 x 8 waves\n", name,
+           (double)h[0] / (iters * 32.0), ms, 256.0 * 8 * iters * 32.0 * 2048.0 / (ms * 1e-3) / 1e12);
+    (void)hipFree(d);
+}
 template <typename K>
 void run(const char* name, K kern, int chains) {
     unsigned long long* d; (void)hipMalloc(&d, 16);
     const int iters = 2000;
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, d, 1.0f, 0.5f, iters);
     unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
-    printf("%s, %d chain(s): %.2f cycles per MFMA\n", name, chains, (double)h[0] / (iters * 32.0));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, d, 1.0f, 0.5f, iters);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%s, %d chain(s): %.2f cycles per MFMA; wall clock %.3f ms for %d MFMAs per wave\n", name, chains, (double)h[0] / (iters * 32.0), ms, iters * 32);
     (void)hipFree(d);
 }
 int main() {
@@ -116,5 +156,7 @@ int main() {
     run("32x32x2 block of 4, bare", k32blk<0>, 1); run("32x32x2 block of 4 + s_nop 0 x 3", k32blk<1>, 1);
     run("32x32x2 block of 4 + s_nop 0 x 3 + ds_read_b128 + wait", k32blk<2>, 1); run("32x32x2 block of 4 + ds_read_b128 + wait", k32blk<3>, 1);
     run("32x32x2 block of 4 in one asm + ds_read_b128 + wait", k32blk<4>, 1);
+    run2("bare", k16v2<0, 0>); run2("1 v_fma between", k16v2<1, 0>); run2("4 v_fma between", k16v2<4, 0>);
+    run2("1 v_exp between", k16v2<0, 1>); run2("2 v_exp between", k16v2<0, 2>); run2("1 v_exp + 2 v_fma between", k16v2<2, 1>);
     return 0;
 }
