@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256, 1) void k32blk(unsigned long long* out, float 
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            if (MODE >= 2) asm volatile("ds_read_b128 %0, %1" : "=v"(f1) : "v"((unsigned)(threadIdx.x * 16 + (r & 3) * 4096)));
+            // MODE 5: lstm_cluster32.hip's fragment addresses ([window 32][8 units]: lane (n, hh) reads 16 bytes at n * 32 + hh * 16);
+            // MODE 6: [half][window][4 units]: n * 16 + hh * 512
+            const unsigned lane_ = threadIdx.x & 63, n_ = lane_ & 31, hh_ = lane_ >> 5;
+            const unsigned a_ = MODE == 5 ? n_ * 32 + hh_ * 16 : MODE == 6 ? n_ * 16 + hh_ * 512 : (threadIdx.x & 63) * 16;
+            if (MODE >= 2) asm volatile("ds_read_b128 %0, %1" : "=v"(f1) : "v"((unsigned)(a_ + (MODE >= 5 ? 0u : (threadIdx.x >> 6) * 1024u) + (r & 3) * 4096)));
             if (MODE == 4) {
                 asm volatile("s_waitcnt lgkmcnt(1)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\tv_mfma_f32_32x32x2_f32 %0, %1, %3, %0\n\t"
                              "v_mfma_f32_32x32x2_f32 %0, %1, %4, %0\n\tv_mfma_f32_32x32x2_f32 %0, %1, %5, %0"
@@ -156,6 +160,8 @@ int main() {
     run("32x32x2 block of 4, bare", k32blk<0>, 1); run("32x32x2 block of 4 + s_nop 0 x 3", k32blk<1>, 1);
     run("32x32x2 block of 4 + s_nop 0 x 3 + ds_read_b128 + wait", k32blk<2>, 1); run("32x32x2 block of 4 + ds_read_b128 + wait", k32blk<3>, 1);
     run("32x32x2 block of 4 in one asm + ds_read_b128 + wait", k32blk<4>, 1);
+    run("32x32x2 block of 4 + ds_read_b128 at the kernel's addresses [window][8]", k32blk<5>, 1);
+    run("32x32x2 block of 4 + ds_read_b128 at [half][window][4]", k32blk<6>, 1);
     run2("bare", k16v2<0, 0>); run2("1 v_fma between", k16v2<1, 0>); run2("4 v_fma between", k16v2<4, 0>);
     run2("1 v_exp between", k16v2<0, 1>); run2("2 v_exp between", k16v2<0, 2>); run2("1 v_exp + 2 v_fma between", k16v2<2, 1>);
     return 0;
