@@ -111,13 +111,13 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // ape_debug_plan share): the second-generation f32 kernel from 513 rows on where the model and the call allow it (`c32`:
 // a 2 x 256 model, eval mode, last-step output), else the first-generation kernel
 // `gen2`: the second-generation kernel the model and the call are eligible for -- 32: lstm_cluster32.hip (2 x 256), 16:
-// lstm_cluster16.hip (3 x 128: a launch costs 24.6 + 6.6 T against the first generation's 15.1 + 7.75 T at 513 .. 1024 rows, so it
-// serves windows of 10 steps and more), 0: none
+// lstm_cluster16.hip (3 x 128: a launch costs 24.6 + 6.6 T against the first generation's 15.5 + 7.5 T at 513 .. 1024 rows -- with
+// its XCD-local clusters; 15.1 + 7.75 T before them --, so it serves windows of 12 steps and more), 0: none
 enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3, PLAN_C16 = 4 };
 static int rest_kernel(int rest, int T, int gen2) {
     if (rest <= 0) return PLAN_NONE;
     if (gen2 == 32 && rest > 512) return PLAN_C32;
-    if (gen2 == 16 && rest > 512 && T >= 10) return PLAN_C16;
+    if (gen2 == 16 && rest > 512 && T >= 12) return PLAN_C16;
     return PLAN_GEN1;
 }
 static int gen2_of(const ape_model* m) { return (m->c32_ok && m->c32_on) ? 32 : (m->c16_ok && m->c32_on) ? 16 : 0; }
@@ -129,6 +129,8 @@ static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bo
     const double t16 = (double)wave * ape_flops_per_window(dims, T) / rate * 1e6;
     // first-generation launches: 25 + 13.7 T (22 + 8.4 T with dropout, 20 + 11 T wide); second-generation f32 kernel, eval mode:
     // 16 + 12.4 T per launch of up to 32 x f16v2_capacity rows -- priced only where rest_kernel() really picks it
+    // (with XCD-local clusters the dropout form measures 12.5 + 8.3 T; the constant stays: it decides which kernel -- and with it which
+    //  Philox chunking -- a Monte-Carlo call gets, and tests/test_hip_round2.py pins the bank's routes against each other)
     const double tcl1 = wide ? 20.0 + 11.0 * T : cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
     const int rpl2 = 32 * f16v2_capacity(n_cus);
     auto cost = [&](int w) {
@@ -622,6 +624,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                              int x_ring, const float* h0_dev = nullptr, const float* c0_dev = nullptr, FkTail* fk = nullptr) {
     if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
+    flags &= ~(uint32_t)APE_FLAG_XCD_CLASSES;            // (the launcher's own bit)
     if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
     if ((flags & APE_FLAG_NORMALIZE_INPUT) && !m->has_stats)
         return fail(APE_ERR_NOT_READY, "lstm_forward: NORMALIZE_INPUT without norm stats");
@@ -883,7 +886,15 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             if ((flags & APE_FLAG_DROPOUT_MASKS) && b0 + nb < B && cdrop)
                 return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
             if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
-            const int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
+            int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
+            // f32 first-generation kernel: whole groups of 8 clusters (if the device holds them) form XCD-local clusters and hand
+            // their slices over inside that XCD's L2 (lstm_cluster.hip, APE_FLAG_XCD_CLASSES); the extra clusters own no rows
+            if (!small && !f16 && m->gen1_classes && !(flags & APE_DIAG_NO_XSTAGE)) {        // (diagnostic bit: A/B on one box)
+                const int c8 = (clusters + 7) / 8 * 8;
+                // (a launch of fewer than four clusters -- one stream's 25 Monte-Carlo rows -- stays as it is: there the rendezvous costs
+                //  more than the shorter hops save, 44.7 vs 43.8 us)
+                if (clusters >= 4 && c8 <= cluster_capacity(m->n_cus, H)) { clusters = c8; c.flags |= APE_FLAG_XCD_CLASSES; }
+            }
             // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
             hipError_t e = small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), small_uw, c, (hipStream_t)stream)
                            : f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
@@ -1335,8 +1346,8 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
     if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
     // (APE_DIAG_WRITE_THROUGH: internal, tests only -- the cluster kernels take their any-placement exchange form, same bits)
-    const uint32_t diag_wt = flags & APE_DIAG_WRITE_THROUGH;
-    flags &= ~(uint32_t)APE_DIAG_WRITE_THROUGH;
+    const uint32_t diag_wt = flags & (APE_DIAG_WRITE_THROUGH | APE_DIAG_NO_XSTAGE);     // (+ the A/B bit of the first generation's classes)
+    flags &= ~(uint32_t)(APE_DIAG_WRITE_THROUGH | APE_DIAG_NO_XSTAGE);
     if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_PACKED_MSG))
         return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT and PACKED_MSG are accepted");
     if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_step: unknown dtype selector");
@@ -1599,7 +1610,7 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
         if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, gen2_of(m), m->wide_cluster) > B) return m->kernel_name.c_str();
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
-    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 10) return "ape_lstm_cluster16<128, 3, 64>";
+    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 12) return "ape_lstm_cluster16<128, 3, 64>";
     return m->cluster_name.c_str();
 }
 

@@ -6,13 +6,20 @@
 extern "C" {
 
 // internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
-// 2 departure counter, 3 launch number of the latency kernel, 4 / 5 status word / a class ticket of the MLP pipeline -- so that tests
+// 2 departure counter, 3 launch number of the latency kernel, 4 / 5 status word / a class ticket of the MLP pipeline, 6 the class-0 ticket of
+// the cluster kernels that form their clusters within block-index classes -- so that tests
 // can stage the state an aborted launch leaves behind
 int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
     if (m && m->ffp_ok && (which == 4 || which == 5)) {          // the MLP pipeline's status word / first class ticket
         APE_DBG_TRY(hipSetDevice(m->dims.device));
         APE_DBG_TRY(hipDeviceSynchronize());
         APE_DBG_TRY(hipMemcpy(m->ffp_ctl + (which == 4 ? 8 * 16 : 0), &value, sizeof(value), hipMemcpyHostToDevice));
+        return APE_OK;
+    }
+    if (m && m->cluster_ok && which == 6) {
+        APE_DBG_TRY(hipSetDevice(m->dims.device));
+        APE_DBG_TRY(hipDeviceSynchronize());
+        APE_DBG_TRY(hipMemcpy(m->xcc_slots + 64, &value, sizeof(value), hipMemcpyHostToDevice));
         return APE_OK;
     }
     if (!m || !m->cluster_ok || which < 0 || which > 3) return APE_ERR_INVALID_ARG;

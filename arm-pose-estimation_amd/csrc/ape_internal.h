@@ -18,6 +18,7 @@
 #define APE_DIAG_WRITE_THROUGH 0x08000000u   // small-batch kernel: use the any-placement (sc1) exchange even when the
                                             // members share an XCD -- results are the same; lets tests run that path
 
+#define APE_FLAG_XCD_CLASSES 0x00800000u   // internal (set by the launcher): the first-generation kernel forms its clusters within block-index classes
 #define APE_DIAG_SMALL_UW4   0x01000000u   // small-batch kernel: the H/16-member form also where the H/8-member one is available
                                             // (same results up to f32 summation order; lets tests run that form)
 

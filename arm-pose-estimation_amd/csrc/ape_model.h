@@ -62,6 +62,7 @@ struct ape_model {
     int small_uw = 4;                // hidden units per wave of the latency kernel: 2 when one XCD holds H/8 members
     bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
     bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
+    bool gen1_classes = true;       // first-generation f32 kernel: XCD-class cluster formation where the grid allows it
     bool c16_ok = false;            // lstm_cluster16.hip covers this model (3 x 128) on this device (switched with c32_on)
     int precision = APE_PRECISION_F32;
     bool wide_cluster = false;      // ImuPoseLSTM: the f32 first-generation cluster kernel with a 256-wide layer-0 input, nothing else

@@ -110,20 +110,35 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // A launch that finds the sticky status word set -- an earlier launch on this model aborted and skipped its
     // self-cleaning, so tickets, flags and counters are stale -- leaves without touching anything (status 2 tells
     // ape_model_check that later launches ran into it), and so does a workgroup whose ticket lies outside the grid.
+    // XCD classes (round 3; the host sets APE_FLAG_XCD_CLASSES when the grid is whole groups of 8 clusters): workgroups of one block-index
+    // class (blockIdx % 8 -- round-robin over the 8 XCDs) form their clusters among themselves, so a cluster's members share an XCD and
+    // its L2; verified at run time below (XCC_ID of every member): then the slices are handed over by PLAIN stores that stay in that L2
+    // instead of write-through ones -- the form lstm_cluster32.hip introduced, here for every launch of the first generation.
+    const bool cls_mode = (p.flags & APE_FLAG_XCD_CLASSES) != 0;
+    unsigned* const class_ticket = p.xcc_slots + 64;
+    unsigned* const xcc_words = p.xcc_slots + 64 + 8 * 16;
+    const int cls = blockIdx.x & 7;
     if (threadIdx.x == 0) {
         ctl[0] = 0;
         ctl[1] = -1;
+        ctl[3] = 0;
         if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            const unsigned tk = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tk < gridDim.x) ctl[1] = (int)tk;
+            const unsigned tk = cls_mode ? __hip_atomic_fetch_add(class_ticket + cls * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < (cls_mode ? gridDim.x / 8 : gridDim.x)) ctl[1] = (int)tk;
             else __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
     if (ctl[1] < 0) return;
     const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
-    const int cluster = ticket / GH, member = ticket % GH;
+    const int cluster = cls_mode ? (ticket / GH) * 8 + cls : ticket / GH, member = ticket % GH;
     const int row0 = cluster * MR;
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
+    if (cls_mode && threadIdx.x == 0)
+        __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     f32x4 bias_r[L];
 #pragma unroll
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     constexpr int NE = (MR * KX) / 256;
     constexpr int RPE = 256 / KX;                 // rows between a thread's consecutive elements
     const int xk = tid % KX, xrow = tid / KX;
-    const int rows_here = bcast_x ? MR : min(MR, p.B - row0);
+    const int rows_here = bcast_x ? MR : max(0, min(MR, p.B - row0));      // (whole clusters past the batch: class-mode grids are rounded up)
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x) + (bcast_x ? (size_t)0 : (size_t)row0 * T * I), 0,
         (int)((size_t)(bcast_x ? 1 : rows_here) * T * I * sizeof(float)), 0x00020000);
@@ -322,7 +337,28 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     }
     stage_x();
     if (T > 1) fetch_x(1);
+    // ---- class mode: do all members of this cluster really share an XCD?  (behind the weight loads: the peers arrive meanwhile) ------
+    if (cls_mode && wave == 0) {
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(xcc_words + cluster * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
     bar();
+    if (ctl[0] != 0) return;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;      // uniform over the cluster
 
     // The flag a wave owes for the slice it stored last: raised once those stores have drained -- a few k-blocks
     // into the NEXT section's MFMAs (the write-through latency hides there), or at the latest before this wave
@@ -527,9 +563,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 const int v = lane / MR, row = lane - v * MR;        // variant 1 = masked slice
                 if (!diag_noex && lane < ((DROP && l < L - 1) ? 2 * MR : MR)) {
                     const f32x4 hv = *reinterpret_cast<const f32x4*>(own + (v * MR + row) * SO + 4 * wave);
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc,
-                        (unsigned)((((member * 4 + wave) * MR + row) * 4) * sizeof(float)), hx_base(l, t & 1, v), 16 /* sc1 */);
+                    const unsigned s_off = (unsigned)((((member * 4 + wave) * MR + row) * 4) * sizeof(float));
+                    if (in_l2)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc, s_off,
+                            hx_base(l, t & 1, v), 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv), hx_rsrc, s_off,
+                            hx_base(l, t & 1, v), 16 /* sc1: write-through */);
                     // all-steps mode (DropoutLSTM.forward returns every step, nn_models.py:188-189): the top layer's raw
                     // output of this step also goes to [B,T,H]; the head runs over those rows afterwards (ape_head_rows)
                     if (p.hseq != nullptr && l == L - 1 && v == 0 && row0 + row < p.B)
@@ -640,6 +682,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
         const int n_words = (int)(gridDim.x / GH) * L * NFL;
         for (int i = tid; i < n_words; i += 256)
             __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cls_mode) {
+            for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid == 0) {
             __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -37,9 +37,9 @@ def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
     m.set_kernel("auto")
     assert np.abs(tile - good).max() < 1e-6
     reissued = aborted = lost = 0
-    # status word set / tickets beyond any grid (the one-cluster latency kernel at B = 1 takes no tickets; the second-generation
-    # kernel at B = 1024 draws its tickets per block-index class, from other words)
-    for which, value in (((0, 1),) if B != 64 else ((0, 1), (1, 100000))):
+    # status word set / tickets beyond any grid (the one-cluster latency kernel at B = 1 takes no tickets; the others draw theirs per
+    # block-index class: word 6 = the class-0 ticket)
+    for which, value in (((0, 1),) if B == 1 else ((0, 1), (6, 100000))):
         assert poke(m.handle, which, value) == 0
         out = m(x, last_step_only=True, normalize_input=True).numpy()      # host output: recovered before it is handed out
         reissued += 1; aborted += 1

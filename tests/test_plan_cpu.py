@@ -73,10 +73,10 @@ def test_split_with_the_second_generation_kernel():
     assert _plan2(pocket, 256, 513, 6)["kernel"] == C32 and _plan2(pocket, 256, 512, 6)["kernel"] == GEN1
     assert _plan2(pocket, 256, 1, 6)["kernel"] == SMALL and _plan2(pocket, 256, 5, 6)["kernel"] == GEN1
     assert _plan2(pocket, 256, 1024, 64, cdrop=1)["kernel"] == GEN1
-    # the 3 x 128 model has its own second-generation kernel (lstm_cluster16.hip): above 512 rows, windows of 10 steps and more
+    # the 3 x 128 model has its own second-generation kernel (lstm_cluster16.hip): above 512 rows, windows of 12 steps and more
     assert _plan2(uarm, 256, 1024, 64) == dict(n16=0, nmt=2, clusters=32, launches=1, capacity=32, kernel=C16)
     assert _plan2(uarm, 256, 1024, 6)["kernel"] == GEN1 and _plan2(uarm, 256, 512, 64)["kernel"] == GEN1
-    assert _plan2(uarm, 256, 1024, 10)["kernel"] == C16 and _plan2(uarm, 256, 1024, 64, cdrop=1)["kernel"] == GEN1
+    assert _plan2(uarm, 256, 1024, 12)["kernel"] == C16 and _plan2(uarm, 256, 1024, 11)["kernel"] == GEN1 and _plan2(uarm, 256, 1024, 64, cdrop=1)["kernel"] == GEN1
     assert _plan2(uarm, 256, 1024, 64, c32=0)["kernel"] == GEN1
     # round 2's test case: 4396 rows x 64 frames stay on the cluster kernel altogether (five launches of it are priced below a
     # batch-tile wave + one more launch) ...

@@ -10,7 +10,7 @@ cfg = orc.MODEL_CONFIGS["uarm"]
 m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0)
 m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 3))
 worst = 0.0
-for B, T in [(513, 10), (600, 11), (700, 12), (1024, 13), (1000, 14), (1024, 64), (2100, 15), (1024, 200), (533, 31)]:
+for B, T in [(513, 12), (600, 13), (700, 14), (1024, 15), (1000, 16), (1024, 64), (2100, 17), (1024, 200), (533, 31)]:
     x = torch.randn(B, T, cfg["I"], device="cuda")
     y2 = m.set_kernel("cluster")(x, last_step_only=True).cpu().numpy()[:, 0]
     name = m.kernel_name(B, T)

@@ -18,7 +18,7 @@ while time.time() - t0 < budget:
     m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], int(rng.integers(1000))))
     m.set_norm_stats(rng.normal(size=cfg["I"]), rng.uniform(0.5, 2.0, size=cfg["I"]), np.zeros(cfg["O"]), np.ones(cfg["O"]))
     for _ in range(12):
-        B, T = int(rng.integers(513, 2600)), int(rng.choice([10, 11, 12, 13, 16, 31, 64, 77]))
+        B, T = int(rng.integers(513, 2600)), int(rng.choice([12, 13, 14, 15, 16, 31, 64, 77]))
         flags = (_hip.FLAG_NORMALIZE_INPUT if rng.integers(2) else 0) | (0x08000000 if rng.integers(3) == 0 else 0)
         x = torch.randn(B, T, cfg["I"], device="cuda")
         ys = [torch.empty(B, cfg["O"], device="cuda") for _ in range(3)]
