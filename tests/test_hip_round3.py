@@ -54,3 +54,33 @@ def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
     e_ref, e_gen, e_t16 = float(np.abs(y2 - y_ref).max()), float(np.abs(y2 - y1).max()), float(np.abs(y2 - y0).max())
     print(f"\n[uarm B={B} T={T} cluster16] vs oracle {e_ref:.2e}, vs gen-1 kernel {e_gen:.2e}, vs batch-tile kernel {e_t16:.2e}")
     assert e_ref < 1e-6 and e_gen < 1e-6 and e_t16 < 1e-6
+
+
+@pytest.mark.parametrize("name,B,T,drop", [("uarm", 1024, 6, False), ("pocket", 512, 8, False), ("pocket", 300, 6, True), ("watch", 64, 8, True),
+                                           ("pocket", 77, 3, False), ("uarm", 2100, 5, True)])
+def test_first_generation_kernel_forms_xcd_local_clusters(norm_stats, name, B, T, drop):
+    """lstm_cluster.hip from four clusters on: clusters formed within block-index classes (one XCD each, verified at run time) hand their
+    slices over by plain stores inside that XCD's L2.  The same bits as the any-placement formation (internal A/B bit 0x02000000: global
+    tickets, write-through stores) and as the class formation with write-through stores forced (0x08000000); eval mode also against the
+    oracle; repeat launches bit-equal (the class tickets and XCD words are self-cleaning)."""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats[name]
+    model, sd, cfg = make_model(name, 9, st)
+    x = _synthetic_windows(st, B, T, cfg["I"], 23)
+    xd = torch.from_numpy(x).cuda()
+    model.set_kernel("cluster_gen1")
+    assert "ape_lstm_cluster<" in model.kernel_name(B, T)
+    base = _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_DROPOUT_PHILOX if drop else 0)
+    outs = []
+    for extra in (0, 0, 0x02000000, 0x08000000):
+        y = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+        _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, base | extra, None, 0.2 if drop else 0.0, 11,
+                                               C.c_void_p(y.data_ptr()), None), "ape_lstm_forward")
+        torch.cuda.synchronize()
+        model.check()
+        outs.append(y.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
+    if not drop:
+        xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+        assert float(np.abs(outs[0] - orc.lstm_forward(sd, xn)[:, -1]).max()) < 1e-6
+    model.set_kernel("auto")
