@@ -9,10 +9,11 @@ from wear_mocap_ape_amd.estimate import nn_models
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 kern = sys.argv[3] if len(sys.argv) > 3 else "auto"
+FLAGS = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0       # diagnostic bits, e.g. 0x02000000: any-placement clusters
 m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0); m.load_state_dict(orc.make_imupose_state_dict(22, 14, 0)); m.set_kernel(kern)
 x = torch.randn(B, T, 22, device="cuda"); y = torch.empty(B, 14, device="cuda"); lib = _hip.lib()
-run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, 0, None, 0.0, 0, C.c_void_p(y.data_ptr()), None), "fwd")
-for _ in range(5): run()
+run = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, FLAGS, None, 0.0, 0, C.c_void_p(y.data_ptr()), None), "fwd")
+for _ in range(15): run()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record()
 n = 20
 for _ in range(n): run()
