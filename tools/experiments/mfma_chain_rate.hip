@@ -122,6 +122,27 @@ __global__ __launch_bounds__(512, 1) void k16v2(unsigned long long* out, float a
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0][0] + acc[1][0] + v0 + v1); }
 }
+// weights as the MFMA's A operand from the accumulation file ("a") against the architectural one ("v"): 32 DIFFERENT registers
+template <bool AG>
+__global__ __launch_bounds__(256, 1) void k32src(unsigned long long* out, float a, float b, int iters) {
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    float w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { w[i] = a + i + threadIdx.x; asm volatile("" : "+v"(w[i])); }
+    float wb = b;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w[r]), "v"(wb));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w[r]), "v"(wb));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)acc[0]; }
+}
 template <typename K>
 void run2(const char* name, K kern) {
     unsigned long long* d; (void)hipMalloc(&d, 16);
@@ -162,6 +183,7 @@ int main() {
     run("32x32x2 block of 4 in one asm + ds_read_b128 + wait", k32blk<4>, 1);
     run("32x32x2 block of 4 + ds_read_b128 at the kernel's addresses [window][8]", k32blk<5>, 1);
     run("32x32x2 block of 4 + ds_read_b128 at [half][window][4]", k32blk<6>, 1);
+    run("32x32x2, 32 different weights from VGPRs", k32src<false>, 1); run("32x32x2, 32 different weights from AGPRs", k32src<true>, 1);
     run2("bare", k16v2<0, 0>); run2("1 v_fma between", k16v2<1, 0>); run2("4 v_fma between", k16v2<4, 0>);
     run2("1 v_exp between", k16v2<0, 1>); run2("2 v_exp between", k16v2<0, 2>); run2("1 v_exp + 2 v_fma between", k16v2<2, 1>);
     return 0;

@@ -1,5 +1,5 @@
 # rocprofv3 passes behind profiles/r03_*.md (run on the GPU box: bash tools/prof_r03.sh <what>); the trace databases are summarised
-# here because they are too big to travel back.  <what> = cluster32 | bank_mc | f16 | pipe | uarm
+# here because they are too big to travel back.  <what> = cluster32 | bank_mc | f16 | pipe | uarm | imupose
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -40,6 +40,10 @@ pipe)
 uarm)
   passes python3 tests/tools/time_uarm.py
   python3 tools/summarize_prof.py r03_uarm_T64 $P/trace $P/fetch $P/write "ape_lstm_cluster16<128, 3, 64>" 131072 1024 --wg-threads 512 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster16.hip --lds 92944 --flop-per-launch 4.5502955520e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "WatchPhoneUarmNN's regressor (I = 38, H = 128, L = 3, O = 12; watch_phone_uarm_nn.py:13-41), 1024 windows x 64 frames, eval mode, on the second-generation kernel of that shape (DESIGN.md 4.14; the first generation ran this at 532 us under rocprofv3, 284 MB per launch); \`python3 tests/tools/time_uarm.py\`; recipe \`tools/prof_r03.sh uarm\`."
+  ;;
+imupose)
+  passes python3 tests/tools/time_imupose.py
+  python3 tools/summarize_prof.py r03_imupose_cluster $P/trace $P/fetch $P/write "ape_lstm_cluster<256, 2, 256, 2, false>" 65536 512 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster.hip --flop-per-launch 6.8723671040e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "ImuPoseLSTM (nn_models.py:210-249: Linear 22 -> 256 + ReLU, 2 x 256 LSTM with a 256-wide layer-0 input, Linear 256 -> 14), 1024 windows x 64 frames = TWO launches of 512 windows (16 clusters x 16 members x 32 rows) of the first-generation kernel, this round with XCD-local clusters (DESIGN 4.1); algorithmic FLOP of one launch = 512 x (64 x 2 x 4H x (512 + 512) + 2 x 14 x 256); \`python3 tests/tools/time_imupose.py\`; recipe \`tools/prof_r03.sh imupose\`."
   ;;
 esac
 cp profiles/r03_*.md gpurun_out/ 2>/dev/null || true
