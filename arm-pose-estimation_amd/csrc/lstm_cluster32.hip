@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     bool prefetched = false;
 #ifdef APE_CLUSTER_STAMPS
     unsigned long long dg_block[2] = {0, 0}, dg_go[2] = {0, 0};      // diagnostic counters per layer (cluster 0, member 0)
+    unsigned long long dgh[2][6] = {};       // ... and inside the spans: store drain + flag, x staging, judge, gather issue, (unused), eight hook-free blocks
     unsigned long long dgc[2][5] = {};       // steady-state sections: cycles in the top wait, the barrier, the MFMA spans, everything behind the barrier; count
     auto now = [&]() -> unsigned long long {
         const unsigned long long c = __builtin_readcyclecounter();
@@ -370,25 +371,48 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         //  acknowledgement, later the peers' look finds nothing; look 12 blocks ahead of the judge instead of 4 -> 840: the flags are not up yet)
         constexpr int QF = 3, QP = NBL / 2 - 2, QJ = NBL / 2 + 2;
         bool staged = false;
+#ifdef APE_CLUSTER_STAMPS
+        unsigned long long hk0 = 0, hk_free = 0;
+#define HK_BEGIN() do { if (ST) hk0 = now(); } while (0)
+#define HK_END(k) do { if (ST) dgh[l][k] += now() - hk0; } while (0)
+#else
+#define HK_BEGIN() do {} while (0)
+#define HK_END(k) do {} while (0)
+#endif
         auto mid = [&](int q) {
+#ifdef APE_CLUSTER_STAMPS
+            // eight k-blocks without any hook (after QF + 1, before QP): what does a bare block cost inside the real kernel?
+            if (ST && q == QF + 2) hk_free = now();
+            if (ST && q == QF + 10) dgh[l][5] += now() - hk_free;
+#endif
             if (q == QF) {
+                HK_BEGIN();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
+                HK_END(0);
             }
             // x of the next layer-0 step: registers -> LDS (layer 0's readers of xin finished before this section's barrier), and
             // the fetch of the step after it EARLY in the section: issued at its end the loads were the youngest entries but one of
             // the memory queue, and the counted wait at the top of the next section sat out their whole latency (13 us per launch)
             if (l == L - 1 && q == QF + 1 && (ST || ph + 1 < T)) {
+                HK_BEGIN();
                 stage_x();
                 if (ST || ph + 2 < T) fetch_x(ph + 2);
                 staged = true;
+                HK_END(1);
             }
             if (q == QP) peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));     // (always: no branch around it)
             if (q == QJ) {
+                HK_BEGIN();
                 peek_wait(peek);
                 go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
+                HK_END(2);
             }
-            if (q >= QJ && q < QJ + NDMA && go) issue_piece(ln, tn - 1, q - QJ);
+            if (q >= QJ && q < QJ + NDMA && go) {
+                HK_BEGIN();
+                issue_piece(ln, tn - 1, q - QJ);
+                HK_END(3);
+            }
         };
         float hnew[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (active) {
@@ -486,6 +510,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     if (p.dbg_wg != nullptr && lane == 0 && cluster == 0 && member == 0)
         for (int l = 0; l < 2; ++l)
             for (int k = 0; k < 5; ++k) p.dbg_wg[32 + wave * 16 + l * 5 + k] = dgc[l][k];
+    if (p.dbg_wg != nullptr && lane == 0 && cluster == 0 && member == 0)
+        for (int l = 0; l < 2; ++l)
+            for (int k = 0; k < 6; ++k) p.dbg_wg[128 + wave * 16 + l * 6 + k] = dgh[l][k];
 #endif
     // ---- head: member m finishes windows 4m .. 4m+3 of the cluster's 32 ----------------------------------------------------------------
     {

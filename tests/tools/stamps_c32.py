@@ -28,3 +28,11 @@ for w in range(4):
         n = max(d[w, l, 4], 1)
         top, bar, span, behind = (d[w, l, k] / n for k in range(4))
         print(f"  wave {w} layer {l}: top wait {top:6.1f}  barrier {bar:6.1f}  spans {span:8.1f}  drain + cell update + publish {behind - span:7.1f}  total {top + bar + behind:8.1f}   ({int(n)} sections)")
+
+h = np.frombuffer(buf, dtype=np.uint64)[128:128 + 64].reshape(4, 16)[:, :12].reshape(4, 2, 6).astype(np.float64)
+print("inside the spans (cycles per section, each figure includes one stamp pair ~ 2 x s_memtime + LDS drain):")
+for w in range(4):
+    for l in range(2):
+        n = max(d[w, l, 4], 1)
+        print(f"  wave {w} layer {l}: store drain + flag {h[w, l, 0] / n:6.1f}  x staging {h[w, l, 1] / n:6.1f}  judge {h[w, l, 2] / n:6.1f}  gather issue (8 pieces) {h[w, l, 3] / n:6.1f}"
+              f"  eight hook-free k-blocks {h[w, l, 5] / n:7.1f} (2048 of MFMA)")
