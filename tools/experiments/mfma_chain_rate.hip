@@ -143,6 +143,50 @@ __global__ __launch_bounds__(256, 1) void k32src(unsigned long long* out, float 
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)acc[0]; }
 }
+// four 32x32x2 MFMAs + ONE LDS-DMA instruction (s_mov m0, buffer_load_dwordx4 ... lds: 1 KB global -> LDS) per block: what does the issue
+// of a gather piece cost inside an MFMA stream?  MODE 0: MFMAs only; 1: + the DMA; 2: + a global_load_dword (the flag look)
+typedef unsigned u32x4_ __attribute__((__vector_size__(16)));
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k32dma(unsigned long long* out, float a, float b, int iters, const float* src) {
+    __shared__ float lds[8192];
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    float wa = a + threadIdx.x, wb = b;
+    const unsigned long long sa = reinterpret_cast<unsigned long long>(src);
+    u32x4_ desc;
+    desc[0] = __builtin_amdgcn_readfirstlane((unsigned)sa); desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(sa >> 32) & 0xFFFFu);
+    desc[2] = 1u << 20; desc[3] = 0x00020000u;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(lds) + (threadIdx.x >> 6) * 8192);
+    const unsigned soff0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 8192u);
+    const unsigned voff = (threadIdx.x & 63) * 16;
+    unsigned peek = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(wb));
+            if (MODE == 1)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                             :: "s"(lds_base + (r & 7) * 1024), "v"(voff), "s"(desc), "s"(soff0 + (unsigned)(r * 1024)) : "memory");
+            if (MODE == 2) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(peek) : "v"(src + (threadIdx.x & 31)) : "memory");
+        }
+        if (MODE != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(acc[0] + lds[threadIdx.x] + peek); }
+}
+template <typename K>
+void run3(const char* name, K kern) {
+    unsigned long long* d; (void)hipMalloc(&d, 16);
+    float* src; (void)hipMalloc(&src, 4 << 20);
+    const int iters = 2000;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, d, 1.0f, 0.5f, iters, src);
+    unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    printf("%s: %.2f cycles per MFMA\n", name, (double)h[0] / (iters * 32.0));
+    (void)hipFree(d); (void)hipFree(src);
+}
 template <typename K>
 void run2(const char* name, K kern) {
     unsigned long long* d; (void)hipMalloc(&d, 16);
@@ -184,6 +228,8 @@ int main() {
     run("32x32x2 block of 4 + ds_read_b128 at the kernel's addresses [window][8]", k32blk<5>, 1);
     run("32x32x2 block of 4 + ds_read_b128 at [half][window][4]", k32blk<6>, 1);
     run("32x32x2, 32 different weights from VGPRs", k32src<false>, 1); run("32x32x2, 32 different weights from AGPRs", k32src<true>, 1);
+    run3("32x32x2 block of 4 (DMA test), MFMAs only", k32dma<0>); run3("32x32x2 block of 4 + one LDS-DMA piece (1 KB) per block", k32dma<1>);
+    run3("32x32x2 block of 4 + one global_load_dword sc1 per block", k32dma<2>);
     run2("bare", k16v2<0, 0>); run2("1 v_fma between", k16v2<1, 0>); run2("4 v_fma between", k16v2<4, 0>);
     run2("1 v_exp between", k16v2<0, 1>); run2("2 v_exp between", k16v2<0, 2>); run2("1 v_exp + 2 v_fma between", k16v2<2, 1>);
     return 0;
