@@ -3,21 +3,26 @@
 // exact float32, eval mode, last-step output.
 //
 // lstm_cluster32.hip needs 32 hidden units per member (a wave = 8 units x 4 gates = the 32 columns of a 32x32x2 tile), i.e. four
-// members per cluster at H = 128 -- half the chip at 1024 windows.  Here a member owns 16 units, a wave 4 of them: 16 columns
-// ordered unit * 4 + gate on v_mfma_f32_16x16x4_f32, two 16-window row tiles per cluster (two independent accumulator chains per
-// wave, so the 32-cycle issue rate is met), 8 members x 32 clusters = 256 CUs at 1024 windows -- the decomposition of the
-// first-generation kernel (lstm_cluster.hip), with the second generation's exchange:
-//   * exchange layout = LDS layout = fragment order [member][wave][window 32][4 units]: a lane (window n, k-group g) reads the 16
-//     bytes of member q's wave g for its window -- units 16 q + 4 g + j, j = 0..3 -- and feeds four MFMAs (the weights are packed
+// members per cluster at H = 128 -- half the chip at 1024 windows.  Here a member owns 16 units, a unit group of 4 of them = 16 columns
+// ordered unit * 4 + gate on v_mfma_f32_16x16x4_f32; clusters of 8 members x 32 windows (RT = 2 row tiles of 16; 32 clusters = 256 CUs at
+// 1024 windows); a workgroup = 4 unit groups x RT row tiles = eight waves, two per SIMD, ONE accumulator chain each (a single dependent
+// chain already runs at the issue rate, tools/experiments/mfma_chain_rate.hip) -- the decomposition of the first-generation kernel
+// (lstm_cluster.hip), with the second generation's exchange:
+//   * exchange layout = LDS layout = fragment order [member][unit group][window][4 units]: a lane (window n, k-group g) reads the 16
+//     bytes of member q's unit group g for its window -- units 16 q + 4 g + j, j = 0..3 -- and feeds four MFMAs (the weights are packed
 //     with the same k permutation: the first generation's register image, wcl); gathered slices never pass through registers, a
-//     layer-step's slice set (GH x 2 KB) is copied global -> LDS by LDS-DMA, prefetched by the section in front;
+//     layer-step's slice set (GH x 1 KB x RT) is copied global -> LDS by LDS-DMA, prefetched by the section in front;
 //   * layers software-pipelined (phase p: layer l on step p - l): with three layers every section's hand-over has two other
 //     sections to hide in;
+//   * the workgroup barrier sits BETWEEN a section's two spans (input part, recurrent part); the cell update and the publish of a section
+//     ride in single-MFMA slots of the NEXT section's first span (see `section` below);
 //   * XCD-class clusters (arrival tickets within blockIdx % 8, verified at run time: plain stores in one XCD's L2, else
 //     write-through), asynchronous flag look (inline-asm load, judged blocks later), bounded spins, sticky status, self-cleaning
 //     -- all as lstm_cluster32.hip;
 //   * the four gates of a (unit, window) cell land in one lane's four accumulator registers: lane-local cell update; the fresh
-//     h values (one per lane and row tile) are transposed through a wave-private LDS patch into 16-byte pieces for the publish.
+//     h value (one per lane) is transposed through a wave-private LDS patch into 16-byte pieces for the publish.
+// Inline-asm MFMAs: hipcc guards neither their operands nor their results (tools/check_mfma_hazards.py checks the assembly): weights that
+// do not fit the VGPR budget are AGPR operands explicitly, and a section's last MFMA carries the drain in its own asm statement.
 #include <type_traits>
 
 #include "ape_internal.h"
