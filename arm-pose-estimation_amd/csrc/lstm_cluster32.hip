@@ -437,12 +437,22 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
 #endif
             mfma_drain(acc);
             // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
+            // (two cells at a time, the plain arithmetic on float2 values: v_pk_mul / v_pk_add / v_pk_fma_f32 do both cells in one issue
+            //  slot -- VALU work is serial with the MFMAs, tools/experiments/mfma_chain_rate.hip; the transcendentals stay one by one)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float iv = sigm(acc[j]), fv = sigm(acc[4 + j]), gv = tanh_(acc[8 + j]), ov = sigm(acc[12 + j]);
-                const float c = fv * cst[l][j] + iv * gv;
-                cst[l][j] = c;
-                hnew[j] = ov * tanh_(c);
+            for (int j = 0; j < 4; j += 2) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
+                auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
+                const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
+                const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
+                const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
+                const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
+                const f32x2 ov = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ao));
+                const f32x2 c = fv * f32x2{cst[l][j], cst[l][j + 1]} + iv * gv;
+                cst[l][j] = c[0]; cst[l][j + 1] = c[1];
+                const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
+                hnew[j] = h[0]; hnew[j + 1] = h[1];
             }
         }
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
