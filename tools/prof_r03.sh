@@ -39,7 +39,7 @@ pipe)
   ;;
 uarm)
   passes python3 tests/tools/time_uarm.py
-  python3 tools/summarize_prof.py r03_uarm_T64 $P/trace $P/fetch $P/write "ape_lstm_cluster16<128, 3, 64>" 131072 1024 --wg-threads 512 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster16.hip --lds 92944 --flop-per-launch 4.5502955520e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "WatchPhoneUarmNN's regressor (I = 38, H = 128, L = 3, O = 12; watch_phone_uarm_nn.py:13-41), 1024 windows x 64 frames, eval mode, on the second-generation kernel of that shape (DESIGN.md 4.14; the first generation ran this at 532 us under rocprofv3, 284 MB per launch); \`python3 tests/tools/time_uarm.py\`; recipe \`tools/prof_r03.sh uarm\`."
+  python3 tools/summarize_prof.py r03_uarm_T64 $P/trace $P/fetch $P/write "ape_lstm_cluster16<128, 3, 64, 2>" 131072 1024 --wg-threads 512 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster16.hip --lds 92944 --flop-per-launch 4.5502955520e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "WatchPhoneUarmNN's regressor (I = 38, H = 128, L = 3, O = 12; watch_phone_uarm_nn.py:13-41), 1024 windows x 64 frames, eval mode, on the second-generation kernel of that shape (DESIGN.md 4.14; the first generation ran this at 532 us under rocprofv3, 284 MB per launch); \`python3 tests/tools/time_uarm.py\`; recipe \`tools/prof_r03.sh uarm\`."
   ;;
 imupose)
   passes python3 tests/tools/time_imupose.py
