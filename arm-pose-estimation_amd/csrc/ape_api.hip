@@ -1280,6 +1280,9 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->ypart) (void)hipFree(b->ypart);
     if (b->xfrag0) (void)hipFree(b->xfrag0);
     if (b->hfrag) (void)hipFree(b->hfrag);
+    if (b->h_rows) (void)hipHostFree(b->h_rows);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->h_status) (void)hipHostFree(b->h_status);
     for (auto ev : b->prof_ev) if (ev) (void)hipEventDestroy(ev);
     if (ape_model* m = b->model) {      // pending steps of this bank can no longer be re-issued
         int k = 0;
@@ -1340,7 +1343,16 @@ int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* strea
     return APE_OK;
 }
 
+static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream,
+                             unsigned* status_out);
+
 int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream) {
+    return streams_step_impl(b, flags, msg_dev, tail_dev, out_dtype, stream, nullptr);
+}
+
+// status_out (host frames): pinned word that receives the model's sticky status word behind the step's kernels
+static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream,
+                             unsigned* status_out) {
     if (!b || !msg_dev) return fail(APE_ERR_INVALID_ARG, "streams_step: NULL argument");
     if (!b->xring || !b->yring || !b->y_new)
         return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
@@ -1352,8 +1364,8 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
         return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT and PACKED_MSG are accepted");
     if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_step: unknown dtype selector");
     const bool packed = (flags & APE_FLAG_PACKED_MSG) != 0;
-    if (packed && (out_dtype != APE_F32 || tail_dev))
-        return fail(APE_ERR_INVALID_ARG, "streams_step: PACKED_MSG rows are float32 and carry the tail themselves (tail_dev must be NULL)");
+    if (packed && tail_dev)
+        return fail(APE_ERR_INVALID_ARG, "streams_step: PACKED_MSG rows carry the tail themselves (tail_dev must be NULL)");
     flags &= ~(uint32_t)APE_FLAG_PACKED_MSG;
     ape_model* m = b->model;
     const bool norm = (flags & APE_FLAG_NORMALIZE_INPUT) != 0;
@@ -1475,10 +1487,59 @@ int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail
     q.pos = (int)(b->steps % b->smooth);
     q.cold = b->steps == 0 ? 1 : 0;
     q.msg_dtype = out_dtype; q.packed = packed ? 1 : 0;
+    if (status_out != nullptr && m->cluster_ok) { q.status_in = m->xflags + m->xflag_bytes / sizeof(unsigned); q.status_out = status_out; }
     hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
     ++b->steps;
     journal_add(m, je);
+    return APE_OK;
+}
+
+// One iteration of Estimator.processing_loop (estimator.py:174-177) for every stream of the bank, HOST buffers in and out.
+// The raw rows are copied into pinned, device-visible staging the feature builder reads directly; the post kernel writes the
+// datagram rows and the model's status word straight into pinned host memory: the frame holds no copy command, just the
+// step's kernels and one stream synchronisation.  An aborted cooperative launch is recovered here (ape_model_recover).
+int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_host, uint32_t flags, void* out_host,
+                           int32_t out_dtype, void* stream) {
+    if (!b || !rows_host || !out_host) return fail(APE_ERR_INVALID_ARG, "streams_frame_host: NULL argument");
+    if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_frame_host: unknown dtype selector");
+    if (flags & ~(uint32_t)APE_FLAG_NORMALIZE_INPUT) return fail(APE_ERR_INVALID_ARG, "streams_frame_host: only NORMALIZE_INPUT is accepted");
+    int width, I;
+    if (!parse_kind_dims(kind & ~APE_PARSE_BIG_ENDIAN, &width, &I)) return fail(APE_ERR_INVALID_ARG, "streams_frame_host: unknown kind %d", kind);
+    ape_model* m = b->model;
+    HIP_TRY(hipSetDevice(m->dims.device));           // (the consumer thread of an estimator starts on device 0)
+    const size_t N = (size_t)b->smooth * b->n_mc;
+    const size_t rows_bytes = (size_t)b->S * width * sizeof(float);
+    const size_t out_bytes = (size_t)b->S * (25 + 6 * N) * (out_dtype == APE_F64 ? sizeof(double) : sizeof(float));
+    if (rows_bytes > b->h_rows_bytes) {
+        if (b->h_rows) { HIP_TRY(hipHostFree(b->h_rows)); b->h_rows = nullptr; b->h_rows_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void**)&b->h_rows, rows_bytes, hipHostMallocDefault));
+        b->h_rows_bytes = rows_bytes;
+    }
+    if (out_bytes > b->h_out_bytes) {
+        if (b->h_out) { HIP_TRY(hipHostFree(b->h_out)); b->h_out = nullptr; b->h_out_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&b->h_out, out_bytes, hipHostMallocDefault));
+        b->h_out_bytes = out_bytes;
+    }
+    if (!b->h_status) {
+        HIP_TRY(hipHostMalloc((void**)&b->h_status, 64, hipHostMallocDefault));
+        *b->h_status = 0u;
+    }
+    memcpy(b->h_rows, rows_host, rows_bytes);
+    *b->h_status = 0u;
+    if (int rc = ape_streams_push_rows(b, kind, b->h_rows, stream)) return rc;
+    if (int rc = streams_step_impl(b, flags | APE_FLAG_PACKED_MSG, b->h_out, nullptr, out_dtype, stream, b->h_status)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (*b->h_status != 0u) {
+        // the regressor launch gave up (bounded spins): the step is still the bank's newest one, so it can be issued again on
+        // the kernels that need no co-residency -- into the same pinned rows
+        if (int rc = ape_model_recover(m)) return rc;
+    } else {
+        // the status word was read behind the step's kernels on the step's own stream and one handle serialises on one
+        // stream: nothing aborted since the last check, what the journal holds is done
+        journal_clear(m);
+    }
+    memcpy(out_host, b->h_out, out_bytes);
     return APE_OK;
 }
 

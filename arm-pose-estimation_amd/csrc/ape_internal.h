@@ -184,6 +184,8 @@ struct StreamPostParams {
     int cold;            // 1: first step after a reset -- every slot takes this prediction (estimator.py:114-115)
     int msg_dtype;
     int packed;          // 1: msg rows are [25 + 6*smooth*n_mc] wide and carry the tail behind the message
+    const unsigned* status_in;   // host frames: the model's sticky status word ...
+    unsigned* status_out;        // ... copied here (pinned host memory) by the step's last kernel, or nullptr
 };
 
 struct MsgParams {

@@ -118,4 +118,10 @@ struct ape_streams {
     std::vector<hipEvent_t> prof_ev;
     long long frames = 0;        // rows pushed since the last reset
     long long steps = 0;         // predictions made since the last reset
+    // host frames (ape_streams_frame_host): pinned, device-visible staging the kernels read the raw rows from and write the
+    // datagram rows (+ the model's status word) to -- no copy command in the frame, one stream synchronisation
+    float* h_rows = nullptr;     // [S, 55|28]
+    void* h_out = nullptr;       // [S, 25 + 6 * smooth * n_mc] of the frame's dtype
+    unsigned* h_status = nullptr;
+    size_t h_rows_bytes = 0, h_out_bytes = 0;
 };

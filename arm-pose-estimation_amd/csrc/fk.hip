@@ -273,6 +273,9 @@ __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostPa
     if (threadIdx.x < 21) e0_s[threadIdx.x] = 0.0;
     if (threadIdx.x < 12) outq_s[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;
     if (threadIdx.x < 9) omean_s[threadIdx.x] = 0.0;
+    // host frames: the health of the regressor launch in front of this kernel travels with the datagrams
+    if (p.status_out != nullptr && s == 0 && threadIdx.x == 255)
+        *p.status_out = __hip_atomic_load(p.status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     // stacked row i = (prediction j of the last `smooth`, oldest first; Monte-Carlo sample k of it): lanes take
     // rows lane, lane + 64, ... (trip count uniform over the workgroup)

@@ -54,6 +54,9 @@ class WatchOnlyNN(Estimator):
     def _hip_model(self):
         return self.__nn_model
 
+    def _frame_samples(self):
+        return self.__mc_samples
+
     def parse_row_to_xx(self, row) -> np.array:
         return features_from_row(row, self.__slp)
 

@@ -65,6 +65,9 @@ class WatchPhonePocketNN(Estimator):
     def _hip_model(self):
         return self.__nn_model
 
+    def _frame_samples(self):
+        return self.__mc_samples
+
     _parse_kind = _hip.PARSE_WATCH_PHONE_POCKET
 
     def parse_row_to_xx(self, row):

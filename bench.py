@@ -306,6 +306,71 @@ def batch1_latency(model, stats, n_frames=1000):
     return out
 
 
+def estimator_loop(sd, n_frames=1000):
+    """The drop-in `Estimator` surface north_star names, driven exactly like the consumer loop of the reference
+    (estimator.py:174-177: parse_row_to_xx -> add_xx_to_row_hist_and_make_prediction -> msg_from_pred): one
+    `WatchPhonePocketNN.process_row(row)` per raw 55-float message (array('f'), the listener's wire type, imu.py:66-69) over the
+    rows of tests/golden/stream_trace_pocket.npz cycled, host in / host out, wall-clock per frame.  `device_frame` is the
+    path `processing_loop` runs (one one-stream bank per estimator: 220 B in, feature build / window / regressor / FK / mean on
+    the GPU, 25 + 6N values out -- one call into the C ABI); `staged` the reference-shaped methods one by one (host feature
+    build and histories, two device round trips), kept for callers that use them singly."""
+    import shutil
+    import tempfile
+    from array import array
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    out = {"workload": "configs[1] through the Python call surface: WatchPhonePocketNN.process_row per 55-float message, T = 6"}
+    old_deploy = config.PATHS["deploy"]
+    tmp = Path(tempfile.mkdtemp(prefix="ape_bench_"))
+    try:
+        src, dst = Path(old_deploy), tmp / "deploy"
+        h = "670b66fa7664252d1cfb3b5a8a362002ffeeba5c"
+        shutil.copytree(src / "data_stats", dst / "data_stats")
+        (dst / "nn" / h).mkdir(parents=True)
+        shutil.copy(src / "nn" / h / "results.json", dst / "nn" / h / "results.json")      # deployed settings: dropout 0.2, T = 6
+        torch.save(({k: torch.from_numpy(v) for k, v in sd.items()}, {"state": {}, "param_groups": []}), dst / "nn" / h / "checkpoint.pt")
+        config.PATHS["deploy"] = dst
+        g = np.load(REPO / "tests" / "golden" / "stream_trace_pocket.npz")
+        rows = [array("f", r.tolist()) for r in g["rows"]]
+        for mc, smooth in ((1, 1), (25, 1), (60, 5)):
+            ent = {}
+            for form in ("device_frame", "staged"):
+                est = WatchPhonePocketNN(model_hash=h, smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
+                est.use_device_frame = form == "device_frame"
+                n = n_frames if form == "device_frame" else max(200, n_frames // 4)
+                for i in range(30):
+                    msg = est.process_row(rows[i % len(rows)])
+                us = np.empty(n)
+                t_all = time.perf_counter()
+                for i in range(n):
+                    t0 = time.perf_counter()
+                    msg = est.process_row(rows[i % len(rows)])
+                    us[i] = (time.perf_counter() - t0) * 1e6
+                t_all = time.perf_counter() - t_all
+                ent[form] = {"p50_us": float(np.percentile(us, 50)), "p99_us": float(np.percentile(us, 99)),
+                             "frames_per_s": n / t_all, "frames": n, "msg_len": len(msg)}
+                if form == "staged":           # where the staged form's time goes (tests/tools/stream_bench.py's split)
+                    tt = np.zeros((200, 3))
+                    for i in range(200):
+                        a = time.perf_counter(); xx = est.parse_row_to_xx(rows[i % len(rows)])
+                        b = time.perf_counter(); pred = est.add_xx_to_row_hist_and_make_prediction(xx)
+                        c = time.perf_counter(); est.msg_from_pred(pred, True)
+                        tt[i] = (b - a, c - b, time.perf_counter() - c)
+                    ent[form]["split_p50_us"] = {"parse_row_to_xx": float(np.median(tt[:, 0]) * 1e6),
+                                                 "add_xx_to_row_hist_and_make_prediction": float(np.median(tt[:, 1]) * 1e6),
+                                                 "msg_from_pred": float(np.median(tt[:, 2]) * 1e6)}
+                else:
+                    ent[form]["aborted_checks"] = est._hip_model().stats()["aborted_checks"]
+                del est
+            out[f"mc{mc}_smooth{smooth}"] = ent
+    except Exception as exc:                # reported, never fatal for the headline line
+        out["error"] = str(exc)[:300]
+    finally:
+        config.PATHS["deploy"] = old_deploy
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def stream_bank_numbers(model, stats):
     """SURVEY 8 rows a1/a15/f1/f2/f4 at scale: S streams stepped together with all state on the device
     (ape_streams_*): raw 55-float rows in, window rings, regressor, FK, smoothing, packed datagram rows out.  T=6 as
@@ -801,6 +866,7 @@ def main():
             raise SystemExit("bench.py: ranks hold different weight blobs after the broadcast")
         if world == 1:
             out["batch1"] = batch1_latency(model, stats)
+            out["batch1"]["estimator_loop"] = estimator_loop(sd)
             out["stream_bank_T6"] = stream_bank_numbers(model, stats)
             out["other_paths"] = other_paths()
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
@@ -819,6 +885,13 @@ def main():
                 if best:
                     out["batch1"]["mc60_smooth5_cpu_frames_per_s"] = cb["legs"][best[0]]["frames_per_s"]
                     out["batch1"]["mc60_smooth5_cpu_leg"] = best[0]
+                # the matching CPU legs beside the drop-in loop (same settings, the oracle's reference-equivalent route)
+                for key, leg in (("mc1_smooth1", "config1_B1_T6_mc1/"), ("mc25_smooth1", "config1_B1_T6_mc25/"),
+                                 ("mc60_smooth5", "config1_B1_T6_mc60_smooth5/")):
+                    best = [k for k in cb["legs"] if k.startswith(leg) and "best" in k and k.endswith("fk_eigh")]
+                    if best and key in out["batch1"].get("estimator_loop", {}):
+                        out["batch1"]["estimator_loop"][key]["cpu_frames_per_s"] = cb["legs"][best[0]]["frames_per_s"]
+                        out["batch1"]["estimator_loop"][key]["cpu_leg"] = best[0]
         os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

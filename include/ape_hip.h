@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 5
+#define APE_ABI_VERSION 6
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -224,11 +224,11 @@ int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev,
  *                              msg_dev  [S,25] of out_dtype, layout of compose_msg.py:72-78
  *                              tail_dev [S,smooth,6] of out_dtype or NULL: hand and elbow xyz of every smoothing row
  *                              (what msg_from_pred appends to the message when add_mc_samples is set and smooth > 1)
- *                              flags: APE_FLAG_NORMALIZE_INPUT and / or APE_FLAG_PACKED_MSG.  PACKED_MSG with
- *                              out_dtype APE_F32: msg_dev is [S, 25+6N] (N = smooth*n_mc stacked rows), every row
- *                              the message followed by its tail = the float32 payload the reference sends per
- *                              estimator (pose_est_udp.py:47 struct.pack('f'*len(msg)) of estimator.py:131-137's
- *                              list), tail_dev must be NULL
+ *                              flags: APE_FLAG_NORMALIZE_INPUT and / or APE_FLAG_PACKED_MSG.  PACKED_MSG:
+ *                              msg_dev is [S, 25+6N] of out_dtype (N = smooth*n_mc stacked rows), every row the
+ *                              message followed by its tail = the list Estimator.msg_from_pred returns
+ *                              (estimator.py:131-137); as APE_F32 it is byte for byte the payload the reference sends
+ *                              per estimator (pose_est_udp.py:47 struct.pack('f'*len(msg))); tail_dev must be NULL
  *   ape_streams_reset          cold start: the next row fills the whole window, the next prediction the whole stack
  *   ape_streams_set_mc         Monte-Carlo dropout per stream, as every reference estimator runs it
  *                              (monte_carlo_samples, watch_phone_pocket_nn.py:105-110 -> nn_models.py:191-207): each
@@ -248,6 +248,17 @@ int ape_streams_set_mc(ape_streams_t* bank, int32_t n_mc, float dropout_p, uint6
 int ape_streams_push_rows(ape_streams_t* bank, int32_t kind, const float* rows_dev, void* stream);
 int ape_streams_push_features(ape_streams_t* bank, const float* xx_dev, void* stream);
 int ape_streams_step(ape_streams_t* bank, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream);
+/* ONE iteration of Estimator.processing_loop (estimator.py:174-177: parse_row_to_xx -> add_xx_to_row_hist_and_make_prediction
+ * -> msg_from_pred) for every stream of the bank, with HOST buffers (ABI 6): what the drop-in Estimator classes call per frame.
+ *   rows_host  f32 [S,55|28] raw messages of `kind` (may carry APE_PARSE_BIG_ENDIAN), ordinary host memory
+ *   out_host   [S, 25+6N] of out_dtype (N = smooth*n_mc): message + tail of every stream, ordinary host memory
+ *   flags      APE_FLAG_NORMALIZE_INPUT or 0
+ * = ape_streams_push_rows + ape_streams_step(PACKED_MSG) + the copies either side, BLOCKING: the rows travel through pinned
+ * staging the kernels read and write directly (no copy command on the stream), the call returns when out_host is filled.
+ * The health of the frame's launches is part of the frame: an aborted weight-stationary launch is re-issued as by
+ * ape_model_recover before the call returns, and a clean frame clears the handle's journal. */
+int ape_streams_frame_host(ape_streams_t* bank, int32_t kind, const float* rows_host, uint32_t flags, void* out_host,
+                           int32_t out_dtype, void* stream);
 /* measurement aid (bench.py `stream_bank_T6.*.roofline`): with profiling on, every launch of the step's dominant kernel (the
  * regressor: ape_lstm_upper32 in a Monte-Carlo bank, else the LSTM launch) is bracketed by a pair of HIP events on the
  * step's own stream; ape_streams_profile_read synchronises, returns the summed duration and the number of launches since

@@ -432,6 +432,50 @@ def gen_stream_traces():
     ref_nn.load_deployed_model_from_hash = real_loader
 
 
+def gen_trace_mc_stats():
+    """The reference ESTIMATORS in their Monte-Carlo mode, end to end: each class is built with its deployed dropout rate and
+    4000 samples per frame, driven through the 20-row trace of `stream_trace_<name>.npz` exactly as `processing_loop` does
+    (estimator.py:174-177), and the hand / elbow rows `msg_from_pred` appends to the message (estimator.py:131-137) are kept for
+    the LAST frame; six passes (reset in between, as `processing_loop` resets on start) give 24 000 samples of one window's
+    distribution.  Mean, covariance and quantiles go to trace_mc_stats.npz: the drop-in loop of the build (one
+    `process_row` per message, device-resident) is held to them by tests/mc_check.py."""
+    from wear_mocap_ape.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+    classes = {"pocket": WatchPhonePocketNN, "watch": WatchOnlyNN, "uarm": WatchPhoneUarmNN}
+    real_loader = ref_nn.load_deployed_model_from_hash
+    per_frame = 4000
+    blob = {"quantile_levels": np.array(MC_QUANTILES), "n_samples": np.array(MC_SAMPLES), "weights_seed": np.array(0)}
+    for name, cls in classes.items():
+        def fake_load(hash_str, _name=name):
+            model, p, _ = ref_model(_name, 0)            # deployed dropout rate (results.json)
+            return model, p
+        ref_nn.load_deployed_model_from_hash = fake_load
+        rows = np.load(OUT / f"stream_trace_{name}.npz")["rows"]
+        torch.manual_seed(4242)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            est = cls(model_hash=HASHES[name], smooth=1, add_mc_samples=True, monte_carlo_samples=per_frame)
+        tails, means = [], []
+        for _ in range(MC_SAMPLES // per_frame):
+            est.reset()
+            for row32 in rows:
+                row = array("f", row32.tolist())
+                msg = est.msg_from_pred(est.add_xx_to_row_hist_and_make_prediction(est.parse_row_to_xx(row)), True)
+            msg = np.asarray(msg, dtype=np.float64)
+            assert msg.shape == (25 + 6 * per_frame,)
+            tails.append(msg[25:].reshape(per_frame, 6))
+            means.append(msg[:25])
+        t6 = np.concatenate(tails)
+        blob[f"est6_mean_{name}"] = t6.mean(axis=0)
+        blob[f"est6_cov_{name}"] = np.cov(t6, rowvar=False)
+        blob[f"est6_quant_{name}"] = np.quantile(t6, MC_QUANTILES, axis=0)
+        blob[f"msg_mean_{name}"] = np.array(means)        # the six 4000-sample mean-pose messages (sign-aligned quaternion means)
+        blob[f"dropout_{name}"] = np.array(ref_params(name)["dropout"])
+    ref_nn.load_deployed_model_from_hash = real_loader
+    np.savez_compressed(OUT / "trace_mc_stats.npz", **blob)
+
+
 def gen_bookkeeping():
     """column-name enums and UDP message lookups, verbatim values from the reference (data)"""
     from wear_mocap_ape.data_types import messaging
@@ -471,6 +515,10 @@ def main():
         gen_lstm_hs()
         print("wrote", OUT / "lstm_hs.npz")
         return
+    if sys.argv[1:] == ["trace_mc"]:         # add this one fixture without rewriting the others
+        gen_trace_mc_stats()
+        print("wrote", OUT / "trace_mc_stats.npz")
+        return
     if sys.argv[1:] == ["mc"]:
         gen_mc_stats()
         print("wrote", OUT / "mc_stats.npz")
@@ -489,6 +537,7 @@ def main():
     gen_quat_ops()
     gen_fk(stats)
     gen_stream_traces()
+    gen_trace_mc_stats()
     gen_csv_header()
     total = sum(f.stat().st_size for f in OUT.glob("*.np*")) + (OUT / "norm_stats.json").stat().st_size
     print("golden fixtures written to", OUT, f"({total / 1024:.0f} KiB)")

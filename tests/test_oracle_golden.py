@@ -227,3 +227,27 @@ def test_oracle_mc_dropout_matches_reference_distribution(golden, name):
             assert mc_check.compare(_oracle_mc_samples(sd, cfg, x, n, 0.5 * p, rng), *args)               # wrong rate
             assert mc_check.compare(orc.lstm_forward(sd, np.repeat(x[None], 64, axis=0))[:, -1, :] +
                                     np.zeros((64, 1), np.float32), *args)                                  # no dropout
+
+
+@pytest.mark.parametrize("name", ["pocket", "uarm"])
+def test_oracle_consumer_loop_mc_matches_reference_estimators(golden, norm_stats, name):
+    """tests/golden/trace_mc_stats.npz (the reference ESTIMATORS in Monte-Carlo mode over the 20-row trace, hand / elbow rows
+    of the last frame) against the oracle's chain for that frame: window of the last T feature rows, float64 z-score, masked
+    cell loop with Bernoulli masks, de-normalisation, FK -- pins the fixture the GPU consumer-loop test is held to"""
+    from tests import mc_check
+    g, tr = golden("trace_mc_stats.npz"), golden(f"stream_trace_{name}.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], int(g["weights_seed"]))
+    st = norm_stats[name]
+    xx = tr["xx_s1_mc1"][-cfg["T"]:]
+    xx = xx.astype(np.float32) if str(tr["xx_dtype_s1_mc1"]) == "float32" else xx
+    x = ((xx - st["xx_m"]) / st["xx_s"]).astype(np.float32)                          # estimator.py:103-104 + the float32 cast
+    p, n_ref, levels = float(g[f"dropout_{name}"]), int(g["n_samples"]), g["quantile_levels"]
+    rng = np.random.default_rng(78)
+    y = _oracle_mc_samples(sd, cfg, x, 8000, p, rng).astype(np.float64) * st["yy_s"] + st["yy_m"]
+    est6 = orc.arm_pose_from_targets(y, tr["body"], cfg["layout"], "closed")[:, :6]
+    args = (g[f"est6_mean_{name}"], g[f"est6_cov_{name}"], g[f"est6_quant_{name}"], levels, n_ref)
+    bad = mc_check.compare(est6, *args, what=f"{name} trace")
+    assert not bad, bad
+    y_bad = _oracle_mc_samples(sd, cfg, x, 8000, 0.5 * p, rng).astype(np.float64) * st["yy_s"] + st["yy_m"]
+    assert mc_check.compare(orc.arm_pose_from_targets(y_bad, tr["body"], cfg["layout"], "closed")[:, :6], *args)
