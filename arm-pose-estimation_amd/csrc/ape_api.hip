@@ -347,6 +347,15 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
                 e = plan((void**)&m->wcls[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
             m->small_uw = 2;
         }
+        // Monte-Carlo latency kernel (lstm_mc_small.hip): 8 clusters of H/8 members, one per XCD, layer 0 on the latency kernel's
+        // H/8-member register image
+        if (ape_mc_small_supported(H, L, m->KX) && m->small_uw == 2 && m->n_cus >= 8 * (H / 8) && !imupose) {
+            for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wmc[l], (size_t)8 * H * H * sizeof(float));
+            m->gxm_cluster_bytes = ape_mc_small_cluster_bytes(H, L);
+            if (e == hipSuccess) e = plan((void**)&m->gxm, 256 + 8 * m->gxm_cluster_bytes);
+            if (e == hipSuccess) e = ape_prepare_lstm_mc_small(H, L, m->KX);
+            m->mcs_ok = true;
+        }
         if (ape_cluster32_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0) {
             for (int l = 0; l < L && e == hipSuccess; ++l)
                 e = plan((void**)&m->wcl32[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(float));
@@ -536,6 +545,26 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                             }
                 HIP_TRY(hipMemcpy(m->wcls[l], ps.data(), ps.size() * sizeof(float), hipMemcpyHostToDevice));
             }
+            if (m->mcs_ok && l >= 1) {
+                // Monte-Carlo latency kernel, layers above layer 0: H/8 members x 4 waves, wave = (column tile ct = w & 1, K half
+                // kh = w >> 1); lane = (g << 4) | (u << 2) | gate holds Wcat[gate*H + member*8 + ct*4 + u][kh*H + 16q + 4g + j] in
+                // register 4q + j; stored [member][wave][q][lane][4]
+                const int GM = H / 8, NQm = H / 16;
+                std::vector<float> pm((size_t)GM * 4 * NQm * 64 * 4);
+                for (int mem = 0; mem < GM; ++mem)
+                    for (int w = 0; w < 4; ++w)
+                        for (int q = 0; q < NQm; ++q)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int c = lane & 15, g = lane >> 4, u = c >> 2, gate = c & 3, ct = w & 1, kh = w >> 1;
+                                const int row = gate * H + mem * 8 + ct * 4 + u;
+                                for (int j = 0; j < 4; ++j) {
+                                    const int k = 16 * q + 4 * g + j;
+                                    pm[((((size_t)(mem * 4 + w) * NQm) + q) * 64 + lane) * 4 + j] =
+                                        kh == 0 ? w_ih[(size_t)row * H + k] : w_hh[(size_t)row * H + k];
+                                }
+                            }
+                HIP_TRY(hipMemcpy(m->wmc[l], pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             // fp16 variant: [member][wave][32-deep k-block q][lane][8]: lane holds Wcat[row][32q + 8g + j] as binary16
             const int NB = (KXl + H) / 32;
             std::vector<_Float16> ph((size_t)GH * 4 * NB * 64 * 8);
@@ -617,6 +646,40 @@ struct FkTail {
     bool denormalize;
     bool done;
 };
+
+// Monte-Carlo latency kernel (lstm_mc_small.hip): n_streams windows (stream s at x + s * x_stream_stride) x n_mc dropout samples each,
+// rows dealt over the 8 XCD clusters; y [n_streams * n_mc, O].  The caller has checked mc_small_fits().
+static bool mc_small_fits(const ape_model* m, int n_streams, int n_mc) {
+    if (!m->mcs_ok || !m->c32_on || m->kernel_choice != APE_KERNEL_AUTO || m->precision != APE_PRECISION_F32 || m->replaying) return false;
+    if (n_streams < 1 || n_streams > 8 || n_mc < 1) return false;
+    const int cps = 8 / n_streams;
+    return (n_mc + cps - 1) / cps <= 16;
+}
+static int mc_small_launch(ape_model_t* m, const float* x, size_t x_stream_stride, int n_streams, int n_mc, int T, uint32_t flags,
+                           const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream, int x_ring) {
+    McSmallParams q{};
+    const int L = m->dims.num_layers, I = m->dims.input_size, O = m->dims.output_size;
+    q.x = x; q.x_stream_stride = x_stream_stride; q.y = y_dev;
+    q.w0 = m->wcls[0];
+    for (int l = 0; l < L; ++l) { q.w[l] = m->wmc[l]; q.bias[l] = m->bias[l]; }
+    q.w_out = m->w_out; q.b_out = m->b_out;
+    q.xx_m = m->stats; q.xx_s = m->stats + I; q.xx_r = m->stats + 2 * I + 2 * O;
+    q.gx = m->gxm + 256; q.gx_cluster_bytes = (unsigned)m->gxm_cluster_bytes;
+    q.seq = reinterpret_cast<unsigned*>(m->gxm);
+    q.status = m->xflags + m->xflag_bytes / sizeof(unsigned); q.done = q.status - 3;
+    q.xcc_slots = m->xcc_slots;
+    q.masks = masks_dev;
+    q.rows = n_streams * n_mc; q.n_mc = n_mc; q.n_streams = n_streams;
+    q.cps = 8 / n_streams; q.R = (n_mc + q.cps - 1) / q.cps;
+    q.T = T; q.I = I; q.O = O; q.x_ring = x_ring;
+    q.flags = flags & (APE_FLAG_NORMALIZE_INPUT | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX | APE_DIAG_WRITE_THROUGH);
+    q.dropout_p = (flags & APE_FLAG_DROPOUT_PHILOX) ? dropout_p : 0.0f; q.seed = seed;
+    q.dbg_wg = m->dbg_wg;
+    m->last_kernel = "ape_lstm_mc_small";
+    hipError_t e = ape_launch_lstm_mc_small(m->dims.hidden_size, L, m->KX, q, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "Monte-Carlo latency kernel launch failed: %s", hipGetErrorString(e));
+    return APE_OK;
+}
 
 // x_ring: time step t of every window lives in slot (t + x_ring) mod T (0 = the linear layout of the public entry)
 static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
@@ -728,6 +791,9 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     if (f16) use_cluster = true;
     if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster && !m->replaying)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
+    // one window, n dropout samples (monte_carlo_predictions, nn_models.py:191-207) up to 128 rows: the Monte-Carlo latency kernel
+    if (use_cluster && cdrop_c && (flags & APE_FLAG_BROADCAST_X) && !all_steps && !f16 && B <= 128 && T + L <= 4096 && mc_small_fits(m, 1, B))
+        return mc_small_launch(m, x_dev, 0, 1, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, x_ring);
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
         const int w = auto_tile16_waves(&m->dims, m->n_cus, B, T, cdrop_c, drop ? 0 : gen2_of(m), m->wide_cluster);
@@ -750,6 +816,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         p.dropout_p = dropout_p;
         p.seed = seed;
         p.h0 = h0_dev; p.c0 = c0_dev; p.hs_rows = B;
+        m->last_kernel = "ape_lstm_tile16";
         hipError_t e = ape_launch_lstm_tile16(H, L, p, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "lstm kernel launch failed: %s", hipGetErrorString(e));
         if (n16 == B) return APE_OK;
@@ -781,6 +848,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.flags = flags; c.x_ring = x_ring;
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
+                m->last_kernel = "ape_lstm_cluster32";
                 hipError_t e = ape_launch_lstm_cluster32(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster32 lstm launch failed: %s", hipGetErrorString(e));
             }
@@ -805,6 +873,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.flags = flags; c.x_ring = x_ring;
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
+                m->last_kernel = "ape_lstm_cluster16";
                 hipError_t e = ape_launch_lstm_cluster16(H, L, m->KX, nb, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster16 lstm launch failed: %s", hipGetErrorString(e));
             }
@@ -829,6 +898,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.flags = flags; c.x_ring = x_ring;
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
+                m->last_kernel = "ape_lstm_cluster_f16v2";
                 hipError_t e = ape_launch_lstm_cluster_f16v2(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "fp16 cluster lstm launch failed: %s", hipGetErrorString(e));
             }
@@ -896,6 +966,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 if (clusters >= 4 && c8 <= cluster_capacity(m->n_cus, H)) { clusters = c8; c.flags |= APE_FLAG_XCD_CLASSES; }
             }
             // no memset in the launch path: the kernel's last workgroup re-zeroes every polled word (self-cleaning)
+            m->last_kernel = small ? "ape_lstm_cluster_small" : f16 ? "ape_lstm_cluster_f16" : "ape_lstm_cluster";
             hipError_t e = small ? ape_launch_lstm_cluster_small(H, L, m->KX, B == 1 ? 1 : (B == 2 ? 2 : 4), small_uw, c, (hipStream_t)stream)
                            : f16 ? ape_launch_lstm_cluster_f16(H, L, m->KX, nmt, clusters, c, (hipStream_t)stream)
                                  : ape_launch_lstm_cluster(H, L, m->KX, nmt, cdrop, clusters, c, (hipStream_t)stream);
@@ -1058,6 +1129,7 @@ static int check_and_reset(ape_model_t* m) {
         HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
         HIP_TRY(hipMemset(m->xcc_slots, 0, APE_XCC_WORDS * sizeof(unsigned)));
         HIP_TRY(hipMemset(m->hxs, 0, 256 + m->hxs_bytes));     // the aborted launch's granules carry tags the next launch would await
+        if (m->gxm) HIP_TRY(hipMemset(m->gxm, 0, 256 + 8 * m->gxm_cluster_bytes));
         HIP_TRY(hipDeviceSynchronize());
         return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
                     "since the last successful check are invalid; the model is usable again", st,
@@ -1467,6 +1539,19 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
         ++b->mc_calls;
         }
+    } else if (drop && b->S <= 8 && m->cluster_ok && b->T + m->dims.num_layers <= 4096 && mc_small_fits(m, b->S, b->n_mc)) {
+        // a few streams in Monte-Carlo mode (one estimator's frame: S = 1): the latency kernel reads the first copy of every
+        // stream's window and deals the sample rows over the XCDs
+        if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
+        hipEvent_t ev_a, ev_z;
+        prof_pair(&ev_a, &ev_z);
+        if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
+        if (int rc = mc_small_launch(m, b->xring, (size_t)b->n_mc * b->T * m->dims.input_size, b->S, b->n_mc, b->T,
+                                     flags | diag_wt | APE_FLAG_DROPOUT_PHILOX, nullptr, b->dropout_p, b->seed + b->mc_calls, b->y_new,
+                                     stream, x_ring))
+            return rc;
+        if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
+        ++b->mc_calls;
     } else {
         hipEvent_t ev_a, ev_z;
         prof_pair(&ev_a, &ev_z);
@@ -1657,6 +1742,8 @@ int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, i
     if (rc == APE_OK) for (int i = 0; i < 5; ++i) out[i] = o6[i];
     return rc;
 }
+
+const char* ape_model_last_kernel(const ape_model_t* m) { return m ? m->last_kernel : ""; }
 
 const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (!m) return "";

@@ -138,6 +138,38 @@ struct ExpandParams {
     int hseq_frag;                      // 1: hseq is the layer-0 cluster kernel's [S / 32][T][k-block 32][stream 32][8] (fragment order)
 };
 
+// Kernel arguments of the Monte-Carlo latency kernel (lstm_mc_small.hip): n_streams windows x n_mc dropout samples, dealt over the
+// 8 XCDs -- cluster c serves stream c / cps, sample rows [part * R, part * R + R) of it (part = c % cps).
+struct McSmallParams {
+    const float* x;                     // windows: stream s at x + s * x_stream_stride, [T][I]
+    size_t x_stream_stride;
+    float* y;                           // [rows, O] normalised NN targets of the last step
+    const float* w0;                    // layer 0: the latency kernel's H/8-member register image (ape_model::wcls[0])
+    const float* w[APE_MAX_LAYERS];     // layers >= 1 (index = layer): [member H/8][wave 4][k-block H/16][lane 64][4]
+    const float* bias[APE_MAX_LAYERS];
+    const float* w_out;
+    const float* b_out;
+    const double* xx_m;
+    const double* xx_s;
+    const double* xx_r;
+    char* gx;                           // granules {value, tag}: [cluster 8][parity 2][pair][16 B]
+    unsigned gx_cluster_bytes;
+    unsigned* seq;                      // [1] launch number of this kernel on this model (upper bits of the tags)
+    unsigned* done;                     // [1] departure counter
+    unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
+    unsigned* xcc_slots;                // as ClusterParams::xcc_slots: words [192, 448) hold (0x10 | XCC id) of the 8 x 32 workgroups
+    const float* masks;                 // injected [L-1, rows, T, H] or nullptr
+    int rows;                           // n_streams * n_mc
+    int n_mc, n_streams;
+    int cps;                            // clusters per stream
+    int R;                              // sample rows per cluster (<= 16)
+    int T, I, O, x_ring;
+    unsigned flags;                     // NORMALIZE_INPUT, DROPOUT_MASKS | DROPOUT_PHILOX, APE_DIAG_WRITE_THROUGH
+    float dropout_p;
+    unsigned long long seed;
+    unsigned long long* dbg_wg;         // diagnostic builds only
+};
+
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor
 
 // Kernel arguments of the MLP (DropoutFF) kernel.
@@ -246,6 +278,10 @@ hipError_t ape_launch_lstm_lower32(const UpperParams& p, const XFragParams& xq, 
 hipError_t ape_prepare_lstm_upper32();
 hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
                                    hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+bool ape_mc_small_supported(int H, int L, int KX);
+size_t ape_mc_small_cluster_bytes(int H, int L);
+hipError_t ape_prepare_lstm_mc_small(int H, int L, int KX);
+hipError_t ape_launch_lstm_mc_small(int H, int L, int KX, const McSmallParams& p, hipStream_t stream);
 bool ape_cluster_f16v2_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);

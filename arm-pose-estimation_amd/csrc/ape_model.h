@@ -59,6 +59,10 @@ struct ape_model {
     float* wcls[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // the latency kernel's H/8-member form (two units per wave)
     char* hxs = nullptr;             // latency kernel: [256 B: launch number][granules {h, tag}: layer, parity, 4 rows, H units]
     size_t hxs_bytes = 0;
+    float* wmc[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};    // Monte-Carlo latency kernel: layers >= 1, wave = column tile x K half
+    char* gxm = nullptr;             // ... [256 B: launch number][8 clusters of granules]
+    size_t gxm_cluster_bytes = 0;
+    bool mcs_ok = false;             // lstm_mc_small.hip covers this model on this device
     int small_uw = 4;                // hidden units per wave of the latency kernel: 2 when one XCD holds H/8 members
     bool c32_ok = false;            // lstm_cluster32.hip covers this model (2 x 256) on this device
     bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
@@ -86,6 +90,7 @@ struct ape_model {
     f32x4* ff_wpack[APE_MAX_FF_LAYERS] = {};
     float* ff_bias[APE_MAX_FF_LAYERS] = {};
     std::string kernel_name, cluster_name;
+    const char* last_kernel = "";   // the LSTM kernel the newest compute call launched last (ape_model_last_kernel)
     // calls since the last successful check (ape_model_recover replays them), and what became of aborted launches
     ApeJournalEntry journal[APE_JOURNAL_CAP];
     int journal_n = 0;

@@ -1,0 +1,479 @@
+// Latency kernel of the Monte-Carlo frame: ONE stream (or up to eight), n dropout samples of its window -- the frame every deployed
+// estimator runs (watch_phone_pocket_nn.py:13-19 -> nn_models.py:191-207: lstm.train(), x.repeat((n,1,1)), last step), n <= 128.
+//
+// Built on lstm_cluster_small.hip's frame (weights resident in registers for the launch, a member = a CU owns 8 hidden units of
+// every layer, 8-byte tagged granules {value, tag} through ONE XCD's L2 as the only hand-over) with what this mode allows:
+//   * the SAMPLES ARE INDEPENDENT, so they are dealt over the EIGHT XCDs: the launch is 8 clusters (cluster = blockIdx % 8 = one
+//     XCD under the round-robin placement, verified at run time like the other kernels), each runs the whole network for its
+//     R <= 16 sample rows with its own copy of the weights in its CUs' registers.  Nothing crosses an XCD; the exchange of a
+//     cluster carries its own rows only (a one-XCD form moved n x 256 granules per layer past every member: 66 us at n = 25);
+//   * nn.LSTM's dropout sits BETWEEN the layers (nn_models.py:169-174), so layer 0 sees the same input and state for every
+//     sample of a stream: ONE row, the register-resident VALU GEMV of the latency kernel, computed per cluster;
+//   * the layers above are GEMMs over the cluster's rows: v_mfma_f32_16x16x4_f32, a member's 32 gate columns as two 16-column
+//     A tiles ordered unit * 4 + gate, K = [masked h of the layer below | own h] split over wave pairs (wave = column tile x K
+//     half, the halves joined through LDS), the rows as ONE 16-row B tile in LDS -- a lane ends up with the four gates of one
+//     (unit, row) cell, the cell update is lane-local;
+//   * the dropout masks never travel: a layer's output is published ONCE, plain, and every consumer applies the mask of its
+//     rows when it puts the value into its B tile.  The mask multipliers (Philox4x32-10 with the counters of every other kernel
+//     of this library -- row quad, step, unit, layer: same seed, same masks -- or the caller's injected masks) do not depend on
+//     data, so each phase computes those of the NEXT phase between its publish and its poll, where it would otherwise wait.
+// Phase ph: layer l works on step ph - l; one collect and two workgroup barriers per phase.  Same arithmetic as the other kernels
+// up to float32 summation order.
+#include <type_traits>
+#include "ape_internal.h"
+#include "lstm_latency_common.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+// NI polling loads in one statement (poll_granules covers up to four)
+template <int NI>
+__device__ __forceinline__ void poll_pairs(u32x4 (&v)[NI], const unsigned (&off)[NI], u32x4 rsrc) {
+    if constexpr (NI <= 4) {
+        poll_granules<NI>(v, off, rsrc);
+    } else {
+        static_assert(NI == 5 || NI == 9, "pairs per thread of the built row capacities");
+#define MCS_LD(i) "buffer_load_dwordx4 %" #i ", %[o" #i "], %[rs], 0 offen sc1\n\t"
+        if constexpr (NI == 5)
+            asm volatile(MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) "s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                         : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [rs] "s"(rsrc)
+                         : "memory");
+        else
+            asm volatile(MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) MCS_LD(5) MCS_LD(6) MCS_LD(7) MCS_LD(8) "s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                           "=&v"(v[8])
+                         : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
+                           [o6] "v"(off[6]), [o7] "v"(off[7]), [o8] "v"(off[8]), [rs] "s"(rsrc)
+                         : "memory");
+#undef MCS_LD
+    }
+}
+
+// H, L, KX: the deployed shapes (2 x 256 with KX = 32; 3 x 128 with KX = 64).  RC: row capacity of a cluster (4, 8, 16) -- sizes the
+// exchange, the mask tables and the polls; the MFMA tile is 16 rows whatever RC.
+template <int H, int L, int KX, int RC>
+__global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams p) {
+    constexpr int GH = H / 8;                     // members of a cluster
+    constexpr int LM = L - 1;                     // layers above layer 0 (MFMA)
+    constexpr int SA = 2 * H + 8;                 // row stride of an activation tile: [masked input | own h] + pad
+    constexpr int SX = KX + 8, KB = 32, QX = KX / KB, QH = H / KB, NW0 = (KX + H) / 8;
+    constexpr int NQ = H / 16;                    // 16-deep k-blocks of one K half
+    constexpr int PH = H / 2;                     // 16-byte granule pairs per row
+    constexpr int PAIRS = PH * (1 + LM * RC);     // pairs of one parity of one cluster: [h_0][layer 1: RC rows][layer 2: RC rows]
+    constexpr int NI = (PAIRS + 255) / 256;
+    constexpr unsigned PAR_BYTES = (unsigned)PAIRS * 16u;
+    static_assert(L >= 2 && L <= 3 && (H == 128 || H == 256) && GH <= 32 && RC <= 16 && RC <= GH, "shape");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cluster = blockIdx.x & 7, member = blockIdx.x >> 3;
+    const int T = p.T, I = p.I, O = p.O;
+    const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
+    const bool inj_masks = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
+    // this cluster's rows: stream = cluster / cps, its `part`-th run of R sample rows
+    const int stream = cluster / p.cps, part = cluster - stream * p.cps;
+    int rv = (stream < p.n_streams) ? p.n_mc - part * p.R : 0;
+    rv = rv < 0 ? 0 : (rv > p.R ? p.R : rv);
+    const int row0 = stream * p.n_mc + part * p.R;          // global index of the cluster's first sample row
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* a = smem;                               // [2 phase parity][LM][16][SA]  B tiles of the MFMA layers
+    float* mv = a + 2 * LM * 16 * SA;              // [2][LM][RC][H]  mask multipliers (0 or 1/(1-p)) by phase parity
+    float* h0buf = mv + 2 * LM * RC * H;           // [2][H]  layer 0's own state
+    float* xin = h0buf + 2 * H;                    // [2][SX]
+    float* red = xin + 2 * SX;                     // [LM][2 column tiles][64][4]  partial sums of the recurrent K half
+    int* ctl = reinterpret_cast<int*>(red + LM * 2 * 64 * 4);
+#ifdef APE_CLUSTER_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const unsigned seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu;
+    if (rv > 0) {
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
+    unsigned* const xcc_words = p.xcc_slots + 192 + cluster * 32;
+
+    // ---- layer 0 (GEMV): lane = (k-group g, column c = unit * 4 + gate) of this wave's two units
+    const int c = lane & 7, g = lane >> 3, gate = c & 3, u = c >> 2;
+    const int unit0 = (member * 4 + wave) * 2 + u;
+    const float bias0 = p.bias[0][gate * H + unit0];
+    // ---- layers above (MFMA): column tile ct (units 8 m + 4 ct + 0..3), K half kh; lane = (row nn, unit ug of the tile)
+    const int ct = wave & 1, kh = wave >> 1, nn = lane & 15, ug = lane >> 4;
+    const int unit1 = member * 8 + ct * 4 + ug;
+    f32x4 bias1[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias1[l][i] = (kh == 0) ? p.bias[l + 1][i * H + unit1] : 0.0f;
+    float w0[NW0];
+    {
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.w0) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NW0 / 4; ++i) {
+            const f32x4 v = s0[i * 64];
+            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
+        }
+    }
+    float wa[LM][4 * NQ];                          // register 4 q + j = Wcat_l[gate * H + unit][kh * H + 16 q + 4 (lane >> 4) + j]
+#pragma unroll
+    for (int l = 0; l < LM; ++l) {
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.w[l + 1]) + ((size_t)(member * 4 + wave) * NQ) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const f32x4 v = s1[i * 64];
+            wa[l][4 * i] = v[0]; wa[l][4 * i + 1] = v[1]; wa[l][4 * i + 2] = v[2]; wa[l][4 * i + 3] = v[3];
+        }
+    }
+    if (tid == 0) {
+        ctl[0] = (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+        if (ctl[0] == 0)
+            __hip_atomic_store(xcc_words + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // zero state, zero rows beyond the cluster's own in the B tiles (a tile row is a batch row: garbage would stay in its row,
+    // but NaN bit patterns of an earlier kernel's LDS are not worth reasoning about)
+    for (int i = tid; i < (2 * LM * 16 * SA + 2 * LM * RC * H + 2 * H + 2 * SX) / 4; i += 256)
+        reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ctl[0] != 0) return;
+
+    char* const gx = p.gx + (size_t)cluster * p.gx_cluster_bytes;
+    const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(gx, 0, (int)p.gx_cluster_bytes, 0x00020000);
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(gx);
+    u32x4 hx_desc;
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane(p.gx_cluster_bytes);
+    hx_desc[3] = 0x00020000u;
+
+    // the pairs this thread collects: e = tid + 256 i -> (layer, row, pair of units)
+    int it_l[NI], it_r[NI], it_pr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + 256 * i;
+        if (e < PH) { it_l[i] = 0; it_r[i] = 0; it_pr[i] = e; }
+        else {
+            const int e1 = e - PH;
+            it_l[i] = (e < PAIRS) ? 1 + e1 / (RC * PH) : -1;
+            it_r[i] = (e1 / PH) % RC;
+            it_pr[i] = e1 % PH;
+        }
+    }
+
+    // x_t of the stream's window: f64 z-score, cast f32 (estimator.py:103-104), fetched a phase ahead (as lstm_cluster_small.hip)
+    const bool x_live = tid < KX && tid < I;
+    const double x_mean = (normalize && x_live) ? p.xx_m[tid] : 0.0;
+    const double x_std = (normalize && x_live) ? p.xx_s[tid] : 1.0;
+    const double x_rstd = (normalize && x_live) ? p.xx_r[tid] : 1.0;
+    const float* const x_src = p.x + (size_t)stream * p.x_stream_stride;
+    float xr = 0.0f;
+    auto fetch_x = [&](int t) {
+        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + tid];
+    };
+    auto stage_x = [&](int t) {
+        if (tid < KX) {
+            const double d = (double)xr - x_mean;
+            const double q0 = d * x_rstd;
+            const double rr = fma(-q0, x_std, d);
+            const double q1 = fma(rr, x_rstd, q0);
+            xin[(t & 1) * SX + tid] = x_live ? (float)((rr == rr) ? q1 : q0) : 0.0f;
+        }
+    };
+    fetch_x(0);
+    stage_x(0);
+    if (T > 1) fetch_x(1);
+
+    // mask multipliers of the values collected in phase `target`: layer l's output of step target - l, rows of this cluster
+    const float keep_scale = 1.0f / (1.0f - p.dropout_p);
+    auto mask_fill = [&](int target) {
+        for (int idx = tid; idx < LM * H; idx += 256) {
+            const int l = idx / H, unit = idx - l * H, t = target - l;
+            if (t < 0 || t >= T) continue;
+            float* dst = mv + (((target & 1) * LM + l) * RC) * H + unit;
+            if (inj_masks) {
+                for (int r = 0; r < rv; ++r) dst[r * H] = p.masks[(((size_t)l * p.rows + row0 + r) * T + t) * H + unit];
+            } else {
+                for (int qb = row0 & ~3; qb < row0 + rv; qb += 4) {
+                    uint32_t rnd[4];
+                    philox4x32((uint32_t)qb, (uint32_t)t, (uint32_t)unit, (uint32_t)l, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = qb + i - row0;
+                        const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                        if (r >= 0 && r < rv) dst[r * H] = (uf >= p.dropout_p) ? keep_scale : 0.0f;
+                    }
+                }
+            }
+        }
+    };
+    mask_fill(0);
+
+    if (wave == 0) {                               // do all members of this cluster share an XCD?
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(xcc_words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ctl[0] != 0) return;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
+    auto store_granule = [&](float val, unsigned tag, unsigned off) {
+        u32x2 gran;
+        gran[0] = __builtin_bit_cast(unsigned, val);
+        gran[1] = tag;
+        if (in_l2) __builtin_amdgcn_raw_buffer_store_b64(gran, hx_rsrc, off, 0, 0);      // stays in the XCD's L2
+        else __builtin_amdgcn_raw_buffer_store_b64(gran, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+    };
+
+    float c0 = 0.0f, c1[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) c1[l] = 0.0f;
+    asm volatile("" :: "v"(bias0));
+    const int P = T + L - 1;
+    SM_STAMP(0);                                    // 0: prologue
+#pragma unroll 1
+    for (int ph = 0; ph < P; ++ph) {
+        const unsigned want = (seq << 12) | (unsigned)(ph + 1);
+        if (ph + 1 < T) stage_x(ph + 1);
+        if (ph + 2 < T) fetch_x(ph + 2);
+        // ---- layer 0, step ph: one row
+        if (ph < T) {
+            const float* hrd = h0buf + (ph & 1) * H;
+            f32x4 ax[QX], ah[QH];
+            span_load<QX, KB>(ax, xin + (ph & 1) * SX + 4 * g);
+            span_load<QH, KB>(ah, hrd + 4 * g);
+            f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            span_fma<QX, NW0>(part4, ax, w0, 0);
+            span_fma<QH, NW0>(part4, ah, w0, 4 * QX);
+            float v = (part4[0] + part4[1]) + (part4[2] + part4[3]);
+            v = sum_ror8(v);
+            v = sum_xor16(v);
+            v = sum_xor32(v);
+            const float av = gate_act(v + bias0, gate == 2);
+            const float iv = quad_bcast<0>(av), fv = quad_bcast<1>(av), gv = quad_bcast<2>(av), ov = quad_bcast<3>(av);
+            const float cn = fv * c0 + iv * gv;
+            c0 = cn;
+            const float h0 = ov * gate_act(cn, true);
+            store_granule(h0, want, (gate == 0 && g == 0) ? (unsigned)(ph & 1) * PAR_BYTES + (unsigned)unit0 * 8u : 0x80000000u);
+        }
+        SM_STAMP(1);                                // 1: x staging + layer 0
+        // ---- layers above, step ph - l: this wave's K half of its column tile
+        f32x4 acc[LM];
+#pragma unroll
+        for (int l = 0; l < LM; ++l) {
+            const int t = ph - 1 - l;
+            acc[l] = bias1[l];
+            if (t < 0 || t >= T || (kh == 1 && t == 0)) continue;      // uniform; h_{-1} = 0: no recurrent half at step 0
+            const float* src = a + (((ph & 1) * LM + l) * 16 + nn) * SA + kh * H + 4 * ug;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(src + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[l][4 * q + j], b[j], acc[l], 0, 0, 0);
+            }
+            if (kh == 1) *reinterpret_cast<f32x4*>(red + ((l * 2 + ct) * 64 + lane) * 4) = acc[l];
+        }
+        SM_STAMP(2);                                // 2: MFMA spans
+        __syncthreads();                            // the recurrent halves' partial sums are in LDS
+        SM_STAMP(3);
+        if (kh == 0) {
+#pragma unroll
+            for (int l = 0; l < LM; ++l) {
+                const int t = ph - 1 - l;
+                if (t < 0 || t >= T) continue;
+                f32x4 s = acc[l];
+                if (t > 0) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((l * 2 + ct) * 64 + lane) * 4);
+                    s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+                }
+                const float iv = gate_act(s[0], false), fv = gate_act(s[1], false);
+                const float gv = gate_act(s[2], true), ov = gate_act(s[3], false);
+                const float cn = fv * c1[l] + iv * gv;
+                c1[l] = cn;
+                const float hv = ov * gate_act(cn, true);
+                store_granule(hv, want, (nn < rv) ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(PH + (l * RC + nn) * PH) * 16u + (unsigned)unit1 * 8u
+                                                  : 0x80000000u);
+            }
+        }
+        SM_STAMP(4);                                // 4: cell updates + publish
+        // ---- the masks of the NEXT phase's values: data-independent, computed where this phase would otherwise wait for its peers
+        if (ph + 1 < P) mask_fill(ph + 1);
+        SM_STAMP(5);                                // 5: mask multipliers
+        // ---- collect: every thread polls ITS pairs of granules until they carry this phase's tag, then puts the values where the
+        //      next phase reads them: own-layer recurrent input as it is, the next layer's input under the rows' masks
+        {
+            unsigned off[NI];
+            bool act[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int t = ph - it_l[i];
+                act[i] = it_l[i] >= 0 && t >= 0 && t < T && (it_l[i] == 0 || it_r[i] < rv);
+                off[i] = act[i] ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(tid + 256 * i) * 16u : 0x80000000u;
+            }
+            unsigned val0[NI], val1[NI];
+            unsigned spins = 0;
+            while (true) {
+                u32x4 v[NI];
+                poll_pairs<NI>(v, off, hx_desc);
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    val0[i] = v[i][0];
+                    val1[i] = v[i][2];
+                    bad = bad || (act[i] && (v[i][1] != want || v[i][3] != want));
+                }
+                if (!__any((int)bad)) break;
+                if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                             __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (lane == 0) {
+                        ctl[0] = 1;
+                        __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                if (spins > 64u) __builtin_amdgcn_s_sleep(1);
+            }
+            SM_STAMP(6);                            // 6: publish -> every awaited granule seen
+            float* const anext = a + ((ph + 1) & 1) * (LM * 16 * SA);
+            const float* const mcur = mv + (ph & 1) * (LM * RC * H);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (!act[i]) continue;
+                const float v0 = __builtin_bit_cast(float, val0[i]), v1 = __builtin_bit_cast(float, val1[i]);
+                const int l = it_l[i], pr = it_pr[i];
+                if (l == 0) {
+                    float* hw = h0buf + ((ph + 1) & 1) * H + 2 * pr;
+                    hw[0] = v0; hw[1] = v1;
+                    for (int r = 0; r < rv; ++r) {                       // layer 1's input rows: the one value under each row's mask
+                        const float* m2 = mcur + r * H + 2 * pr;
+                        float* dst = anext + r * SA + 2 * pr;
+                        dst[0] = v0 * m2[0]; dst[1] = v1 * m2[1];
+                    }
+                } else {
+                    const int r = it_r[i];
+                    float* rec = anext + ((l - 1) * 16 + r) * SA + H + 2 * pr;
+                    rec[0] = v0; rec[1] = v1;
+                    if (l < L - 1) {
+                        const float* m2 = mcur + (l * RC + r) * H + 2 * pr;
+                        float* dst = anext + (l * 16 + r) * SA + 2 * pr;
+                        dst[0] = v0 * m2[0]; dst[1] = v1 * m2[1];
+                    }
+                }
+            }
+        }
+        SM_STAMP(7);                                // 7: values into LDS
+        __syncthreads();                            // the next phase's operands are in LDS
+        if (ctl[0] != 0) return;
+    }
+
+    // ---- head: member m finishes row m of the cluster from the top layer's h(T-1) in its B tile; 16 lanes per target
+    if (member < rv) {
+        const int hw_o = tid >> 4, hw_part = tid & 15;
+        float s_acc = 0.0f;
+        if (hw_o < O) {
+            const float* hv = a + (((P & 1) * LM + (LM - 1)) * 16 + member) * SA + H + hw_part * (H / 16);
+            const float* wv = p.w_out + (size_t)hw_o * H + hw_part * (H / 16);
+#pragma unroll
+            for (int i = 0; i < H / 64; ++i) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(hv + 4 * i);
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(wv + 4 * i);
+                s_acc = fmaf(av[0], wq[0], s_acc); s_acc = fmaf(av[1], wq[1], s_acc);
+                s_acc = fmaf(av[2], wq[2], s_acc); s_acc = fmaf(av[3], wq[3], s_acc);
+            }
+        }
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0xB1, 0xF, 0xF, false));
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x4E, 0xF, 0xF, false));
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x141, 0xF, 0xF, false));
+        s_acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_acc), 0x140, 0xF, 0xF, false));
+        if (hw_o < O && hw_part == 0) p.y[(size_t)(row0 + member) * O + hw_o] = s_acc + p.b_out[hw_o];
+    }
+    SM_STAMP(8);                                    // 8: head
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && tid == 0 && member == 0 && cluster == 0) {
+        for (int k = 0; k < 10; ++k) p.dbg_wg[k] = st_acc[k];
+        p.dbg_wg[10] = __builtin_amdgcn_s_memtime() - st_begin;
+        p.dbg_wg[11] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    }
+#endif
+    }   // rv > 0
+    // ---- departure: the last workgroup out of the whole launch (idle clusters included) bumps the launch number and re-zeroes
+    //      the XCD words (self-cleaning: a captured launch replays correctly)
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8u * GH - 1u) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        // the next launch's tags differ from every tag of this one; when the 20-bit launch number wraps, the granules go back to
+        // zero (tag 0 is never awaited)
+        if (seq == 0xFFFFFu)
+            for (size_t i = tid; i < (size_t)8 * p.gx_cluster_bytes / 4; i += 256)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(p.gx) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.seq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.xcc_slots + 192 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int H, int L, int KX, int RC>
+constexpr size_t mcs_smem() {
+    return ((size_t)2 * (L - 1) * 16 * (2 * H + 8) + (size_t)2 * (L - 1) * RC * H + 2 * H + 2 * (KX + 8) + (size_t)(L - 1) * 2 * 64 * 4 + 8) *
+           sizeof(float);
+}
+
+template <int H, int L, int KX, int RC>
+hipError_t launch_mcs(const McSmallParams& p, hipStream_t stream) {
+    constexpr size_t smem_bytes = mcs_smem<H, L, KX, RC>();
+    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC>), dim3(8 * (H / 8)), dim3(256), smem_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <int H, int L, int KX>
+hipError_t launch_mcs_rc(const McSmallParams& p, hipStream_t stream) {
+    if (p.R <= 4) return launch_mcs<H, L, KX, 4>(p, stream);
+    if (p.R <= 8) return launch_mcs<H, L, KX, 8>(p, stream);
+    if (p.R <= 16) return launch_mcs<H, L, KX, 16>(p, stream);
+    return hipErrorInvalidValue;
+}
+
+template <int H, int L, int KX>
+hipError_t prepare_mcs() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    return e;
+}
+
+}  // namespace
+
+bool ape_mc_small_supported(int H, int L, int KX) { return (H == 256 && L == 2 && KX == 32) || (H == 128 && L == 3 && KX == 64); }
+
+// bytes of one cluster's granule region (two parities, 16 rows) -- the launch uses eight of them
+size_t ape_mc_small_cluster_bytes(int H, int L) { return (size_t)2 * (H / 2) * (1 + (L - 1) * 16) * 16; }
+
+hipError_t ape_prepare_lstm_mc_small(int H, int L, int KX) {
+    if (H == 256 && L == 2 && KX == 32) return prepare_mcs<256, 2, 32>();
+    if (H == 128 && L == 3 && KX == 64) return prepare_mcs<128, 3, 64>();
+    return hipErrorInvalidValue;
+}
+
+// p.R rows per cluster (<= 16), p.cps clusters per stream, p.n_streams * p.cps <= 8
+hipError_t ape_launch_lstm_mc_small(int H, int L, int KX, const McSmallParams& p, hipStream_t stream) {
+    if (H == 256 && L == 2 && KX == 32) return launch_mcs_rc<256, 2, 32>(p, stream);
+    if (H == 128 && L == 3 && KX == 64) return launch_mcs_rc<128, 3, 64>(p, stream);
+    return hipErrorInvalidValue;
+}

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ape_streams_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "ape_streams_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "ape_lstm_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ape_model_last_kernel": (C.c_char_p, [C.c_void_p]),
     "ape_flops_per_window": (C.c_double, [C.POINTER(ApeDims), C.c_int32]),
     "ape_kalman_create": (C.c_int, [C.POINTER(ApeKalmanDims), C.POINTER(C.c_void_p)]),
     "ape_kalman_destroy": (C.c_int, [C.c_void_p]),

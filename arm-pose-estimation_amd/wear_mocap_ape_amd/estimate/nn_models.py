@@ -309,6 +309,10 @@ class DropoutLSTM:
     def kernel_name(self, B: int, T: int) -> str:
         return _hip.lib().ape_lstm_kernel_name(self._handle, B, T).decode()
 
+    def last_kernel(self) -> str:
+        """the LSTM kernel the newest call on this model launched (``ape_model_last_kernel``)"""
+        return _hip.lib().ape_model_last_kernel(self._handle).decode()
+
     def flops_per_window(self, T: int) -> float:
         import ctypes as C
         return float(_hip.lib().ape_flops_per_window(C.byref(self._dims), T))

@@ -300,6 +300,9 @@ int ape_model_stats(const ape_model_t* model, ape_model_stats_t* out);
 /* introspection for benchmarks: name of the dominant kernel for (B,T) and its algorithmic
  * FLOP per window (sum_layers 2*4H*(in_l+H) per step, + 2*O*H head once). */
 const char* ape_lstm_kernel_name(const ape_model_t* model, int32_t B, int32_t T);
+/* the LSTM kernel the newest call on this handle launched last ("ape_lstm_mc_small", "ape_lstm_cluster32", "ape_lstm_tile16", ...;
+ * "" before the first call): tests and benchmarks assert the route they mean to measure */
+const char* ape_model_last_kernel(const ape_model_t* model);
 double ape_flops_per_window(const ape_dims_t* dims, int32_t T);
 
 /* ---- ensemble Kalman estimator (tail; ABI 4) ----------------------------------------

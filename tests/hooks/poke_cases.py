@@ -290,3 +290,66 @@ def test_recover_reissues_a_chain_and_reports_what_it_cannot(norm_stats):
     m.check()
     chain(); m.recover()
     assert np.array_equal(y.cpu().numpy(), good[0])
+
+
+def test_mc_latency_kernel_abort_recover_and_launch_number_wrap(norm_stats, golden, tmp_path, monkeypatch):
+    """the Monte-Carlo latency kernel (lstm_mc_small.hip) behind the state an aborted launch leaves: a host-output call is re-issued
+    on the batch-tile kernel under the same Philox counters (same samples, 1e-6); the estimators' device-resident frame
+    (ape_streams_frame_host) recovers inside the call; the 20-bit launch number of its granule tags wraps without a stale tag
+    being taken for a fresh one."""
+    from array import array
+    from wear_mocap_ape_amd import _hip, config
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from tests.test_hip_parity import _deploy_dir
+    name = "pocket"
+    m, sd, cfg = make_model(name, 0, norm_stats[name])
+    poke = _poke(_hip.lib())
+    x = torch.from_numpy(_synthetic_windows(norm_stats[name], 1, cfg["T"], cfg["I"], 3))
+
+    def sample(n=25):
+        m.manual_seed(5)
+        return m.monte_carlo_predictions(n, x, last_step_only=True).numpy().copy()
+    good = sample()
+    assert m.last_kernel() == "ape_lstm_mc_small"
+    m.set_kernel("tile16")
+    tile = sample()
+    m.set_kernel("auto")
+    assert np.abs(tile - good).max() < 1e-6 and np.abs(good - good[0]).max() > 1e-3
+    assert poke(m.handle, 0, 1) == 0
+    out = sample()                                   # host output: recovered before it is handed out
+    assert np.array_equal(out, tile), "the re-issue runs on the batch-tile kernel with the same masks"
+    assert m.stats() == {"aborted_checks": 1, "reissued_calls": 1, "lost_calls": 0}
+    assert np.array_equal(sample(), good)
+    # launch-number wrap
+    big = sample(100)
+    assert poke(m.handle, 7, 0xFFFFD) == 0
+    for rep in range(6):
+        assert np.array_equal(sample(), good) and np.array_equal(sample(100), big)
+    m.check()
+    # the consumer loop's frame: recovery is part of ape_streams_frame_host
+    g = golden("stream_trace_pocket.npz")
+    deploy, h = _deploy_dir(tmp_path, name, int(g["weights_seed"]), dropout=0.0)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    est = WatchPhonePocketNN(model_hash=h, smooth=3, add_mc_samples=True, monte_carlo_samples=4)
+    for f, row32 in enumerate(g["rows"][:10]):
+        if f in (2, 7):
+            assert poke(est._hip_model().handle, 0, 1) == 0
+        msg = est.process_row(array("f", row32.tolist()))
+        assert np.abs(np.asarray(msg) - g["msg_s3_mc4"][f]).max() < 5e-6, f
+    st = est._hip_model().stats()
+    assert st["aborted_checks"] == 2 and st["reissued_calls"] == 2 and st["lost_calls"] == 0, st
+    # ... also with dropout on (the latency kernel aborts, the batch-tile route draws the same samples)
+    deploy, h = _deploy_dir(tmp_path / "d", name, int(g["weights_seed"]), dropout=0.2)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    runs = []
+    for abort_at in (-1, 3):
+        est = WatchPhonePocketNN(model_hash=h, smooth=1, add_mc_samples=True, monte_carlo_samples=25)
+        msgs = []
+        for f, row32 in enumerate(g["rows"][:6]):
+            if f == abort_at:
+                assert poke(est._hip_model().handle, 0, 1) == 0
+            msgs.append(np.asarray(est.process_row(array("f", row32.tolist()))))
+        assert est._hip_model().last_kernel() == "ape_lstm_mc_small"
+        runs.append(msgs)
+    for f, (a, b) in enumerate(zip(*runs)):
+        assert np.abs(a - b).max() < (5e-5 if f == 3 else 1e-30), f

@@ -2,6 +2,7 @@
   * the drop-in `Estimator` consumer loop on its device-resident frame (`ape_streams_frame_host`): the reference's own
     20-frame traces in eval mode, the reference estimators' Monte-Carlo distribution end to end.
 """
+import ctypes as C
 import queue
 import time
 from array import array
@@ -132,3 +133,141 @@ def test_consumer_loop_monte_carlo_matches_reference_estimators(golden, tmp_path
     # negative control: half the rate must be flagged
     tails_bad, _ = last_frame_tails(0.5 * p, 128)
     assert mc_check.compare(tails_bad, *stats)
+
+
+# ---------------- the Monte-Carlo latency kernel (lstm_mc_small.hip) ---------------------------------------------------------
+@pytest.mark.parametrize("name,n,T", [("pocket", 25, 6), ("pocket", 1, 6), ("pocket", 60, 6), ("pocket", 128, 3), ("pocket", 7, 1),
+                                      ("pocket", 33, 13), ("watch", 25, 8), ("watch", 100, 2), ("uarm", 50, 6), ("uarm", 3, 6),
+                                      ("uarm", 128, 9), ("uarm", 17, 1)])
+def test_mc_latency_kernel_with_injected_masks(norm_stats, name, n, T):
+    """one window, n dropout samples (monte_carlo_predictions, nn_models.py:191-207) on the Monte-Carlo latency kernel with the
+    caller's masks, against the oracle's masked cell loop fed the same masks (1e-6 per sample row): row counts around the
+    cluster capacities (4 / 8 / 16 rows on each of 8 XCDs), window lengths around the pipeline depth, all three deployed shapes;
+    the fused z-score; the forced any-placement exchange; run-to-run determinism."""
+    from tests.test_hip_parity import make_model
+    from wear_mocap_ape_amd import _hip
+    m, sd, cfg = make_model(name, 1, norm_stats[name])
+    rng = np.random.default_rng(n * 100 + T)
+    x = rng.normal(size=(1, T, cfg["I"])).astype(np.float32)
+    p = 0.2
+    masks = [(rng.random((n, T, cfg["H"])) >= p).astype(np.float32) / np.float32(1.0 - p) for _ in range(cfg["L"] - 1)]
+    ref = orc.lstm_forward(sd, np.repeat(x, n, axis=0), masks=masks)[:, -1, :]
+    md = torch.from_numpy(np.stack(masks)).cuda()
+    y = m(torch.from_numpy(x).cuda(), masks=md, last_step_only=True, rows=n)
+    assert m.last_kernel() == "ape_lstm_mc_small"
+    y = y.cpu().numpy()[:, 0]
+    assert y.shape == ref.shape and np.abs(y - ref).max() < 1e-6, np.abs(y - ref).max()
+    y2 = m(torch.from_numpy(x).cuda(), masks=md, last_step_only=True, rows=n).cpu().numpy()[:, 0]
+    assert np.array_equal(y, y2)
+    # raw features + fused float64 z-score
+    st = norm_stats[name]
+    raw = (x.astype(np.float64) * st["xx_s"] + st["xx_m"]).astype(np.float32)
+    xn = ((raw.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+    ref_n = orc.lstm_forward(sd, np.repeat(xn, n, axis=0), masks=masks)[:, -1, :]
+    yn = m(torch.from_numpy(raw).cuda(), masks=md, last_step_only=True, rows=n, normalize_input=True).cpu().numpy()[:, 0]
+    assert np.abs(yn - ref_n).max() < 1e-6
+    # the other kernels under the same masks (other float32 summation orders only)
+    m.set_kernel("tile16")
+    yt = m(torch.from_numpy(x).cuda(), masks=md, last_step_only=True, rows=n).cpu().numpy()[:, 0]
+    assert m.last_kernel() == "ape_lstm_tile16"
+    m.set_kernel("auto")
+    assert np.abs(y - yt).max() < 1e-6
+    m.check()
+
+
+@pytest.mark.parametrize("name,n", [("pocket", 25), ("pocket", 128), ("uarm", 50), ("watch", 60)])
+def test_mc_latency_kernel_draws_the_masks_of_the_other_kernels(norm_stats, name, n):
+    """in-kernel Philox: counters (row quad, step, unit, layer) and key as in every other kernel of the library, so the same seed
+    gives the same samples whatever kernel the dispatch picks (batch-tile kernel: 1e-6 per row)"""
+    from tests.test_hip_parity import make_model
+    m, sd, cfg = make_model(name, 2, norm_stats[name])
+    x = torch.from_numpy(np.random.default_rng(3).normal(size=(1, cfg["T"], cfg["I"])).astype(np.float32)).cuda()
+    outs = {}
+    for kernel in ("auto", "tile16", "auto_gen1"):
+        m.set_kernel(kernel)
+        m.manual_seed(77)
+        outs[kernel] = m.monte_carlo_predictions(n, x, last_step_only=True).cpu().numpy()[:, 0]
+        outs[kernel + "_name"] = m.last_kernel()
+    m.set_kernel("auto")
+    assert outs["auto_name"] == "ape_lstm_mc_small" and outs["tile16_name"] == "ape_lstm_tile16" and outs["auto_gen1_name"] == "ape_lstm_cluster"
+    assert np.abs(outs["auto"] - outs["tile16"]).max() < 1e-6 and np.abs(outs["auto"] - outs["auto_gen1"]).max() < 1e-6
+    assert np.abs(outs["auto"] - outs["auto"][0]).max() > 1e-3          # the samples differ from each other
+    m.check()
+
+
+@pytest.mark.parametrize("name", ["pocket", "uarm"])
+def test_mc_latency_kernel_matches_reference_distribution(golden, name):
+    """64 calls of `monte_carlo_predictions(128, x)` on the latency kernel = 8192 samples of one window, against the statistics of
+    the 24 000 samples the REFERENCE drew (tests/golden/mc_stats.npz); half the rate is flagged"""
+    from tests.test_hip_parity import make_model
+    g = golden("mc_stats.npz")
+    cfg = orc.MODEL_CONFIGS[name]
+    m, sd, _ = make_model(name, 0)
+    p, n_ref, levels = float(g[f"dropout_{name}"]), int(g["n_samples"]), g["quantile_levels"]
+    m.manual_seed(31)
+    for w in (0, 2):
+        x = torch.from_numpy(g[f"x_{name}"][w:w + 1]).cuda()
+        args = (g[f"y_mean_{name}"][w], g[f"y_cov_{name}"][w], g[f"y_quant_{name}"][w], levels, n_ref)
+        ys = [m.monte_carlo_predictions(128, x, last_step_only=True)[:, 0].cpu().numpy() for _ in range(64)]
+        assert m.last_kernel() == "ape_lstm_mc_small"
+        bad = mc_check.compare(np.concatenate(ys), *args, what=f"{name} w{w} latency kernel")
+        assert not bad, bad
+    m.dropout = 0.5 * p
+    x = torch.from_numpy(g[f"x_{name}"][0:1]).cuda()
+    ys = [m.monte_carlo_predictions(128, x, last_step_only=True)[:, 0].cpu().numpy() for _ in range(64)]
+    assert mc_check.compare(np.concatenate(ys), g[f"y_mean_{name}"][0], g[f"y_cov_{name}"][0], g[f"y_quant_{name}"][0], levels, n_ref)
+    m.check()
+
+
+@pytest.mark.parametrize("name,S,n_mc,smooth", [("pocket", 1, 25, 1), ("pocket", 1, 60, 5), ("pocket", 2, 64, 1), ("pocket", 8, 16, 2),
+                                                ("pocket", 3, 25, 1), ("uarm", 1, 50, 1), ("uarm", 5, 11, 1), ("watch", 1, 25, 10)])
+def test_small_monte_carlo_banks_run_on_the_latency_kernel(norm_stats, name, S, n_mc, smooth):
+    """a bank of up to eight streams in Monte-Carlo mode (one estimator's frame: S = 1) steps on the latency kernel: every sample
+    against `ape_lstm_forward` on explicitly repeated windows with the bank's key (the batch-tile kernel under the same Philox
+    counters, 5e-6 on hand / elbow positions and messages), window ring and smoothing stack against the oracle's bookkeeping"""
+    from tests.test_hip_parity import make_model, _synthetic_windows
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 4, st)
+    m.set_body(orc.DEFAULT_BODY)
+    T, I, O = cfg["T"], cfg["I"], cfg["O"]
+    frames = T + 3
+    feats = _synthetic_windows(st, S, frames, I, 50 + S)
+    seed, p = 1234, 0.2
+    bank = StreamBank(m, S, T, smooth=smooth, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=p, seed=seed)
+    hist = [[] for _ in range(S)]
+    stack = [[] for _ in range(S)]
+    for f in range(frames):
+        bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+        msg, tail = bank.step(with_tail=True)
+        assert m.last_kernel() == "ape_lstm_mc_small"
+        msg, tail = msg.cpu().numpy().copy(), tail.cpu().numpy().copy()
+        # the same samples through ape_lstm_forward on explicitly repeated windows (rows s * n_mc + k), the bank's key for this step
+        wins = []
+        for s in range(S):
+            hist[s].append(feats[s, f])
+            while len(hist[s]) < T:
+                hist[s].append(feats[s, f])
+            del hist[s][:len(hist[s]) - T]
+            wins.append(np.repeat(np.stack(hist[s])[None], n_mc, axis=0))
+        xw = torch.from_numpy(np.concatenate(wins).astype(np.float32)).cuda()
+        y = torch.empty((S * n_mc, O), dtype=torch.float32, device="cuda")
+        m.set_kernel("tile16")
+        _hip.check(_hip.lib().ape_lstm_forward(m.handle, C.c_void_p(xw.data_ptr()), S * n_mc, T,
+                                               _hip.FLAG_NORMALIZE_INPUT | _hip.FLAG_DROPOUT_PHILOX, None, p, seed + f,
+                                               C.c_void_p(y.data_ptr()), None), "fwd")
+        m.set_kernel("auto")
+        yd = y.cpu().numpy().astype(np.float64) * st["yy_s"] + st["yy_m"]
+        for s in range(S):
+            pred = yd[s * n_mc:(s + 1) * n_mc]
+            stack[s].append(pred)
+            while len(stack[s]) < smooth:
+                stack[s].append(pred)
+            del stack[s][:len(stack[s]) - smooth]
+            rows = np.vstack(stack[s])
+            est = orc.arm_pose_from_targets(rows, orc.DEFAULT_BODY, cfg["layout"], "closed")
+            ref_msg = orc.msg_from_est(est, orc.DEFAULT_BODY, cfg["layout"])
+            assert np.abs(tail[s] - est[:, :6]).max() < 5e-6, (f, s)
+            assert np.abs(msg[s] - ref_msg).max() < 5e-6, (f, s)
+    m.check()
