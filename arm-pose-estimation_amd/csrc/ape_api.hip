@@ -1134,6 +1134,8 @@ static int check_and_reset(ape_model_t* m) {
         return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
                     "since the last successful check are invalid; the model is usable again", st,
                     st == 1 ? "a workgroup gave up waiting for a peer -- not all workgroups of a cluster were resident"
+                    : st == 5 ? "the Monte-Carlo latency kernel gave up waiting for the members of a cluster -- not all workgroups were resident"
+                    : st >= 16 ? "the Monte-Carlo latency kernel gave up waiting for a peer's values (16 + phase)"
                             : "a launch found the state of an earlier aborted launch");
     }
     return APE_OK;

@@ -13,22 +13,25 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int MR = 4;                      // rows per cluster of the small-batch kernel (row = lane group)
 
 // NI polling loads (16 bytes per lane, L1-bypassing) and the wait for them in ONE statement: the compiler knows nothing of the
-// asynchronous return, so no use (or copy) of a result may be scheduled between a load and the wait
+// asynchronous return, so no use (or copy) of a result may be scheduled between a load and the wait.
+// The leading `s_nop 4`: a VALU instruction that writes a scalar register needs 5 wait states before a vector-memory instruction
+// reads it, and hipcc pads only its own loads -- when it reloads a spilled descriptor with v_readlane_b32 right in front of this
+// statement (the diagnostic build of lstm_mc_small.hip did: every launch aborted on a stale descriptor) nothing else provides them
 template <int NI>
 __device__ __forceinline__ void poll_granules(u32x4 (&v)[NI], const unsigned (&off)[NI], u32x4 rsrc) {
     static_assert(NI >= 1 && NI <= 4, "pairs per thread");
     if constexpr (NI == 1)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(v[0]) : "v"(off[0]), "s"(rsrc) : "memory");
     else if constexpr (NI == 2)
-        asm volatile("buffer_load_dwordx4 %0, %2, %4, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(v[0]), "=&v"(v[1]) : "v"(off[0]), "v"(off[1]), "s"(rsrc) : "memory");
     else if constexpr (NI == 3)
-        asm volatile("buffer_load_dwordx4 %0, %3, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen sc1\n\t"
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %3, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen sc1\n\t"
                      "buffer_load_dwordx4 %2, %5, %6, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "s"(rsrc) : "memory");
     else
-        asm volatile("buffer_load_dwordx4 %0, %4, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen sc1\n\t"
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen sc1\n\t"
                      "buffer_load_dwordx4 %2, %6, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %3, %7, %8, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(rsrc) : "memory");

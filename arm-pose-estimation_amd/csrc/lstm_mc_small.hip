@@ -32,15 +32,15 @@ __device__ __forceinline__ void poll_pairs(u32x4 (&v)[NI], const unsigned (&off)
     if constexpr (NI <= 4) {
         poll_granules<NI>(v, off, rsrc);
     } else {
-        static_assert(NI == 5 || NI == 9, "pairs per thread of the built row capacities");
+        static_assert(NI == 5, "pairs per thread of the built row capacities");
 #define MCS_LD(i) "buffer_load_dwordx4 %" #i ", %[o" #i "], %[rs], 0 offen sc1\n\t"
         if constexpr (NI == 5)
-            asm volatile(MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) "s_waitcnt vmcnt(0)"
+            asm volatile("s_nop 4\n\t" MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) "s_waitcnt vmcnt(0)"
                          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
                          : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [rs] "s"(rsrc)
                          : "memory");
         else
-            asm volatile(MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) MCS_LD(5) MCS_LD(6) MCS_LD(7) MCS_LD(8) "s_waitcnt vmcnt(0)"
+            asm volatile("s_nop 4\n\t" MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) MCS_LD(5) MCS_LD(6) MCS_LD(7) MCS_LD(8) "s_waitcnt vmcnt(0)"
                          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
                            "=&v"(v[8])
                          : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]),
@@ -52,21 +52,32 @@ __device__ __forceinline__ void poll_pairs(u32x4 (&v)[NI], const unsigned (&off)
 
 // H, L, KX: the deployed shapes (2 x 256 with KX = 32; 3 x 128 with KX = 64).  RC: row capacity of a cluster (4, 8, 16) -- sizes the
 // exchange, the mask tables and the polls; the MFMA tile is 16 rows whatever RC.
+//
+// Eight waves, two roles (two waves per SIMD, so that the two roles overlap): waves 0..3 are the MATRIX waves of the layers above
+// layer 0 (wave = column tile ct x K half kh), waves 4..7 the ROW-0 waves (layer 0's GEMV -- wave w owns two units --, the x
+// staging and the mask multipliers of the next phase).  One register array serves both: a wave holds either its MFMA
+// fragments or its GEMV weights.  All eight waves collect.
 template <int H, int L, int KX, int RC>
-__global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams p) {
+__global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams p) {
     constexpr int GH = H / 8;                     // members of a cluster
     constexpr int LM = L - 1;                     // layers above layer 0 (MFMA)
     constexpr int SA = 2 * H + 8;                 // row stride of an activation tile: [masked input | own h] + pad
     constexpr int SX = KX + 8, KB = 32, QX = KX / KB, QH = H / KB, NW0 = (KX + H) / 8;
     constexpr int NQ = H / 16;                    // 16-deep k-blocks of one K half
+    constexpr int NWR = (LM * 4 * NQ > NW0) ? LM * 4 * NQ : NW0;     // weight registers per lane (either role)
     constexpr int PH = H / 2;                     // 16-byte granule pairs per row
-    constexpr int PAIRS = PH * (1 + LM * RC);     // pairs of one parity of one cluster: [h_0][layer 1: RC rows][layer 2: RC rows]
-    constexpr int NI = (PAIRS + 255) / 256;
+    constexpr int PAIRS1 = LM * RC * PH;          // pairs of the layers above, one parity: [layer 1: RC rows][layer 2: RC rows]
+    constexpr int PAIRS = PH + PAIRS1;            // ... behind the PH pairs of h_0
+    constexpr int NG = 512 / PH;                  // every h_0 pair is polled by NG threads: thread (pair, group) fans it out to rows r = group (mod NG)
+    constexpr int RG = (RC + NG - 1) / NG;
+    constexpr int NI1 = (PAIRS1 + 511) / 512;
+    constexpr int NI = 1 + NI1;                   // polled pairs per thread
     constexpr unsigned PAR_BYTES = (unsigned)PAIRS * 16u;
-    static_assert(L >= 2 && L <= 3 && (H == 128 || H == 256) && GH <= 32 && RC <= 16 && RC <= GH, "shape");
+    static_assert(L >= 2 && L <= 3 && (H == 128 || H == 256) && GH <= 32 && RC <= 16 && RC <= GH && 512 % PH == 0, "shape");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool matrix = wave < 4;
     const int cluster = blockIdx.x & 7, member = blockIdx.x >> 3;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
@@ -96,35 +107,42 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     my_xcc &= 0xFu;
     unsigned* const xcc_words = p.xcc_slots + 192 + cluster * 32;
 
-    // ---- layer 0 (GEMV): lane = (k-group g, column c = unit * 4 + gate) of this wave's two units
+    // ---- row-0 waves, layer 0 (GEMV): lane = (k-group g, column c = unit * 4 + gate) of the wave's two units
+    const int rw = wave & 3;
     const int c = lane & 7, g = lane >> 3, gate = c & 3, u = c >> 2;
-    const int unit0 = (member * 4 + wave) * 2 + u;
-    const float bias0 = p.bias[0][gate * H + unit0];
-    // ---- layers above (MFMA): column tile ct (units 8 m + 4 ct + 0..3), K half kh; lane = (row nn, unit ug of the tile)
-    const int ct = wave & 1, kh = wave >> 1, nn = lane & 15, ug = lane >> 4;
+    const int unit0 = (member * 4 + rw) * 2 + u;
+    // ---- matrix waves, layers above (MFMA): column tile ct (units 8 m + 4 ct + 0..3), K half kh; lane = (row nn, unit ug of the tile)
+    const int ct = wave & 1, kh = (wave >> 1) & 1, nn = lane & 15, ug = lane >> 4;
     const int unit1 = member * 8 + ct * 4 + ug;
+    float bias0 = 0.0f;
     f32x4 bias1[LM];
 #pragma unroll
-    for (int l = 0; l < LM; ++l)
+    for (int l = 0; l < LM; ++l) bias1[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float wr[NWR];                                 // matrix wave: register l * 4 NQ + 4 q + j = Wcat_l[gate * H + unit][kh * H + 16 q + 4 (lane >> 4) + j];
+                                                   // row-0 wave: the latency kernel's GEMV image (register 4 q + j = Wcat_0[..][32 q + 4 g + j])
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias1[l][i] = (kh == 0) ? p.bias[l + 1][i * H + unit1] : 0.0f;
-    float w0[NW0];
-    {
-        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.w0) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+    for (int i = 0; i < NWR; ++i) wr[i] = 0.0f;
+    if (matrix) {
+#pragma unroll
+        for (int l = 0; l < LM; ++l) {
+            if (kh == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bias1[l][i] = p.bias[l + 1][i * H + unit1];
+            }
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.w[l + 1]) + ((size_t)(member * 4 + wave) * NQ) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const f32x4 v = s1[i * 64];
+                wr[l * 4 * NQ + 4 * i] = v[0]; wr[l * 4 * NQ + 4 * i + 1] = v[1]; wr[l * 4 * NQ + 4 * i + 2] = v[2]; wr[l * 4 * NQ + 4 * i + 3] = v[3];
+            }
+        }
+    } else {
+        bias0 = p.bias[0][gate * H + unit0];
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.w0) + ((size_t)(member * 4 + rw) * (NW0 / 4)) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NW0 / 4; ++i) {
             const f32x4 v = s0[i * 64];
-            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
-        }
-    }
-    float wa[LM][4 * NQ];                          // register 4 q + j = Wcat_l[gate * H + unit][kh * H + 16 q + 4 (lane >> 4) + j]
-#pragma unroll
-    for (int l = 0; l < LM; ++l) {
-        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.w[l + 1]) + ((size_t)(member * 4 + wave) * NQ) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const f32x4 v = s1[i * 64];
-            wa[l][4 * i] = v[0]; wa[l][4 * i + 1] = v[1]; wa[l][4 * i + 2] = v[2]; wa[l][4 * i + 3] = v[3];
+            wr[4 * i] = v[0]; wr[4 * i + 1] = v[1]; wr[4 * i + 2] = v[2]; wr[4 * i + 3] = v[3];
         }
     }
     if (tid == 0) {
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     }
     // zero state, zero rows beyond the cluster's own in the B tiles (a tile row is a batch row: garbage would stay in its row,
     // but NaN bit patterns of an earlier kernel's LDS are not worth reasoning about)
-    for (int i = tid; i < (2 * LM * 16 * SA + 2 * LM * RC * H + 2 * H + 2 * SX) / 4; i += 256)
+    for (int i = tid; i < (2 * LM * 16 * SA + 2 * LM * RC * H + 2 * H + 2 * SX) / 4; i += 512)
         reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ctl[0] != 0) return;
@@ -148,47 +166,47 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     hx_desc[2] = __builtin_amdgcn_readfirstlane(p.gx_cluster_bytes);
     hx_desc[3] = 0x00020000u;
 
-    // the pairs this thread collects: e = tid + 256 i -> (layer, row, pair of units)
-    int it_l[NI], it_r[NI], it_pr[NI];
+    // the pairs this thread collects: slot 0 = h_0 pair pr0 (fanned out to the rows of group rg); slots 1.. = pair e1 = tid + 512 (i - 1)
+    // of the layers above -> (layer, row, pair of units)
+    const int pr0 = tid % PH, rg = tid / PH;
+    int it_l[NI1], it_r[NI1], it_pr[NI1];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int e = tid + 256 * i;
-        if (e < PH) { it_l[i] = 0; it_r[i] = 0; it_pr[i] = e; }
-        else {
-            const int e1 = e - PH;
-            it_l[i] = (e < PAIRS) ? 1 + e1 / (RC * PH) : -1;
-            it_r[i] = (e1 / PH) % RC;
-            it_pr[i] = e1 % PH;
-        }
+    for (int i = 0; i < NI1; ++i) {
+        const int e1 = tid + 512 * i;
+        it_l[i] = (e1 < PAIRS1) ? 1 + e1 / (RC * PH) : -1;
+        it_r[i] = (e1 / PH) % RC;
+        it_pr[i] = e1 % PH;
     }
 
-    // x_t of the stream's window: f64 z-score, cast f32 (estimator.py:103-104), fetched a phase ahead (as lstm_cluster_small.hip)
-    const bool x_live = tid < KX && tid < I;
-    const double x_mean = (normalize && x_live) ? p.xx_m[tid] : 0.0;
-    const double x_std = (normalize && x_live) ? p.xx_s[tid] : 1.0;
-    const double x_rstd = (normalize && x_live) ? p.xx_r[tid] : 1.0;
+    // x_t of the stream's window (row-0 wave 4): f64 z-score, cast f32 (estimator.py:103-104), fetched a phase ahead (as lstm_cluster_small.hip)
+    const int xt = tid - 256;
+    const bool x_live = xt >= 0 && xt < KX && xt < I;
+    const double x_mean = (normalize && x_live) ? p.xx_m[xt] : 0.0;
+    const double x_std = (normalize && x_live) ? p.xx_s[xt] : 1.0;
+    const double x_rstd = (normalize && x_live) ? p.xx_r[xt] : 1.0;
     const float* const x_src = p.x + (size_t)stream * p.x_stream_stride;
     float xr = 0.0f;
     auto fetch_x = [&](int t) {
-        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + tid];
+        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + xt];
     };
     auto stage_x = [&](int t) {
-        if (tid < KX) {
+        if (xt >= 0 && xt < KX) {
             const double d = (double)xr - x_mean;
             const double q0 = d * x_rstd;
             const double rr = fma(-q0, x_std, d);
             const double q1 = fma(rr, x_rstd, q0);
-            xin[(t & 1) * SX + tid] = x_live ? (float)((rr == rr) ? q1 : q0) : 0.0f;
+            xin[(t & 1) * SX + xt] = x_live ? (float)((rr == rr) ? q1 : q0) : 0.0f;
         }
     };
     fetch_x(0);
     stage_x(0);
     if (T > 1) fetch_x(1);
 
-    // mask multipliers of the values collected in phase `target`: layer l's output of step target - l, rows of this cluster
+    // mask multipliers of the values collected in phase `target` (row-0 waves: thread = (layer, unit)): layer l's output of step
+    // target - l, rows of this cluster
     const float keep_scale = 1.0f / (1.0f - p.dropout_p);
     auto mask_fill = [&](int target) {
-        for (int idx = tid; idx < LM * H; idx += 256) {
+        for (int idx = tid - 256; idx < LM * H; idx += 256) {
             const int l = idx / H, unit = idx - l * H, t = target - l;
             if (t < 0 || t >= T) continue;
             float* dst = mv + (((target & 1) * LM + l) * RC) * H + unit;
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
             }
         }
     };
-    mask_fill(0);
+    if (!matrix) mask_fill(0);
 
     if (wave == 0) {                               // do all members of this cluster share an XCD?
         unsigned spins = 0, v = 0u;
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
             if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 if (lane == 0) {
                     ctl[0] = 1;
-                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.status, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (5: the XCD rendezvous)
                 }
                 break;
             }
@@ -248,50 +266,57 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
         const unsigned want = (seq << 12) | (unsigned)(ph + 1);
-        if (ph + 1 < T) stage_x(ph + 1);
-        if (ph + 2 < T) fetch_x(ph + 2);
-        // ---- layer 0, step ph: one row
-        if (ph < T) {
-            const float* hrd = h0buf + (ph & 1) * H;
-            f32x4 ax[QX], ah[QH];
-            span_load<QX, KB>(ax, xin + (ph & 1) * SX + 4 * g);
-            span_load<QH, KB>(ah, hrd + 4 * g);
-            f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            span_fma<QX, NW0>(part4, ax, w0, 0);
-            span_fma<QH, NW0>(part4, ah, w0, 4 * QX);
-            float v = (part4[0] + part4[1]) + (part4[2] + part4[3]);
-            v = sum_ror8(v);
-            v = sum_xor16(v);
-            v = sum_xor32(v);
-            const float av = gate_act(v + bias0, gate == 2);
-            const float iv = quad_bcast<0>(av), fv = quad_bcast<1>(av), gv = quad_bcast<2>(av), ov = quad_bcast<3>(av);
-            const float cn = fv * c0 + iv * gv;
-            c0 = cn;
-            const float h0 = ov * gate_act(cn, true);
-            store_granule(h0, want, (gate == 0 && g == 0) ? (unsigned)(ph & 1) * PAR_BYTES + (unsigned)unit0 * 8u : 0x80000000u);
-        }
-        SM_STAMP(1);                                // 1: x staging + layer 0
-        // ---- layers above, step ph - l: this wave's K half of its column tile
         f32x4 acc[LM];
 #pragma unroll
-        for (int l = 0; l < LM; ++l) {
-            const int t = ph - 1 - l;
-            acc[l] = bias1[l];
-            if (t < 0 || t >= T || (kh == 1 && t == 0)) continue;      // uniform; h_{-1} = 0: no recurrent half at step 0
-            const float* src = a + (((ph & 1) * LM + l) * 16 + nn) * SA + kh * H + 4 * ug;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(src + 16 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[l][4 * q + j], b[j], acc[l], 0, 0, 0);
+        for (int l = 0; l < LM; ++l) acc[l] = bias1[l];
+        if (!matrix) {
+            if (ph + 1 < T) stage_x(ph + 1);
+            if (ph + 2 < T) fetch_x(ph + 2);
+            // ---- layer 0, step ph: one row
+            if (ph < T) {
+                const float* hrd = h0buf + (ph & 1) * H;
+                f32x4 ax[QX], ah[QH];
+                span_load<QX, KB>(ax, xin + (ph & 1) * SX + 4 * g);
+                span_load<QH, KB>(ah, hrd + 4 * g);
+                f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                span_fma<QX, NWR>(part4, ax, wr, 0);
+                span_fma<QH, NWR>(part4, ah, wr, 4 * QX);
+                float v = (part4[0] + part4[1]) + (part4[2] + part4[3]);
+                v = sum_ror8(v);
+                v = sum_xor16(v);
+                v = sum_xor32(v);
+                const float av = gate_act(v + bias0, gate == 2);
+                const float iv = quad_bcast<0>(av), fv = quad_bcast<1>(av), gv = quad_bcast<2>(av), ov = quad_bcast<3>(av);
+                const float cn = fv * c0 + iv * gv;
+                c0 = cn;
+                const float h0 = ov * gate_act(cn, true);
+                store_granule(h0, want, (gate == 0 && g == 0) ? (unsigned)(ph & 1) * PAR_BYTES + (unsigned)unit0 * 8u : 0x80000000u);
             }
-            if (kh == 1) *reinterpret_cast<f32x4*>(red + ((l * 2 + ct) * 64 + lane) * 4) = acc[l];
+            SM_STAMP(1);                            // 1 (row-0 waves): x staging + layer 0
+            // ---- the masks of the NEXT phase's values: data-independent, computed beside the matrix waves' spans
+            if (ph + 1 < P) mask_fill(ph + 1);
+            SM_STAMP(5);                            // 5 (row-0 waves): mask multipliers
+        } else {
+            // ---- layers above, step ph - l: this wave's K half of its column tile
+#pragma unroll
+            for (int l = 0; l < LM; ++l) {
+                const int t = ph - 1 - l;
+                if (t < 0 || t >= T || (kh == 1 && t == 0)) continue;      // uniform; h_{-1} = 0: no recurrent half at step 0
+                const float* src = a + (((ph & 1) * LM + l) * 16 + nn) * SA + kh * H + 4 * ug;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(src + 16 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l * 4 * NQ + 4 * q + j], b[j], acc[l], 0, 0, 0);
+                }
+                if (kh == 1) *reinterpret_cast<f32x4*>(red + ((l * 2 + ct) * 64 + lane) * 4) = acc[l];
+            }
+            SM_STAMP(2);                            // 2 (matrix waves): MFMA spans
         }
-        SM_STAMP(2);                                // 2: MFMA spans
         __syncthreads();                            // the recurrent halves' partial sums are in LDS
         SM_STAMP(3);
-        if (kh == 0) {
+        if (matrix && kh == 0) {
 #pragma unroll
             for (int l = 0; l < LM; ++l) {
                 const int t = ph - 1 - l;
@@ -311,19 +336,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
             }
         }
         SM_STAMP(4);                                // 4: cell updates + publish
-        // ---- the masks of the NEXT phase's values: data-independent, computed where this phase would otherwise wait for its peers
-        if (ph + 1 < P) mask_fill(ph + 1);
-        SM_STAMP(5);                                // 5: mask multipliers
         // ---- collect: every thread polls ITS pairs of granules until they carry this phase's tag, then puts the values where the
         //      next phase reads them: own-layer recurrent input as it is, the next layer's input under the rows' masks
         {
             unsigned off[NI];
             bool act[NI];
+            act[0] = ph < T;
+            off[0] = act[0] ? (unsigned)(ph & 1) * PAR_BYTES + (unsigned)pr0 * 16u : 0x80000000u;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NI1; ++i) {
                 const int t = ph - it_l[i];
-                act[i] = it_l[i] >= 0 && t >= 0 && t < T && (it_l[i] == 0 || it_r[i] < rv);
-                off[i] = act[i] ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(tid + 256 * i) * 16u : 0x80000000u;
+                act[1 + i] = it_l[i] >= 1 && t >= 0 && t < T && it_r[i] < rv;
+                off[1 + i] = act[1 + i] ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(PH + tid + 512 * i) * 16u : 0x80000000u;
             }
             unsigned val0[NI], val1[NI];
             unsigned spins = 0;
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
                                              __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     if (lane == 0) {
                         ctl[0] = 1;
-                        __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(p.status, 16u + (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (16 + phase: a collect)
                     }
                     break;
                 }
@@ -351,38 +375,39 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
             SM_STAMP(6);                            // 6: publish -> every awaited granule seen
             float* const anext = a + ((ph + 1) & 1) * (LM * 16 * SA);
             const float* const mcur = mv + (ph & 1) * (LM * RC * H);
+            if (act[0]) {
+                const f32x2 hv = {__builtin_bit_cast(float, val0[0]), __builtin_bit_cast(float, val1[0])};
+                if (rg == 0) *reinterpret_cast<f32x2*>(h0buf + ((ph + 1) & 1) * H + 2 * pr0) = hv;
+                // layer 1's input rows of this thread's group: the one value under each row's mask
+                f32x2 m2[RG];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                if (!act[i]) continue;
-                const float v0 = __builtin_bit_cast(float, val0[i]), v1 = __builtin_bit_cast(float, val1[i]);
-                const int l = it_l[i], pr = it_pr[i];
-                if (l == 0) {
-                    float* hw = h0buf + ((ph + 1) & 1) * H + 2 * pr;
-                    hw[0] = v0; hw[1] = v1;
-                    for (int r = 0; r < rv; ++r) {                       // layer 1's input rows: the one value under each row's mask
-                        const float* m2 = mcur + r * H + 2 * pr;
-                        float* dst = anext + r * SA + 2 * pr;
-                        dst[0] = v0 * m2[0]; dst[1] = v1 * m2[1];
-                    }
-                } else {
-                    const int r = it_r[i];
-                    float* rec = anext + ((l - 1) * 16 + r) * SA + H + 2 * pr;
-                    rec[0] = v0; rec[1] = v1;
-                    if (l < L - 1) {
-                        const float* m2 = mcur + (l * RC + r) * H + 2 * pr;
-                        float* dst = anext + (l * 16 + r) * SA + 2 * pr;
-                        dst[0] = v0 * m2[0]; dst[1] = v1 * m2[1];
-                    }
+                for (int k = 0; k < RG; ++k) m2[k] = *reinterpret_cast<const f32x2*>(mcur + ((rg + NG * k) % RC) * H + 2 * pr0);
+#pragma unroll
+                for (int k = 0; k < RG; ++k) {
+                    const int r = rg + NG * k;
+                    if (r < rv) *reinterpret_cast<f32x2*>(anext + r * SA + 2 * pr0) = f32x2{hv[0] * m2[k][0], hv[1] * m2[k][1]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI1; ++i) {
+                if (!act[1 + i]) continue;
+                const f32x2 hv = {__builtin_bit_cast(float, val0[1 + i]), __builtin_bit_cast(float, val1[1 + i])};
+                const int l = it_l[i], pr = it_pr[i], r = it_r[i];
+                *reinterpret_cast<f32x2*>(anext + ((l - 1) * 16 + r) * SA + H + 2 * pr) = hv;
+                if (l < L - 1) {
+                    const f32x2 m2 = *reinterpret_cast<const f32x2*>(mcur + (l * RC + r) * H + 2 * pr);
+                    *reinterpret_cast<f32x2*>(anext + (l * 16 + r) * SA + 2 * pr) = f32x2{hv[0] * m2[0], hv[1] * m2[1]};
                 }
             }
         }
         SM_STAMP(7);                                // 7: values into LDS
         __syncthreads();                            // the next phase's operands are in LDS
+        SM_STAMP(9);                                // 9: end-of-phase barrier
         if (ctl[0] != 0) return;
     }
 
     // ---- head: member m finishes row m of the cluster from the top layer's h(T-1) in its B tile; 16 lanes per target
-    if (member < rv) {
+    if (member < rv && tid < 256) {
         const int hw_o = tid >> 4, hw_part = tid & 15;
         float s_acc = 0.0f;
         if (hw_o < O) {
@@ -404,10 +429,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     }
     SM_STAMP(8);                                    // 8: head
 #ifdef APE_CLUSTER_STAMPS
-    if (p.dbg_wg != nullptr && tid == 0 && member == 0 && cluster == 0) {
-        for (int k = 0; k < 10; ++k) p.dbg_wg[k] = st_acc[k];
-        p.dbg_wg[10] = __builtin_amdgcn_s_memtime() - st_begin;
-        p.dbg_wg[11] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    // (wave 0 = a matrix wave, wave 4 = a row-0 wave: two stamp sets)
+    if (p.dbg_wg != nullptr && lane == 0 && (wave == 0 || wave == 4) && member == 0 && cluster == 0) {
+        unsigned long long* d = p.dbg_wg + (wave == 0 ? 0 : 16);
+        for (int k = 0; k < 10; ++k) d[k] = st_acc[k];
+        d[10] = __builtin_amdgcn_s_memtime() - st_begin;
+        d[11] = __builtin_amdgcn_s_memrealtime() - st_rt0;
     }
 #endif
     }   // rv > 0
@@ -421,10 +448,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
         // the next launch's tags differ from every tag of this one; when the 20-bit launch number wraps, the granules go back to
         // zero (tag 0 is never awaited)
         if (seq == 0xFFFFFu)
-            for (size_t i = tid; i < (size_t)8 * p.gx_cluster_bytes / 4; i += 256)
+            for (size_t i = tid; i < (size_t)8 * p.gx_cluster_bytes / 4; i += 512)
                 __hip_atomic_store(reinterpret_cast<unsigned*>(p.gx) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.seq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p.xcc_slots + 192 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 256) __hip_atomic_store(p.xcc_slots + 192 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -438,7 +465,7 @@ constexpr size_t mcs_smem() {
 template <int H, int L, int KX, int RC>
 hipError_t launch_mcs(const McSmallParams& p, hipStream_t stream) {
     constexpr size_t smem_bytes = mcs_smem<H, L, KX, RC>();
-    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC>), dim3(8 * (H / 8)), dim3(256), smem_bytes, stream, p);
+    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC>), dim3(8 * (H / 8)), dim3(512), smem_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """hipcc cannot see inside inline asm, so it inserts no wait states between a VALU instruction it emits and an asm MFMA that reads the
-VALU's result as SrcA / SrcB (gfx950 needs them; a stale operand goes unnoticed by everything but a parity test).  This scans the
+VALU's result as SrcA / SrcB / SrcC (gfx950 needs them; a stale operand goes unnoticed by everything but a parity test).  This scans the
 device assembly of a kernel file for that pattern: a VALU write (v_mov, v_accvgpr_read, any v_* but MFMA) of a register that one of the
-next `window` instructions, an MFMA, reads as its first or second source.
+next `window` instructions, an MFMA, reads as a source.
+A third pattern, found in round 4 (lstm_mc_small.hip's diagnostic build: every launch aborted): a VALU instruction that writes a SCALAR
+register (v_readlane_b32 reloading a spilled buffer descriptor, v_readfirstlane_b32, a v_cmp with an SGPR destination) needs 5 wait states
+before a vector-memory instruction reads that register; hipcc pads its own loads and stores, not the ones inside an asm statement.
     tools/check_mfma_hazards.py file.hip [extra hipcc flags]     exit code 1 when a hazard is found"""
 import re, subprocess, sys, tempfile
 
@@ -23,12 +26,49 @@ def scan(path, window=2):
         if not t.startswith("v_mfma") and not t.startswith("v_smfmac"): continue
         ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
         src = regs(ops[1]) | regs(ops[2])
+        src_c = regs(ops[3]) if len(ops) > 3 else set()        # the accumulator's start value: flagged when written by the instruction right in front
         for k in range(1, window + 1):
             if i - k < 0: break
             pn, pt = ins[i - k]
             if pt.startswith(("v_mfma", "v_smfmac")) or not pt.startswith("v_"): continue
             dst = regs(pt.split(None, 1)[1].split(",")[0].strip())
-            if dst & src: bad.append((pn, pt, n, t))
+            if dst & (src | src_c if k == 1 else src): bad.append((pn, pt, n, t))
+    return bad
+
+def sregs(tok):
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+def scan_sgpr_into_asm_vmem(path, need=5):
+    """a vector-memory instruction INSIDE an asm statement (between ;;#ASMSTART and ;;#ASMEND) that reads a scalar register a VALU
+    instruction wrote fewer than `need` wait states earlier (an s_nop k counts k + 1, any other instruction 1; a label or branch ends
+    the look-back: straight-line code only, which is where a spill reload sits)"""
+    ins, in_asm = [], False
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"): in_asm = True; continue
+        if t.startswith(";;#ASMEND"): in_asm = False; continue
+        if t.endswith(":") and not t.startswith(";"):
+            ins.append((n, "LABEL", False)); continue
+        if not t or t.startswith((";", ".", "//")): continue
+        ins.append((n, t.split(";")[0].strip(), in_asm))
+    bad = []
+    for i, (n, t, a) in enumerate(ins):
+        if not a or not t.startswith(("buffer_", "global_", "flat_", "scratch_")) or " " not in t: continue
+        used = set()
+        for o in t.split(None, 1)[1].replace(",", " ").split(): used |= sregs(o)
+        if not used: continue
+        states, k = 0, i - 1
+        while k >= 0 and states < need:
+            pn, pt, _ = ins[k]
+            if pt == "LABEL" or pt.startswith(("s_branch", "s_cbranch", "s_barrier")): break
+            if pt.startswith("v_") and " " in pt:
+                dst = sregs(pt.split(None, 1)[1].split(",")[0].strip())
+                if dst & used: bad.append((pn, pt, n, t, states))
+            states += (int(pt.split()[1]) + 1) if pt.startswith("s_nop") else 1
+            k -= 1
     return bad
 
 def scan_early_reads(path, window=12):
@@ -68,9 +108,13 @@ if __name__ == "__main__":
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *sys.argv[2:], src, "-o", f.name],
                        check=True, stderr=subprocess.DEVNULL)
-        bad = scan(f.name)
-        early = scan_early_reads(f.name) if "asm" in open(src).read() else []
+        asm_mfma = '"v_mfma' in open(src).read()          # MFMAs issued as asm statements (a builtin's hazards are the compiler's)
+        bad = scan(f.name) if asm_mfma else []
+        early = scan_early_reads(f.name) if asm_mfma else []
+        sg = scan_sgpr_into_asm_vmem(f.name)
     for pn, pt, n, t in bad: print(f"{src}: line {pn}: {pt}   ->   line {n}: {t}")
     for n, t, qn, qt in early: print(f"{src}: line {n}: {t}   read early by   line {qn}: {qt}")
-    print(f"{src}: {len(bad)} VALU-write -> MFMA SrcA/SrcB adjacencies, {len(early)} early reads of an MFMA result")
-    sys.exit(1 if bad or early else 0)
+    for pn, pt, n, t, st in sg: print(f"{src}: line {pn}: {pt}   ->   asm line {n}: {t}   ({st} wait states, 5 needed)")
+    print(f"{src}: {len(bad)} VALU-write -> MFMA SrcA/SrcB adjacencies, {len(early)} early reads of an MFMA result, "
+          f"{len(sg)} VALU-written SGPRs read early by an asm vector-memory instruction")
+    sys.exit(1 if bad or early or sg else 0)
