@@ -351,6 +351,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         // H/8-member register image
         if (ape_mc_small_supported(H, L, m->KX) && m->small_uw == 2 && m->n_cus >= 8 * (H / 8) && !imupose) {
             for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wmc[l], (size_t)8 * H * H * sizeof(float));
+            for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wmc16[l], (size_t)8 * H * H * sizeof(float));
             m->gxm_cluster_bytes = ape_mc_small_cluster_bytes(H, L);
             if (e == hipSuccess) e = plan((void**)&m->gxm, 256 + 8 * m->gxm_cluster_bytes);
             if (e == hipSuccess) e = ape_prepare_lstm_mc_small(H, L, m->KX);
@@ -546,11 +547,25 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                 HIP_TRY(hipMemcpy(m->wcls[l], ps.data(), ps.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             if (m->mcs_ok && l >= 1) {
-                // Monte-Carlo latency kernel, layers above layer 0: H/8 members x 4 waves, wave = (column tile ct = w & 1, K half
-                // kh = w >> 1); lane = (g << 4) | (u << 2) | gate holds Wcat[gate*H + member*8 + ct*4 + u][kh*H + 16q + 4g + j] in
-                // register 4q + j; stored [member][wave][q][lane][4]
-                const int GM = H / 8, NQm = H / 16;
-                std::vector<float> pm((size_t)GM * 4 * NQm * 64 * 4);
+                // Monte-Carlo latency kernel, layers above layer 0 (v_mfma_f32_4x4x1_16b_f32): H/8 members x 4 waves, wave w = K quarter w of
+                // [W_ih | W_hh]; lane = (block b = lane >> 2: unit b & 7 of the member, k slice ks = b >> 3; gate = lane & 3) holds
+                // Wcat[gate*H + member*8 + (b & 7)][w*H/2 + 8 (i/4) + 4 ks + (i%4)] in register i; stored [member][wave][i/4][lane][i%4]
+                const int GM = H / 8, NI4 = H / 4;
+                std::vector<float> pm((size_t)GM * 4 * NI4 * 64);
+                for (int mem = 0; mem < GM; ++mem)
+                    for (int w = 0; w < 4; ++w)
+                        for (int i = 0; i < NI4; ++i)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int gate = lane & 3, ub = (lane >> 2) & 7, ks = lane >> 5;
+                                const int row = gate * H + mem * 8 + ub;
+                                const int k = w * (H / 2) + 8 * (i / 4) + 4 * ks + (i % 4);
+                                pm[((((size_t)(mem * 4 + w) * (NI4 / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] =
+                                    k < H ? w_ih[(size_t)row * H + k] : w_hh[(size_t)row * H + (k - H)];
+                            }
+                HIP_TRY(hipMemcpy(m->wmc[l], pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
+                // ... and the 16 x 16 x 4 image of its 16-row form: wave = (column tile ct = w & 1, K half kh = w >> 1); lane = (g << 4) | (u << 2) |
+                // gate holds Wcat[gate*H + member*8 + ct*4 + u][kh*H + 16q + 4g + j] in register 4q + j; stored [member][wave][q][lane][4]
+                const int NQm = H / 16;
                 for (int mem = 0; mem < GM; ++mem)
                     for (int w = 0; w < 4; ++w)
                         for (int q = 0; q < NQm; ++q)
@@ -563,7 +578,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                                         kh == 0 ? w_ih[(size_t)row * H + k] : w_hh[(size_t)row * H + k];
                                 }
                             }
-                HIP_TRY(hipMemcpy(m->wmc[l], pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(m->wmc16[l], pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             // fp16 variant: [member][wave][32-deep k-block q][lane][8]: lane holds Wcat[row][32q + 8g + j] as binary16
             const int NB = (KXl + H) / 32;
@@ -661,7 +676,7 @@ static int mc_small_launch(ape_model_t* m, const float* x, size_t x_stream_strid
     const int L = m->dims.num_layers, I = m->dims.input_size, O = m->dims.output_size;
     q.x = x; q.x_stream_stride = x_stream_stride; q.y = y_dev;
     q.w0 = m->wcls[0];
-    for (int l = 0; l < L; ++l) { q.w[l] = m->wmc[l]; q.bias[l] = m->bias[l]; }
+    for (int l = 0; l < L; ++l) { q.w[l] = m->wmc[l]; q.w16[l] = m->wmc16[l]; q.bias[l] = m->bias[l]; }
     q.w_out = m->w_out; q.b_out = m->b_out;
     q.xx_m = m->stats; q.xx_s = m->stats + I; q.xx_r = m->stats + 2 * I + 2 * O;
     q.gx = m->gxm + 256; q.gx_cluster_bytes = (unsigned)m->gxm_cluster_bytes;
@@ -792,7 +807,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     if (m->kernel_choice == APE_KERNEL_CLUSTER && !use_cluster && !m->replaying)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: the cluster kernel does not cover this model / these flags");
     // one window, n dropout samples (monte_carlo_predictions, nn_models.py:191-207) up to 128 rows: the Monte-Carlo latency kernel
-    if (use_cluster && cdrop_c && (flags & APE_FLAG_BROADCAST_X) && !all_steps && !f16 && B <= 128 && T + L <= 4096 && mc_small_fits(m, 1, B))
+    if (use_cluster && cdrop_c && (flags & APE_FLAG_BROADCAST_X) && !all_steps && !f16 && B <= 128 && T <= 64 && mc_small_fits(m, 1, B))
         return mc_small_launch(m, x_dev, 0, 1, B, T, flags, masks_dev, dropout_p, seed, y_dev, stream, x_ring);
     int n16 = use_cluster ? 0 : B;               // leading rows that go to the batch-tile kernel
     if (use_cluster && m->kernel_choice == APE_KERNEL_AUTO && !f16 && !all_steps && !(flags & APE_FLAG_DROPOUT_MASKS) && B > 4) {
@@ -1541,7 +1556,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
         ++b->mc_calls;
         }
-    } else if (drop && b->S <= 8 && m->cluster_ok && b->T + m->dims.num_layers <= 4096 && mc_small_fits(m, b->S, b->n_mc)) {
+    } else if (drop && b->S <= 8 && m->cluster_ok && b->T <= 64 && mc_small_fits(m, b->S, b->n_mc)) {
         // a few streams in Monte-Carlo mode (one estimator's frame: S = 1): the latency kernel reads the first copy of every
         // stream's window and deals the sample rows over the XCDs
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");

@@ -145,7 +145,8 @@ struct McSmallParams {
     size_t x_stream_stride;
     float* y;                           // [rows, O] normalised NN targets of the last step
     const float* w0;                    // layer 0: the latency kernel's H/8-member register image (ape_model::wcls[0])
-    const float* w[APE_MAX_LAYERS];     // layers >= 1 (index = layer): [member H/8][wave 4][k-block H/16][lane 64][4]
+    const float* w[APE_MAX_LAYERS];     // layers >= 1 (index = layer): [member H/8][wave 4][H/16][lane 64][4], the 4x4x1 MFMA's A fragments
+    const float* w16[APE_MAX_LAYERS];   // the same layers as 16 x 16 x 4 fragments (16-row clusters): wave = column tile x K half
     const float* bias[APE_MAX_LAYERS];
     const float* w_out;
     const float* b_out;

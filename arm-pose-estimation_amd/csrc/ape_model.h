@@ -59,7 +59,8 @@ struct ape_model {
     float* wcls[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // the latency kernel's H/8-member form (two units per wave)
     char* hxs = nullptr;             // latency kernel: [256 B: launch number][granules {h, tag}: layer, parity, 4 rows, H units]
     size_t hxs_bytes = 0;
-    float* wmc[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};    // Monte-Carlo latency kernel: layers >= 1, wave = column tile x K half
+    float* wmc[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};    // Monte-Carlo latency kernel: layers >= 1, wave = K quarter (4x4x1 MFMA fragments)
+    float* wmc16[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};  // ... and as 16 x 16 x 4 fragments (16-row clusters: wave = column tile x K half)
     char* gxm = nullptr;             // ... [256 B: launch number][8 clusters of granules]
     size_t gxm_cluster_bytes = 0;
     bool mcs_ok = false;             // lstm_mc_small.hip covers this model on this device

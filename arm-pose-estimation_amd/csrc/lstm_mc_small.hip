@@ -32,7 +32,7 @@ __device__ __forceinline__ void poll_pairs(u32x4 (&v)[NI], const unsigned (&off)
     if constexpr (NI <= 4) {
         poll_granules<NI>(v, off, rsrc);
     } else {
-        static_assert(NI == 5, "pairs per thread of the built row capacities");
+        static_assert(NI == 5 || NI == 9, "pairs per thread of the built row capacities");
 #define MCS_LD(i) "buffer_load_dwordx4 %" #i ", %[o" #i "], %[rs], 0 offen sc1\n\t"
         if constexpr (NI == 5)
             asm volatile("s_nop 4\n\t" MCS_LD(0) MCS_LD(1) MCS_LD(2) MCS_LD(3) MCS_LD(4) "s_waitcnt vmcnt(0)"
@@ -51,37 +51,39 @@ __device__ __forceinline__ void poll_pairs(u32x4 (&v)[NI], const unsigned (&off)
 }
 
 // H, L, KX: the deployed shapes (2 x 256 with KX = 32; 3 x 128 with KX = 64).  RC: row capacity of a cluster (4, 8, 16) -- sizes the
-// exchange, the mask tables and the polls; the MFMA tile is 16 rows whatever RC.
+// B tiles, the exchange, the polls and the number of 4-row groups of the matrix product.  INJ: the caller's masks (float
+// multipliers, fetched a phase ahead) instead of the in-kernel Philox draws (keep / drop bits for all steps, laid down in the
+// weight prologue's shadow).
 //
-// Eight waves, two roles (two waves per SIMD, so that the two roles overlap): waves 0..3 are the MATRIX waves of the layers above
-// layer 0 (wave = column tile ct x K half kh), waves 4..7 the ROW-0 waves (layer 0's GEMV -- wave w owns two units --, the x
-// staging and the mask multipliers of the next phase).  One register array serves both: a wave holds either its MFMA
-// fragments or its GEMV weights.  All eight waves collect.
-template <int H, int L, int KX, int RC>
-__global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams p) {
+// The layers above layer 0 run on v_mfma_f32_4x4x1_16b_f32: sixteen 4 x 4 outer products per instruction, block = (unit of the member,
+// k slice), the four A rows of a block = the unit's four gates, the four B columns = four sample rows -- so a 4-row cluster pays for 4
+// rows, not for a 16-row tile (one window x 25 samples: 0.9 -> 0.25 us per phase), and a lane ends up with the four gates of one
+// (unit, row) cell.  K = [masked h of the layer below | own h] is split over the four waves (waves 0, 1: the input half; 2, 3: the
+// recurrent half, skipped at step 0), two k per instruction (the wave's halves), the partial sums meet in LDS.
+template <int H, int L, int KX, int RC, bool INJ>
+__global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams p) {
     constexpr int GH = H / 8;                     // members of a cluster
     constexpr int LM = L - 1;                     // layers above layer 0 (MFMA)
+    constexpr int NRG = RC / 4;                   // 4-row groups
     constexpr int SA = 2 * H + 8;                 // row stride of an activation tile: [masked input | own h] + pad
     constexpr int SX = KX + 8, KB = 32, QX = KX / KB, QH = H / KB, NW0 = (KX + H) / 8;
-    constexpr int NQ = H / 16;                    // 16-deep k-blocks of one K half
-    constexpr int NWR = (LM * 4 * NQ > NW0) ? LM * 4 * NQ : NW0;     // weight registers per lane (either role)
+    constexpr int NI4 = H / 4;                    // 4x4x1 instructions per wave, layer and row group: a K quarter (H / 2 values), two k each
     constexpr int PH = H / 2;                     // 16-byte granule pairs per row
     constexpr int PAIRS1 = LM * RC * PH;          // pairs of the layers above, one parity: [layer 1: RC rows][layer 2: RC rows]
     constexpr int PAIRS = PH + PAIRS1;            // ... behind the PH pairs of h_0
-    constexpr int NG = 512 / PH;                  // every h_0 pair is polled by NG threads: thread (pair, group) fans it out to rows r = group (mod NG)
+    constexpr int NG = 256 / PH;                  // every h_0 pair is polled by NG threads: thread (pair, group) fans it out to rows r = group (mod NG)
     constexpr int RG = (RC + NG - 1) / NG;
-    constexpr int NI1 = (PAIRS1 + 511) / 512;
+    constexpr int NI1 = (PAIRS1 + 255) / 256;
     constexpr int NI = 1 + NI1;                   // polled pairs per thread
     constexpr unsigned PAR_BYTES = (unsigned)PAIRS * 16u;
-    static_assert(L >= 2 && L <= 3 && (H == 128 || H == 256) && GH <= 32 && RC <= 16 && RC <= GH && 512 % PH == 0, "shape");
+    static_assert(L >= 2 && L <= 3 && (H == 128 || H == 256) && GH <= 32 && (RC == 4 || RC == 8 || RC == 16) && RC <= GH && 256 % PH == 0 &&
+                  LM * H == 256, "shape");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool matrix = wave < 4;
     const int cluster = blockIdx.x & 7, member = blockIdx.x >> 3;
     const int T = p.T, I = p.I, O = p.O;
     const bool normalize = (p.flags & APE_FLAG_NORMALIZE_INPUT) != 0;
-    const bool inj_masks = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
     // this cluster's rows: stream = cluster / cps, its `part`-th run of R sample rows
     const int stream = cluster / p.cps, part = cluster - stream * p.cps;
     int rv = (stream < p.n_streams) ? p.n_mc - part * p.R : 0;
@@ -89,12 +91,13 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
     const int row0 = stream * p.n_mc + part * p.R;          // global index of the cluster's first sample row
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* a = smem;                               // [2 phase parity][LM][16][SA]  B tiles of the MFMA layers
-    float* mv = a + 2 * LM * 16 * SA;              // [2][LM][RC][H]  mask multipliers (0 or 1/(1-p)) by phase parity
-    float* h0buf = mv + 2 * LM * RC * H;           // [2][H]  layer 0's own state
+    float* a = smem;                               // [2 phase parity][LM][RC][SA]  B tiles of the MFMA layers
+    float* h0buf = a + 2 * LM * RC * SA;           // [2][H]  layer 0's own state
     float* xin = h0buf + 2 * H;                    // [2][SX]
-    float* red = xin + 2 * SX;                     // [LM][2 column tiles][64][4]  partial sums of the recurrent K half
-    int* ctl = reinterpret_cast<int*>(red + LM * 2 * 64 * 4);
+    float* red = xin + 2 * SX;                     // [LM][NRG][4 waves][32][4]  partial sums of the K quarters
+    int* ctl = reinterpret_cast<int*>(red + LM * NRG * 4 * 32 * 4);
+    float* mv = reinterpret_cast<float*>(ctl + 8); // INJ: [2][LM][RC][H] mask multipliers by phase parity
+    unsigned short* mbits = reinterpret_cast<unsigned short*>(ctl + 8);   // else: [64 steps][LM * H] (the launcher refuses longer windows) bit r = row r of the cluster keeps (layer, unit) at that step
 #ifdef APE_CLUSTER_STAMPS
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
@@ -107,55 +110,57 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
     my_xcc &= 0xFu;
     unsigned* const xcc_words = p.xcc_slots + 192 + cluster * 32;
 
-    // ---- row-0 waves, layer 0 (GEMV): lane = (k-group g, column c = unit * 4 + gate) of the wave's two units
-    const int rw = wave & 3;
+    // ---- layer 0 (GEMV): lane = (k-group g, column c = unit * 4 + gate) of this wave's two units
     const int c = lane & 7, g = lane >> 3, gate = c & 3, u = c >> 2;
-    const int unit0 = (member * 4 + rw) * 2 + u;
-    // ---- matrix waves, layers above (MFMA): column tile ct (units 8 m + 4 ct + 0..3), K half kh; lane = (row nn, unit ug of the tile)
-    const int ct = wave & 1, kh = (wave >> 1) & 1, nn = lane & 15, ug = lane >> 4;
-    const int unit1 = member * 8 + ct * 4 + ug;
-    float bias0 = 0.0f;
-    f32x4 bias1[LM];
-#pragma unroll
-    for (int l = 0; l < LM; ++l) bias1[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float wr[NWR];                                 // matrix wave: register l * 4 NQ + 4 q + j = Wcat_l[gate * H + unit][kh * H + 16 q + 4 (lane >> 4) + j];
-                                                   // row-0 wave: the latency kernel's GEMV image (register 4 q + j = Wcat_0[..][32 q + 4 g + j])
-#pragma unroll
-    for (int i = 0; i < NWR; ++i) wr[i] = 0.0f;
-    if (matrix) {
-#pragma unroll
-        for (int l = 0; l < LM; ++l) {
-            if (kh == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bias1[l][i] = p.bias[l + 1][i * H + unit1];
-            }
-            const f32x4* s1 = reinterpret_cast<const f32x4*>(p.w[l + 1]) + ((size_t)(member * 4 + wave) * NQ) * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const f32x4 v = s1[i * 64];
-                wr[l * 4 * NQ + 4 * i] = v[0]; wr[l * 4 * NQ + 4 * i + 1] = v[1]; wr[l * 4 * NQ + 4 * i + 2] = v[2]; wr[l * 4 * NQ + 4 * i + 3] = v[3];
-            }
-        }
-    } else {
-        bias0 = p.bias[0][gate * H + unit0];
-        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.w0) + ((size_t)(member * 4 + rw) * (NW0 / 4)) * 64 + lane;
+    const int unit0 = (member * 4 + wave) * 2 + u;
+    const float bias0 = p.bias[0][gate * H + unit0];
+    // ---- layers above (4x4x1 MFMA): lane = (block b = lane >> 2: unit ub = b & 7 of the member, k slice ks = b >> 3; q = lane & 3: the
+    //      gate on the A side, the row of the group on the B side)
+    const int q4 = lane & 3, ub = (lane >> 2) & 7, ks = lane >> 5;
+    const int unit1 = member * 8 + ub;
+    float w0[NW0];
+    {
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.w0) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NW0 / 4; ++i) {
             const f32x4 v = s0[i * 64];
-            wr[4 * i] = v[0]; wr[4 * i + 1] = v[1]; wr[4 * i + 2] = v[2]; wr[4 * i + 3] = v[3];
+            w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
         }
     }
-    if (tid == 0) {
-        ctl[0] = (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
-        if (ctl[0] == 0)
-            __hip_atomic_store(xcc_words + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // 16-row clusters (more than 64 samples of one window) take the 16 x 16 x 4 form instead: its 32 MAC per cycle beat the 4x4x1's 16 once
+    // the tile is full.  Wave = (column tile ct16 = wave & 1: units 8 m + 4 ct16 + 0..3, K half kh16 = wave >> 1), lane = (row nn16, unit
+    // ug16 of the tile); the halves meet in LDS, the waves with kh16 = 0 finish the cells.
+    constexpr bool WIDE = RC == 16;
+    const int ct16 = wave & 1, kh16 = wave >> 1, nn16 = lane & 15, ug16 = lane >> 4;
+    const int unit16 = member * 8 + ct16 * 4 + ug16;
+    float wa[LM][NI4];                             // register i = Wcat_l[gate q4 * H + unit1][wave * H/2 + 8 (i / 4) + 4 ks + (i % 4)]
+                                                   // (WIDE: register 4 q + j = Wcat_l[(lane & 3) * H + unit16][kh16 * H + 16 q + 4 ug16 + j])
+#pragma unroll
+    for (int l = 0; l < LM; ++l) {
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(WIDE ? p.w16[l + 1] : p.w[l + 1]) + ((size_t)(member * 4 + wave) * (NI4 / 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NI4 / 4; ++i) {
+            const f32x4 v = s1[i * 64];
+            wa[l][4 * i] = v[0]; wa[l][4 * i + 1] = v[1]; wa[l][4 * i + 2] = v[2]; wa[l][4 * i + 3] = v[3];
+        }
     }
-    // zero state, zero rows beyond the cluster's own in the B tiles (a tile row is a batch row: garbage would stay in its row,
-    // but NaN bit patterns of an earlier kernel's LDS are not worth reasoning about)
-    for (int i = tid; i < (2 * LM * 16 * SA + 2 * LM * RC * H + 2 * H + 2 * SX) / 4; i += 512)
+    // the cell (layer l, row group rgp) is finished by wave (l * NRG + rgp) & 3, lanes 0..31: lane = (unit ub, row q4 of the group)
+    constexpr int NCS = WIDE ? LM : (LM * NRG + 3) / 4;        // cells per lane of a finishing wave
+    f32x4 biasc[NCS];
+    float cst[NCS];
+#pragma unroll
+    for (int k = 0; k < NCS; ++k) {
+        const int cid = wave + 4 * k, l = WIDE ? k : cid / NRG;
+        const bool mine = WIDE ? kh16 == 0 : cid < LM * NRG;
+        cst[k] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) biasc[k][i] = mine ? p.bias[l + 1][i * H + (WIDE ? unit16 : unit1)] : 0.0f;
+    }
+    // (a store only: nothing here may wait for a load yet -- vmcnt counts in order, the first awaited result waits for every weight)
+    if (tid == 0) __hip_atomic_store(xcc_words + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // zero state (h_{-1} = 0 of every layer)
+    for (int i = tid; i < (2 * LM * RC * SA + 2 * H + 2 * SX) / 4; i += 256)
         reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ctl[0] != 0) return;
 
     char* const gx = p.gx + (size_t)cluster * p.gx_cluster_bytes;
     const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(gx, 0, (int)p.gx_cluster_bytes, 0x00020000);
@@ -166,67 +171,77 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
     hx_desc[2] = __builtin_amdgcn_readfirstlane(p.gx_cluster_bytes);
     hx_desc[3] = 0x00020000u;
 
-    // the pairs this thread collects: slot 0 = h_0 pair pr0 (fanned out to the rows of group rg); slots 1.. = pair e1 = tid + 512 (i - 1)
+    // the pairs this thread collects: slot 0 = h_0 pair pr0 (fanned out to the rows of group rg); slots 1.. = pair e1 = tid + 256 (i - 1)
     // of the layers above -> (layer, row, pair of units)
     const int pr0 = tid % PH, rg = tid / PH;
     int it_l[NI1], it_r[NI1], it_pr[NI1];
 #pragma unroll
     for (int i = 0; i < NI1; ++i) {
-        const int e1 = tid + 512 * i;
+        const int e1 = tid + 256 * i;
         it_l[i] = (e1 < PAIRS1) ? 1 + e1 / (RC * PH) : -1;
         it_r[i] = (e1 / PH) % RC;
         it_pr[i] = e1 % PH;
     }
 
-    // x_t of the stream's window (row-0 wave 4): f64 z-score, cast f32 (estimator.py:103-104), fetched a phase ahead (as lstm_cluster_small.hip)
-    const int xt = tid - 256;
-    const bool x_live = xt >= 0 && xt < KX && xt < I;
-    const double x_mean = (normalize && x_live) ? p.xx_m[xt] : 0.0;
-    const double x_std = (normalize && x_live) ? p.xx_s[xt] : 1.0;
-    const double x_rstd = (normalize && x_live) ? p.xx_r[xt] : 1.0;
+    // x_t of the stream's window: f64 z-score, cast f32 (estimator.py:103-104), fetched a phase ahead (as lstm_cluster_small.hip)
+    const bool x_live = tid < KX && tid < I;
+    const double x_mean = (normalize && x_live) ? p.xx_m[tid] : 0.0;
+    const double x_std = (normalize && x_live) ? p.xx_s[tid] : 1.0;
+    const double x_rstd = (normalize && x_live) ? p.xx_r[tid] : 1.0;
     const float* const x_src = p.x + (size_t)stream * p.x_stream_stride;
     float xr = 0.0f;
     auto fetch_x = [&](int t) {
-        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + xt];
+        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + tid];
     };
     auto stage_x = [&](int t) {
-        if (xt >= 0 && xt < KX) {
+        if (tid < KX) {
             const double d = (double)xr - x_mean;
             const double q0 = d * x_rstd;
             const double rr = fma(-q0, x_std, d);
             const double q1 = fma(rr, x_rstd, q0);
-            xin[(t & 1) * SX + xt] = x_live ? (float)((rr == rr) ? q1 : q0) : 0.0f;
+            xin[(t & 1) * SX + tid] = x_live ? (float)((rr == rr) ? q1 : q0) : 0.0f;
         }
     };
+    // ---- dropout masks.  Thread = (layer l, unit) of the layers that are masked (LM * H = 256 of them).
+    //      Philox: the keep bits of layer l's output of step t for the cluster's rows, one call per four rows with the counters of
+    //      every other kernel (row quad, step, unit, layer); the first steps here, where the weight loads are in flight and the
+    //      VALU has nothing to do, the rest a few steps ahead of their use inside the phases.
+    //      Injected: the caller's multipliers of the values collected in phase `target`, fetched a phase ahead.
+    const float keep_scale = 1.0f / (1.0f - p.dropout_p);
+    const int m_l = tid / H, m_unit = tid - m_l * H;
+    const int quads = ((row0 + rv + 3) >> 2) - (row0 >> 2);          // Philox calls per (layer, step, unit)
+    auto mask_bits = [&](int t) {
+        unsigned word = 0u;
+        for (int qb = row0 & ~3; qb < row0 + rv; qb += 4) {
+            uint32_t rnd[4];
+            philox4x32((uint32_t)qb, (uint32_t)t, (uint32_t)m_unit, (uint32_t)m_l, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = qb + i - row0;
+                const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                if (r >= 0 && r < rv && uf >= p.dropout_p) word |= 1u << r;
+            }
+        }
+        mbits[t * (LM * H) + tid] = (unsigned short)word;
+    };
+    auto mask_fill = [&](int target) {             // INJ
+        const int t = target - m_l;
+        if (t < 0 || t >= T) return;
+        float* dst = mv + (((target & 1) * LM + m_l) * RC) * H + m_unit;
+        for (int r = 0; r < rv; ++r) dst[r * H] = p.masks[(((size_t)m_l * p.rows + row0 + r) * T + t) * H + m_unit];
+    };
+    // steps laid down ahead: about eight Philox calls per thread in the prologue
+    int pre_t = 8 / quads;
+    pre_t = pre_t < 1 ? 1 : (pre_t > T ? T : pre_t);
+    if constexpr (!INJ) for (int t = 0; t < pre_t; ++t) mask_bits(t);
+    // a launch that finds the sticky status word set (an earlier launch on this model aborted) leaves without touching anything
+    if (tid == 0) ctl[0] = (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+    if constexpr (INJ) mask_fill(0);
     fetch_x(0);
     stage_x(0);
     if (T > 1) fetch_x(1);
-
-    // mask multipliers of the values collected in phase `target` (row-0 waves: thread = (layer, unit)): layer l's output of step
-    // target - l, rows of this cluster
-    const float keep_scale = 1.0f / (1.0f - p.dropout_p);
-    auto mask_fill = [&](int target) {
-        for (int idx = tid - 256; idx < LM * H; idx += 256) {
-            const int l = idx / H, unit = idx - l * H, t = target - l;
-            if (t < 0 || t >= T) continue;
-            float* dst = mv + (((target & 1) * LM + l) * RC) * H + unit;
-            if (inj_masks) {
-                for (int r = 0; r < rv; ++r) dst[r * H] = p.masks[(((size_t)l * p.rows + row0 + r) * T + t) * H + unit];
-            } else {
-                for (int qb = row0 & ~3; qb < row0 + rv; qb += 4) {
-                    uint32_t rnd[4];
-                    philox4x32((uint32_t)qb, (uint32_t)t, (uint32_t)unit, (uint32_t)l, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = qb + i - row0;
-                        const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
-                        if (r >= 0 && r < rv) dst[r * H] = (uf >= p.dropout_p) ? keep_scale : 0.0f;
-                    }
-                }
-            }
-        }
-    };
-    if (!matrix) mask_fill(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ctl[0] != 0) return;
 
     if (wave == 0) {                               // do all members of this cluster share an XCD?
         unsigned spins = 0, v = 0u;
@@ -257,85 +272,129 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
         else __builtin_amdgcn_raw_buffer_store_b64(gran, hx_rsrc, off, 0, 16 /* sc1: write-through */);
     };
 
-    float c0 = 0.0f, c1[LM];
-#pragma unroll
-    for (int l = 0; l < LM; ++l) c1[l] = 0.0f;
+    float c0 = 0.0f;
     asm volatile("" :: "v"(bias0));
     const int P = T + L - 1;
     SM_STAMP(0);                                    // 0: prologue
 #pragma unroll 1
     for (int ph = 0; ph < P; ++ph) {
         const unsigned want = (seq << 12) | (unsigned)(ph + 1);
-        f32x4 acc[LM];
+        if (ph + 1 < T) stage_x(ph + 1);
+        if (ph + 2 < T) fetch_x(ph + 2);
+        // ---- layer 0, step ph: one row
+        if (ph < T) {
+            const float* hrd = h0buf + (ph & 1) * H;
+            f32x4 ax[QX], ah[QH];
+            span_load<QX, KB>(ax, xin + (ph & 1) * SX + 4 * g);
+            span_load<QH, KB>(ah, hrd + 4 * g);
+            f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            span_fma<QX, NW0>(part4, ax, w0, 0);
+            span_fma<QH, NW0>(part4, ah, w0, 4 * QX);
+            float v = (part4[0] + part4[1]) + (part4[2] + part4[3]);
+            v = sum_ror8(v);
+            v = sum_xor16(v);
+            v = sum_xor32(v);
+            const float av = gate_act(v + bias0, gate == 2);
+            const float iv = quad_bcast<0>(av), fv = quad_bcast<1>(av), gv = quad_bcast<2>(av), ov = quad_bcast<3>(av);
+            const float cn = fv * c0 + iv * gv;
+            c0 = cn;
+            const float h0 = ov * gate_act(cn, true);
+            store_granule(h0, want, (gate == 0 && g == 0) ? (unsigned)(ph & 1) * PAR_BYTES + (unsigned)unit0 * 8u : 0x80000000u);
+        }
+        SM_STAMP(1);                                // 1: x staging + layer 0
+        // ---- layers above, step ph - l
+        f32x4 acc16[LM];
 #pragma unroll
-        for (int l = 0; l < LM; ++l) acc[l] = bias1[l];
-        if (!matrix) {
-            if (ph + 1 < T) stage_x(ph + 1);
-            if (ph + 2 < T) fetch_x(ph + 2);
-            // ---- layer 0, step ph: one row
-            if (ph < T) {
-                const float* hrd = h0buf + (ph & 1) * H;
-                f32x4 ax[QX], ah[QH];
-                span_load<QX, KB>(ax, xin + (ph & 1) * SX + 4 * g);
-                span_load<QH, KB>(ah, hrd + 4 * g);
-                f32x4 part4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                span_fma<QX, NWR>(part4, ax, wr, 0);
-                span_fma<QH, NWR>(part4, ah, wr, 4 * QX);
-                float v = (part4[0] + part4[1]) + (part4[2] + part4[3]);
-                v = sum_ror8(v);
-                v = sum_xor16(v);
-                v = sum_xor32(v);
-                const float av = gate_act(v + bias0, gate == 2);
-                const float iv = quad_bcast<0>(av), fv = quad_bcast<1>(av), gv = quad_bcast<2>(av), ov = quad_bcast<3>(av);
-                const float cn = fv * c0 + iv * gv;
-                c0 = cn;
-                const float h0 = ov * gate_act(cn, true);
-                store_granule(h0, want, (gate == 0 && g == 0) ? (unsigned)(ph & 1) * PAR_BYTES + (unsigned)unit0 * 8u : 0x80000000u);
-            }
-            SM_STAMP(1);                            // 1 (row-0 waves): x staging + layer 0
-            // ---- the masks of the NEXT phase's values: data-independent, computed beside the matrix waves' spans
-            if (ph + 1 < P) mask_fill(ph + 1);
-            SM_STAMP(5);                            // 5 (row-0 waves): mask multipliers
-        } else {
-            // ---- layers above, step ph - l: this wave's K half of its column tile
+        for (int l = 0; l < LM; ++l) {
+            const int t = ph - 1 - l;
+            if constexpr (WIDE) {                   // this wave's K half of its column tile, 16 rows
+                acc16[l] = biasc[l];
+                if (t < 0 || t >= T || (kh16 == 1 && t == 0)) continue;    // uniform; h_{-1} = 0: no recurrent half at step 0
+                const float* src = a + (((ph & 1) * LM + l) * RC + nn16) * SA + kh16 * H + 4 * ug16;
 #pragma unroll
-            for (int l = 0; l < LM; ++l) {
-                const int t = ph - 1 - l;
-                if (t < 0 || t >= T || (kh == 1 && t == 0)) continue;      // uniform; h_{-1} = 0: no recurrent half at step 0
-                const float* src = a + (((ph & 1) * LM + l) * 16 + nn) * SA + kh * H + 4 * ug;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
+                for (int q = 0; q < H / 16; ++q) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(src + 16 * q);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[l * 4 * NQ + 4 * q + j], b[j], acc[l], 0, 0, 0);
+                        acc16[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[l][4 * q + j], b[j], acc16[l], 0, 0, 0);
                 }
-                if (kh == 1) *reinterpret_cast<f32x4*>(red + ((l * 2 + ct) * 64 + lane) * 4) = acc[l];
-            }
-            SM_STAMP(2);                            // 2 (matrix waves): MFMA spans
-        }
-        __syncthreads();                            // the recurrent halves' partial sums are in LDS
-        SM_STAMP(3);
-        if (matrix && kh == 0) {
+                if (kh16 == 1) *reinterpret_cast<f32x4*>(red + ((l * 2 + ct16) * 64 + lane) * 4) = acc16[l];
+            } else {                                // this wave's K quarter, every row group
+                if (t < 0 || t >= T || (wave >= 2 && t == 0)) continue;    // uniform; h_{-1} = 0: no recurrent half at step 0
+                const float* src = a + (((ph & 1) * LM + l) * RC + q4) * SA + wave * (H / 2) + 4 * ks;
+                f32x4 acc[NRG][2];
 #pragma unroll
-            for (int l = 0; l < LM; ++l) {
-                const int t = ph - 1 - l;
-                if (t < 0 || t >= T) continue;
-                f32x4 s = acc[l];
-                if (t > 0) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((l * 2 + ct) * 64 + lane) * 4);
-                    s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+                for (int r = 0; r < NRG; ++r) { acc[r][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[r][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+                for (int i4 = 0; i4 < NI4 / 4; ++i4) {
+                    f32x4 b[NRG];
+#pragma unroll
+                    for (int r = 0; r < NRG; ++r) b[r] = *reinterpret_cast<const f32x4*>(src + 4 * r * SA + 8 * i4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < NRG; ++r)      // (two accumulators per group: a chain of dependent 4x4x1 MFMAs needs wait states)
+                            acc[r][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[l][4 * i4 + j], b[r][j], acc[r][j & 1], 0, 0, 0);
                 }
-                const float iv = gate_act(s[0], false), fv = gate_act(s[1], false);
-                const float gv = gate_act(s[2], true), ov = gate_act(s[3], false);
-                const float cn = fv * c1[l] + iv * gv;
-                c1[l] = cn;
-                const float hv = ov * gate_act(cn, true);
-                store_granule(hv, want, (nn < rv) ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(PH + (l * RC + nn) * PH) * 16u + (unsigned)unit1 * 8u
-                                                  : 0x80000000u);
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) {
+                    f32x4 sv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sv[i] = sum_xor32(acc[r][0][i] + acc[r][1][i]);      // the two k slices of the wave
+                    if (lane < 32) *reinterpret_cast<f32x4*>(red + (((l * NRG + r) * 4 + wave) * 32 + lane) * 4) = sv;
+                }
+            }
+        }
+        SM_STAMP(2);                                // 2: MFMA spans
+        __syncthreads();                            // the partial sums are in LDS
+        SM_STAMP(3);
+        auto finish_cell = [&](f32x4 sv, int k, int t, int l, int row, int unit) {
+            const float iv = gate_act(sv[0], false), fv = gate_act(sv[1], false);
+            const float gv = gate_act(sv[2], true), ov = gate_act(sv[3], false);
+            const float cn = fv * cst[k] + iv * gv;
+            cst[k] = cn;
+            const float hv = ov * gate_act(cn, true);
+            store_granule(hv, want, (row < rv) ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(PH + (l * RC + row) * PH) * 16u + (unsigned)unit * 8u
+                                               : 0x80000000u);
+        };
+        if constexpr (WIDE) {
+            if (kh16 == 0) {
+#pragma unroll
+                for (int l = 0; l < LM; ++l) {
+                    const int t = ph - 1 - l;
+                    if (t < 0 || t >= T) continue;
+                    f32x4 sv = acc16[l];
+                    if (t > 0) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((l * 2 + ct16) * 64 + lane) * 4);
+                        sv[0] += o[0]; sv[1] += o[1]; sv[2] += o[2]; sv[3] += o[3];
+                    }
+                    finish_cell(sv, l, t, l, nn16, unit16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCS; ++k) {
+                const int cid = wave + 4 * k;
+                if (cid >= LM * NRG) continue;
+                const int l = cid / NRG, r = cid - l * NRG, t = ph - 1 - l;
+                if (t < 0 || t >= T) continue;
+                if (lane < 32) {
+                    f32x4 sv = biasc[k];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (w >= 2 && t == 0) continue;
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(red + (((l * NRG + r) * 4 + w) * 32 + lane) * 4);
+                        sv[0] += o[0]; sv[1] += o[1]; sv[2] += o[2]; sv[3] += o[3];
+                    }
+                    finish_cell(sv, k, t, l, 4 * r + q4, unit1);
+                }
             }
         }
         SM_STAMP(4);                                // 4: cell updates + publish
+        // ---- masks of later steps: data-independent, computed where this phase would otherwise wait for its peers
+        if constexpr (INJ) { if (ph + 1 < P) mask_fill(ph + 1); }
+        else { if (ph + pre_t < T) mask_bits(ph + pre_t); }
+        SM_STAMP(5);                                // 5: masks
         // ---- collect: every thread polls ITS pairs of granules until they carry this phase's tag, then puts the values where the
         //      next phase reads them: own-layer recurrent input as it is, the next layer's input under the rows' masks
         {
@@ -347,8 +406,23 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
             for (int i = 0; i < NI1; ++i) {
                 const int t = ph - it_l[i];
                 act[1 + i] = it_l[i] >= 1 && t >= 0 && t < T && it_r[i] < rv;
-                off[1 + i] = act[1 + i] ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(PH + tid + 512 * i) * 16u : 0x80000000u;
+                off[1 + i] = act[1 + i] ? (unsigned)(t & 1) * PAR_BYTES + (unsigned)(PH + tid + 256 * i) * 16u : 0x80000000u;
             }
+            // (the multipliers do not depend on the awaited values: fetched in front of the poll, not behind it)
+            float* const anext = a + ((ph + 1) & 1) * (LM * RC * SA);
+            auto mask2 = [&](int l, int r, int pr) -> f32x2 {      // layer l's output of step ph - l, row r, units 2 pr, 2 pr + 1
+                if constexpr (INJ) {
+                    return *reinterpret_cast<const f32x2*>(mv + (((ph & 1) * LM + l) * RC + r) * H + 2 * pr);
+                } else {
+                    const unsigned w2 = *reinterpret_cast<const unsigned*>(mbits + (ph - l) * (LM * H) + l * H + 2 * pr);
+                    return f32x2{((w2 >> r) & 1u) ? keep_scale : 0.0f, ((w2 >> (16 + r)) & 1u) ? keep_scale : 0.0f};
+                }
+            };
+            f32x2 m0[RG], m1[NI1];
+#pragma unroll
+            for (int k = 0; k < RG; ++k) m0[k] = act[0] ? mask2(0, (rg + NG * k) % RC, pr0) : f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < NI1; ++i) m1[i] = (L > 2 && act[1 + i] && it_l[i] < L - 1) ? mask2(it_l[i], it_r[i], it_pr[i]) : f32x2{0.0f, 0.0f};
             unsigned val0[NI], val1[NI];
             unsigned spins = 0;
             while (true) {
@@ -373,19 +447,14 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
                 if (spins > 64u) __builtin_amdgcn_s_sleep(1);
             }
             SM_STAMP(6);                            // 6: publish -> every awaited granule seen
-            float* const anext = a + ((ph + 1) & 1) * (LM * 16 * SA);
-            const float* const mcur = mv + (ph & 1) * (LM * RC * H);
             if (act[0]) {
                 const f32x2 hv = {__builtin_bit_cast(float, val0[0]), __builtin_bit_cast(float, val1[0])};
                 if (rg == 0) *reinterpret_cast<f32x2*>(h0buf + ((ph + 1) & 1) * H + 2 * pr0) = hv;
                 // layer 1's input rows of this thread's group: the one value under each row's mask
-                f32x2 m2[RG];
-#pragma unroll
-                for (int k = 0; k < RG; ++k) m2[k] = *reinterpret_cast<const f32x2*>(mcur + ((rg + NG * k) % RC) * H + 2 * pr0);
 #pragma unroll
                 for (int k = 0; k < RG; ++k) {
                     const int r = rg + NG * k;
-                    if (r < rv) *reinterpret_cast<f32x2*>(anext + r * SA + 2 * pr0) = f32x2{hv[0] * m2[k][0], hv[1] * m2[k][1]};
+                    if (r < rv) *reinterpret_cast<f32x2*>(anext + r * SA + 2 * pr0) = f32x2{hv[0] * m0[k][0], hv[1] * m0[k][1]};
                 }
             }
 #pragma unroll
@@ -393,11 +462,8 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
                 if (!act[1 + i]) continue;
                 const f32x2 hv = {__builtin_bit_cast(float, val0[1 + i]), __builtin_bit_cast(float, val1[1 + i])};
                 const int l = it_l[i], pr = it_pr[i], r = it_r[i];
-                *reinterpret_cast<f32x2*>(anext + ((l - 1) * 16 + r) * SA + H + 2 * pr) = hv;
-                if (l < L - 1) {
-                    const f32x2 m2 = *reinterpret_cast<const f32x2*>(mcur + (l * RC + r) * H + 2 * pr);
-                    *reinterpret_cast<f32x2*>(anext + (l * 16 + r) * SA + 2 * pr) = f32x2{hv[0] * m2[0], hv[1] * m2[1]};
-                }
+                *reinterpret_cast<f32x2*>(anext + ((l - 1) * RC + r) * SA + H + 2 * pr) = hv;
+                if (L > 2 && l < L - 1) *reinterpret_cast<f32x2*>(anext + (l * RC + r) * SA + 2 * pr) = f32x2{hv[0] * m1[i][0], hv[1] * m1[i][1]};
             }
         }
         SM_STAMP(7);                                // 7: values into LDS
@@ -407,11 +473,11 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
     }
 
     // ---- head: member m finishes row m of the cluster from the top layer's h(T-1) in its B tile; 16 lanes per target
-    if (member < rv && tid < 256) {
+    if (member < rv) {
         const int hw_o = tid >> 4, hw_part = tid & 15;
         float s_acc = 0.0f;
         if (hw_o < O) {
-            const float* hv = a + (((P & 1) * LM + (LM - 1)) * 16 + member) * SA + H + hw_part * (H / 16);
+            const float* hv = a + (((P & 1) * LM + (LM - 1)) * RC + member) * SA + H + hw_part * (H / 16);
             const float* wv = p.w_out + (size_t)hw_o * H + hw_part * (H / 16);
 #pragma unroll
             for (int i = 0; i < H / 64; ++i) {
@@ -429,12 +495,10 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
     }
     SM_STAMP(8);                                    // 8: head
 #ifdef APE_CLUSTER_STAMPS
-    // (wave 0 = a matrix wave, wave 4 = a row-0 wave: two stamp sets)
-    if (p.dbg_wg != nullptr && lane == 0 && (wave == 0 || wave == 4) && member == 0 && cluster == 0) {
-        unsigned long long* d = p.dbg_wg + (wave == 0 ? 0 : 16);
-        for (int k = 0; k < 10; ++k) d[k] = st_acc[k];
-        d[10] = __builtin_amdgcn_s_memtime() - st_begin;
-        d[11] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+    if (p.dbg_wg != nullptr && tid == 0 && member == 0 && cluster == 0) {
+        for (int k = 0; k < 10; ++k) p.dbg_wg[k] = st_acc[k];
+        p.dbg_wg[10] = __builtin_amdgcn_s_memtime() - st_begin;
+        p.dbg_wg[11] = __builtin_amdgcn_s_memrealtime() - st_rt0;
     }
 #endif
     }   // rv > 0
@@ -448,40 +512,48 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_mc_small(const McSmallParams 
         // the next launch's tags differ from every tag of this one; when the 20-bit launch number wraps, the granules go back to
         // zero (tag 0 is never awaited)
         if (seq == 0xFFFFFu)
-            for (size_t i = tid; i < (size_t)8 * p.gx_cluster_bytes / 4; i += 512)
+            for (size_t i = tid; i < (size_t)8 * p.gx_cluster_bytes / 4; i += 256)
                 __hip_atomic_store(reinterpret_cast<unsigned*>(p.gx) + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.seq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 256) __hip_atomic_store(p.xcc_slots + 192 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.xcc_slots + 192 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int H, int L, int KX, int RC>
+// LDS: B tiles, layer 0's state, x slab, partial sums, control words, then the mask table (Philox: bits for up to 64 steps; injected:
+// float multipliers of two phases)
+template <int H, int L, int KX, int RC, bool INJ>
 constexpr size_t mcs_smem() {
-    return ((size_t)2 * (L - 1) * 16 * (2 * H + 8) + (size_t)2 * (L - 1) * RC * H + 2 * H + 2 * (KX + 8) + (size_t)(L - 1) * 2 * 64 * 4 + 8) *
-           sizeof(float);
+    return ((size_t)2 * (L - 1) * RC * (2 * H + 8) + 2 * H + 2 * (KX + 8) + (size_t)(L - 1) * (RC / 4) * 4 * 32 * 4 + 8) * sizeof(float) +
+           (INJ ? (size_t)2 * (L - 1) * RC * H * sizeof(float) : (size_t)64 * (L - 1) * H * sizeof(unsigned short));
 }
 
-template <int H, int L, int KX, int RC>
+template <int H, int L, int KX, int RC, bool INJ>
 hipError_t launch_mcs(const McSmallParams& p, hipStream_t stream) {
-    constexpr size_t smem_bytes = mcs_smem<H, L, KX, RC>();
-    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC>), dim3(8 * (H / 8)), dim3(512), smem_bytes, stream, p);
+    constexpr size_t smem_bytes = mcs_smem<H, L, KX, RC, INJ>();
+    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC, INJ>), dim3(8 * (H / 8)), dim3(256), smem_bytes, stream, p);
     return hipGetLastError();
 }
 
-template <int H, int L, int KX>
+template <int H, int L, int KX, bool INJ>
 hipError_t launch_mcs_rc(const McSmallParams& p, hipStream_t stream) {
-    if (p.R <= 4) return launch_mcs<H, L, KX, 4>(p, stream);
-    if (p.R <= 8) return launch_mcs<H, L, KX, 8>(p, stream);
-    if (p.R <= 16) return launch_mcs<H, L, KX, 16>(p, stream);
+    if (p.R <= 4) return launch_mcs<H, L, KX, 4, INJ>(p, stream);
+    if (p.R <= 8) return launch_mcs<H, L, KX, 8, INJ>(p, stream);
+    if (p.R <= 16) return launch_mcs<H, L, KX, 16, INJ>(p, stream);
     return hipErrorInvalidValue;
 }
 
+template <int H, int L, int KX, int RC>
+hipError_t prepare_mcs_rc() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    return e;
+}
 template <int H, int L, int KX>
 hipError_t prepare_mcs() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    hipError_t e = prepare_mcs_rc<H, L, KX, 4>();
+    if (e == hipSuccess) e = prepare_mcs_rc<H, L, KX, 8>();
+    if (e == hipSuccess) e = prepare_mcs_rc<H, L, KX, 16>();
     return e;
 }
 
@@ -498,9 +570,11 @@ hipError_t ape_prepare_lstm_mc_small(int H, int L, int KX) {
     return hipErrorInvalidValue;
 }
 
-// p.R rows per cluster (<= 16), p.cps clusters per stream, p.n_streams * p.cps <= 8
+// p.R rows per cluster (<= 16), p.cps clusters per stream, p.n_streams * p.cps <= 8, p.T <= 64
 hipError_t ape_launch_lstm_mc_small(int H, int L, int KX, const McSmallParams& p, hipStream_t stream) {
-    if (H == 256 && L == 2 && KX == 32) return launch_mcs_rc<256, 2, 32>(p, stream);
-    if (H == 128 && L == 3 && KX == 64) return launch_mcs_rc<128, 3, 64>(p, stream);
+    const bool inj = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
+    if (p.T > 64) return hipErrorInvalidValue;
+    if (H == 256 && L == 2 && KX == 32) return inj ? launch_mcs_rc<256, 2, 32, true>(p, stream) : launch_mcs_rc<256, 2, 32, false>(p, stream);
+    if (H == 128 && L == 3 && KX == 64) return inj ? launch_mcs_rc<128, 3, 64, true>(p, stream) : launch_mcs_rc<128, 3, 64, false>(p, stream);
     return hipErrorInvalidValue;
 }

@@ -26,14 +26,14 @@ for it in range(60):
     buf = (C.c_ulonglong * (256 * 8))()
     assert lib.ape_debug_read_wg(m.handle, buf) == 0
     if it >= 20:
-        acc.append(np.array(buf[:32], dtype=np.float64))
+        acc.append(np.array(buf[:16], dtype=np.float64))
 vv = np.median(np.array(acc), axis=0)
 P = T + cfg["L"] - 1
 names = ["prologue: weights into registers, x_0, masks of phase 0, XCD rendezvous", "x staging + layer 0 (GEMV, gates, granule)",
          "MFMA spans of the layers above", "barrier between the spans and the cell updates", "cell updates + granule stores",
          "mask multipliers of the next phase", "publish -> every awaited granule seen", "values into LDS (masks applied)", "head",
          "end-of-phase barrier"]
-for role, v in (("matrix wave 0", vv[:16]), ("row-0 wave 4", vv[16:])):
+for role, v in (("wave 0", vv[:16]),):
     mhz = v[10] / v[11] * 100
     print(f"{name} n={n} T={T}: kernel (cluster 0, member 0, {role}) {v[10]:.0f} cycles = {v[11] / 100:.2f} us at {mhz:.0f} MHz; {P} phases")
     for k, nm in enumerate(names):
