@@ -103,8 +103,8 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 
 // APE_KERNEL_AUTO: how many whole waves of the batch-tile kernel to peel off the front of a batch.  Measured on a
 // whole MI355X (microseconds): a batch-tile wave sustains 125 TFLOP/s at H = 256 and 109 at H = 128 whatever T and
-// the dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (22 + 8.4 T for the 2-tile
-// dropout variant) however few of its rows are used.  Both rates scale with the CU count of the device.
+// the dropout mode (a partial wave costs a whole one); a cluster launch costs 25 + 13.7 T (12.5 + 8.3 T for the 2-tile
+// dropout variant with XCD-local clusters) however few of its rows are used.  Both rates scale with the CU count of the device.
 // `wide` (ImuPoseLSTM, 256-wide layer-0 input): a full batch-tile wave sustains 123 TFLOP/s, the two-tile cluster launch
 // (512 rows) costs 20 + 11 T -- 95 TFLOP/s when full, so whole waves go to the batch-tile kernel and the rest to the cluster.
 // which cluster kernel serves `rest` rows behind the batch-tile waves (the ONE rule lstm_forward_impl, the cost model and
@@ -127,11 +127,11 @@ static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bo
     if (rpl == 0) return (B + wave - 1) / wave;          // no cluster fits on this device
     const double rate = (wide ? 1.23e14 : dims->hidden_size == 256 ? 1.25e14 : 1.09e14) * n_cus / 256.0;
     const double t16 = (double)wave * ape_flops_per_window(dims, T) / rate * 1e6;
-    // first-generation launches: 25 + 13.7 T (22 + 8.4 T with dropout, 20 + 11 T wide); second-generation f32 kernel, eval mode:
+    // first-generation launches: 25 + 13.7 T (12.5 + 8.3 T with dropout, 20 + 11 T wide); second-generation f32 kernel, eval mode:
     // 16 + 12.4 T per launch of up to 32 x f16v2_capacity rows -- priced only where rest_kernel() really picks it
-    // (with XCD-local clusters the dropout form measures 12.5 + 8.3 T; the constant stays: it decides which kernel -- and with it which
-    //  Philox chunking -- a Monte-Carlo call gets, and tests/test_hip_round2.py pins the bank's routes against each other)
-    const double tcl1 = wide ? 20.0 + 11.0 * T : cdrop ? 22.0 + 8.4 * T : 25.0 + 13.7 * T;
+    // (round 4: the dropout form is priced at what it measures with XCD-local clusters, 12.5 + 8.3 T -- the Philox counters name global
+    //  rows in every kernel now, so the route a Monte-Carlo call takes no longer decides which samples it draws)
+    const double tcl1 = wide ? 20.0 + 11.0 * T : cdrop ? 12.5 + 8.3 * T : 25.0 + 13.7 * T;
     const int rpl2 = 32 * f16v2_capacity(n_cus);
     auto cost = [&](int w) {
         const int rest = B - wave * w;
@@ -970,7 +970,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             }
             if ((flags & APE_FLAG_DROPOUT_MASKS) && b0 + nb < B && cdrop)
                 return fail(APE_ERR_UNSUPPORTED, "lstm_forward: injected masks with B=%d exceed one cluster launch", B);
-            if (flags & APE_FLAG_DROPOUT_PHILOX) c.seed = seed + (unsigned long long)b0 * 0x9E3779B97F4A7C15ull;
+            c.row_base = b0;                          // Philox counters over the call's global rows, whatever the split
             int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // f32 first-generation kernel: whole groups of 8 clusters (if the device holds them) form XCD-local clusters and hand
             // their slices over inside that XCD's L2 (lstm_cluster.hip, APE_FLAG_XCD_CLASSES); the extra clusters own no rows

@@ -79,6 +79,8 @@ struct ClusterParams {
     float dropout_p;
     unsigned long long seed;
     float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
+    int row_base;                       // first-generation kernel, Philox dropout: global index of this launch's row 0 in the caller's batch
+                                        // (the counters name GLOBAL rows: the samples of a call do not depend on how it is split over launches)
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)
     unsigned* seq;                      // latency kernel: [1] launch number of this model (the upper bits of its granule tags)
     // latency kernel only: the post-filter in the same launch (ape_infer at B <= 4).  est row b = FK of y row b, de-normalised when

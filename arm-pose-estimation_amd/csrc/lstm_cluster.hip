@@ -547,7 +547,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                         } else {
                             // same counters as the batch-tile kernel (group of 4 rows, index row & 3): same masks
                             uint32_t rnd[4];
-                            philox4x32((uint32_t)(b & ~3), (uint32_t)t, (uint32_t)unit, (uint32_t)l, (uint32_t)p.seed,
+                            // (row_base: the launch's first row in the caller's batch -- a multiple of 16 -- so that a batch served by
+                            //  several launches, or partly by the batch-tile kernel, draws the masks of ONE call over its global rows)
+                            philox4x32((uint32_t)((p.row_base + b) & ~3), (uint32_t)t, (uint32_t)unit, (uint32_t)l, (uint32_t)p.seed,
                                        (uint32_t)(p.seed >> 32), rnd);
                             const float uf = (float)(rnd[b & 3] >> 8) * (1.0f / 16777216.0f);
                             m = (uf >= p.dropout_p) ? 1.0f / (1.0f - p.dropout_p) : 0.0f;

@@ -289,6 +289,9 @@ class Estimator:
                                             C.c_void_p(y.data_ptr()) if y is not None else None,
                                             C.c_void_p(est.data_ptr()),
                                             _hip.F64 if est_dtype == torch.float64 else _hip.F32, stream), "ape_infer")
+            model._pending.append((xd, y, est))      # journaled by the handle: alive until its next check / recover (nn_models._run)
+            if len(model._pending) > 64:
+                del model._pending[0]
         return (est, y) if return_targets else est
 
     # read-only views, same names as the reference's properties (estimator.py:188-218)

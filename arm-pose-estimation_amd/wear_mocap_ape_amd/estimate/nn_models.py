@@ -63,6 +63,7 @@ class DropoutLSTM:
         self._mc_calls = 0
         self._seed = 0x5EED
         self._state = None
+        self._pending = []
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self.device_index = int(device)
@@ -237,6 +238,12 @@ class DropoutLSTM:
                 _hip.check(_hip.lib().ape_lstm_forward(self._handle, C.c_void_p(xd.data_ptr()), B, T, flags, mptr,
                                                        float(dropout_p), int(seed), C.c_void_p(y.data_ptr()), stream),
                            "ape_lstm_forward")
+        # ape_model_recover re-issues every call the handle has journaled since its last check, from the raw device pointers it was
+        # given -- so the buffers of a journaled call must stay alive (and out of the caching allocator's hands) until then: the mirror
+        # holds references, at most the journal's 64 calls (beyond that the library refuses to replay anyway), dropped by check / recover
+        self._pending.append((xd, y, masks, hc if hs is not None else None))
+        if len(self._pending) > 64:
+            del self._pending[0]
         if on_host:
             # the one place where results reach the host, so the health of the launch is checked here: an aborted
             # weight-stationary launch leaves `y` unwritten, and ape_model_recover then runs the call again on the
@@ -291,13 +298,19 @@ class DropoutLSTM:
     def check(self):
         """blocking health check: raises if a cluster-kernel launch gave up waiting for a peer workgroup (the handle is
         reset; the outputs of the calls since the last check are invalid)"""
-        _hip.check(_hip.lib().ape_model_check(self._handle), "ape_model_check")
+        try:
+            _hip.check(_hip.lib().ape_model_check(self._handle), "ape_model_check")
+        finally:
+            self._pending.clear()            # the journal is empty behind a check, whatever it found
 
     def recover(self):
         """blocking health check that survives an abort (``ape_model_recover``): the calls made since the last check are
         issued again on the kernels that need no co-residency; raises only if that is impossible.  The device inputs of
         those calls must still be alive and unchanged."""
-        _hip.check(_hip.lib().ape_model_recover(self._handle), "ape_model_recover")
+        try:
+            _hip.check(_hip.lib().ape_model_recover(self._handle), "ape_model_recover")
+        finally:
+            self._pending.clear()
 
     def stats(self) -> dict:
         """{'aborted_checks', 'reissued_calls', 'lost_calls'} of this handle (``ape_model_stats``)"""
@@ -337,6 +350,7 @@ class DropoutFF(DropoutLSTM):
         self._mc_calls = 0
         self._seed = 0x5EED
         self._state = None
+        self._pending = []
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self.device_index = int(device)

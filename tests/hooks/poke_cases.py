@@ -353,3 +353,30 @@ def test_mc_latency_kernel_abort_recover_and_launch_number_wrap(norm_stats, gold
         runs.append(msgs)
     for f, (a, b) in enumerate(zip(*runs)):
         assert np.abs(a - b).max() < (5e-5 if f == 3 else 1e-30), f
+
+
+def test_recover_replays_only_into_memory_the_mirror_still_owns(norm_stats):
+    """the handle's journal keeps raw device pointers of every call since the last check; the Python mirror hides buffer
+    lifetimes, so a device-output call whose tensors were dropped could be replayed into memory the caching allocator had handed to
+    somebody else.  The mirror now holds references to the buffers of journaled calls until the next check / recover: tensors
+    allocated behind a dropped call do not alias them, and a recovery leaves them untouched."""
+    from wear_mocap_ape_amd import _hip
+    name = "pocket"
+    m, sd, cfg = make_model(name, 0, norm_stats[name])
+    poke = _poke(_hip.lib())
+    B, T = 300, cfg["T"]
+    x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 3))
+    good = m(x, last_step_only=True, normalize_input=True).numpy().copy()
+    xd = x.cuda()
+    yd = m(xd, last_step_only=True, normalize_input=True)              # device output: journaled, not checked
+    ptr_x, ptr_y = xd.data_ptr(), yd.data_ptr()
+    del xd, yd
+    # same sizes: without the mirror's references the caching allocator would hand out the very blocks the journal points at
+    others = [torch.full((B, T, cfg["I"]), 7.0, device="cuda") for _ in range(4)] + [torch.full((B, 1, cfg["O"]), 7.0, device="cuda") for _ in range(4)]
+    assert all(o.data_ptr() not in (ptr_x, ptr_y) for o in others)
+    assert poke(m.handle, 0, 1) == 0
+    out = m(x, last_step_only=True, normalize_input=True).numpy()       # host output: recover re-issues BOTH journaled calls
+    assert np.abs(out - good).max() < 1e-6
+    assert m.stats()["reissued_calls"] == 2
+    assert all(bool((o == 7.0).all()) for o in others)
+    assert m._pending == []

@@ -407,7 +407,7 @@ def test_error_behaviour():
     xx = torch.zeros((4, cfg["I"]), dtype=torch.float32, device="cuda")
     assert lib.ape_streams_push_features(h, C.c_void_p(xx.data_ptr()), None) == 0
     assert lib.ape_streams_push_rows(h, _hip.PARSE_WATCH_ONLY, C.c_void_p(xx.data_ptr()), None) != 0   # 20 features, model takes 22
-    assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), None, _hip.F64, None) != 0   # packed rows are f32
+    assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), None, 7, None) != 0          # unknown dtype selector
     assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), C.c_void_p(msg.data_ptr()), _hip.F32, None) != 0
     assert lib.ape_streams_step(h, _hip.FLAG_ALL_STEPS, C.c_void_p(msg.data_ptr()), None, _hip.F32, None) != 0     # not a step flag
     assert lib.ape_streams_step(h, _hip.FLAG_PACKED_MSG, C.c_void_p(msg.data_ptr()), None, _hip.F32, None) == 0
