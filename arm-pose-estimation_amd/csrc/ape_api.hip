@@ -1520,6 +1520,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
                 ExpandParams xq{};
                 xq.hseq = b->hfrag; xq.hseq_frag = 1; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
                 xq.layer = 0; xq.dropout_p = b->dropout_p; xq.seed = b->seed + b->mc_calls;
+                xq.masks = b->inj_masks; xq.masks_rows = total;
                 UpperParams u{};
                 u.xfrag = b->xfrag; u.xfrag_bytes = ape_upper32_xfrag_bytes(rows, b->T); u.ypart = b->ypart;
                 u.w = m->wcl32[1]; u.bias = m->bias[1]; u.w_out = m->w_out;
@@ -1534,12 +1535,14 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
 #endif
                 hipEvent_t ev_a, ev_z;
                 prof_pair(&ev_a, &ev_z);
+                m->last_kernel = "ape_lstm_upper32";
                 e = ape_launch_lstm_upper32(u, xq, m->b_out, b->y_new + (size_t)r0 * O, f16v2_capacity(m->n_cus), (hipStream_t)stream,
                                             ev_a, ev_z);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
             }
             ++b->mc_calls;
         } else {
+        if (b->inj_masks) return fail(APE_ERR_UNSUPPORTED, "streams_step: injected masks (test hook) on the batch-tile shared-layer-0 route");
         LstmParams q{};
         const int LU = m->dims.num_layers - 1;
         q.x = m->hseq_ws; q.y = b->y_new;
@@ -1551,6 +1554,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         hipEvent_t ev_a, ev_z;
         prof_pair(&ev_a, &ev_z);
         if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
+        m->last_kernel = "ape_lstm_tile16";
         e = ape_launch_lstm_tile16(H, LU, q, (hipStream_t)stream);
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
@@ -1564,8 +1568,8 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         prof_pair(&ev_a, &ev_z);
         if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
         if (int rc = mc_small_launch(m, b->xring, (size_t)b->n_mc * b->T * m->dims.input_size, b->S, b->n_mc, b->T,
-                                     flags | diag_wt | APE_FLAG_DROPOUT_PHILOX, nullptr, b->dropout_p, b->seed + b->mc_calls, b->y_new,
-                                     stream, x_ring))
+                                     flags | diag_wt | (b->inj_masks ? APE_FLAG_DROPOUT_MASKS : APE_FLAG_DROPOUT_PHILOX), b->inj_masks,
+                                     b->dropout_p, b->seed + b->mc_calls, b->y_new, stream, x_ring))
             return rc;
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         ++b->mc_calls;
@@ -1573,8 +1577,9 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         hipEvent_t ev_a, ev_z;
         prof_pair(&ev_a, &ev_z);
         if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
-        if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T, flags | diag_wt | (drop ? APE_FLAG_DROPOUT_PHILOX : 0u), nullptr,
-                                       drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring))
+        if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T,
+                                       flags | diag_wt | (!drop ? 0u : b->inj_masks ? APE_FLAG_DROPOUT_MASKS : APE_FLAG_DROPOUT_PHILOX),
+                                       drop ? b->inj_masks : nullptr, drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring))
             return rc;
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         ++b->mc_calls;

@@ -47,4 +47,21 @@ int ape_debug_set_chunk_rows(ape_streams_t* b, int rows) {
     return APE_OK;
 }
 
+// injected dropout multipliers for a Monte-Carlo bank, [L-1, S * n_mc, T, H] float32 on the device (NULL: back to the Philox draws): the
+// bank's routes against the oracle's masked loop under the SAME masks (the product library draws its masks itself)
+int ape_debug_set_bank_masks(ape_streams_t* b, const float* masks_dev) {
+    if (!b) return APE_ERR_INVALID_ARG;
+    b->inj_masks = masks_dev;
+    return APE_OK;
+}
+
+// the normalised NN targets of the bank's newest step, [S * n_mc, O] float32 -> host
+int ape_debug_bank_targets(ape_streams_t* b, float* out_host) {
+    if (!b || !out_host || !b->y_new) return APE_ERR_INVALID_ARG;
+    APE_DBG_TRY(hipSetDevice(b->model->dims.device));
+    APE_DBG_TRY(hipDeviceSynchronize());
+    APE_DBG_TRY(hipMemcpy(out_host, b->y_new, (size_t)b->S * b->n_mc * b->model->dims.output_size * sizeof(float), hipMemcpyDeviceToHost));
+    return APE_OK;
+}
+
 }  // extern "C"

@@ -138,6 +138,8 @@ struct ExpandParams {
     float dropout_p;
     unsigned long long seed;
     int hseq_frag;                      // 1: hseq is the layer-0 cluster kernel's [S / 32][T][k-block 32][stream 32][8] (fragment order)
+    const float* masks;                 // injected multipliers [L-1, masks_rows, T, H] instead of the Philox draws (test hooks only), or nullptr
+    long long masks_rows;               // sample rows of the whole bank (the masks' row stride)
 };
 
 // Kernel arguments of the Monte-Carlo latency kernel (lstm_mc_small.hip): n_streams windows x n_mc dropout samples, dealt over the

@@ -122,6 +122,7 @@ struct ape_streams {
     bool prof_on = false;        // ape_streams_profile: event pairs around the dominant kernel's launches
     int prof_n = 0;
     std::vector<hipEvent_t> prof_ev;
+    const float* inj_masks = nullptr;   // test hooks only (ape_debug_set_bank_masks): injected multipliers [L-1, S*n_mc, T, H] instead of Philox
     long long frames = 0;        // rows pushed since the last reset
     long long steps = 0;         // predictions made since the last reset
     // host frames (ape_streams_frame_host): pinned, device-visible staging the kernels read the raw rows from and write the

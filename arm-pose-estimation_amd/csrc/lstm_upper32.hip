@@ -573,14 +573,16 @@ __global__ __launch_bounds__(256) void ape_mc_expand_kernel(const ExpandParams q
     for (int g = 0; g < MR / 4; ++g) {
         const unsigned r4 = g0 + 4 * g;                           // global index of the row quad (a multiple of 4)
         uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (drop) philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)q.layer, (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rnd);
+        if (drop && q.masks == nullptr) philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)q.layer, (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rnd);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v = 0.0f;
             if (row0 + 4 * g + i < (unsigned)q.rows) {
                 v = q.hseq_frag ? q.hseq[((size_t)(stream >> 5) * q.T + t) * HL + (unit >> 3) * (MR * 8) + (stream & 31) * 8 + (unit & 7)]
                                 : q.hseq[((size_t)stream * q.T + t) * UH + unit];
-                if (drop) {
+                if (q.masks != nullptr) {          // the caller's multipliers (test hooks: the bank against the oracle under the same masks)
+                    v *= q.masks[(((size_t)q.layer * q.masks_rows + (r4 + i)) * q.T + t) * UH + unit];
+                } else if (drop) {
                     const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
                     v = (uf >= q.dropout_p) ? v * keep : 0.0f;
                 }

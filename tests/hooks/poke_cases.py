@@ -380,3 +380,49 @@ def test_recover_replays_only_into_memory_the_mirror_still_owns(norm_stats):
     assert m.stats()["reissued_calls"] == 2
     assert all(bool((o == 7.0).all()) for o in others)
     assert m._pending == []
+
+
+@pytest.mark.parametrize("name,S,n_mc,T,route", [("pocket", 330, 25, 6, "ape_lstm_upper32"), ("watch", 90, 25, 8, "ape_lstm_upper32"),
+                                                  ("pocket", 3, 25, 6, "ape_lstm_mc_small"), ("uarm", 1, 50, 6, "ape_lstm_mc_small"),
+                                                  ("pocket", 40, 7, 6, "ape_lstm_cluster")])
+def test_bank_routes_under_injected_masks_against_the_oracle(norm_stats, name, S, n_mc, T, route):
+    """the bank's weight-stationary Monte-Carlo route (layer 0 once per stream, `ape_mc_expand_kernel`,
+    `ape_lstm_upper32`) was pinned to the oracle only through the batch-tile route under the same Philox counters.  The test-hooks
+    library lets a bank take the caller's masks: every sample row of `ape_streams_step` against `orc.lstm_forward(..., masks=)`
+    (1e-6), for the weight-stationary route, the latency kernel and the first-generation kernel."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    lib = _hip.lib()
+    lib.ape_debug_set_bank_masks.restype, lib.ape_debug_set_bank_masks.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+    lib.ape_debug_bank_targets.restype, lib.ape_debug_bank_targets.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 5, st)
+    m.set_body(orc.DEFAULT_BODY)
+    assert T == cfg["T"]
+    I, O, H, L = cfg["I"], cfg["O"], cfg["H"], cfg["L"]
+    rows = S * n_mc
+    rng = np.random.default_rng(S * 1000 + n_mc)
+    feats = _synthetic_windows(st, S, T + 2, I, 8)
+    bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=3)
+    hist = [[] for _ in range(S)]
+    for f in range(T + 2):
+        masks = [(rng.random((rows, T, H)) >= 0.2).astype(np.float32) / np.float32(0.8) for _ in range(L - 1)]
+        md = torch.from_numpy(np.stack(masks)).cuda()
+        assert lib.ape_debug_set_bank_masks(bank._handle, C.c_void_p(md.data_ptr())) == 0
+        bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+        bank.step()
+        assert m.last_kernel() == route
+        y = np.empty((rows, O), dtype=np.float32)
+        assert lib.ape_debug_bank_targets(bank._handle, y.ctypes.data_as(C.c_void_p)) == 0
+        wins = []
+        for s in range(S):
+            hist[s].append(feats[s, f])
+            while len(hist[s]) < T:
+                hist[s].append(feats[s, f])
+            del hist[s][:len(hist[s]) - T]
+            xn = ((np.stack(hist[s]).astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+            wins.append(np.repeat(xn[None], n_mc, axis=0))
+        ref = orc.lstm_forward(sd, np.concatenate(wins), masks=masks)[:, -1, :]
+        assert np.abs(y - ref).max() < 1e-6, (f, float(np.abs(y - ref).max()))
+    assert lib.ape_debug_set_bank_masks(bank._handle, None) == 0
+    m.check()
