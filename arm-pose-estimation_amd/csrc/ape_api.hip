@@ -703,6 +703,13 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
     flags &= ~(uint32_t)APE_FLAG_XCD_CLASSES;            // (the launcher's own bit)
+#if !defined(APE_ABLATE) && !defined(APE_CLUSTER_STAMPS)
+    // the product library knows the documented flags and the three exchange-form selectors of include/ape_hip.h; the timing-only
+    // ablation bits (results are garbage) exist in the diagnostic builds alone
+    if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_ALL_STEPS | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX | APE_FLAG_BROADCAST_X |
+                            APE_FLAG_ANY_PLACEMENT | APE_FLAG_NO_XCD_CLASSES | APE_FLAG_ALT_FORM))
+        return fail(APE_ERR_INVALID_ARG, "lstm_forward: unknown flag bits 0x%x", flags);
+#endif
     if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
     if ((flags & APE_FLAG_NORMALIZE_INPUT) && !m->has_stats)
         return fail(APE_ERR_NOT_READY, "lstm_forward: NORMALIZE_INPUT without norm stats");

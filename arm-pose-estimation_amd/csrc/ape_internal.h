@@ -14,7 +14,7 @@
 #define APE_DIAG_NO_ACT      0x20000000u
 #define APE_DIAG_STAMP       0x10000000u
 #define APE_DIAG_NO_MFMA     0x04000000u   // diagnostic builds of the fp16 v2 kernel only: skip the matrix work
-#define APE_DIAG_NO_XSTAGE   0x02000000u   // ... skip the staging / fetch of the next step's inputs
+#define APE_DIAG_NO_XSTAGE   0x02000000u   // ... skip the staging / fetch of the next step's inputs (product: = APE_FLAG_NO_XCD_CLASSES, include/ape_hip.h)
                                              // (product dispatch: the same bit keeps a first-generation launch on any-placement clusters -- A/B runs
                                              //  and tests/test_hip_round3.py; same results either way)
 #define APE_DIAG_WRITE_THROUGH 0x08000000u   // small-batch kernel: use the any-placement (sc1) exchange even when the

@@ -371,54 +371,85 @@ def estimator_loop(sd, n_frames=1000):
     return out
 
 
-def stream_bank_numbers(model, stats):
+UARM = dict(I=38, H=128, L=3, O=12, layout=1)
+
+
+def _bank_model(cfg, stats_names):
+    """a model of one of the deployed shapes with seeded random weights and the deployed statistics (for the other estimators' banks)"""
+    from wear_mocap_ape_amd.estimate import nn_models
+    from wear_mocap_ape_amd.utility import data_stats
+    m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], device=torch.cuda.current_device())
+    m.load_state_dict(synthetic_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], seed=0))
+    st = data_stats.get_norm_stats(*stats_names)
+    m.set_norm_stats(st["xx_m"], st["xx_s"], st["yy_m"], st["yy_s"])
+    m.set_body(DEFAULT_BODY)
+    return m
+
+
+def stream_bank_numbers(model, stats, cases=None):
     """SURVEY 8 rows a1/a15/f1/f2/f4 at scale: S streams stepped together with all state on the device
-    (ape_streams_*): raw 55-float rows in, window rings, regressor, FK, smoothing, packed datagram rows out.  T=6 as
-    deployed; eval mode and the estimators' default Monte-Carlo mode (25 dropout samples per stream)."""
+    (ape_streams_*): raw 55- / 28-float rows in, window rings, regressor, FK, smoothing, packed datagram rows out.  The pocket model in
+    eval mode and in the estimators' default Monte-Carlo mode (25 dropout samples per stream, T = 6), and -- round 4 -- the other two
+    deployed estimators in THEIR default modes: WatchPhoneUarmNN (3 x 128, 50 samples, T = 6; watch_phone_uarm_nn.py:14-20) and
+    WatchOnlyNN (2 x 256, 25 samples, T = 8, smooth 10; watch_only.py:14-21)."""
     from wear_mocap_ape_amd import _hip
     from wear_mocap_ape_amd.streams import StreamBank
+    from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
     out = {}
+    if cases is None:
+        cases = [("S1024_mc1", "pocket", 1024, None, 1, 100), ("S1024_mc25", "pocket", 1024, 25, 1, 30), ("S8192_mc25", "pocket", 8192, 25, 1, 8),
+                 ("uarm_S1024_mc50_T6", "uarm", 1024, 50, 1, 12), ("watch_S1024_mc25_T8", "watch", 1024, 25, 10, 20)]
+    shapes = {"pocket": (POCKET, 6, _hip.PARSE_WATCH_PHONE_POCKET, None),
+              "uarm": (UARM, 6, _hip.PARSE_WATCH_PHONE_UARM, (NNS_INPUTS.WATCH_PHONE_CAL_ALL, NNS_TARGETS.ORI_CAL_LARM_UARM)),
+              "watch": (WATCH, 8, _hip.PARSE_WATCH_ONLY, (NNS_INPUTS.WATCH_ONLY_CAL, NNS_TARGETS.ORI_CAL_LARM_UARM))}
+    models = {"pocket": model}
     try:
         rng = np.random.default_rng(3)
-        for S, n_mc, frames in ((1024, None, 100), (1024, 25, 30), (8192, 25, 8)):
-            rows = [torch.from_numpy(rng.normal(size=(S, 55)).astype(np.float32)).cuda() for _ in range(4)]
-            bank = StreamBank(model, S, 6, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc,
-                              dropout=0.2)
-            for f in range(6):
-                bank.push_rows(rows[f % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+        for key, name, S, n_mc, smooth, frames in cases:
+            cfg, T, kind, stats_names = shapes[name]
+            if name not in models:
+                models[name] = _bank_model(cfg, stats_names)
+            mdl = models[name]
+            H, L, O, I = cfg["H"], cfg["L"], cfg["O"], cfg["I"]
+            width = _hip.PARSE_SHAPES[kind][0]
+            rows = [torch.from_numpy(rng.normal(size=(S, width)).astype(np.float32)).cuda() for _ in range(4)]
+            bank = StreamBank(mdl, S, T, smooth=smooth, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc, dropout=0.2)
+            for f in range(T + smooth):
+                bank.push_rows(rows[f % 4], kind)
                 bank.step_datagrams()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for f in range(frames):
-                bank.push_rows(rows[f % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+                bank.push_rows(rows[f % 4], kind)
                 bank.step_datagrams()
             b.record()
             b.synchronize()
-            model.check()
+            mdl.check()
             ms = a.elapsed_time(b) / frames
-            ent = {"ms_per_frame_of_all_streams": ms, "stream_frames_per_s": S / (ms * 1e-3),
+            ent = {"model": f"{name} ({I}, {H}, {L}, {O})", "T": T, "smooth": smooth,
+                   "ms_per_frame_of_all_streams": ms, "stream_frames_per_s": S / (ms * 1e-3),
                    "sample_windows_per_s": S * (n_mc or 1) / (ms * 1e-3)}
             # the frame's dominant kernel, bracketed by HIP events on the step's own stream in a SEPARATE pass of the same
             # frames (ape_streams_profile: two event records per launch, kept out of the pass timed above)
             bank.profile(True)
             for f in range(frames):
-                bank.push_rows(rows[f % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+                bank.push_rows(rows[f % 4], kind)
                 bank.step_datagrams()
             kms, launches = bank.profile_read()
             bank.profile(False)
-            model.check()
+            mdl.check()
             rows_total = S * (n_mc or 1)
+            kname = mdl.last_kernel()
             if n_mc:
-                # Monte-Carlo bank: layer 0 once per stream, then ONE layer over the S x n_mc sample rows -- algorithmic work of
-                # that launch = 2 * 4H * (H + H) FLOP per row and step + the head (the reference repeats the window n_mc
-                # times through BOTH layers, nn_models.py:191-207; the shared layer 0 is work the bank does not do)
-                flop = rows_total * (6 * 2.0 * 4 * POCKET["H"] * (POCKET["H"] + POCKET["H"]) + 2.0 * POCKET["O"] * POCKET["H"])
-                kname = "ape_lstm_upper32"
-                alg_bytes = S * 6 * POCKET["H"] * 4 + rows_total * POCKET["O"] * 4      # layer-0 sequence in, NN targets out
+                # Monte-Carlo bank: layer 0 once per stream, then the layers above over the S x n_mc sample rows -- algorithmic work of
+                # that launch = (L - 1) x 2 * 4H * (H + H) FLOP per row and step + the head (the reference repeats the window n_mc
+                # times through ALL layers, nn_models.py:191-207; the shared layer 0 is work the bank does not do)
+                flop = rows_total * (T * (L - 1) * 2.0 * 4 * H * (H + H) + 2.0 * O * H)
+                alg_bytes = S * T * H * 4 + rows_total * O * 4      # layer-0 sequence in, NN targets out
             else:
-                flop = model.flops_per_window(6) * rows_total
-                kname = model.kernel_name(rows_total, 6)
-                alg_bytes = rows_total * (6 * POCKET["I"] * 4 + POCKET["O"] * 4)
+                flop = mdl.flops_per_window(T) * rows_total
+                kname = mdl.kernel_name(rows_total, T)
+                alg_bytes = rows_total * (T * I * 4 + O * 4)
             k_ms = kms / frames                  # all launches of the kernel in one frame (8192 x 25: five chunks)
             tf = flop / (k_ms * 1e-3) / 1e12
             traffic, ttag, stale = load_traffic(kname, rows_total)
@@ -428,15 +459,106 @@ def stream_bank_numbers(model, stats):
                                "flop_per_frame": flop, "hbm_algorithmic_bytes_per_frame": alg_bytes,
                                "kernel_share_of_frame": k_ms / ms}
             if n_mc:
-                # stated plainly: h_{-1} = 0, so step 0's recurrent span is algorithmic work the kernel does not execute (like
-                # the batch-tile kernel before it): 11/12 of the FLOP above run on the matrix cores at T = 6
-                ex = rows_total * ((6 * 2 - 1) * 2.0 * 4 * POCKET["H"] * POCKET["H"] + 2.0 * POCKET["O"] * POCKET["H"])
+                # stated plainly: h_{-1} = 0, so step 0's recurrent span is algorithmic work the kernels do not execute:
+                # per layer above layer 0, (2 T - 1) / 2 T of the FLOP above run on the matrix cores
+                ex = rows_total * ((L - 1) * (T * 2 - 1) * 2.0 * 4 * H * H + 2.0 * O * H)
                 ent["roofline"]["flop_executed_per_frame"] = ex
                 ent["roofline"]["frac_executed"] = ex / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
-            out[f"S{S}_mc{n_mc or 1}"] = ent
+            out[key] = ent
             del bank
     except Exception as exc:                # reported, never fatal for the headline line
         out["error"] = str(exc)[:200]
+    return out
+
+
+def dispatch_boundaries(n_iter=30):
+    """APE_KERNEL_AUTO at its dispatch boundaries, on THIS box: at each threshold of the plan (csrc/ape_api.hip: 512 / 513 eval rows for
+    the second-generation kernels, windows of 11 / 12 steps for the 3 x 128 model, 4 / 5 rows and 128 / 129 samples for the latency
+    kernels, 2047 / 2048 sample rows for the bank's weight-stationary route, 3 / 4 clusters for the first generation's XCD classes)
+    AUTO and every kernel the public switch can force are timed on the same inputs (HIP events, median of n_iter launches after a
+    warm-up); `auto_over_best` = AUTO's time over the fastest candidate's -- 1.00 means AUTO picked the fastest there."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
+    lib = _hip.lib()
+    out = {}
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        us = []
+        for _ in range(n_iter):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); b.synchronize()
+            us.append(a.elapsed_time(b) * 1e3)
+        return float(np.median(us))
+
+    try:
+        models = {"pocket": _bank_model(POCKET, (NNS_INPUTS.WATCH_PHONE_CAL_HIP, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)),
+                  "uarm": _bank_model(UARM, (NNS_INPUTS.WATCH_PHONE_CAL_ALL, NNS_TARGETS.ORI_CAL_LARM_UARM))}
+        rng = np.random.default_rng(11)
+
+        def forward_case(key, name, B, T, drop, bcast, kernels, extra=0):
+            m = models[name]
+            cfg = POCKET if name == "pocket" else UARM
+            x = torch.from_numpy(rng.normal(size=(1 if bcast else B, T, cfg["I"])).astype(np.float32)).cuda()
+            y = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+            flags = (_hip.FLAG_DROPOUT_PHILOX if drop else 0) | (_hip.FLAG_BROADCAST_X if bcast else 0)
+            ent = {"candidates_us": {}, "kernels": {}}
+            for k in kernels:
+                kk, fl = (k, flags) if isinstance(k, str) else (k[0], flags | k[1])
+                m.set_kernel(kk)
+                call = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, fl, None, 0.2 if drop else 0.0, 7,
+                                                               C.c_void_p(y.data_ptr()), None), "fwd")
+                tag = kk if isinstance(k, str) else f"{kk}+0x{k[1]:x}"
+                ent["candidates_us"][tag] = timed(call)
+                ent["kernels"][tag] = m.last_kernel()
+            m.set_kernel("auto")
+            m.check()
+            ent["auto_over_best"] = ent["candidates_us"]["auto"] / min(ent["candidates_us"].values())
+            out[key] = ent
+
+        # eval rows 512 | 513: first generation | ape_lstm_cluster32
+        for B in (512, 513):
+            for T in (6, 64):
+                forward_case(f"pocket_eval_B{B}_T{T}", "pocket", B, T, False, False, ("auto", "cluster_gen1", "tile16"))
+        # 3 x 128, 1024 rows, windows of 11 | 12 steps: first generation | ape_lstm_cluster16
+        for T in (11, 12):
+            forward_case(f"uarm_eval_B1024_T{T}", "uarm", 1024, T, False, False, ("auto", "cluster_gen1", "tile16"))
+        # eval rows 4 | 5: latency kernel | first generation
+        for B in (4, 5):
+            forward_case(f"pocket_eval_B{B}_T6", "pocket", B, 6, False, False, ("auto", "cluster_gen1", "tile16"))
+        # one window x 128 | 129 samples: Monte-Carlo latency kernel | first generation
+        for B in (128, 129):
+            forward_case(f"pocket_mc_one_window_n{B}_T6", "pocket", B, 6, True, True, ("auto", "auto_gen1", "tile16"))
+        # first generation, dropout rows in 3 | 4 clusters of 32: any-placement | XCD classes (the selector bit forces the former)
+        for B in (96, 128):
+            forward_case(f"pocket_dropout_B{B}_T6_clusters{B // 32}", "pocket", B, 6, True, False,
+                         ("auto", ("auto", _hip.FLAG_NO_XCD_CLASSES), "tile16"))
+        # Monte-Carlo bank, 2047 | 2048 sample rows: fused first-generation launches | layer 0 shared + ape_lstm_upper32
+        for S, n_mc in ((89, 23), (128, 16)):
+            ent = {"candidates_us": {}, "kernels": {}}
+            m = models["pocket"]
+            rows = [torch.from_numpy(rng.normal(size=(S, 55)).astype(np.float32)).cuda() for _ in range(4)]
+            for k in ("auto", "auto_gen1"):
+                m.set_kernel(k)
+                bank = StreamBank(m, S, 6, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc, dropout=0.2)
+                st = {"i": 0}
+
+                def frame():
+                    bank.push_rows(rows[st["i"] % 4], _hip.PARSE_WATCH_PHONE_POCKET)
+                    bank.step_datagrams()
+                    st["i"] += 1
+                ent["candidates_us"][k] = timed(frame)
+                ent["kernels"][k] = m.last_kernel()
+                m.check()
+                del bank
+            m.set_kernel("auto")
+            ent["auto_over_best"] = ent["candidates_us"]["auto"] / min(ent["candidates_us"].values())
+            out[f"pocket_mc_bank_{S * n_mc}_sample_rows_T6"] = ent
+        out["worst_auto_over_best"] = max(v["auto_over_best"] for v in out.values() if isinstance(v, dict))
+    except Exception as exc:                # reported, never fatal for the headline line
+        out["error"] = str(exc)[:300]
     return out
 
 
@@ -820,13 +942,20 @@ def main():
     model.check()           # blocking health check of the cluster kernel (bounded spins never expired)
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_k]))
+    # BASELINE configs[3] literally: 8192 independent streams, one shard of 1024 per GPU, in the estimators' default Monte-Carlo mode --
+    # in an N-rank run every rank also steps ITS 1024-stream x 25-sample bank (device-side frame: rows in, datagram rows out) and
+    # reports the frame time, so that the per-node load of configs[3] is in the line rank by rank
+    bank_ms = float("nan")
+    if use_dist:
+        bk = stream_bank_numbers(model, stats, cases=[("S1024_mc25", "pocket", 1024, 25, 1, 20)])
+        bank_ms = float(bk.get("S1024_mc25", {}).get("ms_per_frame_of_all_streams", float("nan")))
     # every rank's own numbers travel to rank 0 (a straggler GPU must be visible in the one line the driver gets)
-    mine_t = torch.tensor([rank, kernel_ms, own_elapsed / args.steps * 1e3], dtype=torch.float64, device=comm_dev)
+    mine_t = torch.tensor([rank, kernel_ms, own_elapsed / args.steps * 1e3, bank_ms], dtype=torch.float64, device=comm_dev)
     rank_times = [mine_t]
     if use_dist:
         rank_times = [torch.empty_like(mine_t) for _ in range(world)]
         dist.all_gather(rank_times, mine_t)
-    rank_times = {int(t_[0].item()): (float(t_[1].item()), float(t_[2].item())) for t_ in rank_times}
+    rank_times = {int(t_[0].item()): (float(t_[1].item()), float(t_[2].item()), float(t_[3].item())) for t_ in rank_times}
     flop_per_launch = model.flops_per_window(T_FRAMES) * B
     achieved_tf = flop_per_launch / (kernel_ms * 1e-3) / 1e12
 
@@ -847,7 +976,11 @@ def main():
                                     "collectives": "one broadcast of the weight blob + stats at start-up; none per step",
                                     "per_rank": [{"rank": int(s_[0]), "streams": [int(s_[1]), int(s_[2])], "device": int(s_[3]),
                                                   "weight_blob_sum": s_[4], "kernel_ms": rank_times[int(s_[0])][0],
-                                                  "ms_per_step": rank_times[int(s_[0])][1]} for s_ in shards]},
+                                                  "ms_per_step": rank_times[int(s_[0])][1],
+                                                  "bank_S1024_mc25_T6_ms_per_frame": (None if rank_times[int(s_[0])][2] != rank_times[int(s_[0])][2]
+                                                                                      else rank_times[int(s_[0])][2])} for s_ in shards],
+                                    "bank_note": "per rank: one frame of its 1024-stream x 25-sample Monte-Carlo bank (configs[3]'s shard in the "
+                                                 "estimators' default mode); null in a 1-rank run, where stream_bank_T6 carries it"},
                        "preroll_steps": PREROLL},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag,
@@ -869,6 +1002,7 @@ def main():
             out["batch1"]["estimator_loop"] = estimator_loop(sd)
             out["stream_bank_T6"] = stream_bank_numbers(model, stats)
             out["other_paths"] = other_paths()
+            out["dispatch_boundaries"] = dispatch_boundaries()
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
                                                                          NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:

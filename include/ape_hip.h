@@ -101,6 +101,16 @@ enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1, APE_PRECISION_F16_GEN1 = 2 
 #define APE_FLAG_BROADCAST_X     0x10u /* x_dev is ONE window [1,T,I] shared by all B rows: the x.repeat((n,1,1)) of
                                          monte_carlo_predictions (nn_models.py:206) without materialising it    */
 
+/* Exchange-form selectors of the weight-stationary kernels, for A/B runs and tests (ape_lstm_forward, ape_streams_step).  They change
+ * HOW the workgroups of a cluster hand their slices over, never the arithmetic: results are bit-equal (ALT_FORM: equal up to float32
+ * summation order).  Every other undeclared bit is refused. */
+#define APE_FLAG_ANY_PLACEMENT   0x08000000u /* hand-over by write-through stores: the form that is valid wherever the workgroups of a
+                                               cluster run (what a cluster takes by itself when its members do not share an XCD) */
+#define APE_FLAG_NO_XCD_CLASSES  0x02000000u /* first-generation cluster kernel: clusters by global arrival ticket instead of within
+                                               block-index classes (one XCD each) */
+#define APE_FLAG_ALT_FORM        0x01000000u /* the alternative decomposition where a kernel has two: the latency kernel's H/16-member form,
+                                               lstm_cluster16's one-workgroup-per-CU form */
+
 typedef struct ape_model ape_model_t;
 
 /* DropoutLSTM(input_size, hidden_layer_size, hidden_layer_count, output_size) -- nn_models.py:160-178,

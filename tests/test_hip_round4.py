@@ -302,3 +302,36 @@ def test_philox_samples_do_not_depend_on_the_split(norm_stats, name, B, T):
     # the dropout is really on
     m2, _, _ = make_model(name, 6, norm_stats[name])
     assert np.abs(outs["tile16"][0] - m2(x, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]).max() > 1e-3
+
+
+# ---------------- AUTO's dispatch thresholds on the box that runs the tests ----------------------------------------------------------
+def test_auto_dispatch_is_near_the_fastest_candidate_at_every_boundary():
+    """bench.py's `dispatch_boundaries` leg (AUTO and every forceable kernel timed on the same inputs at each threshold of the plan):
+    AUTO's choice must never be grossly wrong on this box.  The bench line reports the ratios themselves (1.00 = AUTO picked the
+    fastest); the assertion here is 1.15 -- box-to-box spread on this pool is +-3 %, a test that fails on 5 % would flake -- and the
+    kernels the plan names at either side of each boundary."""
+    import bench
+    d = bench.dispatch_boundaries(n_iter=20)
+    assert "error" not in d, d
+    k = {key: v["kernels"]["auto"] for key, v in d.items() if isinstance(v, dict)}
+    assert k["pocket_eval_B512_T64"] == "ape_lstm_cluster" and k["pocket_eval_B513_T64"] == "ape_lstm_cluster32"
+    assert k["uarm_eval_B1024_T11"] == "ape_lstm_cluster" and k["uarm_eval_B1024_T12"] == "ape_lstm_cluster16"
+    assert k["pocket_eval_B4_T6"] == "ape_lstm_cluster_small" and k["pocket_eval_B5_T6"] == "ape_lstm_cluster"
+    assert k["pocket_mc_one_window_n128_T6"] == "ape_lstm_mc_small" and k["pocket_mc_one_window_n129_T6"] == "ape_lstm_cluster"
+    assert k["pocket_mc_bank_2047_sample_rows_T6"] == "ape_lstm_cluster" and k["pocket_mc_bank_2048_sample_rows_T6"] == "ape_lstm_upper32"
+    slow = {key: round(v["auto_over_best"], 3) for key, v in d.items() if isinstance(v, dict) and v["auto_over_best"] > 1.15}
+    assert not slow, (slow, d)
+
+
+def test_undeclared_flag_bits_are_refused(norm_stats):
+    from tests.test_hip_parity import make_model
+    from wear_mocap_ape_amd import _hip
+    m, sd, cfg = make_model("pocket", 1, norm_stats["pocket"])
+    x = torch.zeros((8, 6, cfg["I"]), device="cuda")
+    y = torch.zeros((8, cfg["O"]), device="cuda")
+    lib = _hip.lib()
+    for bit in (0x40000000, 0x20000000, 0x10000000, 0x04000000, 0x100):
+        assert lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), 8, 6, bit, None, 0.0, 0, C.c_void_p(y.data_ptr()), None) != 0, hex(bit)
+    for bit in (_hip.FLAG_ANY_PLACEMENT, _hip.FLAG_NO_XCD_CLASSES, _hip.FLAG_ALT_FORM):
+        assert lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), 8, 6, bit, None, 0.0, 0, C.c_void_p(y.data_ptr()), None) == 0, hex(bit)
+    m.check()
