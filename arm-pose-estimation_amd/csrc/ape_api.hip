@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -353,7 +354,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
             for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wmc[l], (size_t)8 * H * H * sizeof(float));
             for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wmc16[l], (size_t)8 * H * H * sizeof(float));
             m->gxm_cluster_bytes = ape_mc_small_cluster_bytes(H, L);
-            if (e == hipSuccess) e = plan((void**)&m->gxm, 256 + 8 * m->gxm_cluster_bytes);
+            if (e == hipSuccess) e = plan((void**)&m->gxm, 256 + 8 * m->gxm_cluster_bytes + 8 * 64 * 8);      // + the feature granules of 8 streams
             if (e == hipSuccess) e = ape_prepare_lstm_mc_small(H, L, m->KX);
             m->mcs_ok = true;
         }
@@ -670,8 +671,24 @@ static bool mc_small_fits(const ape_model* m, int n_streams, int n_mc) {
     const int cps = 8 / n_streams;
     return (n_mc + cps - 1) / cps <= 16;
 }
+// what a host frame adds to the regressor's launch: the raw rows of the frame (feature builder workgroups)
+struct McFrameParts {
+    const float* raw_rows = nullptr;
+    int raw_width = 0, raw_kind = 0, raw_big_endian = 0, cold = 0;
+    float* ring_out = nullptr;
+    size_t ring_stream_stride = 0, ring_rep_stride = 0;
+    int ring_rep = 0;
+};
+// can the feature builder's workgroups become resident beside the clusters?  A cluster member takes a CU's worth of LDS only in the
+// 16-row form; with 8-row clusters two workgroups share a CU, and the 3 x 128 model leaves half the CUs free anyway
+static bool mc_small_builder_fits(const ape_model* m, int n_streams, int n_mc, int T) {
+    const int cps = 8 / n_streams;
+    // (8-row clusters: 39 KB of B tiles and sums + 0.5 KB of mask bits per step + 10.5 KB static per member -- two workgroups per CU up to T = 32)
+    return m->dims.hidden_size == 128 || ((n_mc + cps - 1) / cps <= 8 && T <= 32);
+}
 static int mc_small_launch(ape_model_t* m, const float* x, size_t x_stream_stride, int n_streams, int n_mc, int T, uint32_t flags,
-                           const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream, int x_ring) {
+                           const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream, int x_ring,
+                           const McFrameParts* fr = nullptr) {
     McSmallParams q{};
     const int L = m->dims.num_layers, I = m->dims.input_size, O = m->dims.output_size;
     q.x = x; q.x_stream_stride = x_stream_stride; q.y = y_dev;
@@ -690,6 +707,12 @@ static int mc_small_launch(ape_model_t* m, const float* x, size_t x_stream_strid
     q.flags = flags & (APE_FLAG_NORMALIZE_INPUT | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX | APE_DIAG_WRITE_THROUGH);
     q.dropout_p = (flags & APE_FLAG_DROPOUT_PHILOX) ? dropout_p : 0.0f; q.seed = seed;
     q.dbg_wg = m->dbg_wg;
+    q.xg = m->gxm + 256 + 8 * m->gxm_cluster_bytes;
+    if (fr) {
+        q.raw_rows = fr->raw_rows; q.raw_width = fr->raw_width; q.raw_kind = fr->raw_kind; q.raw_big_endian = fr->raw_big_endian;
+        q.cold = fr->cold; q.ring_out = fr->ring_out; q.ring_stream_stride = fr->ring_stream_stride; q.ring_rep_stride = fr->ring_rep_stride;
+        q.ring_rep = fr->ring_rep;
+    }
     m->last_kernel = "ape_lstm_mc_small";
     hipError_t e = ape_launch_lstm_mc_small(m->dims.hidden_size, L, m->KX, q, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "Monte-Carlo latency kernel launch failed: %s", hipGetErrorString(e));
@@ -1151,7 +1174,7 @@ static int check_and_reset(ape_model_t* m) {
         HIP_TRY(hipMemset(m->xflags, 0, m->xflag_bytes + 16));
         HIP_TRY(hipMemset(m->xcc_slots, 0, APE_XCC_WORDS * sizeof(unsigned)));
         HIP_TRY(hipMemset(m->hxs, 0, 256 + m->hxs_bytes));     // the aborted launch's granules carry tags the next launch would await
-        if (m->gxm) HIP_TRY(hipMemset(m->gxm, 0, 256 + 8 * m->gxm_cluster_bytes));
+        if (m->gxm) HIP_TRY(hipMemset(m->gxm, 0, 256 + 8 * m->gxm_cluster_bytes + 8 * 64 * 8));
         HIP_TRY(hipDeviceSynchronize());
         return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
                     "since the last successful check are invalid; the model is usable again", st,
@@ -1379,6 +1402,7 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->h_rows) (void)hipHostFree(b->h_rows);
     if (b->h_out) (void)hipHostFree(b->h_out);
     if (b->h_status) (void)hipHostFree(b->h_status);
+    if (b->h_done) (void)hipHostFree(b->h_done);
     for (auto ev : b->prof_ev) if (ev) (void)hipEventDestroy(ev);
     if (ape_model* m = b->model) {      // pending steps of this bank can no longer be re-issued
         int k = 0;
@@ -1439,16 +1463,24 @@ int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* strea
     return APE_OK;
 }
 
+struct McFrameParts;
 static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream,
-                             unsigned* status_out);
+                             unsigned* status_out, const McFrameParts* fuse = nullptr);
 
 int ape_streams_step(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream) {
     return streams_step_impl(b, flags, msg_dev, tail_dev, out_dtype, stream, nullptr);
 }
 
 // status_out (host frames): pinned word that receives the model's sticky status word behind the step's kernels
+// a few streams in Monte-Carlo mode (one estimator's frame: S = 1) step on the Monte-Carlo latency kernel
+static bool bank_on_mc_small(const ape_streams* b) {
+    const ape_model* m = b->model;
+    return !b->shared_l0 && b->mc && b->dropout_p > 0.0f && m->dims.num_layers > 1 && b->S <= 8 && m->cluster_ok && b->T <= 64 &&
+           mc_small_fits(m, b->S, b->n_mc);
+}
+
 static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream,
-                             unsigned* status_out) {
+                             unsigned* status_out, const McFrameParts* fuse) {
     if (!b || !msg_dev) return fail(APE_ERR_INVALID_ARG, "streams_step: NULL argument");
     if (!b->xring || !b->yring || !b->y_new)
         return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
@@ -1478,6 +1510,21 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         if (!b->prof_on || b->prof_n >= (int)b->prof_ev.size() / 2) return;
         *a = b->prof_ev[2 * b->prof_n]; *z = b->prof_ev[2 * b->prof_n + 1];
         b->prof_n += 1;
+    };
+    auto post_params = [&]() {
+        StreamPostParams q{};
+        q.y_new = b->y_new; q.yring = b->yring; q.msg = msg_dev; q.tail = tail_dev;
+        q.yy_m = norm ? m->stats + 2 * m->dims.input_size : nullptr;      // one switch (estimator.py:103-109)
+        q.yy_s = norm ? m->stats + 2 * m->dims.input_size + m->dims.output_size : nullptr;
+        memcpy(q.body, m->body, sizeof(q.body));
+        q.S = b->S; q.O = m->dims.output_size; q.W = layout_est_width(m->dims.target_layout); q.layout = m->dims.target_layout;
+        q.smooth = b->smooth; q.n_mc = b->n_mc;
+        q.pos = (int)(b->steps % b->smooth);
+        q.cold = b->steps == 0 ? 1 : 0;
+        q.msg_dtype = out_dtype; q.packed = packed ? 1 : 0;
+        if (status_out != nullptr && m->cluster_ok) { q.status_in = m->xflags + m->xflag_bytes / sizeof(unsigned); q.status_out = status_out; }
+        if (status_out != nullptr && b->h_done != nullptr) { q.done_out = b->h_done; q.done_val = b->h_done_val; }
+        return q;
     };
     if (b->shared_l0) {
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
@@ -1567,16 +1614,19 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer launch failed: %s", hipGetErrorString(e));
         ++b->mc_calls;
         }
-    } else if (drop && b->S <= 8 && m->cluster_ok && b->T <= 64 && mc_small_fits(m, b->S, b->n_mc)) {
+    } else if (bank_on_mc_small(b)) {
         // a few streams in Monte-Carlo mode (one estimator's frame: S = 1): the latency kernel reads the first copy of every
-        // stream's window and deals the sample rows over the XCDs
+        // stream's window and deals the sample rows over the XCDs; from ape_streams_frame_host the feature builder rides in the same
+        // launch as extra workgroups (`fuse`: the row has NOT been pushed by a launch of its own)
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
+        McFrameParts fr{};
+        if (fuse) fr = *fuse;
         hipEvent_t ev_a, ev_z;
         prof_pair(&ev_a, &ev_z);
         if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
         if (int rc = mc_small_launch(m, b->xring, (size_t)b->n_mc * b->T * m->dims.input_size, b->S, b->n_mc, b->T,
                                      flags | diag_wt | (b->inj_masks ? APE_FLAG_DROPOUT_MASKS : APE_FLAG_DROPOUT_PHILOX), b->inj_masks,
-                                     b->dropout_p, b->seed + b->mc_calls, b->y_new, stream, x_ring))
+                                     b->dropout_p, b->seed + b->mc_calls, b->y_new, stream, x_ring, &fr))
             return rc;
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         ++b->mc_calls;
@@ -1591,17 +1641,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         ++b->mc_calls;
     }
-    StreamPostParams q{};
-    q.y_new = b->y_new; q.yring = b->yring; q.msg = msg_dev; q.tail = tail_dev;
-    q.yy_m = norm ? m->stats + 2 * m->dims.input_size : nullptr;      // one switch (estimator.py:103-109)
-    q.yy_s = norm ? m->stats + 2 * m->dims.input_size + m->dims.output_size : nullptr;
-    memcpy(q.body, m->body, sizeof(q.body));
-    q.S = b->S; q.O = m->dims.output_size; q.W = layout_est_width(m->dims.target_layout); q.layout = m->dims.target_layout;
-    q.smooth = b->smooth; q.n_mc = b->n_mc;
-    q.pos = (int)(b->steps % b->smooth);
-    q.cold = b->steps == 0 ? 1 : 0;
-    q.msg_dtype = out_dtype; q.packed = packed ? 1 : 0;
-    if (status_out != nullptr && m->cluster_ok) { q.status_in = m->xflags + m->xflag_bytes / sizeof(unsigned); q.status_out = status_out; }
+    StreamPostParams q = post_params();
     hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
     ++b->steps;
@@ -1639,14 +1679,55 @@ int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_hos
         HIP_TRY(hipHostMalloc((void**)&b->h_status, 64, hipHostMallocDefault));
         *b->h_status = 0u;
     }
+    // up to 64 streams: a word per stream that the post kernel's workgroup writes behind its outputs -- the host takes the frame when
+    // all are there instead of waiting for the stream's completion signal to travel (a larger bank waits for the stream)
+    if (!b->h_done && b->S <= 64) {
+        HIP_TRY(hipHostMalloc((void**)&b->h_done, 64 * sizeof(unsigned), hipHostMallocDefault));
+        memset(b->h_done, 0, 64 * sizeof(unsigned));
+    }
+    b->h_done_val += 1;
+    if (b->h_done_val == 0) b->h_done_val = 1;
     memcpy(b->h_rows, rows_host, rows_bytes);
-    *b->h_status = 0u;
-    if (int rc = ape_streams_push_rows(b, kind, b->h_rows, stream)) return rc;
-    if (int rc = streams_step_impl(b, flags | APE_FLAG_PACKED_MSG, b->h_out, nullptr, out_dtype, stream, b->h_status)) return rc;
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (*b->h_status != 0u) {
+    // (a sentinel, not zero: in the single-launch frame an aborted launch never reaches the tail that writes the word)
+    *b->h_status = m->cluster_ok ? 0xFFFFFFFFu : 0u;       // (no cooperative kernel on this model: nothing writes the word, nothing can abort)
+    // where the bank steps on the Monte-Carlo latency kernel its extra workgroups build the rows' features (two launches per frame);
+    // else the feature builder's own launch in front of the step
+    const bool one_launch = bank_on_mc_small(b) && mc_small_builder_fits(m, b->S, b->n_mc, b->T) && I == m->dims.input_size && b->xring != nullptr;
+    float* slot_out; int slot_rep; size_t slot_rep_stride;
+    next_slot(b, (size_t)I, &slot_out, &slot_rep, &slot_rep_stride);
+    if (one_launch) {
+        McFrameParts fr{};
+        fr.raw_rows = b->h_rows; fr.raw_width = width; fr.raw_kind = kind & ~APE_PARSE_BIG_ENDIAN; fr.raw_big_endian = (kind & APE_PARSE_BIG_ENDIAN) ? 1 : 0;
+        fr.cold = b->frames == 0 ? 1 : 0;
+        fr.ring_out = slot_out; fr.ring_stream_stride = (size_t)b->n_mc * b->T * I; fr.ring_rep_stride = slot_rep_stride; fr.ring_rep = slot_rep;
+        ++b->frames;                                   // (what ape_streams_push_rows does behind its launch)
+        if (int rc = streams_step_impl(b, flags | APE_FLAG_PACKED_MSG, b->h_out, nullptr, out_dtype, stream, b->h_status, &fr)) { --b->frames; return rc; }
+    } else {
+        if (int rc = ape_streams_push_rows(b, kind, b->h_rows, stream)) return rc;
+        if (int rc = streams_step_impl(b, flags | APE_FLAG_PACKED_MSG, b->h_out, nullptr, out_dtype, stream, b->h_status)) return rc;
+    }
+    bool seen = false;
+    if (b->h_done) {
+        // ~50 ms of looking (a frame is tens of microseconds; a launch that gives up takes seconds: the stream wait below covers it)
+        volatile unsigned* dw = b->h_done;
+        for (long spin = 0; spin < 20000000L && !seen; ++spin) {
+            seen = true;
+            for (int k = 0; k < b->S; ++k) seen = seen && dw[k] == b->h_done_val;
+            if (!seen) __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (*(volatile unsigned*)b->h_status != 0u) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         // the regressor launch gave up (bounded spins): the step is still the bank's newest one, so it can be issued again on
-        // the kernels that need no co-residency -- into the same pinned rows
+        // the kernels that need no co-residency -- into the same pinned rows.  (Single-launch frame: the builder workgroup may not
+        // have run; its row goes into the ring by the feature builder's own kernel first -- the same slot, the same values.)
+        if (one_launch) {
+            hipError_t e = ape_launch_parse_rows(b->h_rows, b->S, width, kind & ~APE_PARSE_BIG_ENDIAN, slot_out, APE_F32, I, (size_t)b->n_mc * b->T * I,
+                                                 slot_rep, slot_rep_stride, (kind & APE_PARSE_BIG_ENDIAN) ? 1 : 0, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_frame_host: feature builder launch failed: %s", hipGetErrorString(e));
+        }
         if (int rc = ape_model_recover(m)) return rc;
     } else {
         // the status word was read behind the step's kernels on the step's own stream and one handle serialises on one

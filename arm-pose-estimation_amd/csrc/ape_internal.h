@@ -142,39 +142,6 @@ struct ExpandParams {
     long long masks_rows;               // sample rows of the whole bank (the masks' row stride)
 };
 
-// Kernel arguments of the Monte-Carlo latency kernel (lstm_mc_small.hip): n_streams windows x n_mc dropout samples, dealt over the
-// 8 XCDs -- cluster c serves stream c / cps, sample rows [part * R, part * R + R) of it (part = c % cps).
-struct McSmallParams {
-    const float* x;                     // windows: stream s at x + s * x_stream_stride, [T][I]
-    size_t x_stream_stride;
-    float* y;                           // [rows, O] normalised NN targets of the last step
-    const float* w0;                    // layer 0: the latency kernel's H/8-member register image (ape_model::wcls[0])
-    const float* w[APE_MAX_LAYERS];     // layers >= 1 (index = layer): [member H/8][wave 4][H/16][lane 64][4], the 4x4x1 MFMA's A fragments
-    const float* w16[APE_MAX_LAYERS];   // the same layers as 16 x 16 x 4 fragments (16-row clusters): wave = column tile x K half
-    const float* bias[APE_MAX_LAYERS];
-    const float* w_out;
-    const float* b_out;
-    const double* xx_m;
-    const double* xx_s;
-    const double* xx_r;
-    char* gx;                           // granules {value, tag}: [cluster 8][parity 2][pair][16 B]
-    unsigned gx_cluster_bytes;
-    unsigned* seq;                      // [1] launch number of this kernel on this model (upper bits of the tags)
-    unsigned* done;                     // [1] departure counter
-    unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
-    unsigned* xcc_slots;                // as ClusterParams::xcc_slots: words [192, 448) hold (0x10 | XCC id) of the 8 x 32 workgroups
-    const float* masks;                 // injected [L-1, rows, T, H] or nullptr
-    int rows;                           // n_streams * n_mc
-    int n_mc, n_streams;
-    int cps;                            // clusters per stream
-    int R;                              // sample rows per cluster (<= 16)
-    int T, I, O, x_ring;
-    unsigned flags;                     // NORMALIZE_INPUT, DROPOUT_MASKS | DROPOUT_PHILOX, APE_DIAG_WRITE_THROUGH
-    float dropout_p;
-    unsigned long long seed;
-    unsigned long long* dbg_wg;         // diagnostic builds only
-};
-
 #define APE_MAX_FF_LAYERS 8          // input layer + up to 7 hidden layers of the MLP regressor
 
 // Kernel arguments of the MLP (DropoutFF) kernel.
@@ -223,6 +190,8 @@ struct StreamPostParams {
     int packed;          // 1: msg rows are [25 + 6*smooth*n_mc] wide and carry the tail behind the message
     const unsigned* status_in;   // host frames: the model's sticky status word ...
     unsigned* status_out;        // ... copied here (pinned host memory) by the step's last kernel, or nullptr
+    unsigned* done_out;          // host frames: [S] pinned words; stream s's workgroup writes done_val behind its (system-fenced) outputs,
+    unsigned done_val;           // so that the host can take the frame the moment it is there instead of waiting for the stream to drain
 };
 
 struct MsgParams {
@@ -231,6 +200,50 @@ struct MsgParams {
     double body[9];
     int N, W, layout;
 };
+
+// Kernel arguments of the Monte-Carlo latency kernel (lstm_mc_small.hip): n_streams windows x n_mc dropout samples, dealt over the
+// 8 XCDs -- cluster c serves stream c / cps, sample rows [part * R, part * R + R) of it (part = c % cps).
+struct McSmallParams {
+    const float* x;                     // windows: stream s at x + s * x_stream_stride, [T][I]
+    size_t x_stream_stride;
+    float* y;                           // [rows, O] normalised NN targets of the last step
+    const float* w0;                    // layer 0: the latency kernel's H/8-member register image (ape_model::wcls[0])
+    const float* w[APE_MAX_LAYERS];     // layers >= 1 (index = layer): [member H/8][wave 4][H/16][lane 64][4], the 4x4x1 MFMA's A fragments
+    const float* w16[APE_MAX_LAYERS];   // the same layers as 16 x 16 x 4 fragments (16-row clusters): wave = column tile x K half
+    const float* bias[APE_MAX_LAYERS];
+    const float* w_out;
+    const float* b_out;
+    const double* xx_m;
+    const double* xx_s;
+    const double* xx_r;
+    char* gx;                           // granules {value, tag}: [cluster 8][parity 2][pair][16 B]
+    unsigned gx_cluster_bytes;
+    unsigned* seq;                      // [1] launch number of this kernel on this model (upper bits of the tags)
+    unsigned* done;                     // [1] departure counter
+    unsigned* status;                   // [1] sticky: 1 = a bounded spin gave up
+    unsigned* xcc_slots;                // as ClusterParams::xcc_slots: words [192, 448) hold (0x10 | XCC id) of the 8 x 32 workgroups
+    const float* masks;                 // injected [L-1, rows, T, H] or nullptr
+    int rows;                           // n_streams * n_mc
+    int n_mc, n_streams;
+    int cps;                            // clusters per stream
+    int R;                              // sample rows per cluster (<= 16)
+    int T, I, O, x_ring;
+    unsigned flags;                     // NORMALIZE_INPUT, DROPOUT_MASKS | DROPOUT_PHILOX, APE_DIAG_WRITE_THROUGH
+    float dropout_p;
+    unsigned long long seed;
+    unsigned long long* dbg_wg;         // diagnostic builds only
+    // ---- the frame's feature builder in the same launch (ape_streams_frame_host, small banks)
+    const float* raw_rows;              // [n_streams][raw_width] raw messages, device-visible (pinned host memory will do), or nullptr: the
+                                        // windows are complete.  One extra workgroup per stream builds the new row (parse_device.h), hands it
+                                        // to the clusters as tagged granules and writes it into the stream's ring for the frames to come
+    int raw_width, raw_kind, raw_big_endian;
+    int cold;                           // first row after a reset: every step of the window is the new row (estimator.py:96-97)
+    float* ring_out;                    // stream 0's first target slot; stream n at + n * ring_stream_stride, copy j at + j * ring_rep_stride
+    size_t ring_stream_stride, ring_rep_stride;
+    int ring_rep;
+    char* xg;                           // feature granules {value, tag}: [n_streams][64] x 8 bytes
+};
+
 
 #ifdef __HIPCC__
 // Philox4x32-10 counter-based generator (Salmon et al. 2011) for in-kernel dropout masks.

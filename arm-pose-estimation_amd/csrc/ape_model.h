@@ -130,5 +130,7 @@ struct ape_streams {
     float* h_rows = nullptr;     // [S, 55|28]
     void* h_out = nullptr;       // [S, 25 + 6 * smooth * n_mc] of the frame's dtype
     unsigned* h_status = nullptr;
+    unsigned* h_done = nullptr;  // [64] pinned: the post kernel's per-stream "outputs are there" words of a host frame
+    unsigned h_done_val = 0;     // ... and the value this frame's are awaited with
     size_t h_rows_bytes = 0, h_out_bytes = 0;
 };

@@ -19,9 +19,18 @@
 //     data, so each phase computes those of the NEXT phase between its publish and its poll, where it would otherwise wait.
 // Phase ph: layer l works on step ph - l; one collect and two workgroup barriers per phase.  Same arithmetic as the other kernels
 // up to float32 summation order.
+//
+// The frame's feature builder in the same launch (ape_streams_frame_host, banks of up to eight streams): one extra workgroup per stream
+// builds the new feature row from the raw message (parse_device.h, the float64 chain of ape_parse_rows_kernel: ~5 us on one lane)
+// BESIDE the clusters' weight prologue, hands it to them as tagged granules (the newest step is the last one the window needs) and
+// writes it into the stream's ring for the frames to come: two launches per frame instead of three, the feature builder off the
+// frame's critical path (one stream x 25 samples, host in / host out: 49.0 -> 43.3 us).  The post-filter as this launch's tail (last
+// workgroup out, targets written through) was built and measured too -- 48.2 us alone, 43.1 with the builder: it buys nothing over
+// its own launch (one workgroup's cold float64 chain behind the slowest cluster costs what the launch boundary does) and is not kept.
 #include <type_traits>
 #include "ape_internal.h"
 #include "lstm_latency_common.h"
+#include "parse_device.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -97,14 +106,42 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     float* red = xin + 2 * SX;                     // [LM][NRG][4 waves][32][4]  partial sums of the K quarters
     int* ctl = reinterpret_cast<int*>(red + LM * NRG * 4 * 32 * 4);
     float* mv = reinterpret_cast<float*>(ctl + 8); // INJ: [2][LM][RC][H] mask multipliers by phase parity
-    unsigned short* mbits = reinterpret_cast<unsigned short*>(ctl + 8);   // else: [64 steps][LM * H] (the launcher refuses longer windows) bit r = row r of the cluster keeps (layer, unit) at that step
+    unsigned short* mbits = reinterpret_cast<unsigned short*>(ctl + 8);   // else: [T steps][LM * H] (T <= 64: the launcher refuses longer windows) bit r = row r of the cluster keeps (layer, unit) at that step
 #ifdef APE_CLUSTER_STAMPS
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_t0, st_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const unsigned seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu;
-    if (rv > 0) {
+    const unsigned want_x = (seq << 12) | 0xFFFu;                       // tag of the feature granules (phase tags stay below)
+    const bool builder = blockIdx.x >= 8 * GH;                          // single-launch frame: the feature builder of stream blockIdx - 8 GH
+    if (builder) {
+        __shared__ float prow[64];
+        __shared__ double pxx[40];
+        const int bs = (int)blockIdx.x - 8 * GH;
+        if (tid < p.raw_width) {
+            float v = p.raw_rows[(size_t)bs * p.raw_width + tid];
+            if (p.raw_big_endian) v = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, v)));
+            prow[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) ape_parsedev::parse_row(prow, p.raw_width, p.raw_kind, pxx);
+        __syncthreads();
+        // for this launch's clusters: {feature, tag} written through (they run on other XCDs)
+        if (tid < I) {
+            u32x2 gran;
+            gran[0] = __builtin_bit_cast(unsigned, (float)pxx[tid]);
+            gran[1] = want_x;
+            const __amdgpu_buffer_rsrc_t xg_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xg, 0, 8 * 64 * 8, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(gran, xg_rsrc, (unsigned)(bs * 64 + tid) * 8u, 0, 16 /* sc1: write-through */);
+        }
+        // for the frames to come: the stream's ring (every copy of its window; every slot on a cold start)
+        for (int idx = tid; idx < p.ring_rep * I; idx += 256) {
+            const int j = idx / I, i = idx - j * I;
+            p.ring_out[(size_t)bs * p.ring_stream_stride + (size_t)j * p.ring_rep_stride + i] = (float)pxx[i];
+        }
+    }
+    if (!builder && rv > 0) {
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xFu;
@@ -190,10 +227,34 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     const double x_rstd = (normalize && x_live) ? p.xx_r[tid] : 1.0;
     const float* const x_src = p.x + (size_t)stream * p.x_stream_stride;
     float xr = 0.0f;
+    // single-launch frame: the newest step (every step on a cold start) comes from the builder workgroup's granules -- requested here,
+    // looked at a phase later in stage_x (the builder is long done then), polled only if it is not
+    const bool fed = p.raw_rows != nullptr;
+    const __amdgpu_buffer_rsrc_t xg_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xg, 0, 8 * 64 * 8, 0x00020000);
+    const unsigned xg_off = x_live ? (unsigned)(stream * 64 + tid) * 8u : 0x80000000u;
+    u32x2 xg2 = {0u, 0u};
+    auto from_builder = [&](int t) { return fed && (p.cold != 0 || t == T - 1); };
     auto fetch_x = [&](int t) {
-        if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + tid];
+        if (from_builder(t)) xg2 = __builtin_amdgcn_raw_buffer_load_b64(xg_rsrc, xg_off, 0, 16 /* sc1 */);
+        else if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + tid];
     };
     auto stage_x = [&](int t) {
+        if (from_builder(t) && tid < 64) {          // (wave 0: the threads that stage)
+            unsigned spins = 0;
+            while (__any((int)(x_live && xg2[1] != want_x))) {
+                xg2 = __builtin_amdgcn_raw_buffer_load_b64(xg_rsrc, xg_off, 0, 16 /* sc1 */);
+                if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                             __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (lane == 0) {
+                        ctl[0] = 1;
+                        __hip_atomic_store(p.status, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (6: the builder's row)
+                    }
+                    break;
+                }
+                if (spins > 16u) __builtin_amdgcn_s_sleep(2);
+            }
+            xr = __builtin_bit_cast(float, xg2[0]);
+        }
         if (tid < KX) {
             const double d = (double)xr - x_mean;
             const double q0 = d * x_rstd;
@@ -506,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     //      the XCD words (self-cleaning: a captured launch replays correctly)
     __syncthreads();
     if (tid == 0)
-        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8u * GH - 1u) ? 1 : 0;
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
     __syncthreads();
     if (ctl[2] != 0) {
         // the next launch's tags differ from every tag of this one; when the 20-bit launch number wraps, the granules go back to
@@ -530,8 +591,10 @@ constexpr size_t mcs_smem() {
 
 template <int H, int L, int KX, int RC, bool INJ>
 hipError_t launch_mcs(const McSmallParams& p, hipStream_t stream) {
-    constexpr size_t smem_bytes = mcs_smem<H, L, KX, RC, INJ>();
-    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC, INJ>), dim3(8 * (H / 8)), dim3(256), smem_bytes, stream, p);
+    // (the keep / drop bits of the window's T steps, not of the 64 the table may hold: at the deployed T = 6 / 8 a member then needs
+    //  little enough LDS for the feature builder's workgroup to share a CU with it)
+    const size_t smem_bytes = mcs_smem<H, L, KX, RC, INJ>() - (INJ ? 0 : (size_t)(64 - p.T) * (L - 1) * H * sizeof(unsigned short));
+    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC, INJ>), dim3(8 * (H / 8) + (p.raw_rows ? p.n_streams : 0)), dim3(256), smem_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -545,8 +608,11 @@ hipError_t launch_mcs_rc(const McSmallParams& p, hipStream_t stream) {
 
 template <int H, int L, int KX, int RC>
 hipError_t prepare_mcs_rc() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    // (what each instantiation asks for, not the CU's 160 KiB: the kernel also has static LDS -- the builder's row, the post-filter's slabs)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)mcs_smem<H, L, KX, RC, false>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)mcs_smem<H, L, KX, RC, true>());
     return e;
 }
 template <int H, int L, int KX>

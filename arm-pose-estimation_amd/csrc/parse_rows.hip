@@ -14,55 +14,13 @@
 // 88-304 B out per row.
 #include "ape_internal.h"
 #include "../../include/ape_hip.h"
+#include "parse_device.h"
 
 #pragma clang fp contract(off)
 
 namespace {
 
-struct Q { double w, x, y, z; };
-
-__device__ __forceinline__ Q qmul(const Q a, const Q b) {
-    return Q{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
-             a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-             a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
-             a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
-}
-__device__ __forceinline__ Q qconj(const Q q) { return Q{q.w, -q.x, -q.y, -q.z}; }
-__device__ __forceinline__ Q qinv(const Q q) {
-    const double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-    return Q{q.w / n, -q.x / n, -q.y / n, -q.z / n};
-}
-// android (X east, Y north, Z up) -> global (X right, Y up, Z forward): [-w, x, z, y]
-__device__ __forceinline__ Q no_north(const Q q) { return Q{-q.w, q.x, q.z, q.y}; }
-// azimuth of q * (0,0,1): atan2(x, z) of the rotated forward axis
-__device__ __forceinline__ double y_rot_of(const Q q) {
-    const Q t = qmul(qmul(q, Q{0.0, 0.0, 0.0, 1.0}), qconj(q));
-    return atan2(t.x, t.z);
-}
-__device__ __forceinline__ Q y_quat(double a) { return Q{cos(0.5 * a), 0.0, sin(0.5 * a), 0.0}; }
-__device__ __forceinline__ Q rd(const float* row, int i) {
-    return Q{(double)row[i], (double)row[i + 1], (double)row[i + 2], (double)row[i + 3]};
-}
-// first two columns of the rotation matrix, row-interleaved [m11,m12,m21,m22,m31,m32] (transforms3d formula)
-__device__ __forceinline__ void six_drr(const Q q, double* o) {
-    const double nq = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-    if (nq < 2.220446049250313e-16) { o[0] = 1; o[1] = 0; o[2] = 0; o[3] = 1; o[4] = 0; o[5] = 0; return; }
-    const double s = 2.0 / nq;
-    const double xs = q.x * s, ys = q.y * s, zs = q.z * s;
-    o[0] = 1.0 - (q.y * ys + q.z * zs); o[1] = q.x * ys - q.w * zs;
-    o[2] = q.x * ys + q.w * zs;         o[3] = 1.0 - (q.x * xs + q.z * zs);
-    o[4] = q.x * zs - q.w * ys;         o[5] = q.y * zs + q.w * xs;
-}
-
-// column positions (data_types/messaging.py)
-struct Cols { int rot, fwd, ph_rot, ph_fwd, init_pres; };
-__device__ __forceinline__ Cols cols_of(int width) {
-    return width == 28 ? Cols{5, 23, -1, -1, 27} : Cols{5, 46, 28, 50, 54};
-}
-// sw_dt, gyro, lvel, lacc at 0,10..18; grav at 20..22 (pressure sits at 19)
-__device__ __forceinline__ int sw_sensor_col(int i) { return i == 0 ? 0 : (i <= 9 ? 9 + i : 10 + i); }
-// ph gyro, lvel, lacc at 33..41; grav at 43..45
-__device__ __forceinline__ int ph_sensor_col(int i) { return i < 9 ? 33 + i : 34 + i; }
+using namespace ape_parsedev;
 
 constexpr int PR_BLOCK = 64;                    // threads per workgroup
 constexpr int PR_ROWS = 16;                     // rows per workgroup: a row is one dependent f64 chain (atan2 -> sin / cos -> quaternion
@@ -92,38 +50,7 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
     __shared__ double xout[PR_ROWS * XW];
     __syncthreads();
     if (tid < n) {
-    const float* row = slab + tid * 57;
-    const Cols cl = cols_of(width);
-    double* xx = xout + tid * XW;
-    int o = 0;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) xx[o++] = (double)row[sw_sensor_col(i)];
-    const double r_pres = (double)row[19] - (double)row[cl.init_pres];
-    const Q sw_fwd = rd(row, cl.fwd), sw_rot = rd(row, cl.rot);
-    Q north = y_quat(-y_rot_of(no_north(sw_fwd)));
-    if (kind == APE_PARSE_WATCH_PHONE_UARM) {
-        // north incl. the left-hand calibration turn; watch / phone offsets to the calibration pose
-        north = qmul(Q{0.7071068, 0.0, -0.7071068, 0.0}, north);
-        const Q larm_dst{-0.7071068, 0.0, -0.7071068, 0.0}, uarm_dst{0.7071068, 0.0, 0.7071068, 0.0};
-        const Q sw_cal = qmul(qmul(north, no_north(sw_rot)), qmul(qinv(qmul(north, no_north(sw_fwd))), larm_dst));
-        six_drr(sw_cal, xx + o); o += 6;
-        xx[o++] = r_pres;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) xx[o++] = (double)row[ph_sensor_col(i)];
-        const Q ph_rot = rd(row, cl.ph_rot), ph_fwd = rd(row, cl.ph_fwd);
-        const Q ph_cal = qmul(qmul(north, no_north(ph_rot)), qmul(qinv(qmul(north, no_north(ph_fwd))), uarm_dst));
-        six_drr(ph_cal, xx + o); o += 6;
-    } else {
-        six_drr(qmul(north, no_north(sw_rot)), xx + o); o += 6;
-        xx[o++] = r_pres;
-        if (kind == APE_PARSE_WATCH_PHONE_POCKET) {
-            const Q ph_rot_g = qmul(north, no_north(rd(row, cl.ph_rot)));
-            const Q ph_fwd_g = qmul(north, no_north(rd(row, cl.ph_fwd)));
-            const double hy = y_rot_of(qmul(ph_rot_g, qinv(ph_fwd_g)));
-            xx[o++] = sin(hy);
-            xx[o++] = cos(hy);
-        }
-    }
+    parse_row(slab + tid * 57, width, kind, xout + tid * XW);
     }
     __syncthreads();
     // all threads of the block write all rows: consecutive threads = consecutive features of one (row, copy)
