@@ -1692,7 +1692,7 @@ int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_hos
     *b->h_status = m->cluster_ok ? 0xFFFFFFFFu : 0u;       // (no cooperative kernel on this model: nothing writes the word, nothing can abort)
     // where the bank steps on the Monte-Carlo latency kernel its extra workgroups build the rows' features (two launches per frame);
     // else the feature builder's own launch in front of the step
-    const bool one_launch = bank_on_mc_small(b) && mc_small_builder_fits(m, b->S, b->n_mc, b->T) && I == m->dims.input_size && b->xring != nullptr;
+    const bool one_launch = bank_on_mc_small(b) && b->inj_masks == nullptr && mc_small_builder_fits(m, b->S, b->n_mc, b->T) && I == m->dims.input_size && b->xring != nullptr;
     float* slot_out; int slot_rep; size_t slot_rep_stride;
     next_slot(b, (size_t)I, &slot_out, &slot_rep, &slot_rep_stride);
     if (one_launch) {

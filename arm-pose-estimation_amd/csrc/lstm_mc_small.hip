@@ -69,7 +69,7 @@ __device__ __forceinline__ void poll_pairs(u32x4 (&v)[NI], const unsigned (&off)
 // rows, not for a 16-row tile (one window x 25 samples: 0.9 -> 0.25 us per phase), and a lane ends up with the four gates of one
 // (unit, row) cell.  K = [masked h of the layer below | own h] is split over the four waves (waves 0, 1: the input half; 2, 3: the
 // recurrent half, skipped at step 0), two k per instruction (the wave's halves), the partial sums meet in LDS.
-template <int H, int L, int KX, int RC, bool INJ>
+template <int H, int L, int KX, int RC, bool INJ, bool FED>
 __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams p) {
     constexpr int GH = H / 8;                     // members of a cluster
     constexpr int LM = L - 1;                     // layers above layer 0 (MFMA)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
 #endif
     const unsigned seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu;
     const unsigned want_x = (seq << 12) | 0xFFFu;                       // tag of the feature granules (phase tags stay below)
-    const bool builder = blockIdx.x >= 8 * GH;                          // single-launch frame: the feature builder of stream blockIdx - 8 GH
+    const bool builder = FED && blockIdx.x >= 8 * GH;                   // host frames: the feature builder of stream blockIdx - 8 GH
     if (builder) {
         __shared__ float prow[64];
         __shared__ double pxx[40];
@@ -227,19 +227,30 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     const double x_rstd = (normalize && x_live) ? p.xx_r[tid] : 1.0;
     const float* const x_src = p.x + (size_t)stream * p.x_stream_stride;
     float xr = 0.0f;
-    // single-launch frame: the newest step (every step on a cold start) comes from the builder workgroup's granules -- requested here,
-    // looked at a phase later in stage_x (the builder is long done then), polled only if it is not
-    const bool fed = p.raw_rows != nullptr;
+    // host frames: the newest step (every step on a cold start) comes from the builder workgroup's granules, the others from the ring --
+    // ONE load instruction either way (descriptor and offset chosen by a uniform select: a load inside a branch makes the compiler
+    // wait for everything in flight at the join, which cost 0.2 us per phase when this was an if / else), requested two phases ahead
+    // of its use, looked at in stage_x (the builder is long done then) and polled only if it is not
+    constexpr bool fed = FED;                   // (its own instantiation: the plain launch pays nothing for the hand-over below)
     const __amdgpu_buffer_rsrc_t xg_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xg, 0, 8 * 64 * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_src), 0, T * I * 4, 0x00020000);
     const unsigned xg_off = x_live ? (unsigned)(stream * 64 + tid) * 8u : 0x80000000u;
     u32x2 xg2 = {0u, 0u};
     auto from_builder = [&](int t) { return fed && (p.cold != 0 || t == T - 1); };
     auto fetch_x = [&](int t) {
-        if (from_builder(t)) xg2 = __builtin_amdgcn_raw_buffer_load_b64(xg_rsrc, xg_off, 0, 16 /* sc1 */);
-        else if (x_live) xr = x_src[(size_t)(t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring) * I + tid];
+        const int slot = t + p.x_ring >= T ? t + p.x_ring - T : t + p.x_ring;
+        if constexpr (!FED) {
+            if (x_live) xr = x_src[(size_t)slot * I + tid];
+            return;
+        }
+        const bool fb = from_builder(t);
+        const unsigned off = fb ? xg_off : (x_live ? (unsigned)(slot * I + tid) * 4u : 0x80000000u);
+        // (an ordinary load: a granule line this XCD's L2 still holds from the last frame carries the last frame's tag, and the poll
+        //  in stage_x -- L2-bypassing -- fetches the fresh one)
+        if (x_live) xg2 = __builtin_amdgcn_raw_buffer_load_b64(fb ? xg_rsrc : xw_rsrc, off, 0, 0);
     };
     auto stage_x = [&](int t) {
-        if (from_builder(t) && tid < 64) {          // (wave 0: the threads that stage)
+        if (FED && from_builder(t) && tid < 64) {   // (wave 0: the threads that stage)
             unsigned spins = 0;
             while (__any((int)(x_live && xg2[1] != want_x))) {
                 xg2 = __builtin_amdgcn_raw_buffer_load_b64(xg_rsrc, xg_off, 0, 16 /* sc1 */);
@@ -253,8 +264,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
                 }
                 if (spins > 16u) __builtin_amdgcn_s_sleep(2);
             }
-            xr = __builtin_bit_cast(float, xg2[0]);
         }
+        if constexpr (FED) xr = __builtin_bit_cast(float, xg2[0]);
         if (tid < KX) {
             const double d = (double)xr - x_mean;
             const double q0 = d * x_rstd;
@@ -589,30 +600,34 @@ constexpr size_t mcs_smem() {
            (INJ ? (size_t)2 * (L - 1) * RC * H * sizeof(float) : (size_t)64 * (L - 1) * H * sizeof(unsigned short));
 }
 
-template <int H, int L, int KX, int RC, bool INJ>
+template <int H, int L, int KX, int RC, bool INJ, bool FED>
 hipError_t launch_mcs(const McSmallParams& p, hipStream_t stream) {
     // (the keep / drop bits of the window's T steps, not of the 64 the table may hold: at the deployed T = 6 / 8 a member then needs
     //  little enough LDS for the feature builder's workgroup to share a CU with it)
     const size_t smem_bytes = mcs_smem<H, L, KX, RC, INJ>() - (INJ ? 0 : (size_t)(64 - p.T) * (L - 1) * H * sizeof(unsigned short));
-    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC, INJ>), dim3(8 * (H / 8) + (p.raw_rows ? p.n_streams : 0)), dim3(256), smem_bytes, stream, p);
+    hipLaunchKernelGGL((ape_lstm_mc_small<H, L, KX, RC, INJ, FED>), dim3(8 * (H / 8) + (FED ? p.n_streams : 0)), dim3(256), smem_bytes, stream, p);
     return hipGetLastError();
 }
 
-template <int H, int L, int KX, bool INJ>
+template <int H, int L, int KX, bool INJ, bool FED>
 hipError_t launch_mcs_rc(const McSmallParams& p, hipStream_t stream) {
-    if (p.R <= 4) return launch_mcs<H, L, KX, 4, INJ>(p, stream);
-    if (p.R <= 8) return launch_mcs<H, L, KX, 8, INJ>(p, stream);
-    if (p.R <= 16) return launch_mcs<H, L, KX, 16, INJ>(p, stream);
+    if (p.R <= 4) return launch_mcs<H, L, KX, 4, INJ, FED>(p, stream);
+    if (p.R <= 8) return launch_mcs<H, L, KX, 8, INJ, FED>(p, stream);
+    if (p.R <= 16) return launch_mcs<H, L, KX, 16, INJ, FED>(p, stream);
     return hipErrorInvalidValue;
 }
 
+template <int H, int L, int KX, int RC, bool INJ, bool FED>
+hipError_t prepare_mcs_one() {
+    // (what the instantiation asks for, not the CU's 160 KiB: the kernel also has static LDS -- the builder's row)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, INJ, FED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)mcs_smem<H, L, KX, RC, INJ>());
+}
 template <int H, int L, int KX, int RC>
 hipError_t prepare_mcs_rc() {
-    // (what each instantiation asks for, not the CU's 160 KiB: the kernel also has static LDS -- the builder's row, the post-filter's slabs)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)mcs_smem<H, L, KX, RC, false>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_mc_small<H, L, KX, RC, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)mcs_smem<H, L, KX, RC, true>());
+    hipError_t e = prepare_mcs_one<H, L, KX, RC, false, false>();
+    if (e == hipSuccess) e = prepare_mcs_one<H, L, KX, RC, true, false>();
+    if (e == hipSuccess) e = prepare_mcs_one<H, L, KX, RC, false, true>();
     return e;
 }
 template <int H, int L, int KX>
@@ -636,11 +651,18 @@ hipError_t ape_prepare_lstm_mc_small(int H, int L, int KX) {
     return hipErrorInvalidValue;
 }
 
-// p.R rows per cluster (<= 16), p.cps clusters per stream, p.n_streams * p.cps <= 8, p.T <= 64
+// p.R rows per cluster (<= 16), p.cps clusters per stream, p.n_streams * p.cps <= 8, p.T <= 64; p.raw_rows: the frame's raw rows (host
+// frames: the feature builder's workgroups ride along; Philox masks only)
+template <int H, int L, int KX>
+hipError_t launch_mcs_sel(const McSmallParams& p, hipStream_t stream) {
+    const bool inj = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0, fed = p.raw_rows != nullptr;
+    if (inj && fed) return hipErrorInvalidValue;
+    if (inj) return launch_mcs_rc<H, L, KX, true, false>(p, stream);
+    return fed ? launch_mcs_rc<H, L, KX, false, true>(p, stream) : launch_mcs_rc<H, L, KX, false, false>(p, stream);
+}
 hipError_t ape_launch_lstm_mc_small(int H, int L, int KX, const McSmallParams& p, hipStream_t stream) {
-    const bool inj = (p.flags & APE_FLAG_DROPOUT_MASKS) != 0;
     if (p.T > 64) return hipErrorInvalidValue;
-    if (H == 256 && L == 2 && KX == 32) return inj ? launch_mcs_rc<256, 2, 32, true>(p, stream) : launch_mcs_rc<256, 2, 32, false>(p, stream);
-    if (H == 128 && L == 3 && KX == 64) return inj ? launch_mcs_rc<128, 3, 64, true>(p, stream) : launch_mcs_rc<128, 3, 64, false>(p, stream);
+    if (H == 256 && L == 2 && KX == 32) return launch_mcs_sel<256, 2, 32>(p, stream);
+    if (H == 128 && L == 3 && KX == 64) return launch_mcs_sel<128, 3, 64>(p, stream);
     return hipErrorInvalidValue;
 }
