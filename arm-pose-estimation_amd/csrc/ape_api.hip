@@ -329,6 +329,11 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         // (second-generation kernel of the 3 x 128 model: one flag per (32-row cluster, layer, member, one of eight waves))
         if (ape_cluster16_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * L * 64 > flag_words)
             flag_words = (size_t)f16v2_capacity(m->n_cus) * L * 64;
+        if (ape_upper128_supported(H, L, O) && !imupose) {
+            const int c128 = (m->n_cus / 4) / 8 * 8;
+            if (ape_upper128_flag_words(c128) > flag_words) flag_words = ape_upper128_flag_words(c128);
+            if (ape_upper128_hx_bytes(c128) > m->hx_bytes) m->hx_bytes = ape_upper128_hx_bytes(c128);
+        }
         m->xflag_bytes = ((flag_words * sizeof(unsigned)) + 15) / 16 * 16 + 16;
         if (e == hipSuccess) e = plan((void**)&m->hx, m->hx_bytes);
         if (e == hipSuccess) e = plan((void**)&m->dbg_wg, 256 * 8 * sizeof(unsigned long long));
@@ -367,6 +372,12 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
                 if (e == hipSuccess) e = ape_prepare_lstm_upper32();
                 m->up32_ok = true;
             }
+        }
+        // the Monte-Carlo bank's weight-stationary route for the 3 x 128 model (lstm_upper128.hip): four-member clusters, whole classes of 8
+        if (ape_upper128_supported(H, L, O) && (m->n_cus / 4) / 8 * 8 >= 8 && !imupose) {
+            for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wup128[l], (size_t)4 * H * 2 * H * sizeof(float));
+            if (e == hipSuccess) e = ape_prepare_lstm_upper128();
+            m->up128_ok = true;
         }
         if (ape_cluster16_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0 && !imupose) {
             if (e == hipSuccess) e = ape_prepare_lstm_cluster16(H, L, m->KX);
@@ -619,6 +630,24 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                             pc[((((size_t)(mem * 4 + w) * (NW / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] = v;
                         }
             HIP_TRY(hipMemcpy(m->wcl32[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (m->up128_ok && l >= 1) {
+            // lstm_upper128.hip: four members x 4 waves, a wave owns 8 units = 32 columns ordered gate * 8 + unit (v_mfma_f32_32x32x2_f32,
+            // weights = A operand); register i = 4 kb + j of lane (column mcol = lane & 31, half hh) = Wcat[gate(mcol) * H + member*32 +
+            // wave*8 + (mcol & 7)][8 kb + 4 hh + j]; [member][wave][i / 4][lane][i % 4]
+            const int NW = (KXl + H) / 2;
+            std::vector<float> pc((size_t)4 * 4 * NW * 64);
+            for (int mem = 0; mem < 4; ++mem)
+                for (int w = 0; w < 4; ++w)
+                    for (int i = 0; i < NW; ++i)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int mcol = lane & 31, hh = lane >> 5;
+                            const int row = (mcol >> 3) * H + mem * 32 + w * 8 + (mcol & 7);
+                            const int k = 8 * (i / 4) + 4 * hh + (i % 4);
+                            pc[((((size_t)(mem * 4 + w) * (NW / 4)) + i / 4) * 64 + lane) * 4 + (i % 4)] =
+                                k < KXl ? w_ih[(size_t)row * in_l + k] : w_hh[(size_t)row * H + (k - KXl)];
+                        }
+            HIP_TRY(hipMemcpy(m->wup128[l], pc.data(), pc.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         std::vector<float> bsum(4 * H);
         for (int i = 0; i < 4 * H; ++i) bsum[i] = b_ih[i] + b_hh[i];
@@ -1349,7 +1378,8 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     // (on the weight-stationary route -- lstm_upper32.hip, both launches -- the sharing pays from 2048 sample rows on: two
     //  32-row tiles per cluster, against four 512-row launches of the fused first-generation dropout kernel)
     const long long sample_rows = (long long)b->S * n_mc;
-    const bool can_up32 = m->up32_ok && m->c32_on && f16v2_capacity(m->n_cus) >= 8;
+    const bool can_up128 = m->up128_ok && m->c32_on;
+    const bool can_up32 = (m->up32_ok && m->c32_on && f16v2_capacity(m->n_cus) >= 8) || can_up128;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
                    dropout_p > 0.0f && n_mc >= 2 &&
                    (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= 2048));
@@ -1358,6 +1388,8 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     if (b->xfrag0) { (void)hipFree(b->xfrag0); b->xfrag0 = nullptr; }
     if (b->hfrag) { (void)hipFree(b->hfrag); b->hfrag = nullptr; }
     b->up32 = false;
+    b->up128 = false;
+    if (b->maskbits) { (void)hipFree(b->maskbits); b->maskbits = nullptr; }
     if (b->shared_l0) {
         const size_t rows = (size_t)b->S * b->T;
         if (rows > m->hseq_cap) {
@@ -1372,18 +1404,28 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
             // launch's prologue and tail cost more than the cache residency of the tiles buys; 288 GB of HBM make the footprint
             // a non-issue.)
             const long long total = (long long)b->S * n_mc;
-            const long long max_chunk = ((2047ll << 20) / ((long long)b->T * 1024)) / 1024 * 1024;
+            // (the pre-laid input is T x 1 KiB per sample row of a 2 x 256 model, T x 512 B of the 3 x 128 model)
+            const long long max_chunk = ((2047ll << 20) / ((long long)b->T * (can_up128 ? 512 : 1024))) / 1024 * 1024;
             if (max_chunk >= 1024 && total < (1ll << 31)) {          // (the input builder indexes sample rows with 32 bits)
                 const long long n_chunks = (total + max_chunk - 1) / max_chunk;
                 long long chunk = ((total + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;
                 if (chunk > total) chunk = (total + 31) / 32 * 32;
                 b->chunk_rows = (int)chunk;
+                if (can_up128) {
+                    // the 3 x 128 model: launch A stays on the batch-tile kernel ([S,T,H] in the model's sequence workspace), launch B =
+                    // layers 1 and 2 on lstm_upper128.hip
+                    HIP_TRY(hipMalloc((void**)&b->xfrag, ape_upper128_xfrag_bytes(b->chunk_rows, b->T)));
+                    HIP_TRY(hipMalloc((void**)&b->ypart, ape_upper128_ypart_bytes(b->chunk_rows)));
+                    HIP_TRY(hipMalloc((void**)&b->maskbits, ape_upper128_maskbits_bytes(b->chunk_rows, b->T)));
+                    b->up128 = true;
+                } else {
                 HIP_TRY(hipMalloc((void**)&b->xfrag, ape_upper32_xfrag_bytes(b->chunk_rows, b->T)));
                 HIP_TRY(hipMalloc((void**)&b->ypart, ape_upper32_ypart_bytes(b->chunk_rows)));
                 // layer 0 on the same cluster structure (its SEQ form): input tiles and the [tile][step] sequence, fragment order
                 HIP_TRY(hipMalloc((void**)&b->xfrag0, ape_lower32_xfrag_bytes(b->S, b->T)));
                 HIP_TRY(hipMalloc((void**)&b->hfrag, ape_lower32_hseq_bytes(b->S, b->T)));
                 b->up32 = true;
+                }
             }
         }
     }
@@ -1399,6 +1441,7 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->ypart) (void)hipFree(b->ypart);
     if (b->xfrag0) (void)hipFree(b->xfrag0);
     if (b->hfrag) (void)hipFree(b->hfrag);
+    if (b->maskbits) (void)hipFree(b->maskbits);
     if (b->h_rows) (void)hipHostFree(b->h_rows);
     if (b->h_out) (void)hipHostFree(b->h_out);
     if (b->h_status) (void)hipHostFree(b->h_status);
@@ -1592,6 +1635,31 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
                 m->last_kernel = "ape_lstm_upper32";
                 e = ape_launch_lstm_upper32(u, xq, m->b_out, b->y_new + (size_t)r0 * O, f16v2_capacity(m->n_cus), (hipStream_t)stream,
                                             ev_a, ev_z);
+                if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
+            }
+            ++b->mc_calls;
+        } else if (b->up128 && !m->replaying) {
+            // the 3 x 128 model: layers 1 and 2 on the four-member weight-stationary clusters (lstm_upper128.hip), per chunk of sample
+            // rows: masked input + layer-1 keep bits, the persistent kernel, the head reduce
+            if (b->inj_masks) return fail(APE_ERR_UNSUPPORTED, "streams_step: injected masks (test hook) on the 3 x 128 weight-stationary route");
+            const long long total = (long long)b->S * b->n_mc;
+            for (long long r0 = 0; r0 < total; r0 += b->chunk_rows) {
+                const int rows = (int)((total - r0 < b->chunk_rows) ? total - r0 : b->chunk_rows);
+                ExpandParams xq{};
+                xq.hseq = m->hseq_ws; xq.hseq_frag = 0; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
+                xq.layer = 0; xq.dropout_p = b->dropout_p; xq.seed = b->seed + b->mc_calls;
+                Upper128Params u{};
+                u.xfrag = b->xfrag; u.xfrag_bytes = ape_upper128_xfrag_bytes(rows, b->T); u.maskbits = b->maskbits; u.ypart = b->ypart;
+                u.w[0] = m->wup128[1]; u.w[1] = m->wup128[2]; u.bias[0] = m->bias[1]; u.bias[1] = m->bias[2]; u.w_out = m->w_out;
+                u.hx = m->hx; u.hx_bytes = m->hx_bytes;
+                u.xflags = m->xflags; u.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u.done = u.status - 3;
+                u.xcc_slots = m->xcc_slots;
+                u.T = b->T; u.O = O; u.n_tiles = (rows + 31) / 32;
+                u.flags = diag_wt; u.dropout_p = b->dropout_p;
+                hipEvent_t ev_a, ev_z;
+                prof_pair(&ev_a, &ev_z);
+                m->last_kernel = "ape_lstm_upper128";
+                e = ape_launch_lstm_upper128(u, xq, m->b_out, b->y_new + (size_t)r0 * O, (m->n_cus / 4) / 8 * 8, (hipStream_t)stream, ev_a, ev_z);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
             }
             ++b->mc_calls;

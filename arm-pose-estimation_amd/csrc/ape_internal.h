@@ -117,6 +117,27 @@ struct UpperParams {
     unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
 };
 
+// Kernel arguments of the weight-stationary kernel for layers 1 and 2 of the 3 x 128 model in a Monte-Carlo stream bank
+// (lstm_upper128.hip): one chunk of sample rows, tiles of 32.
+struct Upper128Params {
+    const float* xfrag;                 // [n_tiles][T][k-block 16][row 32][8 units]: layer 0's output under the rows' masks, fragment order
+    size_t xfrag_bytes;
+    const unsigned* maskbits;           // [n_tiles][T][unit 128]: bit n = row n of the tile keeps layer 1's output of that unit and step
+    float* ypart;                       // [n_tiles * 32][member 4][16] head partial sums
+    const float* w[2];                  // layers 1, 2: [member 4][wave 4][32][lane 64][4] = 128 weight registers per lane each
+    const float* bias[2];               // [4H] = b_ih + b_hh
+    const float* w_out;                 // [O,H]
+    float* hx;                          // exchange [cluster][set 2][kind 3: h_1, h_1 masked, h_2][parity 2][16 KB]
+    size_t hx_bytes;
+    unsigned* xflags;                   // [cluster][set 2][layer 2][16] epoch flags, zero between launches
+    unsigned* done;
+    unsigned* status;
+    unsigned* xcc_slots;
+    int T, O, n_tiles;
+    unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
+    float dropout_p;
+};
+
 // Kernel arguments of the input builder of the layer-0 launch (ape_x_frag_kernel, lstm_upper32.hip).
 struct XFragParams {
     const float* x;                     // window rings: stream s at x + s * x_row_stride, [T][I]
@@ -300,6 +321,15 @@ bool ape_mc_small_supported(int H, int L, int KX);
 size_t ape_mc_small_cluster_bytes(int H, int L);
 hipError_t ape_prepare_lstm_mc_small(int H, int L, int KX);
 hipError_t ape_launch_lstm_mc_small(int H, int L, int KX, const McSmallParams& p, hipStream_t stream);
+bool ape_upper128_supported(int H, int L, int O);
+size_t ape_upper128_xfrag_bytes(int rows, int T);
+size_t ape_upper128_maskbits_bytes(int rows, int T);
+size_t ape_upper128_ypart_bytes(int rows);
+size_t ape_upper128_hx_bytes(int clusters);
+size_t ape_upper128_flag_words(int clusters);
+hipError_t ape_prepare_lstm_upper128();
+hipError_t ape_launch_lstm_upper128(const Upper128Params& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
+                                    hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 bool ape_cluster_f16v2_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);

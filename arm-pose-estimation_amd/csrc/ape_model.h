@@ -75,6 +75,8 @@ struct ape_model {
     bool f16_v2 = true;             // fp16 precision: batches > 256 rows on the row-set-pipelined kernel (lstm_cluster_f16v2.hip)
     bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
     bool up32_ok = false;           // ... and on the weight-stationary upper-layer kernel (lstm_upper32.hip: 2 x 256 models)
+    bool up128_ok = false;          // ... or on lstm_upper128.hip (the 3 x 128 model: layers 1 and 2 in four-member clusters)
+    float* wup128[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // its register image of layers 1, 2
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;
     unsigned long long* dbg_wg = nullptr;   // 256 x 8 words, written by diagnostic builds of the cluster kernel only
@@ -114,6 +116,8 @@ struct ape_streams {
     // shared-layer-0 route on the weight-stationary upper-layer kernel (lstm_upper32.hip): the sample rows go through it in
     // chunks of `chunk_rows` (a multiple of 32), each expand -> LSTM -> head reduce over the two workspaces below
     bool up32 = false;
+    bool up128 = false;          // the same route for the 3 x 128 model (lstm_upper128.hip; launch A stays on the batch-tile kernel)
+    unsigned* maskbits = nullptr;   // ... keep bits of layer 1's outputs [chunk tiles][T][128]
     int chunk_rows = 0;
     float* xfrag = nullptr;      // [chunk tiles][T][32 KB] masked layer-0 output in MFMA fragment order
     float* ypart = nullptr;      // [chunk rows][8][16] head partial sums

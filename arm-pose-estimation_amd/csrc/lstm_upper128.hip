@@ -1,0 +1,589 @@
+// Weight-stationary kernel for the layers above layer 0 of the 3 x 128 upper-arm model in the Monte-Carlo stream bank
+// (WatchPhoneUarmNN: 38 -> 3 x 128 -> 12, 50 dropout samples per frame by default; reference estimate/watch_phone_uarm_nn.py:13-41,
+// estimate/nn_models.py:191-207), exact float32.  The sibling of lstm_upper32.hip (the 2 x 256 models' one layer above layer 0).
+//
+// nn.LSTM's dropout sits between the layers (nn_models.py:169-174): layer 0 runs once per stream (launch A of ape_streams_step), layers
+// 1 and 2 over the S x n_mc sample rows.  Until round 4 they ran on the batch-tile kernel (weights re-streamed from L2 per 16-row tile:
+// 62 % of the f32 MFMA peak by executed FLOP, 95 % of the bank's frame).  Here:
+//
+//   * TWO layers with K = 128 + 128 each are exactly the 256 accumulator-file registers per lane of a FOUR-member cluster: a member
+//     (workgroup = CU) owns 32 hidden units of BOTH layers, a wave 8 of them x 4 gates = the 32 columns of one v_mfma_f32_32x32x2_f32
+//     tile; the weights are the A operand and never move after the prologue.  64 clusters x 4 CUs fill the chip;
+//   * persistent over 32-row tiles (cluster c owns tiles c, c + NC, ...), two tiles in flight per cluster ("sets"), and the sections
+//     of a step alternate  [set 0, layer 1] [set 1, layer 1] [set 0, layer 2] [set 1, layer 2]: every hand-over -- a layer's own h for
+//     its next step, layer 1's masked h for layer 2 of the same step -- has at least one whole section of the OTHER set (8.2K MFMA
+//     cycles) to travel in: store -> acknowledged -> flag -> look -> LDS-DMA gather, all hung into the other set's MFMA stream;
+//   * layer 1's masked input (layer 0's output under each sample's mask) arrives pre-laid in fragment order from
+//     ape_mc_expand128_kernel, like lstm_upper32.hip's; that kernel also draws the keep / drop BITS of layer 1's outputs (Philox with
+//     the counters of every other kernel: row quad, step, unit, layer 1).  A wave publishes its fresh h_1 twice -- plain (layer 1's
+//     recurrence) and under the rows' masks (layer 2's input): one 16-byte mask word load per lane and section, four multiplies;
+//   * h_{-1} = 0: step 0 of a tile is the input span alone, in both layers;
+//   * the head as in lstm_upper32.hip: four more MFMAs on the fresh h_2 of the last step, partial sums per member, reduced in a fixed order.
+// Exchange protocol, cluster formation (arrival tickets within the block-index class = XCD, verified at run time), bounded spins,
+// sticky status word and self-cleaning are those of lstm_cluster32.hip / lstm_upper32.hip.
+#include <type_traits>
+
+#include "ape_internal.h"
+#include "../../include/ape_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+// v_mfma_f32_32x32x2_f32, weight operand (A) in the accumulator file (AG) or in an architectural VGPR; the accumulators are read
+// only behind mfma_drain() (hipcc does not model an asm MFMA's result hazard)
+template <bool AG>
+__device__ __forceinline__ void mfma32(f32x16& acc, float w, float a) {
+    if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_drain(f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc)); }
+
+// NB k-blocks of 8: acc += W (registers w[w0 ...]) x activations (LDS, one ds_read_b128 per block, `stride` floats between
+// blocks), fragments fetched two blocks ahead; `mid(kb)` runs after the MFMAs of block kb (a constant after unrolling)
+template <int NB, int NW, typename Mid>
+__device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ src, int stride, const float (&w)[NW], int w0, Mid&& mid) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+    f32x4 a1 = (NB > 1) ? *reinterpret_cast<const f32x4*>(src + stride) : a0;
+    f32x4 a2 = a1;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        if (kb + 2 < NB) a2 = *reinterpret_cast<const f32x4*>(src + stride * (kb + 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma32<true>(acc, w[w0 + 4 * kb + j], a0[j]);
+        mid(kb);
+        a0 = a1;
+        a1 = a2;
+    }
+}
+
+// a flag look that does not stall the MFMA stream (lstm_upper32.hip): issued by asm, first touched by peek_wait() some k-blocks later
+__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+// the 16 bytes of mask words of this lane's four units: asm as well (the compiler would wait for everything in flight at its first use)
+__device__ __forceinline__ u32x4 words_issue(const u32x4* addr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void words_wait(u32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
+template <bool WT>
+__device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
+    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer to 1 KiB of LDS at the wave-uniform byte address `lds_addr`
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+constexpr int UH = 128;                  // hidden units of a layer = width of its input
+constexpr int GH = 4;                    // members per cluster (32 units each)
+constexpr int MR = 32;                   // sample rows per tile
+constexpr int BH = UH / 8;               // k-blocks of 8 per span (input span and recurrent span alike)
+constexpr int NWL = 4 * 2 * BH;          // weight registers per lane and layer: [W_ih | W_hh]
+constexpr int NFL = 4 * GH;              // flags per (cluster, set, layer): one per member wave
+constexpr int HL = GH * 4 * MR * 8;      // floats of one slice set / one input tile-step [k-block 16][row 32][8] = 16 KB
+constexpr int NDMA = HL * 4 / 1024 / 4;  // LDS-DMA instructions per wave and 16 KB copy (4)
+constexpr int PO = 16;                   // width of a head partial row (O <= 16)
+constexpr unsigned SET_BYTES = HL * sizeof(float);
+
+__global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params p) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5;     // row of the tile, half (units 4 hh .. 4 hh + 3 of the wave's 8)
+    const int T = p.T, O = p.O;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xb = smem;                            // [set 2][HL]  layer 1's input of the set's current step (layer 0's output, masked), fragment order
+    float* h1b = xb + 2 * HL;                    // [set 2][HL]  h_1 of the step before
+    float* m1b = h1b + 2 * HL;                   // [set 2][HL]  layer 2's input: h_1 of the current step under the rows' masks
+    float* h2b = m1b + 2 * HL;                   // [set 2][HL]  h_2 of the step before
+    f32x4* bias_s = reinterpret_cast<f32x4*>(h2b + 2 * HL);       // [layer 2][wave 4][gate 4][hh 2]: accumulator start values (b_ih + b_hh)
+    f32x4* wo_s = bias_s + 2 * 4 * 4 * 2;                         // [wave 4][lane 64]: W_out as the head MFMAs' A fragment
+    float* hp = reinterpret_cast<float*>(wo_s + 4 * 64);          // [wave 4][PO][MR]: head partial sums of the four waves
+    int* ctl = reinterpret_cast<int*>(hp + 4 * PO * MR);          // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+
+    // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words]
+    unsigned* const class_ticket = p.xcc_slots + 64;
+    unsigned* const xcc_words = p.xcc_slots + 64 + 8 * 16;
+    const int cls = blockIdx.x & 7;
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xFu;
+    if (tid == 0) {
+        ctl[0] = 0;
+        ctl[1] = -1;
+        if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            const unsigned tk = __hip_atomic_fetch_add(class_ticket + cls * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < gridDim.x / 8) ctl[1] = (int)tk;
+            else __hip_atomic_store(p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (ctl[1] < 0) return;
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
+    const int cluster = (ticket / GH) * 8 + cls, member = ticket % GH;
+    const int NC = (int)gridDim.x / GH;          // clusters of this launch
+    if (tid == 0)
+        __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- weights: 2 x 128 registers per lane in the accumulator file, for the whole launch.  Host layout (ape_api.hip, wup128):
+    //      per layer [member 4][wave 4][register / 4][lane][4]; register 4 kb + j of lane (column m = lane & 31 = gate * 8 + unit, half hh)
+    //      = [W_ih | W_hh][gate * H + member * 32 + wave * 8 + unit][8 kb + 4 hh + j]
+    float w[2 * NWL];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.w[l]) + ((size_t)(member * 4 + wave) * (NWL / 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NWL / 4; ++i) {
+            const f32x4 v = s1[i * 64];
+            w[l * NWL + 4 * i] = v[0]; w[l * NWL + 4 * i + 1] = v[1]; w[l * NWL + 4 * i + 2] = v[2]; w[l * NWL + 4 * i + 3] = v[3];
+        }
+    }
+    // accumulator start values: registers 4 gate + j <-> unit member*32 + wave*8 + 4 hh + j (the same for every row)
+    if (tid < 2 * 4 * 4 * 2) {
+        const int l = tid >> 5, wv = (tid >> 3) & 3, gate = (tid >> 1) & 3, h2 = tid & 1;
+        f32x4 bv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = p.bias[l][gate * UH + member * 32 + wv * 8 + 4 * h2 + j];
+        bias_s[tid] = bv;
+    }
+    // head: A fragment of the wave's four MFMAs -- column m = lane & 31 is target o = m (zero for m >= O), k = 4 hh + j is the wave's unit 4 hh + j
+    {
+        f32x4 wv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (n < O) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = p.w_out[(size_t)n * UH + member * 32 + wave * 8 + 4 * hh + j];
+        }
+        wo_s[wave * 64 + lane] = wv;
+    }
+
+    // exchange buffer and input: descriptors as scalar tuples for the DMA asm
+    const unsigned long long hx_addr = reinterpret_cast<unsigned long long>(p.hx);
+    u32x4 hx_desc;
+    hx_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)hx_addr);
+    hx_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(hx_addr >> 32) & 0xFFFFu);
+    hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
+    hx_desc[3] = 0x00020000u;
+    const unsigned long long xf_addr = reinterpret_cast<unsigned long long>(p.xfrag);
+    u32x4 xf_desc;
+    xf_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)xf_addr);
+    xf_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xf_addr >> 32) & 0xFFFFu);
+    xf_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.xfrag_bytes);
+    xf_desc[3] = 0x00020000u;
+    // flags [cluster][set 2][layer 2][member wave 16]: epoch = slices published; exchange [cluster][set 2][kind 3][parity 2][16 KB],
+    // kind 0 = h_1, 1 = h_1 masked, 2 = h_2
+    unsigned* const flags_c = p.xflags + (size_t)cluster * 2 * 2 * NFL;
+    auto flags_of = [&](int s, int l) -> unsigned* { return flags_c + (s * 2 + l) * NFL; };
+    auto ex_base = [&](int s, int kind, int par) -> unsigned { return (unsigned)(((((size_t)cluster * 2 + s) * 3 + kind) * 2 + par) * SET_BYTES); };
+    const unsigned xb_lds = (unsigned)reinterpret_cast<unsigned long long>(xb);       // LDS byte addresses
+    const unsigned h1b_lds = (unsigned)reinterpret_cast<unsigned long long>(h1b);
+    const unsigned m1b_lds = (unsigned)reinterpret_cast<unsigned long long>(m1b);
+    const unsigned h2b_lds = (unsigned)reinterpret_cast<unsigned long long>(h2b);
+
+    // ---- do all members of this cluster really share an XCD?
+    if (wave == 0) {
+        unsigned spins = 0, v = 0u;
+        while (true) {
+            v = 0x10u | my_xcc;
+            if (lane < GH) v = __hip_atomic_load(xcc_words + cluster * GH + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v != 0u))) break;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int same = __all((int)((v & 0xFu) == my_xcc));
+        if (lane == 0) ctl[3] = same;
+    }
+    __syncthreads();
+    if (ctl[0] != 0) return;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
+
+    // every wave polls for itself: have all member waves published epoch `want` of (set s, layer l)?
+    auto wait_flags = [&](const unsigned* fl, unsigned want) {
+        unsigned spins = 0;
+        while (true) {
+            unsigned v = want;
+            if (lane < NFL) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v >= want))) return;
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) {
+                    ctl[0] = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    // a 16 KB copy global -> LDS: wave w moves KiB w, w + 4, w + 8, w + 12; piece k on its own so that a copy can be spread over k-blocks
+    const unsigned dma_voff = (unsigned)(lane * 16);
+    auto opaque = [](unsigned v) -> unsigned { asm volatile("" : "+s"(v)); return v; };     // (no hoisted address sums: lstm_upper32.hip)
+    const unsigned wave_kib = (unsigned)(wave * 1024);
+    auto copy_piece = [&](unsigned lds_base, int s, u32x4 desc, unsigned src, int k) {
+        dma_1k(opaque(lds_base + wave_kib) + (unsigned)s * SET_BYTES + (unsigned)(k * 4096), dma_voff, desc, src + (unsigned)(wave * 1024 + k * 4096));
+    };
+    // the flags a wave owes for the slices it stored last (layer 1: two stores, one flag): raised once those stores have drained
+    int pend_idx = -1;
+    unsigned pend_epoch = 0u;
+    auto raise_pending = [&]() {              // caller has waited vmcnt(0)
+        if (pend_idx < 0) return;
+        if (lane == 0) __hip_atomic_store(flags_c + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_idx = -1;
+    };
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- per-set state (uniform over the workgroup AND over the cluster: every member walks the same tiles)
+    float cst[2][2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cst[s][l][j] = 0.0f;
+    int tile_of[2], step_of[2];              // the set's current tile (-1: none left) and step
+    unsigned pub[2][2] = {{0u, 0u}, {0u, 0u}};   // [set][layer]: slices published so far = epoch of the newest ones
+    bool prex[2] = {false, false};           // the input operand / the recurrent operand of the set's NEXT section are on their way
+    bool preh[2] = {false, false};           //   (issued by the other set's section)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int tl = cluster + s * NC;
+        tile_of[s] = tl < p.n_tiles ? tl : -1;
+        step_of[s] = 0;
+    }
+    const int frag = n * 8 + hh * 4;                              // this lane's 16 bytes inside a [row][8 units] block
+    const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
+    const float keep = 1.0f / (1.0f - p.dropout_p);
+
+    // the operands of section (set s, layer l = 0 / 1 for model layers 1 / 2) of step t of tile `tile`:
+    //   input      l = 0: the pre-laid tile-step of p.xfrag;              l = 1: the masked h_1 of THIS step (epoch pub[s][0], kind 1)
+    //   recurrent  (t >= 1)  the layer's own h of the step before: epoch pub[s][l] (kind 0 / 2)
+    auto issue_in_piece = [&](int s, int l, int tile, int t, int k) {
+        if (l == 0) copy_piece(xb_lds, s, xf_desc, (unsigned)(((size_t)tile * T + t) * SET_BYTES), k);
+        else copy_piece(m1b_lds, s, hx_desc, ex_base(s, 1, (int)((pub[s][0] - 1u) & 1u)), k);
+    };
+    auto issue_rec_piece = [&](int s, int l, int k) {
+        if (l == 0) copy_piece(h1b_lds, s, hx_desc, ex_base(s, 0, (int)((pub[s][0] - 1u) & 1u)), k);
+        else copy_piece(h2b_lds, s, hx_desc, ex_base(s, 2, (int)((pub[s][1] - 1u) & 1u)), k);
+    };
+
+    // One section = one layer of one step of one set.  Vector-memory queue of a wave in a steady-state section, in issue order:
+    //   [publish stores of the section in front: 2 behind a layer-1 section, 1 behind a layer-2 one]  mask words (layer 1)
+    //   copies + flag look + copies for the NEXT section (the other set's)  [head partial store]  publish store(s)
+    // so at the top everything but the NPREV youngest entries is waited for, and a few k-blocks in those have drained too.
+    auto section = [&](auto set_tag, auto layer_tag, auto first_tag, auto nprev_tag) -> bool {
+        constexpr int s = decltype(set_tag)::value, o = s ^ 1, l = decltype(layer_tag)::value;
+        constexpr bool first = decltype(first_tag)::value;          // step 0 of a tile: no recurrent span (h_{-1} = 0)
+        constexpr int NPREV = decltype(nprev_tag)::value;
+        const int t = step_of[s], tile = tile_of[s];
+        const bool last = t == T - 1;
+        // ---- S0: this section's operands
+        if (prex[s] && (first || preh[s])) {
+            if constexpr (NPREV == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            raise_pending();
+            if (!prex[s]) {
+                if (l == 1) wait_flags(flags_of(s, 0), pub[s][0]);
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) issue_in_piece(s, l, tile, t, k);
+            }
+            if (!first && !preh[s]) {
+                wait_flags(flags_of(s, l), pub[s][l]);
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) issue_rec_piece(s, l, k);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        prex[s] = false;
+        preh[s] = false;
+        bar();                                                      // (unconditional: lstm_upper32.hip on why)
+        const int abort_word = ctl[0];
+        // the NEXT section: [set 0, l] -> [set 1, l]; [set 1, layer 1] -> [set 0, layer 2]; [set 1, layer 2] -> [set 0, layer 1] of its next step
+        constexpr int nl = (s == 0) ? l : (l ^ 1);
+        const bool o_act = tile_of[o] >= 0;
+        const int o_t = step_of[o];
+        const bool o_h = o_act && o_t >= 1;
+        const unsigned want_x = pub[o][0], want_h = pub[o][nl];
+        unsigned peek = 0u;
+        bool go_x = false, go_h = false;
+        u32x4 mw = {0u, 0u, 0u, 0u};
+        // hooks in the MFMA stream (k-block q of the section, a constant after unrolling):
+        //   QF   the flags owed for the publish stores of the section in front (drained by now); layer 1: request the mask words
+        //   QP   look at the other set's flags (one load per lane: lanes 0..15 the input's, 16..31 the recurrent operand's)      QJ  judge
+        //   QJ .. +3  one piece of the next section's input per block, QJ + 4 .. + 7 one of its recurrent operand
+        constexpr int QF = 3;
+        constexpr int QP = first ? 10 : 20, QJ = first ? 12 : 24;
+        auto mid = [&](int q) {
+            if (q == QF) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_pending();
+                if (l == 0) mw = words_issue(reinterpret_cast<const u32x4*>(p.maskbits + ((size_t)tile * T + t) * UH + member * 32 + wave * 8 + 4 * hh));
+            }
+            if (q == QP) peek = peek_issue(flags_of(o, (lane & 16) ? nl : 0) + (lane & 15));
+            if (q == QJ) {
+                peek_wait(peek);
+                // (layer 1's input needs no flag: it was laid down by the launch in front)
+                go_x = o_act && (nl == 0 || __all((int)((lane & 16) != 0 || peek >= want_x)) != 0);
+                go_h = o_h && __all((int)((lane & 16) == 0 || peek >= want_h)) != 0;
+            }
+            if (q >= QJ && q < QJ + NDMA && go_x) issue_in_piece(o, nl, tile_of[o], o_t, q - QJ);
+            if (q >= QJ + NDMA && q < QJ + 2 * NDMA && go_h) issue_rec_piece(o, nl, q - QJ - NDMA);
+        };
+        // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const f32x4 bv = bias_s[((l * 4 + wave) * 4 + gate) * 2 + hh];
+            acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
+        }
+        span32<BH, 2 * NWL>(acc, (l == 0 ? xb : m1b) + s * HL + frag, MR * 8, w, l * NWL, [&](int q) { mid(q); });
+        if constexpr (!first) span32<BH, 2 * NWL>(acc, (l == 0 ? h1b : h2b) + s * HL + frag, MR * 8, w, l * NWL + 4 * BH, [&](int q) { mid(BH + q); });
+        {
+            constexpr int NBLK = first ? BH : 2 * BH;
+#pragma unroll
+            for (int q = NBLK; q < QJ + 2 * NDMA; ++q) mid(q);
+        }
+        // (the other set idle: THIS set runs the next section too, and its top copies into buffers read above -- every wave must be
+        //  through with them first; `tile_of[o] < 0` is state, uniform over the workgroup, so the extra barrier pairs up)
+        if (tile_of[o] < 0) bar();
+        mfma_drain(acc);
+        // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, row n
+        float hnew[4];
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
+            auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
+            const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
+            const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
+            const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
+            const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
+            const f32x2 ov = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ao));
+            const f32x2 c = first ? iv * gv : fv * f32x2{cst[s][l][j], cst[s][l][j + 1]} + iv * gv;
+            cst[s][l][j] = c[0]; cst[s][l][j + 1] = c[1];
+            const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
+            hnew[j] = h[0]; hnew[j + 1] = h[1];
+        }
+        if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
+        prex[o] = go_x;
+        preh[o] = go_h;
+        if (l == 1 && last) {
+            // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h values are the activation fragment
+            f32x16 ya;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ya[i] = 0.0f;
+            const f32x4 wv = wo_s[wave * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mfma32<false>(ya, wv[j], hnew[j]);
+            mfma_drain(ya);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hp[(wave * PO + 8 * g + 4 * hh + j) * MR + n] = ya[4 * g + j];
+            bar();
+            if (tid < 128) {
+                const int rn = tid >> 2, oq = tid & 3;
+                f32x4 sum;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = (4 * oq + i) * MR + rn;
+                    sum[i] = ((hp[idx] + hp[PO * MR + idx]) + hp[2 * PO * MR + idx]) + hp[3 * PO * MR + idx];
+                }
+                *reinterpret_cast<f32x4*>(p.ypart + (((size_t)tile * MR + rn) * GH + member) * PO + 4 * oq) = sum;
+            }
+        }
+        // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout.  Layer 1: TWO stores, plain (its own
+        //      recurrence; to nowhere on a last step) and under the row's masks (layer 2's input); layer 2: ONE (to nowhere on a last step).
+        //      The counted wait at the top of the next section relies on exactly that many.
+        {
+            const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
+                              __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
+            const int par = (int)(pub[s][l] & 1u);
+            if (l == 0) {
+                words_wait(mw);
+                u32x4 hm;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hm[j] = __builtin_bit_cast(unsigned, ((mw[j] >> n) & 1u) ? hnew[j] * keep : 0.0f);
+                const unsigned off0 = last ? 0x80000000u : ex_base(s, 0, par) + pub_off;
+                const unsigned off1 = ex_base(s, 1, par) + pub_off;
+                if (in_l2) { store_16<false>(hv, off0, hx_desc); store_16<false>(hm, off1, hx_desc); }
+                else { store_16<true>(hv, off0, hx_desc); store_16<true>(hm, off1, hx_desc); }
+                pub[s][0] += 1u;
+                pend_idx = (s * 2 + 0) * NFL + member * 4 + wave;
+                pend_epoch = pub[s][0];
+            } else {
+                const unsigned off = last ? 0x80000000u : ex_base(s, 2, par) + pub_off;
+                if (in_l2) store_16<false>(hv, off, hx_desc);
+                else store_16<true>(hv, off, hx_desc);
+                if (!last) {
+                    pub[s][1] += 1u;
+                    pend_idx = (s * 2 + 1) * NFL + member * 4 + wave;
+                    pend_epoch = pub[s][1];
+                }
+            }
+        }
+        // ---- next step / next tile of this set (behind its layer-2 section)
+        if (l == 1) {
+            if (last) {
+                const int nt = tile + 2 * NC;
+                tile_of[s] = nt < p.n_tiles ? nt : -1;
+                step_of[s] = 0;
+            } else {
+                step_of[s] = t + 1;
+            }
+        }
+        return true;
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using N1 = std::integral_constant<int, 1>;
+    using N2 = std::integral_constant<int, 2>;
+    bool ok = true;
+#pragma unroll 1
+    while (ok && (tile_of[0] >= 0 || tile_of[1] >= 0)) {
+        // (a set's two sections of a step run in this order; which sections surround them decides how many publish stores are the
+        //  youngest entries of the queue at a top: [0, L1] follows [1, L2] (one), [1, L1] follows [0, L1] (two), [0, L2] follows
+        //  [1, L1] (two), [1, L2] follows [0, L2] (one) -- with one set idle every top takes the blocking form anyway)
+        const bool a0 = tile_of[0] >= 0, a1 = tile_of[1] >= 0;
+        const bool f0 = step_of[0] == 0, f1 = step_of[1] == 0;
+        if (a0) ok = f0 ? section(S0{}, S0{}, std::true_type{}, N1{}) : section(S0{}, S0{}, std::false_type{}, N1{});
+        if (ok && a1) ok = f1 ? section(S1{}, S0{}, std::true_type{}, N2{}) : section(S1{}, S0{}, std::false_type{}, N2{});
+        if (ok && a0) ok = f0 ? section(S0{}, S1{}, std::true_type{}, N2{}) : section(S0{}, S1{}, std::false_type{}, N2{});
+        if (ok && a1) ok = f1 ? section(S1{}, S1{}, std::true_type{}, N1{}) : section(S1{}, S1{}, std::false_type{}, N1{});
+    }
+    if (!ok) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (a flag still owed is awaited by nobody: dropped, lstm_upper32.hip)
+
+    // ---- self-cleaning: the last workgroup out re-zeroes every polled word
+    __syncthreads();
+    if (tid == 0)
+        ctl[2] = (__hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (ctl[2] != 0) {
+        const int n_flags = NC * 2 * 2 * NFL;
+        for (int i = tid; i < n_flags; i += 256) __hip_atomic_store(p.xflags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+constexpr size_t smem_upper128() {
+    return (size_t)8 * HL * sizeof(float) + (size_t)(2 * 4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + 16;
+}
+
+// ---- launch B's inputs: layer 0's output under each sample row's mask in fragment order [tile][step][k-block 16][row 32][8 units], and
+//      the keep bits of layer 1's outputs [tile][step][unit 128] (bit n = row n of the tile).  Sample row r (row_base + its index in this
+//      chunk) is sample r % n_mc of stream r / n_mc.  Philox with the counters every fused kernel uses (rows r & ~3, step, unit, layer;
+//      value index r & 3 -- lstm_tile16.hip), so the samples are the ones the batch-tile route draws.  One workgroup (128 threads = units)
+//      per (tile, step).
+constexpr int XS = 8 * MR + 8;           // LDS stride of a k-block (floats)
+
+__global__ __launch_bounds__(128) void ape_mc_expand128_kernel(const ExpandParams q, unsigned* __restrict__ maskbits) {
+    __shared__ __attribute__((aligned(16))) float sl[BH * XS];
+    const int unit = threadIdx.x;
+    const unsigned tile = blockIdx.x / (unsigned)q.T, t = blockIdx.x - tile * (unsigned)q.T;
+    const unsigned row0 = tile * MR;                              // first row of the tile, chunk-local
+    const float keep = 1.0f / (1.0f - q.dropout_p);
+    const bool drop = q.dropout_p > 0.0f;
+    const unsigned g0 = (unsigned)q.row_base + row0;              // global index of the tile's first row (< 2^31)
+    unsigned stream = g0 / (unsigned)q.n_mc, rem = g0 - stream * (unsigned)q.n_mc;
+    unsigned bits1 = 0u;
+#pragma unroll
+    for (int g = 0; g < MR / 4; ++g) {
+        const unsigned r4 = g0 + 4 * g;                           // global index of the row quad (a multiple of 4)
+        uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, rn1[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (drop) {
+            philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)q.layer, (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rnd);
+            philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)(q.layer + 1), (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rn1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = 0.0f;
+            if (row0 + 4 * g + i < (unsigned)q.rows) {
+                v = q.hseq[((size_t)stream * q.T + t) * UH + unit];
+                if (drop) {
+                    const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
+                    v = (uf >= q.dropout_p) ? v * keep : 0.0f;
+                }
+            }
+            const float uf1 = (float)(rn1[i] >> 8) * (1.0f / 16777216.0f);
+            if (!drop || uf1 >= q.dropout_p) bits1 |= 1u << (4 * g + i);
+            sl[(unit >> 3) * XS + (4 * g + i) * 8 + (unit & 7)] = v;
+            if (++rem == (unsigned)q.n_mc) { rem = 0u; ++stream; }
+        }
+    }
+    maskbits[((size_t)tile * q.T + t) * UH + unit] = bits1;
+    __syncthreads();
+    f32x4* dst = reinterpret_cast<f32x4*>(q.xfrag + ((size_t)tile * q.T + t) * HL);
+#pragma unroll
+    for (int e = 0; e < HL / 4 / 128; ++e) {
+        const int idx = threadIdx.x + 128 * e;                    // float4 index: k-block idx / 64, inside it idx % 64
+        dst[idx] = *reinterpret_cast<const f32x4*>(sl + (idx >> 6) * XS + (idx & 63) * 4);
+    }
+}
+
+// y[r][o] = b_out[o] + the four members' partial sums, member 0 first (a fixed order: run-to-run identical bits)
+__global__ __launch_bounds__(256) void ape_head_reduce128_kernel(const float* __restrict__ ypart, const float* __restrict__ b_out,
+                                                                 float* __restrict__ y, int rows, int O) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * PO) return;
+    const int r = idx / PO, o = idx - r * PO;
+    if (o >= O) return;
+    const float* src = ypart + (size_t)r * GH * PO + o;
+    float s = src[0];
+#pragma unroll
+    for (int m = 1; m < GH; ++m) s += src[m * PO];
+    y[(size_t)r * O + o] = s + b_out[o];
+}
+
+}  // namespace
+
+bool ape_upper128_supported(int H, int L, int O) { return H == UH && L == 3 && O <= PO; }
+size_t ape_upper128_xfrag_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * SET_BYTES; }
+size_t ape_upper128_maskbits_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * UH * sizeof(unsigned); }
+size_t ape_upper128_ypart_bytes(int rows) { return (size_t)((rows + MR - 1) / MR) * MR * GH * PO * sizeof(float); }
+size_t ape_upper128_hx_bytes(int clusters) { return (size_t)clusters * 2 * 3 * 2 * SET_BYTES; }
+size_t ape_upper128_flag_words(int clusters) { return (size_t)clusters * 2 * 2 * NFL; }
+
+hipError_t ape_prepare_lstm_upper128() {
+    static_assert(smem_upper128() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper128), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+}
+
+// one chunk of sample rows: expand -> layers 1 and 2 -> head reduce, all on `stream`.  `max_clusters` = 4-member clusters the device holds
+// at once (a multiple of 8: whole block-index classes); the grid is the smaller of that and the tiles, rounded up to 8.
+hipError_t ape_launch_lstm_upper128(const Upper128Params& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
+                                    hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    if (p.n_tiles < 1 || max_clusters < 8 || p.O > PO) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ape_mc_expand128_kernel, dim3(p.n_tiles * p.T), dim3(128), 0, stream, q, const_cast<unsigned*>(p.maskbits));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int clusters = (p.n_tiles + 7) / 8 * 8;
+    if (clusters > max_clusters) clusters = max_clusters;
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);          // (measurement aid: ape_streams_profile)
+    hipLaunchKernelGGL(ape_lstm_upper128, dim3(clusters * GH), dim3(256), smem_upper128(), stream, p);
+    e = hipGetLastError();
+    if (ev_end) (void)hipEventRecord(ev_end, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ape_head_reduce128_kernel, dim3((q.rows * PO + 255) / 256), dim3(256), 0, stream, p.ypart, b_out, y, q.rows, p.O);
+    return hipGetLastError();
+}

@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "arm-pose-estimation_amd", "csrc")
 
 
 @pytest.mark.parametrize("name", ["lstm_cluster16.hip", "lstm_cluster32.hip", "lstm_upper32.hip", "lstm_cluster_f16v2.hip", "lstm_mc_small.hip",
-                                  "lstm_cluster_small.hip"])
+                                  "lstm_cluster_small.hip", "lstm_upper128.hip"])
 def test_no_unguarded_adjacency_around_asm_mfmas(name):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py"), name], cwd=CSRC, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
