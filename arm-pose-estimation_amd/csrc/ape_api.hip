@@ -1655,7 +1655,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
                 u.xflags = m->xflags; u.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u.done = u.status - 3;
                 u.xcc_slots = m->xcc_slots;
                 u.T = b->T; u.O = O; u.n_tiles = (rows + 31) / 32;
-                u.flags = diag_wt; u.dropout_p = b->dropout_p;
+                u.flags = diag_wt; u.dropout_p = b->dropout_p; u.dbg_wg = m->dbg_wg;
                 hipEvent_t ev_a, ev_z;
                 prof_pair(&ev_a, &ev_z);
                 m->last_kernel = "ape_lstm_upper128";

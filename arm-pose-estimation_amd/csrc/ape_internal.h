@@ -136,6 +136,7 @@ struct Upper128Params {
     int T, O, n_tiles;
     unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
     float dropout_p;
+    unsigned long long* dbg_wg;         // diagnostic build only (APE_CLUSTER_STAMPS): shader-clock sums of cluster 0 / member 0 / wave 0
 };
 
 // Kernel arguments of the input builder of the layer-0 launch (ape_x_frag_kernel, lstm_upper32.hip).

@@ -66,6 +66,7 @@ __device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
     return v;
 }
 __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+__device__ __forceinline__ void peek_wait(unsigned& v, u32x4& w) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(w) :: "memory"); }
 // the 16 bytes of mask words of this lane's four units: asm as well (the compiler would wait for everything in flight at its first use)
 __device__ __forceinline__ u32x4 words_issue(const u32x4* addr) {
     u32x4 v;
@@ -76,15 +77,35 @@ __device__ __forceinline__ void words_wait(u32x4& v) { asm volatile("s_waitcnt v
 
 template <bool WT>
 __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
-    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
-    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    // (s_nop 4: the descriptor may have been reloaded from a spill lane by v_readlane_b32 right in front -- a VALU write of an SGPR needs
+    //  five wait states before a vector-memory instruction reads it, and hipcc does not look inside an asm statement)
+    if constexpr (WT) asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer to 1 KiB of LDS at the wave-uniform byte address `lds_addr`
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"        // (five wait states, as above)
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// hook positions of a section (k-block indices; see `mid` below)
+#ifndef UP128_QF
+#define UP128_QF 3
+#endif
+#ifndef UP128_QP
+#define UP128_QP 20
+#endif
+#ifndef UP128_QP_FIRST
+#define UP128_QP_FIRST 10
+#endif
+#ifndef UP128_QD
+#define UP128_QD 2
+#endif
+// timing experiments only (tests/tools/build_variant.sh; results are garbage): 1 no copies, 2 no flag looks (operands taken for present),
+// 4 no wait / flag raise / mask words at QF, 8 no gate transcendentals, 16 no publish stores
+#ifndef UP128_ABL
+#define UP128_ABL 0
+#endif
 constexpr int UH = 128;                  // hidden units of a layer = width of its input
 constexpr int GH = 4;                    // members per cluster (32 units each)
 constexpr int MR = 32;                   // sample rows per tile
@@ -214,8 +235,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     if (ctl[0] != 0) return;
     const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
 
+    // per-lane addresses of the hooks' loads, computed once: the look at the other set's flags (lanes 0..15 the input operand's layer-1
+    // flags, lanes 16..31 the recurrent operand's -- layer 1's again when the next section is a layer-1 one, else layer 2's; + the set's
+    // 2 * NFL words), the mask words of this lane's four units (+ (tile * T + t) * 128 words)
+    const unsigned* const peek_lane0 = flags_c + (lane & 15);
+    const unsigned* const peek_lane1 = flags_c + (lane & 15) + ((lane & 16) ? NFL : 0);
+    const u32x4* const mask_lane = reinterpret_cast<const u32x4*>(p.maskbits + member * 32 + wave * 8 + 4 * hh);
     // every wave polls for itself: have all member waves published epoch `want` of (set s, layer l)?
     auto wait_flags = [&](const unsigned* fl, unsigned want) {
+        if (UP128_ABL & 4) return;
         unsigned spins = 0;
         while (true) {
             unsigned v = want;
@@ -235,16 +263,28 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     const unsigned dma_voff = (unsigned)(lane * 16);
     auto opaque = [](unsigned v) -> unsigned { asm volatile("" : "+s"(v)); return v; };     // (no hoisted address sums: lstm_upper32.hip)
     const unsigned wave_kib = (unsigned)(wave * 1024);
-    auto copy_piece = [&](unsigned lds_base, int s, u32x4 desc, unsigned src, int k) {
+    // (`nrec` = the descriptor's record count: 0 turns the instruction into one that touches no memory -- zeros into an LDS buffer nobody
+    //  reads before its real copy -- so that the hooks of a section need no branch on a verdict)
+    auto copy_piece = [&](unsigned lds_base, int s, u32x4 desc, unsigned nrec, unsigned src, int k) {
+        if (UP128_ABL & 1) return;
+        desc[2] = nrec;
         dma_1k(opaque(lds_base + wave_kib) + (unsigned)s * SET_BYTES + (unsigned)(k * 4096), dma_voff, desc, src + (unsigned)(wave * 1024 + k * 4096));
     };
     // the flags a wave owes for the slices it stored last (layer 1: two stores, one flag): raised once those stores have drained
-    int pend_idx = -1;
+    // (address and value sit in vector registers from the publish on: no VALU instruction for them inside the next section's MFMA stream)
+    bool pend = false;
+    unsigned* pend_ptr = flags_c;
     unsigned pend_epoch = 0u;
     auto raise_pending = [&]() {              // caller has waited vmcnt(0)
-        if (pend_idx < 0) return;
-        if (lane == 0) __hip_atomic_store(flags_c + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pend_idx = -1;
+        if (!pend) return;
+        if (lane == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(pend_ptr), "v"(pend_epoch) : "memory");
+        pend = false;
+    };
+    auto owe = [&](int idx, unsigned epoch) {
+        pend = true;
+        pend_ptr = flags_c + idx;
+        pend_epoch = epoch;
+        asm volatile("" : "+v"(pend_ptr), "+v"(pend_epoch));
     };
     auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -273,15 +313,24 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     // the operands of section (set s, layer l = 0 / 1 for model layers 1 / 2) of step t of tile `tile`:
     //   input      l = 0: the pre-laid tile-step of p.xfrag;              l = 1: the masked h_1 of THIS step (epoch pub[s][0], kind 1)
     //   recurrent  (t >= 1)  the layer's own h of the step before: epoch pub[s][l] (kind 0 / 2)
-    auto issue_in_piece = [&](int s, int l, int tile, int t, int k) {
-        if (l == 0) copy_piece(xb_lds, s, xf_desc, (unsigned)(((size_t)tile * T + t) * SET_BYTES), k);
-        else copy_piece(m1b_lds, s, hx_desc, ex_base(s, 1, (int)((pub[s][0] - 1u) & 1u)), k);
+    const unsigned xf_rec = xf_desc[2], hx_rec = hx_desc[2];
+    auto issue_in_piece = [&](int s, int l, int tile, int t, int k, bool on) {
+        if (l == 0) copy_piece(xb_lds, s, xf_desc, on ? xf_rec : 0u, (unsigned)(((size_t)tile * T + t) * SET_BYTES), k);
+        else copy_piece(m1b_lds, s, hx_desc, on ? hx_rec : 0u, ex_base(s, 1, (int)((pub[s][0] - 1u) & 1u)), k);
     };
-    auto issue_rec_piece = [&](int s, int l, int k) {
-        if (l == 0) copy_piece(h1b_lds, s, hx_desc, ex_base(s, 0, (int)((pub[s][0] - 1u) & 1u)), k);
-        else copy_piece(h2b_lds, s, hx_desc, ex_base(s, 2, (int)((pub[s][1] - 1u) & 1u)), k);
+    auto issue_rec_piece = [&](int s, int l, int k, bool on) {
+        if (l == 0) copy_piece(h1b_lds, s, hx_desc, on ? hx_rec : 0u, ex_base(s, 0, (int)((pub[s][0] - 1u) & 1u)), k);
+        else copy_piece(h2b_lds, s, hx_desc, on ? hx_rec : 0u, ex_base(s, 2, (int)((pub[s][1] - 1u) & 1u)), k);
     };
 
+#ifdef APE_CLUSTER_STAMPS
+    // diagnostic counters and shader-clock sums (cluster 0, member 0, wave 0): sections, blocking tops by cause, cycles in the top of a
+    // section (wait + barrier), its MFMA chain, the gate math (+ head), the publish
+    unsigned long long dg_block_x = 0, dg_block_h = 0, dg_sections = 0, dg_top = 0, dg_chain = 0, dg_gates = 0, dg_pub = 0, dg_t0 = 0;
+#define UP_STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - dg_t0; dg_t0 = now_; }
+#else
+#define UP_STAMP(acc)
+#endif
     // One section = one layer of one step of one set.  Vector-memory queue of a wave in a steady-state section, in issue order:
     //   [publish stores of the section in front: 2 behind a layer-1 section, 1 behind a layer-2 one]  mask words (layer 1)
     //   copies + flag look + copies for the NEXT section (the other set's)  [head partial store]  publish store(s)
@@ -292,6 +341,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         constexpr int NPREV = decltype(nprev_tag)::value;
         const int t = step_of[s], tile = tile_of[s];
         const bool last = t == T - 1;
+#ifdef APE_CLUSTER_STAMPS
+        dg_sections += 1;
+        dg_t0 = __builtin_amdgcn_s_memtime();
+        if (!prex[s]) dg_block_x += 1; else if (!(first || preh[s])) dg_block_h += 1;
+#endif
         // ---- S0: this section's operands
         if (prex[s] && (first || preh[s])) {
             if constexpr (NPREV == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -302,18 +356,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
             if (!prex[s]) {
                 if (l == 1) wait_flags(flags_of(s, 0), pub[s][0]);
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_in_piece(s, l, tile, t, k);
+                for (int k = 0; k < NDMA; ++k) issue_in_piece(s, l, tile, t, k, true);
             }
             if (!first && !preh[s]) {
                 wait_flags(flags_of(s, l), pub[s][l]);
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_rec_piece(s, l, k);
+                for (int k = 0; k < NDMA; ++k) issue_rec_piece(s, l, k, true);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         prex[s] = false;
         preh[s] = false;
         bar();                                                      // (unconditional: lstm_upper32.hip on why)
+        UP_STAMP(dg_top);
         const int abort_word = ctl[0];
         // the NEXT section: [set 0, l] -> [set 1, l]; [set 1, layer 1] -> [set 0, layer 2]; [set 1, layer 2] -> [set 0, layer 1] of its next step
         constexpr int nl = (s == 0) ? l : (l ^ 1);
@@ -328,23 +383,27 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         //   QF   the flags owed for the publish stores of the section in front (drained by now); layer 1: request the mask words
         //   QP   look at the other set's flags (one load per lane: lanes 0..15 the input's, 16..31 the recurrent operand's)      QJ  judge
         //   QJ .. +3  one piece of the next section's input per block, QJ + 4 .. + 7 one of its recurrent operand
-        constexpr int QF = 3;
-        constexpr int QP = first ? 10 : 20, QJ = first ? 12 : 24;
+        constexpr int QF = UP128_QF;
+        constexpr int QP = first ? UP128_QP_FIRST : UP128_QP, QJ = QP + UP128_QD;
+        constexpr int QEND = QJ + 2 * NDMA;
         auto mid = [&](int q) {
-            if (q == QF) {
+            if (q == QF && !(UP128_ABL & 4)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
-                if (l == 0) mw = words_issue(reinterpret_cast<const u32x4*>(p.maskbits + ((size_t)tile * T + t) * UH + member * 32 + wave * 8 + 4 * hh));
+                if (l == 0) mw = words_issue(mask_lane + ((size_t)tile * T + t) * (UH / 4));
             }
-            if (q == QP) peek = peek_issue(flags_of(o, (lane & 16) ? nl : 0) + (lane & 15));
-            if (q == QJ) {
-                peek_wait(peek);
+            if (q == QP && !(UP128_ABL & 2)) peek = peek_issue((nl == 0 ? peek_lane0 : peek_lane1) + o * 2 * NFL);
+            if (q == QJ && (UP128_ABL & 2)) { go_x = o_act; go_h = o_h; }
+            if (q == QJ && !(UP128_ABL & 2)) {
+                if constexpr (l == 0) peek_wait(peek, mw);        // (the mask words, requested at QF, are in by now as well)
+                else peek_wait(peek);
                 // (layer 1's input needs no flag: it was laid down by the launch in front)
-                go_x = o_act && (nl == 0 || __all((int)((lane & 16) != 0 || peek >= want_x)) != 0);
-                go_h = o_h && __all((int)((lane & 16) == 0 || peek >= want_h)) != 0;
+                constexpr unsigned long long IN_LANES = 0x0000FFFF0000FFFFull;       // lanes with (lane & 16) == 0
+                go_x = o_act && (nl == 0 || (__builtin_amdgcn_ballot_w64(peek >= want_x) | ~IN_LANES) == ~0ull);
+                go_h = o_h && (__builtin_amdgcn_ballot_w64(peek >= want_h) | IN_LANES) == ~0ull;
             }
-            if (q >= QJ && q < QJ + NDMA && go_x) issue_in_piece(o, nl, tile_of[o], o_t, q - QJ);
-            if (q >= QJ + NDMA && q < QJ + 2 * NDMA && go_h) issue_rec_piece(o, nl, q - QJ - NDMA);
+            if (q >= QJ && q < QJ + NDMA) issue_in_piece(o, nl, tile_of[o], o_t, q - QJ, go_x);
+            if (q >= QJ + NDMA && q < QJ + 2 * NDMA) issue_rec_piece(o, nl, q - QJ - NDMA, go_h);
         };
         // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs
         f32x16 acc;
@@ -358,12 +417,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         {
             constexpr int NBLK = first ? BH : 2 * BH;
 #pragma unroll
-            for (int q = NBLK; q < QJ + 2 * NDMA; ++q) mid(q);
+            for (int q = NBLK; q < QEND; ++q) mid(q);
         }
         // (the other set idle: THIS set runs the next section too, and its top copies into buffers read above -- every wave must be
         //  through with them first; `tile_of[o] < 0` is state, uniform over the workgroup, so the extra barrier pairs up)
         if (tile_of[o] < 0) bar();
         mfma_drain(acc);
+        UP_STAMP(dg_chain);
         // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, row n
         float hnew[4];
 #pragma unroll
@@ -372,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
             auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
             auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
             const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
+            if (UP128_ABL & 8) { hnew[j] = ai[0] + af[0] + ag[0] + ao[0]; hnew[j + 1] = ai[1] + af[1] + ag[1] + ao[1]; continue; }
             const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
             const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
             const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
@@ -409,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
                 *reinterpret_cast<f32x4*>(p.ypart + (((size_t)tile * MR + rn) * GH + member) * PO + 4 * oq) = sum;
             }
         }
+        UP_STAMP(dg_gates);
         // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout.  Layer 1: TWO stores, plain (its own
         //      recurrence; to nowhere on a last step) and under the row's masks (layer 2's input); layer 2: ONE (to nowhere on a last step).
         //      The counted wait at the top of the next section relies on exactly that many.
@@ -417,28 +479,28 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
                               __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
             const int par = (int)(pub[s][l] & 1u);
             if (l == 0) {
-                words_wait(mw);
                 u32x4 hm;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hm[j] = __builtin_bit_cast(unsigned, ((mw[j] >> n) & 1u) ? hnew[j] * keep : 0.0f);
                 const unsigned off0 = last ? 0x80000000u : ex_base(s, 0, par) + pub_off;
                 const unsigned off1 = ex_base(s, 1, par) + pub_off;
-                if (in_l2) { store_16<false>(hv, off0, hx_desc); store_16<false>(hm, off1, hx_desc); }
+                if (UP128_ABL & 16) { asm volatile("" :: "v"(hv), "v"(hm)); }
+                else if (in_l2) { store_16<false>(hv, off0, hx_desc); store_16<false>(hm, off1, hx_desc); }
                 else { store_16<true>(hv, off0, hx_desc); store_16<true>(hm, off1, hx_desc); }
                 pub[s][0] += 1u;
-                pend_idx = (s * 2 + 0) * NFL + member * 4 + wave;
-                pend_epoch = pub[s][0];
+                owe((s * 2 + 0) * NFL + member * 4 + wave, pub[s][0]);
             } else {
                 const unsigned off = last ? 0x80000000u : ex_base(s, 2, par) + pub_off;
-                if (in_l2) store_16<false>(hv, off, hx_desc);
+                if (UP128_ABL & 16) { asm volatile("" :: "v"(hv)); }
+                else if (in_l2) store_16<false>(hv, off, hx_desc);
                 else store_16<true>(hv, off, hx_desc);
                 if (!last) {
                     pub[s][1] += 1u;
-                    pend_idx = (s * 2 + 1) * NFL + member * 4 + wave;
-                    pend_epoch = pub[s][1];
+                    owe((s * 2 + 1) * NFL + member * 4 + wave, pub[s][1]);
                 }
             }
         }
+        UP_STAMP(dg_pub);
         // ---- next step / next tile of this set (behind its layer-2 section)
         if (l == 1) {
             if (last) {
@@ -472,6 +534,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     if (!ok) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (a flag still owed is awaited by nobody: dropped, lstm_upper32.hip)
 
+#ifdef APE_CLUSTER_STAMPS
+    if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) {
+        p.dbg_wg[16] = dg_block_x; p.dbg_wg[17] = dg_block_h; p.dbg_wg[18] = dg_sections;
+        p.dbg_wg[19] = dg_top; p.dbg_wg[20] = dg_chain; p.dbg_wg[21] = dg_gates; p.dbg_wg[22] = dg_pub;
+    }
+#endif
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word
     __syncthreads();
     if (tid == 0)

@@ -15,4 +15,14 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     cases = [ALL[k] for k in (sys.argv[1:] or ["uarm_S1024_mc50_T6"])]
     model = bench._bank_model(bench.POCKET, (NNS_INPUTS.WATCH_PHONE_CAL_HIP, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS))
-    print(json.dumps(bench.stream_bank_numbers(model, None, cases=cases), indent=1))
+    out = bench.stream_bank_numbers(model, None, cases=cases)
+    if os.environ.get("BRIEF"):
+        for k, v in out.items():
+            if isinstance(v, dict):
+                r = v["roofline"]
+                print(f"{k}: frame {v['ms_per_frame_of_all_streams']:.4f} ms, kernel {r['kernel']} {r['kernel_ms']:.4f} ms, "
+                      f"frac {r['frac']:.3f} executed {r.get('frac_executed', 0):.3f}")
+            else:
+                print(k, v)
+    else:
+        print(json.dumps(out, indent=1))
