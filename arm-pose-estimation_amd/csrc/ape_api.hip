@@ -1352,6 +1352,22 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
     return APE_OK;
 }
 
+// Sample rows per launch of a Monte-Carlo bank's weight-stationary route (pure arithmetic: ape_debug_bank_chunks, tests/test_plan_cpu.py).
+// The pre-laid input is T x 1 KiB per sample row of a 2 x 256 model (lstm_upper32.hip), T x 512 B of the 3 x 128 model
+// (lstm_upper128.hip); it and -- 2 x 256 models -- launch A's sequence and input tiles sit behind ONE 32-bit buffer descriptor each, so
+// a bank that outgrows 2 GiB of any of them is chunked (launch B) or keeps the batch-tile route (launch A: 65 536 streams of 64 steps).
+static bool bank_chunk_plan(bool up128, int S, int T, int n_mc, long long* chunk_rows) {
+    const long long total = (long long)S * n_mc;
+    const long long max_chunk = ((2047ll << 20) / ((long long)T * (up128 ? 512 : 1024))) / 1024 * 1024;
+    const bool l0_fits = up128 || (ape_lower32_hseq_bytes(S, T) < (2047ull << 20) && ape_lower32_xfrag_bytes(S, T) < (2047ull << 20));
+    if (max_chunk < 1024 || total >= (1ll << 31) || !l0_fits) return false;       // (the input builder indexes sample rows with 32 bits)
+    const long long n_chunks = (total + max_chunk - 1) / max_chunk;
+    long long chunk = ((total + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;
+    if (chunk > total) chunk = (total + 31) / 32 * 32;
+    *chunk_rows = chunk;
+    return true;
+}
+
 int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t seed) {
     if (!b) return fail(APE_ERR_INVALID_ARG, "streams_set_mc: NULL bank");
     if (n_mc < 1 || (long long)n_mc * b->smooth > 4096)
@@ -1403,13 +1419,8 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
             // 8192 x 25, T = 6: one 1.26 GB chunk 9.30 ms per frame, five 256 MB chunks -- the Infinity Cache's size -- 9.38 ms: a
             // launch's prologue and tail cost more than the cache residency of the tiles buys; 288 GB of HBM make the footprint
             // a non-issue.)
-            const long long total = (long long)b->S * n_mc;
-            // (the pre-laid input is T x 1 KiB per sample row of a 2 x 256 model, T x 512 B of the 3 x 128 model)
-            const long long max_chunk = ((2047ll << 20) / ((long long)b->T * (can_up128 ? 512 : 1024))) / 1024 * 1024;
-            if (max_chunk >= 1024 && total < (1ll << 31)) {          // (the input builder indexes sample rows with 32 bits)
-                const long long n_chunks = (total + max_chunk - 1) / max_chunk;
-                long long chunk = ((total + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;
-                if (chunk > total) chunk = (total + 31) / 32 * 32;
+            long long chunk = 0;
+            if (bank_chunk_plan(can_up128, b->S, b->T, n_mc, &chunk)) {
                 b->chunk_rows = (int)chunk;
                 if (can_up128) {
                     // the 3 x 128 model: launch A stays on the batch-tile kernel ([S,T,H] in the model's sequence workspace), launch B =
@@ -1573,7 +1584,10 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
         if ((size_t)b->S * b->T > m->hseq_cap) return fail(APE_ERR_CAPACITY, "streams_step: the layer-0 sequence workspace is gone");
         const int H = m->dims.hidden_size, I = m->dims.input_size, O = m->dims.output_size;
-        const bool cluster_route = b->up32 && !m->replaying;
+        // (the cooperative routes were planned by ape_streams_set_mc; a later set_kernel(TILE16 / AUTO_GEN1 / CLUSTER) or set_precision --
+        //  the documented ways to keep persistent clusters off a shared GPU -- sends the step to the batch-tile route like a replay)
+        const bool coop = !m->replaying && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32;
+        const bool cluster_route = b->up32 && coop;
         hipError_t e = hipSuccess;
         if (cluster_route) {
             // launch A on the weight-stationary structure (lstm_upper32.hip, SEQ form): S streams in tiles of 32 on the clusters,
@@ -1638,7 +1652,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: upper-layer cluster launch failed: %s", hipGetErrorString(e));
             }
             ++b->mc_calls;
-        } else if (b->up128 && !m->replaying) {
+        } else if (b->up128 && coop) {
             // the 3 x 128 model: layers 1 and 2 on the four-member weight-stationary clusters (lstm_upper128.hip), per chunk of sample
             // rows: masked input + layer-1 keep bits, the persistent kernel, the head reduce
             if (b->inj_masks) return fail(APE_ERR_UNSUPPORTED, "streams_step: injected masks (test hook) on the 3 x 128 weight-stationary route");
@@ -1914,6 +1928,15 @@ int ape_debug_plan2(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, 
     }
     return APE_OK;
 }
+int ape_debug_bank_chunks(int up128, int S, int T, int n_mc, long long out[3]) {
+    if (!out || S < 1 || T < 1 || n_mc < 1) return APE_ERR_INVALID_ARG;
+    long long chunk = 0;
+    out[0] = bank_chunk_plan(up128 != 0, S, T, n_mc, &chunk) ? 1 : 0;
+    out[1] = chunk;
+    out[2] = out[0] ? ((long long)S * n_mc + chunk - 1) / chunk : 0;
+    return APE_OK;
+}
+
 int ape_debug_plan(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, int out[5]) {
     int o6[6];
     const int rc = ape_debug_plan2(dims, n_cus, B, T, cdrop, 0, o6);
@@ -1936,7 +1959,7 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
         if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, gen2_of(m), m->wide_cluster) > B) return m->kernel_name.c_str();
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
-    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 12) return "ape_lstm_cluster16<128, 3, 64>";
+    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 12) return "ape_lstm_cluster16<128, 3, 64, 2>";
     return m->cluster_name.c_str();
 }
 

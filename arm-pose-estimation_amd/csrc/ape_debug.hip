@@ -42,7 +42,7 @@ int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
 // shrink the chunk of sample rows a Monte-Carlo bank's weight-stationary route handles per launch (a multiple of 32, never
 // above what the bank's workspaces were sized for): lets a test run the multi-chunk path at a size that otherwise fits one
 int ape_debug_set_chunk_rows(ape_streams_t* b, int rows) {
-    if (!b || !b->up32 || rows < 32 || rows % 32 != 0 || rows > b->chunk_rows) return APE_ERR_INVALID_ARG;
+    if (!b || !(b->up32 || b->up128) || rows < 32 || rows % 32 != 0 || rows > b->chunk_rows) return APE_ERR_INVALID_ARG;
     b->chunk_rows = rows;
     return APE_OK;
 }

@@ -29,7 +29,7 @@ def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
     m, sd, cfg = make_model(name, 0, norm_stats[name])
     poke = _poke(_hip.lib())
     T = cfg["T"] if B < 1024 else 64
-    if B == 1024: assert m.kernel_name(B, T) == {"pocket": "ape_lstm_cluster32<256, 2, 32>", "uarm": "ape_lstm_cluster16<128, 3, 64>"}[name]
+    if B == 1024: assert m.kernel_name(B, T) == {"pocket": "ape_lstm_cluster32<256, 2, 32>", "uarm": "ape_lstm_cluster16<128, 3, 64, 2>"}[name]
     x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 3))
     good = m(x, last_step_only=True, normalize_input=True).numpy().copy()
     m.set_kernel("tile16")
@@ -65,19 +65,20 @@ def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
         assert np.array_equal(m(x, last_step_only=True, normalize_input=True).numpy(), good)
 
 
-def test_aborted_infer_and_bank_step_are_reissued(norm_stats):
+@pytest.mark.parametrize("name,S,n_mc,route", [("pocket", 330, 25, "ape_lstm_upper32"), ("uarm", 170, 50, "ape_lstm_upper128")])
+def test_aborted_infer_and_bank_step_are_reissued(norm_stats, name, S, n_mc, route):
     """ape_infer (LSTM + post-filter) and a Monte-Carlo stream-bank step behind an aborted launch: recover re-issues both; a bank
-    that has moved on since the aborted step cannot be re-issued and says so."""
+    that has moved on since the aborted step cannot be re-issued and says so.  Both weight-stationary bank routes (2 x 256: lstm_upper32.hip,
+    3 x 128: lstm_upper128.hip)."""
     from wear_mocap_ape_amd import _hip
     from wear_mocap_ape_amd.streams import StreamBank
-    name = "pocket"
     m, sd, cfg = make_model(name, 2, norm_stats[name])
     m.set_body(orc.DEFAULT_BODY)
     lib = _hip.lib()
     poke = _poke(lib)
     B, T = 700, cfg["T"]
     x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 5)).cuda()
-    est = torch.empty((B, 21), dtype=torch.float64, device="cuda")
+    est = torch.empty((B, 21 if name == "pocket" else 14), dtype=torch.float64, device="cuda")
 
     def infer():
         _hip.check(lib.ape_infer(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT, None, C.c_void_p(est.data_ptr()),
@@ -91,7 +92,6 @@ def test_aborted_infer_and_bank_step_are_reissued(norm_stats):
     assert np.abs(est.cpu().numpy() - good).max() < 2e-6
     assert m.stats()["reissued_calls"] == 1
     # a Monte-Carlo bank on the weight-stationary upper-layer kernel: the same step again on the batch-tile route (same Philox masks)
-    S, n_mc = 330, 25
     feats = _synthetic_windows(norm_stats[name], S, 4, cfg["I"], 6)
     def run(abort_at):
         bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=99)
@@ -101,6 +101,7 @@ def test_aborted_infer_and_bank_step_are_reissued(norm_stats):
             if f == abort_at:
                 assert poke(m.handle, 0, 1) == 0
             msg, tail = bank.step(with_tail=True)
+            assert m.last_kernel() == route
             bank.recover()
             outs.append((msg.cpu().numpy().copy(), tail.cpu().numpy().copy()))
         return outs
@@ -205,13 +206,14 @@ def test_latency_kernel_launch_number_wrap():
     model.check()
 
 
-def test_mc_bank_in_several_chunks(norm_stats):
+@pytest.mark.parametrize("name,S,n_mc", [("pocket", 330, 25), ("uarm", 170, 50)])
+def test_mc_bank_in_several_chunks(norm_stats, name, S, n_mc):
     """the weight-stationary route handles the sample rows in chunks (one launch each, <= 2 GiB of pre-laid input): a bank cut
     into chunks of 2048 rows by the test hook must give the bits of the same bank in one chunk (Philox counters and tile
     contents are functions of the GLOBAL row index)"""
     from wear_mocap_ape_amd import _hip
     from wear_mocap_ape_amd.streams import StreamBank
-    name, S, n_mc = "pocket", 330, 25                      # 8250 sample rows: 4 chunks of 2048 + one of 58
+    # (8250 / 8500 sample rows: 4 chunks of 2048 + a ragged one)
     stats = norm_stats[name]
     cfg = orc.MODEL_CONFIGS[name]
     lib = _hip.lib()

@@ -34,7 +34,7 @@ def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
     xd = torch.from_numpy(x).cuda()
     xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
     model.set_kernel("cluster")
-    assert model.kernel_name(B, T) == "ape_lstm_cluster16<128, 3, 64>"
+    assert model.kernel_name(B, T) == "ape_lstm_cluster16<128, 3, 64, 2>"
     y2 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
     model.check()
     y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]

@@ -104,3 +104,29 @@ def test_monte_carlo_rows_between_the_routes():
     # one row more than a wave's worth of cluster launches costs: whole waves go to the batch-tile kernel
     assert _plan2(pocket, 256, 4096, 6, cdrop=1)["n16"] == 4096
     assert _plan2(pocket, 256, 2460, 64, cdrop=1)["n16"] == 0
+
+
+def test_bank_chunk_plan_keeps_every_32_bit_descriptor_under_2_gib():
+    """ape_streams_set_mc's size rule (round-3 advisor): launch B's pre-laid input is chunked under 2 GiB, and a 2 x 256 bank whose
+    LAUNCH A buffers (sequence / input tiles behind one 32-bit descriptor each) would outgrow 2 GiB keeps the batch-tile route."""
+    from wear_mocap_ape_amd import _hip
+    lib = _hip.lib()
+    lib.ape_debug_bank_chunks.restype = C.c_int
+    lib.ape_debug_bank_chunks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong * 3)]
+
+    def plan(up128, S, T, n_mc):
+        out = (C.c_longlong * 3)()
+        assert lib.ape_debug_bank_chunks(up128, S, T, n_mc, C.byref(out)) == 0
+        return tuple(out)
+
+    assert plan(0, 1024, 6, 25) == (1, 25600, 1)
+    assert plan(0, 8192, 6, 25) == (1, 204800, 1)                  # 1.26 GB in one chunk
+    fits, chunk, n = plan(0, 8192, 64, 25)                         # 13 GB of pre-laid input: chunks of whole 1024-row waves under 2 GiB
+    assert fits == 1 and chunk % 1024 == 0 and chunk * 64 * 1024 < 2047 << 20 and n * chunk >= 8192 * 25 and (n - 1) * chunk < 8192 * 25
+    assert plan(0, 65536, 64, 2)[0] == 0                           # launch A: 4096 tiles x 64 steps x 32 KB = 4 GiB of sequence
+    assert plan(0, 32768, 63, 2)[0] == 1                           # just under it
+    assert plan(1, 65536, 64, 2)[0] == 1                           # the 3 x 128 route keeps launch A on the batch-tile kernel
+    assert plan(1, 1024, 6, 50) == (1, 51200, 1)
+    fits, chunk, n = plan(1, 100, 6, 21)                           # 2100 rows: one ragged chunk, rounded to whole 32-row tiles
+    assert (fits, chunk, n) == (1, 2112, 1)
+    assert plan(0, 2 ** 20, 6, 4096)[0] == 0                       # 2^32 sample rows: beyond the input builder's 32-bit row index

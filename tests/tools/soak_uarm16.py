@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
         x = torch.randn(B, T, cfg["I"], device="cuda")
         ys = [torch.empty(B, cfg["O"], device="cuda") for _ in range(3)]
         m.set_kernel("cluster")
-        assert m.kernel_name(B, T) == "ape_lstm_cluster16<128, 3, 64>"
+        assert m.kernel_name(B, T) == "ape_lstm_cluster16<128, 3, 64, 2>"
         for y in ys:                                     # three launches back to back
             _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, flags, None, 0.0, 0, C.c_void_p(y.data_ptr()), st), "fwd")
         m.check()
