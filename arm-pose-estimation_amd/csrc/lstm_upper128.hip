@@ -88,23 +88,15 @@ __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 r
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
-// hook positions of a section (k-block indices; see `mid` below)
+// hook positions of a section (k-block indices 0 .. 63; see `mid` below)
 #ifndef UP128_QF
 #define UP128_QF 3
 #endif
 #ifndef UP128_QP
 #define UP128_QP 20
 #endif
-#ifndef UP128_QP_FIRST
-#define UP128_QP_FIRST 10
-#endif
 #ifndef UP128_QD
-#define UP128_QD 2
-#endif
-// timing experiments only (tests/tools/build_variant.sh; results are garbage): 1 no copies, 2 no flag looks (operands taken for present),
-// 4 no wait / flag raise / mask words at QF, 8 no gate transcendentals, 16 no publish stores
-#ifndef UP128_ABL
-#define UP128_ABL 0
+#define UP128_QD 4
 #endif
 constexpr int UH = 128;                  // hidden units of a layer = width of its input
 constexpr int GH = 4;                    // members per cluster (32 units each)
@@ -118,6 +110,9 @@ constexpr int PO = 16;                   // width of a head partial row (O <= 16
 constexpr unsigned SET_BYTES = HL * sizeof(float);
 
 __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params p) {
+#ifdef APE_CLUSTER_STAMPS
+    const unsigned long long dg_kstart = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,7 +200,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     // flags [cluster][set 2][layer 2][member wave 16]: epoch = slices published; exchange [cluster][set 2][kind 3][parity 2][16 KB],
     // kind 0 = h_1, 1 = h_1 masked, 2 = h_2
     unsigned* const flags_c = p.xflags + (size_t)cluster * 2 * 2 * NFL;
-    auto flags_of = [&](int s, int l) -> unsigned* { return flags_c + (s * 2 + l) * NFL; };
     auto ex_base = [&](int s, int kind, int par) -> unsigned { return (unsigned)(((((size_t)cluster * 2 + s) * 3 + kind) * 2 + par) * SET_BYTES); };
     const unsigned xb_lds = (unsigned)reinterpret_cast<unsigned long long>(xb);       // LDS byte addresses
     const unsigned h1b_lds = (unsigned)reinterpret_cast<unsigned long long>(h1b);
@@ -235,15 +229,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     if (ctl[0] != 0) return;
     const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
 
-    // per-lane addresses of the hooks' loads, computed once: the look at the other set's flags (lanes 0..15 the input operand's layer-1
-    // flags, lanes 16..31 the recurrent operand's -- layer 1's again when the next section is a layer-1 one, else layer 2's; + the set's
-    // 2 * NFL words), the mask words of this lane's four units (+ (tile * T + t) * 128 words)
-    const unsigned* const peek_lane0 = flags_c + (lane & 15);
-    const unsigned* const peek_lane1 = flags_c + (lane & 15) + ((lane & 16) ? NFL : 0);
+    // per-lane addresses of the hooks' loads, computed once: the look at a set's flags (+ the set's 2 * NFL words; all four quarter-waves
+    // read the same sixteen), the mask words of this lane's four units (+ (tile * T + t) * 128 words)
+    const unsigned* const peek_lane = flags_c + (lane & 15);
     const u32x4* const mask_lane = reinterpret_cast<const u32x4*>(p.maskbits + member * 32 + wave * 8 + 4 * hh);
-    // every wave polls for itself: have all member waves published epoch `want` of (set s, layer l)?
+    // every wave polls for itself: have all member waves published epoch `want` of set s?
     auto wait_flags = [&](const unsigned* fl, unsigned want) {
-        if (UP128_ABL & 4) return;
         unsigned spins = 0;
         while (true) {
             unsigned v = want;
@@ -266,11 +257,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     // (`nrec` = the descriptor's record count: 0 turns the instruction into one that touches no memory -- zeros into an LDS buffer nobody
     //  reads before its real copy -- so that the hooks of a section need no branch on a verdict)
     auto copy_piece = [&](unsigned lds_base, int s, u32x4 desc, unsigned nrec, unsigned src, int k) {
-        if (UP128_ABL & 1) return;
         desc[2] = nrec;
         dma_1k(opaque(lds_base + wave_kib) + (unsigned)s * SET_BYTES + (unsigned)(k * 4096), dma_voff, desc, src + (unsigned)(wave * 1024 + k * 4096));
     };
-    // the flags a wave owes for the slices it stored last (layer 1: two stores, one flag): raised once those stores have drained
+    // the flag a wave owes for the slices it stored last (three stores, one flag): raised once those stores have drained
     // (address and value sit in vector registers from the publish on: no VALU instruction for them inside the next section's MFMA stream)
     bool pend = false;
     unsigned* pend_ptr = flags_c;
@@ -288,7 +278,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     };
     auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // ---- per-set state (uniform over the workgroup AND over the cluster: every member walks the same tiles)
+    // ---- per-set state (uniform over the workgroup AND over the cluster: every member walks the same tiles).  A set's tiles are one
+    //      stream of steps: section k of the set = layer 1 on step k of that stream AND layer 2 on step k - 1 (the last step of the tile
+    //      in front when k is a tile's first), so a set with n tiles has n * T + 1 sections, the first without a layer-2 part, the last
+    //      without a layer-1 part.
     float cst[2][2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -296,163 +289,159 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         for (int l = 0; l < 2; ++l)
 #pragma unroll
             for (int j = 0; j < 4; ++j) cst[s][l][j] = 0.0f;
-    int tile_of[2], step_of[2];              // the set's current tile (-1: none left) and step
-    unsigned pub[2][2] = {{0u, 0u}, {0u, 0u}};   // [set][layer]: slices published so far = epoch of the newest ones
-    bool prex[2] = {false, false};           // the input operand / the recurrent operand of the set's NEXT section are on their way
-    bool preh[2] = {false, false};           //   (issued by the other set's section)
+    int a_tile[2], a_t[2], b_tile[2], b_t[2];    // the (tile, step) of the set's NEXT section: layer-1 part (a), layer-2 part (b)
+    bool a_act[2], b_act[2];                     // ... and whether it has that part
+    unsigned ksec[2] = {0u, 0u};                 // sections the set has run = slices epochs it has published
+    bool pre[2] = {false, false};                // the operands of the set's next section are on their way (issued by the other set's section)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int tl = cluster + s * NC;
-        tile_of[s] = tl < p.n_tiles ? tl : -1;
-        step_of[s] = 0;
+        a_act[s] = tl < p.n_tiles;
+        a_tile[s] = tl; a_t[s] = 0;
+        b_act[s] = false;
+        b_tile[s] = tl; b_t[s] = 0;
     }
     const int frag = n * 8 + hh * 4;                              // this lane's 16 bytes inside a [row][8 units] block
     const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
     const float keep = 1.0f / (1.0f - p.dropout_p);
-
-    // the operands of section (set s, layer l = 0 / 1 for model layers 1 / 2) of step t of tile `tile`:
-    //   input      l = 0: the pre-laid tile-step of p.xfrag;              l = 1: the masked h_1 of THIS step (epoch pub[s][0], kind 1)
-    //   recurrent  (t >= 1)  the layer's own h of the step before: epoch pub[s][l] (kind 0 / 2)
     const unsigned xf_rec = xf_desc[2], hx_rec = hx_desc[2];
-    auto issue_in_piece = [&](int s, int l, int tile, int t, int k, bool on) {
-        if (l == 0) copy_piece(xb_lds, s, xf_desc, on ? xf_rec : 0u, (unsigned)(((size_t)tile * T + t) * SET_BYTES), k);
-        else copy_piece(m1b_lds, s, hx_desc, on ? hx_rec : 0u, ex_base(s, 1, (int)((pub[s][0] - 1u) & 1u)), k);
-    };
-    auto issue_rec_piece = [&](int s, int l, int k, bool on) {
-        if (l == 0) copy_piece(h1b_lds, s, hx_desc, on ? hx_rec : 0u, ex_base(s, 0, (int)((pub[s][0] - 1u) & 1u)), k);
-        else copy_piece(h2b_lds, s, hx_desc, on ? hx_rec : 0u, ex_base(s, 2, (int)((pub[s][1] - 1u) & 1u)), k);
+    constexpr unsigned NOWHERE = 0x80000000u;                     // a store offset beyond the exchange buffer: dropped by the bounds check
+
+    // the sixteen 1-KiB pieces (per wave) of the operands of set s's NEXT section, piece i = 0 .. 15:
+    //   0..3   layer 1's input: the pre-laid tile-step of p.xfrag                              (if the section has a layer-1 part)
+    //   4..7   h_1 of the step before            (kind 0)   ... and that step is not a tile's first
+    //   8..11  layer 2's input: h_1 of ITS step under the rows' masks (kind 1)                 (if it has a layer-2 part)
+    //   12..15 h_2 of the step before            (kind 2)   ... and that step is not a tile's first
+    // the three kinds were published together by the set's section in front (epoch ksec[s], parity of ksec[s] - 1)
+    auto issue_piece = [&](int s, int i, bool go) {
+        const int par = (int)((ksec[s] - 1u) & 1u);
+        const int k = i & 3;
+        if (i < 4) copy_piece(xb_lds, s, xf_desc, (go && a_act[s]) ? xf_rec : 0u, (unsigned)(((size_t)a_tile[s] * T + a_t[s]) * SET_BYTES), k);
+        else if (i < 8) copy_piece(h1b_lds, s, hx_desc, (go && a_act[s] && a_t[s] != 0) ? hx_rec : 0u, ex_base(s, 0, par), k);
+        else if (i < 12) copy_piece(m1b_lds, s, hx_desc, (go && b_act[s]) ? hx_rec : 0u, ex_base(s, 1, par), k);
+        else copy_piece(h2b_lds, s, hx_desc, (go && b_act[s] && b_t[s] != 0) ? hx_rec : 0u, ex_base(s, 2, par), k);
     };
 
 #ifdef APE_CLUSTER_STAMPS
-    // diagnostic counters and shader-clock sums (cluster 0, member 0, wave 0): sections, blocking tops by cause, cycles in the top of a
-    // section (wait + barrier), its MFMA chain, the gate math (+ head), the publish
-    unsigned long long dg_block_x = 0, dg_block_h = 0, dg_sections = 0, dg_top = 0, dg_chain = 0, dg_gates = 0, dg_pub = 0, dg_t0 = 0;
+    // diagnostic counters and shader-clock sums (cluster 0, member 0, wave 0): sections, blocking tops, cycles in the top of a section
+    // (wait + barrier), its MFMA chains, the gate math (+ head), the publish
+    unsigned long long dg_block = 0, dg_sections = 0, dg_top = 0, dg_chain = 0, dg_gates = 0, dg_pub = 0, dg_t0 = 0;
 #define UP_STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - dg_t0; dg_t0 = now_; }
 #else
 #define UP_STAMP(acc)
 #endif
-    // One section = one layer of one step of one set.  Vector-memory queue of a wave in a steady-state section, in issue order:
-    //   [publish stores of the section in front: 2 behind a layer-1 section, 1 behind a layer-2 one]  mask words (layer 1)
-    //   copies + flag look + copies for the NEXT section (the other set's)  [head partial store]  publish store(s)
-    // so at the top everything but the NPREV youngest entries is waited for, and a few k-blocks in those have drained too.
-    auto section = [&](auto set_tag, auto layer_tag, auto first_tag, auto nprev_tag) -> bool {
-        constexpr int s = decltype(set_tag)::value, o = s ^ 1, l = decltype(layer_tag)::value;
-        constexpr bool first = decltype(first_tag)::value;          // step 0 of a tile: no recurrent span (h_{-1} = 0)
-        constexpr int NPREV = decltype(nprev_tag)::value;
-        const int t = step_of[s], tile = tile_of[s];
-        const bool last = t == T - 1;
+    // One section = one step of one set, both layers.  Vector-memory queue of a wave in a steady-state section, in issue order:
+    //   [the three publish stores of the section in front]   QF: their flag; mask words   QP: flag look   QJ ..: the sixteen copies for the
+    //   NEXT section (the other set's)   [head partial store]   three publish stores
+    // so at the top everything but the three youngest entries is waited for, and a few k-blocks in those have drained too.
+    auto section = [&](auto set_tag) -> bool {
+        constexpr int s = decltype(set_tag)::value, o = s ^ 1;
+        const unsigned k = ksec[s];
+        const bool actA = a_act[s], actB = b_act[s];
+        const int tileA = a_tile[s], tA = a_t[s], tileB = b_tile[s], tB = b_t[s];
+        const bool lastA = tA == T - 1, lastB = tB == T - 1;
+        const bool recA = actA && tA != 0, recB = actB && tB != 0;      // (h_{-1} = 0: a tile's first step has no recurrent span)
 #ifdef APE_CLUSTER_STAMPS
         dg_sections += 1;
         dg_t0 = __builtin_amdgcn_s_memtime();
-        if (!prex[s]) dg_block_x += 1; else if (!(first || preh[s])) dg_block_h += 1;
+        if (!pre[s]) dg_block += 1;
 #endif
-        // ---- S0: this section's operands
-        if (prex[s] && (first || preh[s])) {
-            if constexpr (NPREV == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // ---- top: this section's operands
+        if (pre[s]) {
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // the prefetched copies (+ a head partial store); only the publish stores are younger
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             raise_pending();
-            if (!prex[s]) {
-                if (l == 1) wait_flags(flags_of(s, 0), pub[s][0]);
+            if (k != 0u) wait_flags(flags_c + s * 2 * NFL, k);
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_in_piece(s, l, tile, t, k, true);
-            }
-            if (!first && !preh[s]) {
-                wait_flags(flags_of(s, l), pub[s][l]);
-#pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_rec_piece(s, l, k, true);
-            }
+            for (int i = 0; i < 4 * NDMA; ++i) issue_piece(s, i, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        prex[s] = false;
-        preh[s] = false;
+        pre[s] = false;
         bar();                                                      // (unconditional: lstm_upper32.hip on why)
         UP_STAMP(dg_top);
         const int abort_word = ctl[0];
-        // the NEXT section: [set 0, l] -> [set 1, l]; [set 1, layer 1] -> [set 0, layer 2]; [set 1, layer 2] -> [set 0, layer 1] of its next step
-        constexpr int nl = (s == 0) ? l : (l ^ 1);
-        const bool o_act = tile_of[o] >= 0;
-        const int o_t = step_of[o];
-        const bool o_h = o_act && o_t >= 1;
-        const unsigned want_x = pub[o][0], want_h = pub[o][nl];
+        // the NEXT section is the other set's (if it has one left)
+        const bool o_more = a_act[o] || b_act[o];
+        const unsigned want = ksec[o];
         unsigned peek = 0u;
-        bool go_x = false, go_h = false;
+        bool go = false;
         u32x4 mw = {0u, 0u, 0u, 0u};
-        // hooks in the MFMA stream (k-block q of the section, a constant after unrolling):
-        //   QF   the flags owed for the publish stores of the section in front (drained by now); layer 1: request the mask words
-        //   QP   look at the other set's flags (one load per lane: lanes 0..15 the input's, 16..31 the recurrent operand's)      QJ  judge
-        //   QJ .. +3  one piece of the next section's input per block, QJ + 4 .. + 7 one of its recurrent operand
-        constexpr int QF = UP128_QF;
-        constexpr int QP = first ? UP128_QP_FIRST : UP128_QP, QJ = QP + UP128_QD;
-        constexpr int QEND = QJ + 2 * NDMA;
+        // hooks in the MFMA stream (k-block q of the section's 64, a constant after unrolling; a span that does not run -- no layer-1 /
+        // layer-2 part, a tile's first step -- leaves its hooks behind, back to back):
+        //   QF   the flag owed for the publish stores of the section in front (drained by now); the mask words of layer 1's outputs
+        //   QP   look at the other set's flags      QJ   judge      QJ .. QJ + 15   one piece of the next section's operands per block
+        constexpr int QF = UP128_QF, QP = UP128_QP, QJ = QP + UP128_QD;
         auto mid = [&](int q) {
-            if (q == QF && !(UP128_ABL & 4)) {
+            if (q == QF) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
-                if (l == 0) mw = words_issue(mask_lane + ((size_t)tile * T + t) * (UH / 4));
+                mw = words_issue(mask_lane + ((size_t)(actA ? tileA : 0) * T + tA) * (UH / 4));     // (no layer-1 part: a word nobody uses)
             }
-            if (q == QP && !(UP128_ABL & 2)) peek = peek_issue((nl == 0 ? peek_lane0 : peek_lane1) + o * 2 * NFL);
-            if (q == QJ && (UP128_ABL & 2)) { go_x = o_act; go_h = o_h; }
-            if (q == QJ && !(UP128_ABL & 2)) {
-                if constexpr (l == 0) peek_wait(peek, mw);        // (the mask words, requested at QF, are in by now as well)
-                else peek_wait(peek);
-                // (layer 1's input needs no flag: it was laid down by the launch in front)
-                constexpr unsigned long long IN_LANES = 0x0000FFFF0000FFFFull;       // lanes with (lane & 16) == 0
-                go_x = o_act && (nl == 0 || (__builtin_amdgcn_ballot_w64(peek >= want_x) | ~IN_LANES) == ~0ull);
-                go_h = o_h && (__builtin_amdgcn_ballot_w64(peek >= want_h) | IN_LANES) == ~0ull;
+            if (q == QP) peek = peek_issue(peek_lane + o * 2 * NFL);
+            if (q == QJ) {
+                peek_wait(peek, mw);                              // (the mask words, requested at QF, are in by now as well)
+                go = o_more && (want == 0u || __builtin_amdgcn_ballot_w64(peek >= want) == ~0ull);
             }
-            if (q >= QJ && q < QJ + NDMA) issue_in_piece(o, nl, tile_of[o], o_t, q - QJ, go_x);
-            if (q >= QJ + NDMA && q < QJ + 2 * NDMA) issue_rec_piece(o, nl, q - QJ - NDMA, go_h);
+            if (q >= QJ && q < QJ + 4 * NDMA) issue_piece(o, q - QJ, go);
         };
-        // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs
-        f32x16 acc;
+        auto hooks = [&](int q0) {
+#pragma unroll
+            for (int q = q0; q < q0 + BH; ++q) mid(q);
+        };
+        // ---- stacked-gate products: one dependent chain of 32x32x2 MFMAs per layer
+        f32x16 accA, accB;
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
-            const f32x4 bv = bias_s[((l * 4 + wave) * 4 + gate) * 2 + hh];
-            acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
+            const f32x4 b1 = bias_s[((0 * 4 + wave) * 4 + gate) * 2 + hh], b2 = bias_s[((1 * 4 + wave) * 4 + gate) * 2 + hh];
+            accA[4 * gate] = b1[0]; accA[4 * gate + 1] = b1[1]; accA[4 * gate + 2] = b1[2]; accA[4 * gate + 3] = b1[3];
+            accB[4 * gate] = b2[0]; accB[4 * gate + 1] = b2[1]; accB[4 * gate + 2] = b2[2]; accB[4 * gate + 3] = b2[3];
         }
-        span32<BH, 2 * NWL>(acc, (l == 0 ? xb : m1b) + s * HL + frag, MR * 8, w, l * NWL, [&](int q) { mid(q); });
-        if constexpr (!first) span32<BH, 2 * NWL>(acc, (l == 0 ? h1b : h2b) + s * HL + frag, MR * 8, w, l * NWL + 4 * BH, [&](int q) { mid(BH + q); });
-        {
-            constexpr int NBLK = first ? BH : 2 * BH;
-#pragma unroll
-            for (int q = NBLK; q < QEND; ++q) mid(q);
-        }
+        if (actA) span32<BH, 2 * NWL>(accA, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
+        else hooks(0);
+        if (recA) span32<BH, 2 * NWL>(accA, h1b + s * HL + frag, MR * 8, w, 4 * BH, [&](int q) { mid(BH + q); });
+        else hooks(BH);
+        if (actB) span32<BH, 2 * NWL>(accB, m1b + s * HL + frag, MR * 8, w, NWL, [&](int q) { mid(2 * BH + q); });
+        else hooks(2 * BH);
+        if (recB) span32<BH, 2 * NWL>(accB, h2b + s * HL + frag, MR * 8, w, NWL + 4 * BH, [&](int q) { mid(3 * BH + q); });
+        else hooks(3 * BH);
         // (the other set idle: THIS set runs the next section too, and its top copies into buffers read above -- every wave must be
-        //  through with them first; `tile_of[o] < 0` is state, uniform over the workgroup, so the extra barrier pairs up)
-        if (tile_of[o] < 0) bar();
-        mfma_drain(acc);
+        //  through with them first; `o_more` is state, uniform over the workgroup, so the extra barrier pairs up)
+        if (!o_more) bar();
+        mfma_drain(accA);
+        mfma_drain(accB);
         UP_STAMP(dg_chain);
         // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, row n
-        float hnew[4];
+        float hA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, hB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto gates = [&](const f32x16& acc, float (&c_)[4], float (&hn)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
-            auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
-            const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
-            if (UP128_ABL & 8) { hnew[j] = ai[0] + af[0] + ag[0] + ao[0]; hnew[j + 1] = ai[1] + af[1] + ag[1] + ao[1]; continue; }
-            const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
-            const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
-            const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
-            const f32x2 ov = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ao));
-            const f32x2 c = first ? iv * gv : fv * f32x2{cst[s][l][j], cst[s][l][j + 1]} + iv * gv;
-            cst[s][l][j] = c[0]; cst[s][l][j + 1] = c[1];
-            const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
-            hnew[j] = h[0]; hnew[j + 1] = h[1];
-        }
+            for (int j = 0; j < 4; j += 2) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
+                auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
+                const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
+                const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
+                const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
+                const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
+                const f32x2 ov = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ao));
+                const f32x2 c = fv * f32x2{c_[j], c_[j + 1]} + iv * gv;     // (a tile's first step finds c = 0: f * 0 + i * g = i * g exactly)
+                c_[j] = c[0]; c_[j + 1] = c[1];
+                const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
+                hn[j] = h[0]; hn[j + 1] = h[1];
+            }
+        };
+        if (actA) gates(accA, cst[s][0], hA);
+        if (actB) gates(accB, cst[s][1], hB);
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
-        prex[o] = go_x;
-        preh[o] = go_h;
-        if (l == 1 && last) {
-            // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h values are the activation fragment
+        pre[o] = go;
+        if (actB && lastB) {
+            // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h_2 values are the activation fragment
             f32x16 ya;
 #pragma unroll
             for (int i = 0; i < 16; ++i) ya[i] = 0.0f;
             const f32x4 wv = wo_s[wave * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mfma32<false>(ya, wv[j], hnew[j]);
+            for (int j = 0; j < 4; ++j) mfma32<false>(ya, wv[j], hB[j]);
             mfma_drain(ya);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -467,77 +456,73 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
                     const int idx = (4 * oq + i) * MR + rn;
                     sum[i] = ((hp[idx] + hp[PO * MR + idx]) + hp[2 * PO * MR + idx]) + hp[3 * PO * MR + idx];
                 }
-                *reinterpret_cast<f32x4*>(p.ypart + (((size_t)tile * MR + rn) * GH + member) * PO + 4 * oq) = sum;
+                *reinterpret_cast<f32x4*>(p.ypart + (((size_t)tileB * MR + rn) * GH + member) * PO + 4 * oq) = sum;
             }
         }
         UP_STAMP(dg_gates);
-        // ---- publish: this lane's four fresh h values are one 16-byte piece of the exchange layout.  Layer 1: TWO stores, plain (its own
-        //      recurrence; to nowhere on a last step) and under the row's masks (layer 2's input); layer 2: ONE (to nowhere on a last step).
-        //      The counted wait at the top of the next section relies on exactly that many.
+        // ---- publish: a lane's four fresh values of a layer are one 16-byte piece of the exchange layout.  Always THREE stores (the
+        //      counted wait at the next top relies on it): h_1 plain (layer 1's recurrence), h_1 under the rows' masks (layer 2's input),
+        //      h_2 plain; what nobody will read -- a tile's last step's plain values, a part the section did not have -- goes to an
+        //      offset beyond the buffer and is dropped.
         {
-            const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
-                              __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
-            const int par = (int)(pub[s][l] & 1u);
-            if (l == 0) {
-                u32x4 hm;
+            const int par = (int)(k & 1u);
+            const u32x4 v1 = {__builtin_bit_cast(unsigned, hA[0]), __builtin_bit_cast(unsigned, hA[1]),
+                              __builtin_bit_cast(unsigned, hA[2]), __builtin_bit_cast(unsigned, hA[3])};
+            const u32x4 v2 = {__builtin_bit_cast(unsigned, hB[0]), __builtin_bit_cast(unsigned, hB[1]),
+                              __builtin_bit_cast(unsigned, hB[2]), __builtin_bit_cast(unsigned, hB[3])};
+            u32x4 vm;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hm[j] = __builtin_bit_cast(unsigned, ((mw[j] >> n) & 1u) ? hnew[j] * keep : 0.0f);
-                const unsigned off0 = last ? 0x80000000u : ex_base(s, 0, par) + pub_off;
-                const unsigned off1 = ex_base(s, 1, par) + pub_off;
-                if (UP128_ABL & 16) { asm volatile("" :: "v"(hv), "v"(hm)); }
-                else if (in_l2) { store_16<false>(hv, off0, hx_desc); store_16<false>(hm, off1, hx_desc); }
-                else { store_16<true>(hv, off0, hx_desc); store_16<true>(hm, off1, hx_desc); }
-                pub[s][0] += 1u;
-                owe((s * 2 + 0) * NFL + member * 4 + wave, pub[s][0]);
+            for (int j = 0; j < 4; ++j) vm[j] = __builtin_bit_cast(unsigned, ((mw[j] >> n) & 1u) ? hA[j] * keep : 0.0f);
+            const unsigned off0 = (actA && !lastA) ? ex_base(s, 0, par) + pub_off : NOWHERE;
+            const unsigned off1 = actA ? ex_base(s, 1, par) + pub_off : NOWHERE;
+            const unsigned off2 = (actB && !lastB) ? ex_base(s, 2, par) + pub_off : NOWHERE;
+            if (in_l2) { store_16<false>(v1, off0, hx_desc); store_16<false>(vm, off1, hx_desc); store_16<false>(v2, off2, hx_desc); }
+            else { store_16<true>(v1, off0, hx_desc); store_16<true>(vm, off1, hx_desc); store_16<true>(v2, off2, hx_desc); }
+            owe(s * 2 * NFL + member * 4 + wave, k + 1u);
+        }
+        // ---- the set's next section: layer 2 follows layer 1 one step behind; layer 1 moves on, to the set's next tile behind a last step
+        ksec[s] = k + 1u;
+        b_act[s] = actA; b_tile[s] = tileA; b_t[s] = tA;
+        if (actA && tA == 0) {                                    // layer 2 starts that tile next: c_2 = 0
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cst[s][1][j] = 0.0f;
+        }
+        if (actA) {
+            if (lastA) {
+                const int nt = tileA + 2 * NC;
+                a_act[s] = nt < p.n_tiles;
+                a_tile[s] = nt; a_t[s] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cst[s][0][j] = 0.0f;
             } else {
-                const unsigned off = last ? 0x80000000u : ex_base(s, 2, par) + pub_off;
-                if (UP128_ABL & 16) { asm volatile("" :: "v"(hv)); }
-                else if (in_l2) store_16<false>(hv, off, hx_desc);
-                else store_16<true>(hv, off, hx_desc);
-                if (!last) {
-                    pub[s][1] += 1u;
-                    owe((s * 2 + 1) * NFL + member * 4 + wave, pub[s][1]);
-                }
+                a_t[s] = tA + 1;
             }
         }
         UP_STAMP(dg_pub);
-        // ---- next step / next tile of this set (behind its layer-2 section)
-        if (l == 1) {
-            if (last) {
-                const int nt = tile + 2 * NC;
-                tile_of[s] = nt < p.n_tiles ? nt : -1;
-                step_of[s] = 0;
-            } else {
-                step_of[s] = t + 1;
-            }
-        }
         return true;
     };
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    using N1 = std::integral_constant<int, 1>;
-    using N2 = std::integral_constant<int, 2>;
+#ifdef APE_CLUSTER_STAMPS
+    const unsigned long long dg_first = __builtin_amdgcn_s_memtime();
+#endif
     bool ok = true;
 #pragma unroll 1
-    while (ok && (tile_of[0] >= 0 || tile_of[1] >= 0)) {
-        // (a set's two sections of a step run in this order; which sections surround them decides how many publish stores are the
-        //  youngest entries of the queue at a top: [0, L1] follows [1, L2] (one), [1, L1] follows [0, L1] (two), [0, L2] follows
-        //  [1, L1] (two), [1, L2] follows [0, L2] (one) -- with one set idle every top takes the blocking form anyway)
-        const bool a0 = tile_of[0] >= 0, a1 = tile_of[1] >= 0;
-        const bool f0 = step_of[0] == 0, f1 = step_of[1] == 0;
-        if (a0) ok = f0 ? section(S0{}, S0{}, std::true_type{}, N1{}) : section(S0{}, S0{}, std::false_type{}, N1{});
-        if (ok && a1) ok = f1 ? section(S1{}, S0{}, std::true_type{}, N2{}) : section(S1{}, S0{}, std::false_type{}, N2{});
-        if (ok && a0) ok = f0 ? section(S0{}, S1{}, std::true_type{}, N2{}) : section(S0{}, S1{}, std::false_type{}, N2{});
-        if (ok && a1) ok = f1 ? section(S1{}, S1{}, std::true_type{}, N1{}) : section(S1{}, S1{}, std::false_type{}, N1{});
+    while (ok && (a_act[0] || b_act[0] || a_act[1] || b_act[1])) {
+        if (a_act[0] || b_act[0]) ok = section(S0{});
+        if (ok && (a_act[1] || b_act[1])) ok = section(S1{});
     }
     if (!ok) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (a flag still owed is awaited by nobody: dropped, lstm_upper32.hip)
 
 #ifdef APE_CLUSTER_STAMPS
     if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) {
-        p.dbg_wg[16] = dg_block_x; p.dbg_wg[17] = dg_block_h; p.dbg_wg[18] = dg_sections;
+        p.dbg_wg[16] = dg_block; p.dbg_wg[17] = 0; p.dbg_wg[18] = dg_sections;
         p.dbg_wg[19] = dg_top; p.dbg_wg[20] = dg_chain; p.dbg_wg[21] = dg_gates; p.dbg_wg[22] = dg_pub;
+    }
+    if (p.dbg_wg != nullptr && tid == 0 && member == 0 && cluster < 64) {      // per cluster: entry, first section, exit (shader clock)
+        p.dbg_wg[64 + cluster] = dg_kstart; p.dbg_wg[128 + cluster] = dg_first; p.dbg_wg[192 + cluster] = __builtin_amdgcn_s_memtime();
     }
 #endif
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word

@@ -335,3 +335,38 @@ def test_undeclared_flag_bits_are_refused(norm_stats):
     for bit in (_hip.FLAG_ANY_PLACEMENT, _hip.FLAG_NO_XCD_CLASSES, _hip.FLAG_ALT_FORM):
         assert lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), 8, 6, bit, None, 0.0, 0, C.c_void_p(y.data_ptr()), None) == 0, hex(bit)
     m.check()
+
+
+@pytest.mark.parametrize("name,S,n_mc,route", [("pocket", 170, 25, "ape_lstm_upper32"), ("uarm", 100, 50, "ape_lstm_upper128")])
+def test_bank_cooperative_routes_follow_a_later_set_kernel(norm_stats, name, S, n_mc, route):
+    """round-3 advisor: the bank's weight-stationary routes are planned by ape_streams_set_mc, but `set_kernel('tile16')` -- the documented
+    way to keep persistent clusters off a shared GPU -- must reach a bank that already exists: its next steps run on the batch-tile
+    kernel (same Philox masks: within the float32 budget of the route before), and come back with `set_kernel('auto')`, bit-equal."""
+    from tests.test_hip_parity import make_model, _synthetic_windows
+    from wear_mocap_ape_amd.streams import StreamBank
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 6, st)
+    m.set_body(orc.DEFAULT_BODY)
+    T = cfg["T"]
+    feats = _synthetic_windows(st, S, T + 2, cfg["I"], 77)
+
+    def run(choices):
+        bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=5)
+        outs = []
+        for f in range(T + 2):
+            m.set_kernel(choices[f])
+            bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
+            msg, tail = bank.step(with_tail=True)
+            assert m.last_kernel() == (route if choices[f] == "auto" else "ape_lstm_tile16"), (f, m.last_kernel())
+            outs.append((msg.cpu().numpy().copy(), tail.cpu().numpy().copy()))
+        m.set_kernel("auto")
+        m.check()
+        return outs
+
+    ref = run(["auto"] * (T + 2))
+    got = run(["auto"] * 3 + ["tile16", "auto_gen1"] + ["auto"] * (T - 3))
+    for f, ((a, b), (c, d)) in enumerate(zip(ref, got)):
+        if f in (3, 4):
+            assert np.abs(a - c).max() < 5e-5 and np.abs(b - d).max() < 5e-5 and np.abs(a - c).max() > 0.0
+        else:
+            assert np.array_equal(a, c) and np.array_equal(b, d), f

@@ -27,8 +27,15 @@ lib = _hip.lib()
 lib.ape_debug_read_wg.restype, lib.ape_debug_read_wg.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
 buf = (C.c_ulonglong * (256 * 8))()
 assert lib.ape_debug_read_wg(m.handle, buf) == 0
-bx, bh, n, top, chain, gates, pub = list(buf[16:23])
-bare = ((n - n // T) * 8192 + (n // T) * 4096) / n
-print(f"S={S} n_mc={n_mc}: {n} sections of cluster 0; blocking tops: {bx} for the input operand, {bh} for the recurrent one")
-print(f"cycles per section: top {top / n:.0f}  MFMA chain {chain / n:.0f}  gates (+ head) {gates / n:.0f}  publish {pub / n:.0f}  "
-      f"(sum {(top + chain + gates + pub) / n:.0f}; MFMAs alone: {bare:.0f})")
+blk, _, n, top, chain, gates, pub = list(buf[16:23])
+tiles = (S * n_mc + 31) // 32
+bare = (2 * T - 2) * 4096 * 25 / n if False else None
+print(f"S={S} n_mc={n_mc}: {n} sections of cluster 0 (one per step of a set, both layers), {blk} of them with a blocking top")
+print(f"cycles per section: top {top / n:.0f}  MFMA chains {chain / n:.0f}  gates (+ head) {gates / n:.0f}  publish {pub / n:.0f}  "
+      f"(sum {(top + chain + gates + pub) / n:.0f}); whole launch {(top + chain + gates + pub) / 1e6:.3f} M cycles, "
+      f"MFMAs alone {(tiles / 64) * (2 * T - 1) * 2 * 4096 / 1e6:.3f} M")
+k0 = np.array(buf[64:128], dtype=np.float64); k1 = np.array(buf[128:192], dtype=np.float64); k2 = np.array(buf[192:256], dtype=np.float64)
+if k2.max() > 0:
+    print(f"per cluster (member 0): entry -> first section {np.median(k1 - k0):.0f} cycles (max {(k1 - k0).max():.0f}); first section -> exit "
+          f"median {np.median(k2 - k1) / 1e6:.3f} M, min {(k2 - k1).min() / 1e6:.3f} M, max {(k2 - k1).max() / 1e6:.3f} M; "
+          f"classes (cluster % 8) medians {[round(float(np.median((k2 - k1)[c::8])) / 1e6, 3) for c in range(8)]}")
