@@ -75,12 +75,10 @@ __device__ __forceinline__ u32x4 words_issue(const u32x4* addr) {
 }
 __device__ __forceinline__ void words_wait(u32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 
-template <bool WT>
 __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
     // (s_nop 4: the descriptor may have been reloaded from a spill lane by v_readlane_b32 right in front -- a VALU write of an SGPR needs
     //  five wait states before a vector-memory instruction reads it, and hipcc does not look inside an asm statement)
-    if constexpr (WT) asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
-    else asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer to 1 KiB of LDS at the wave-uniform byte address `lds_addr`
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
@@ -93,7 +91,7 @@ __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 r
 #define UP128_QF 3
 #endif
 #ifndef UP128_QP
-#define UP128_QP 20
+#define UP128_QP 24
 #endif
 #ifndef UP128_QD
 #define UP128_QD 4
@@ -227,8 +225,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     }
     __syncthreads();
     if (ctl[0] != 0) return;
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
-
+    // The slices are handed over by WRITE-THROUGH (sc1) stores even though all members of a cluster share an XCD's L2.  Round 4, found
+    // with this kernel: behind a plain store, `s_waitcnt vmcnt(0)` does not mean that an sc1 load of another CU sees the data -- with
+    // the look at the flags moved forward (copies starting ~1.9 us behind the stores instead of ~2.6 us) the first launch of a fresh
+    // process read stale slices in 7 of 8 runs (whole 32-row tiles off by 1e-3 .. 1e-2), with sc1 stores in 0 of 8; and here, with two
+    // tiles in flight per cluster, the later acknowledgement costs nothing (1.181 vs 1.183 ms per launch).  profiles/r04_bank_uarm.md.
     // per-lane addresses of the hooks' loads, computed once: the look at a set's flags (+ the set's 2 * NFL words; all four quarter-waves
     // read the same sixteen), the mask words of this lane's four units (+ (tile * T + t) * 128 words)
     const unsigned* const peek_lane = flags_c + (lane & 15);
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
 #ifdef APE_CLUSTER_STAMPS
     // diagnostic counters and shader-clock sums (cluster 0, member 0, wave 0): sections, blocking tops, cycles in the top of a section
     // (wait + barrier), its MFMA chains, the gate math (+ head), the publish
-    unsigned long long dg_block = 0, dg_sections = 0, dg_top = 0, dg_chain = 0, dg_gates = 0, dg_pub = 0, dg_t0 = 0;
+    unsigned long long dg_block = 0, dg_go = 0, dg_sections = 0, dg_top = 0, dg_chain = 0, dg_gates = 0, dg_pub = 0, dg_t0 = 0;
 #define UP_STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - dg_t0; dg_t0 = now_; }
 #else
 #define UP_STAMP(acc)
@@ -434,6 +435,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         if (actB) gates(accB, cst[s][1], hB);
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         pre[o] = go;
+#ifdef APE_CLUSTER_STAMPS
+        if (go) dg_go += 1;
+#endif
         if (actB && lastB) {
             // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h_2 values are the activation fragment
             f32x16 ya;
@@ -476,8 +480,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
             const unsigned off0 = (actA && !lastA) ? ex_base(s, 0, par) + pub_off : NOWHERE;
             const unsigned off1 = actA ? ex_base(s, 1, par) + pub_off : NOWHERE;
             const unsigned off2 = (actB && !lastB) ? ex_base(s, 2, par) + pub_off : NOWHERE;
-            if (in_l2) { store_16<false>(v1, off0, hx_desc); store_16<false>(vm, off1, hx_desc); store_16<false>(v2, off2, hx_desc); }
-            else { store_16<true>(v1, off0, hx_desc); store_16<true>(vm, off1, hx_desc); store_16<true>(v2, off2, hx_desc); }
+            store_16(v1, off0, hx_desc); store_16(vm, off1, hx_desc); store_16(v2, off2, hx_desc);
             owe(s * 2 * NFL + member * 4 + wave, k + 1u);
         }
         // ---- the set's next section: layer 2 follows layer 1 one step behind; layer 1 moves on, to the set's next tile behind a last step
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
 
 #ifdef APE_CLUSTER_STAMPS
     if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) {
-        p.dbg_wg[16] = dg_block; p.dbg_wg[17] = 0; p.dbg_wg[18] = dg_sections;
+        p.dbg_wg[16] = dg_block; p.dbg_wg[17] = dg_go; p.dbg_wg[18] = dg_sections;
         p.dbg_wg[19] = dg_top; p.dbg_wg[20] = dg_chain; p.dbg_wg[21] = dg_gates; p.dbg_wg[22] = dg_pub;
     }
     if (p.dbg_wg != nullptr && tid == 0 && member == 0 && cluster < 64) {      // per cluster: entry, first section, exit (shader clock)

@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     }
     __syncthreads();
     if (ctl[0] != 0) return;
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
+    // Round 4 (found with lstm_upper128.hip, see there): behind a PLAIN store `s_waitcnt vmcnt(0)` does not guarantee that another CU's sc1
+    // load sees the data, so a flag raised after it can overtake the slice; the hand-over is by write-through (sc1) stores whatever the
+    // placement.  With two tiles in flight per cluster the later acknowledgement is free (tests/tools/ab_wt.py: 1202.1 vs 1200.7 us per
+    // frame of the 1024 x 25 bank, 1626.2 vs 1621.3 us of the watch-only bank).
+    constexpr bool in_l2 = false;
 
     // every wave polls for itself: have all member waves published epoch `want` of set s?
     auto wait_flags = [&](int s, unsigned want) {

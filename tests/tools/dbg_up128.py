@@ -1,0 +1,44 @@
+"""which sample rows of the 3 x 128 Monte-Carlo bank differ between the weight-stationary route and the batch-tile route (same Philox
+masks)?  python tests/tools/dbg_up128.py [S] [n_mc] [frames]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arm-pose-estimation_amd"))
+import numpy as np
+import torch
+from oracle import ape_oracle as orc
+from wear_mocap_ape_amd.estimate import nn_models
+from wear_mocap_ape_amd.streams import StreamBank
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 170
+n_mc = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+cfg = orc.MODEL_CONFIGS["uarm"]
+T = cfg["T"]
+m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0)
+m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5))
+m.set_norm_stats(np.zeros(cfg["I"]), np.ones(cfg["I"]), np.zeros(cfg["O"]), np.ones(cfg["O"])); m.set_body(orc.DEFAULT_BODY)
+rng = np.random.default_rng(1)
+feats = rng.normal(size=(frames, S, cfg["I"])).astype(np.float32)
+res = {}
+for route in ("auto", "tile16"):
+    bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=11)
+    out = []
+    for f in range(frames):
+        m.set_kernel(route)
+        bank.push_features(torch.from_numpy(feats[f]).cuda())
+        msg, tail = bank.step(with_tail=True)
+        out.append(tail.cpu().numpy().reshape(S * n_mc, 6).copy())
+    m.set_kernel("auto"); m.check()
+    res[route] = out
+    print(route, m.last_kernel())
+    del bank
+n_tiles = (S * n_mc + 31) // 32
+NC = min(64, (n_tiles + 7) // 8 * 8)
+for f in range(frames):
+    d = np.abs(res["auto"][f] - res["tile16"][f]).max(axis=1)
+    bad = np.nonzero(d > 2e-5)[0]
+    if len(bad):
+        tiles = sorted(set(int(r) // 32 for r in bad))
+        info = [(t, t % NC, (t // NC) % 2, t // (2 * NC), int((d[t * 32:(t + 1) * 32] > 2e-5).sum())) for t in tiles]
+        print(f"frame {f}: {len(bad)} rows off (max {d.max():.2e}); (tile, cluster, set, index in set, rows off): {info[:12]}")
+    else:
+        print(f"frame {f}: ok (max {d.max():.2e})")

@@ -27,10 +27,10 @@ lib = _hip.lib()
 lib.ape_debug_read_wg.restype, lib.ape_debug_read_wg.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
 buf = (C.c_ulonglong * (256 * 8))()
 assert lib.ape_debug_read_wg(m.handle, buf) == 0
-blk, _, n, top, chain, gates, pub = list(buf[16:23])
+blk, n_go, n, top, chain, gates, pub = list(buf[16:23])
 tiles = (S * n_mc + 31) // 32
 bare = (2 * T - 2) * 4096 * 25 / n if False else None
-print(f"S={S} n_mc={n_mc}: {n} sections of cluster 0 (one per step of a set, both layers), {blk} of them with a blocking top")
+print(f"S={S} n_mc={n_mc}: {n} sections of cluster 0 (one per step of a set, both layers), {blk} of them with a blocking top, {n_go} looks succeeded")
 print(f"cycles per section: top {top / n:.0f}  MFMA chains {chain / n:.0f}  gates (+ head) {gates / n:.0f}  publish {pub / n:.0f}  "
       f"(sum {(top + chain + gates + pub) / n:.0f}); whole launch {(top + chain + gates + pub) / 1e6:.3f} M cycles, "
       f"MFMAs alone {(tiles / 64) * (2 * T - 1) * 2 * 4096 / 1e6:.3f} M")
