@@ -202,6 +202,12 @@ __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostPa
     stream_post<TMsg>(p, (int)blockIdx.x);
 }
 
+// ... and the form for banks without stacking: 64 streams per workgroup (stream_post_wide)
+template <typename TMsg>
+__global__ __launch_bounds__(256) void ape_stream_post_wide_kernel(const StreamPostParams p) {
+    stream_post_wide<TMsg>(p, (int)blockIdx.x * 64);
+}
+
 template <typename TIn, typename TOut>
 hipError_t launch_fk(const FkParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((ape_fk3_kernel<TIn, TOut>), dim3((p.N + FK3_ROWS - 1) / FK3_ROWS), dim3(128), 0, stream, p);
@@ -224,6 +230,12 @@ hipError_t ape_launch_msg_reduce(const MsgParams& p, hipStream_t stream) {
 }
 
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream) {
+    if (p.smooth == 1 && p.n_mc == 1 && p.S >= 8) {        // no stacking: lanes = streams
+        const int wide = (p.S + 63) / 64;
+        if (p.msg_dtype == APE_F32) hipLaunchKernelGGL(ape_stream_post_wide_kernel<float>, dim3(wide), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(ape_stream_post_wide_kernel<double>, dim3(wide), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     const int grid = p.S;                                  // one workgroup (four role waves) per stream
     if (p.msg_dtype == APE_F32) hipLaunchKernelGGL(ape_stream_post_kernel<float>, dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(ape_stream_post_kernel<double>, dim3(grid), dim3(256), 0, stream, p);

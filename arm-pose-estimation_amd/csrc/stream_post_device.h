@@ -227,4 +227,98 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
     }
 }
 
+// The same step for banks WITHOUT stacking (smooth = 1, one sample per stream: the deterministic bank of configs[3]): lane = stream, 64 streams
+// per workgroup, the four role waves as above.  stream_post() gives every stream a workgroup of its own whose waves then run with ONE
+// active lane -- 4096 waves at 1024 streams, four per SIMD, each a chain of ~500 float64 instructions: the kernel was bound by their
+// issue slots (13.6 us at 1024 streams against 6 us for one stream).  Same device functions in the same order: bit-identical outputs.
+template <typename TMsg>
+__device__ inline void stream_post_wide(const StreamPostParams& p, const int s0) {
+#pragma clang fp contract(off)
+
+    __shared__ double rot[64][3][3];
+    __shared__ double e0w[64][21];                          // est row of every stream (the N == 1 message is a copy of it)
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int s = s0 + lane, O = p.O;
+    const bool act = s < p.S;
+    const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
+    const bool full = p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS;
+    const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
+    const int c_in[3] = {full ? 3 : 0, full ? 12 : 6, full ? 18 : 12};
+    if (p.status_out != nullptr && s0 == 0 && threadIdx.x == 255)
+        *p.status_out = __hip_atomic_load(p.status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = role; c < 21; c += 4) e0w[lane][c] = 0.0;
+    __syncthreads();
+    const float* src = p.y_new + (size_t)(act ? s : 0) * O;
+    auto load = [&](int c) -> double {
+        double v = (double)src[c];
+        if (p.yy_m) v = v * p.yy_s[c] + p.yy_m[c];          // estimator.py:108-109
+        return v;
+    };
+    if (role < 2) {
+        if (act) {
+            double s6[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s6[c] = load(c_in[role] + c);
+            const Quat qq = six_drr_to_quat(s6);
+            const Vec3 bone = role ? Vec3{p.body[3], p.body[4], p.body[5]} : Vec3{p.body[0], p.body[1], p.body[2]};
+            const Vec3 v = qrot(qq, bone);
+            rot[lane][role][0] = v.x; rot[lane][role][1] = v.y; rot[lane][role][2] = v.z;
+            e0w[lane][qc[role]] = qq.w; e0w[lane][qc[role] + 1] = qq.x; e0w[lane][qc[role] + 2] = qq.y; e0w[lane][qc[role] + 3] = qq.z;
+        }
+    } else if (role == 2) {
+        if (act) {
+            Vec3 uo{p.body[6], p.body[7], p.body[8]};
+            if (hips) {
+                const Quat hq = hips_quat(load(c_in[2]), load(c_in[2] + 1));
+                uo = qrot(hq, uo);
+                e0w[lane][17] = hq.w; e0w[lane][18] = hq.x; e0w[lane][19] = hq.y; e0w[lane][20] = hq.z;
+                e0w[lane][6] = uo.x; e0w[lane][7] = uo.y; e0w[lane][8] = uo.z;
+            }
+            rot[lane][2][0] = uo.x; rot[lane][2][1] = uo.y; rot[lane][2][2] = uo.z;
+        }
+    } else if (act) {                                       // keep the prediction (the one ring slot of a bank without stacking)
+        float* dst = p.yring + (size_t)s * O;
+#pragma unroll
+        for (int c = 0; c < 20; ++c)
+            if (c < O) dst[c] = src[c];
+    }
+    __syncthreads();
+    if (role == 3 && act) {
+        double e6[6];
+        if (full) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { e6[c] = load(c); e6[3 + c] = load(9 + c); }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                e6[3 + c] = rot[lane][1][c] + rot[lane][2][c];              // qrot(uq, uarm_vec) + uo
+                e6[c] = rot[lane][0][c] + e6[3 + c];                        // qrot(lq, larm_vec) + lo
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) e0w[lane][c] = e6[c];
+        if (p.tail || p.packed) {
+            TMsg* t = p.packed ? static_cast<TMsg*>(p.msg) + (size_t)s * 31 + 25 : static_cast<TMsg*>(p.tail) + (size_t)s * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) t[c] = (TMsg)e6[c];
+        }
+    }
+    __syncthreads();
+    if (act) {                                              // the message: every role wave writes a quarter of its stream's 25 columns
+        double out_q[3][4] = {}, orig_mean[9] = {}, e0[21], m[25];
+#pragma unroll
+        for (int c = 0; c < 21; ++c) e0[c] = e0w[lane][c];
+        finish_msg(p.layout, 1, out_q, orig_mean, e0, p.body, m);
+        TMsg* dst = static_cast<TMsg*>(p.msg) + (size_t)s * (p.packed ? 31 : 25);
+#pragma unroll
+        for (int c = 0; c < 25; ++c)
+            if (c / 7 == role) dst[c] = (TMsg)m[c];
+    }
+    if (p.done_out != nullptr) {
+        __threadfence_system();
+        __syncthreads();
+        if (role == 0 && act) __hip_atomic_store(p.done_out + s, p.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace ape_postdev

@@ -343,6 +343,7 @@ def test_bank_cooperative_routes_follow_a_later_set_kernel(norm_stats, name, S, 
     way to keep persistent clusters off a shared GPU -- must reach a bank that already exists: its next steps run on the batch-tile
     kernel (same Philox masks: within the float32 budget of the route before), and come back with `set_kernel('auto')`, bit-equal."""
     from tests.test_hip_parity import make_model, _synthetic_windows
+    from wear_mocap_ape_amd import _hip
     from wear_mocap_ape_amd.streams import StreamBank
     st = norm_stats[name]
     m, sd, cfg = make_model(name, 6, st)
@@ -370,3 +371,47 @@ def test_bank_cooperative_routes_follow_a_later_set_kernel(norm_stats, name, S, 
             assert np.abs(a - c).max() < 5e-5 and np.abs(b - d).max() < 5e-5 and np.abs(a - c).max() > 0.0
         else:
             assert np.array_equal(a, c) and np.array_equal(b, d), f
+
+
+# ---------------- the post-filter of banks without stacking: lanes = streams (round 4) --------------------------------------------------
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_wide_post_kernel_equals_the_per_stream_one(norm_stats, name, dtype):
+    """banks with smooth = 1 and one sample per stream run `ape_stream_post_wide_kernel` from 8 streams on (64 streams per workgroup);
+    below that every stream has a workgroup of its own (`ape_stream_post_kernel`).  Same device functions in the same order: the first
+    streams of a 70-stream bank (two workgroups of the wide form, the second ragged) must equal, bit for bit, a 7-stream bank fed the
+    same rows -- message, 6-float tails and packed datagram rows -- and the oracle's FK on the bank's own targets (1e-11 in float64)."""
+    from tests.test_hip_parity import make_model, _synthetic_windows
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 6, st)
+    m.set_body(orc.DEFAULT_BODY)
+    T, I = cfg["T"], cfg["I"]
+    S_wide, S_narrow = 70, 7
+    feats = _synthetic_windows(st, S_wide, T + 2, I, 77)
+    wide = StreamBank(m, S_wide, T, smooth=1, normalize=True, dtype=dtype)
+    narrow = StreamBank(m, S_narrow, T, smooth=1, normalize=True, dtype=dtype)
+    for f in range(T + 2):
+        fw = torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda()
+        wide.push_features(fw)
+        narrow.push_features(fw[:S_narrow].contiguous())
+        if f % 2 == 0:
+            mw, tw = (v.cpu().numpy().copy() for v in wide.step(with_tail=True))
+            mn, tn = (v.cpu().numpy().copy() for v in narrow.step(with_tail=True))
+            assert np.array_equal(mw[:S_narrow], mn) and np.array_equal(tw[:S_narrow], tn), f
+            assert np.isfinite(mw).all() and np.isfinite(tw).all()
+            # rows 64 .. 69 are the ragged second workgroup: the message's origins are the tail's
+            assert np.array_equal(mw[:, 4:7], tw.reshape(S_wide, -1)[:, 0:3]) and np.array_equal(mw[:, 11:14], tw.reshape(S_wide, -1)[:, 3:6])
+        else:
+            # packed rows [25 + 6] straight through the C ABI (the Python surface, like the reference, adds a tail only to stacked rows)
+            def packed(bank, S):
+                out = torch.empty((S, 31), dtype=dtype, device="cuda")
+                _hip.check(_hip.lib().ape_streams_step(bank._handle, bank._flags | _hip.FLAG_PACKED_MSG, C.c_void_p(out.data_ptr()), None,
+                                                       bank._sel, None), "ape_streams_step")
+                torch.cuda.synchronize()
+                return out.cpu().numpy()
+            dw, dn = packed(wide, S_wide), packed(narrow, S_narrow)
+            assert np.array_equal(dw[:S_narrow], dn) and np.isfinite(dw).all(), f
+            assert np.array_equal(dw[:, 4:7], dw[:, 25:28]) and np.array_equal(dw[:, 11:14], dw[:, 28:31])
+    m.check()
