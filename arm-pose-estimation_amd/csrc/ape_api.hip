@@ -1958,7 +1958,8 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
         if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, gen2_of(m), m->wide_cluster) > B) return m->kernel_name.c_str();
     }
-    if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512) return "ape_lstm_cluster32<256, 2, 32>";
+    if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512)      // (two instantiations: lstm_cluster32.hip on ENDS)
+        return T <= APE_C32_ENDS_MAX_T ? "ape_lstm_cluster32<256, 2, 32, true>" : "ape_lstm_cluster32<256, 2, 32, false>";
     if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 12) return "ape_lstm_cluster16<128, 3, 64, 2>";
     return m->cluster_name.c_str();
 }

@@ -8,6 +8,7 @@
 #define APE_MAX_OUTPUT 32
 #define APE_TILE_ROWS 16          // windows per workgroup in the batch-tile LSTM kernel
 #define APE_XCC_WORDS 1024
+#define APE_C32_ENDS_MAX_T 8      // lstm_cluster32.hip: windows of up to this many steps run the instantiation with the end forms
 #define APE_LDS_BYTES (160 * 1024) // LDS of a gfx950 CU: the dynamic-LDS limit every kernel instantiation is raised to, once
 // internal timing-only diagnostics (never set by the public API's documented flags; outputs are wrong)
 #define APE_DIAG_NO_EXCHANGE 0x40000000u

@@ -41,6 +41,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
+// diagnostic builds: timeline of a short launch (cluster 0, member 0, thread 0) in dbg_wg[256 + i] -- 0 entry, 1 rendezvous done, 2 step 0
+// of layer 0 and the weights done, 8 + 2 * (2 * ph + l) / + 1: section (ph, l) behind its top barrier / at its end, 4 final gather, 5 head
+#ifdef APE_CLUSTER_STAMPS
+#define C32_TL(i) do { if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0 && (i) < 200) p.dbg_wg[256 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C32_TL(i) do {} while (0)
+#endif
+
 // hardware v_exp_f32 (2^x) and v_rcp_f32, both ~1 ulp -- the formulas of the other kernels (lstm_cluster_common.h)
 __device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 __device__ __forceinline__ float tanh_(float v) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390081777927f * v)) - 1.0f; }
@@ -77,9 +85,25 @@ __device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ sr
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
 // the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes.  M0 is written in the
 // same statement that reads it (the compiler does not preserve it across statements).
-__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+// HOT = inside a section's MFMA stream, where every scalar instruction between two MFMAs is paid for (round 4, 1024 x 64: `s_nop 3`
+// instead of `s_nop 0` in the eight copies of a section +4.7 us per launch, one more s_add per copy +5.8 us): there `soff` comes straight
+// from scalar arithmetic.  The copies of the blocking forms (pipeline fill, final gather) are not in anybody's way, and there hipcc does
+// reload `soff` from a spill lane (v_readlane_b32) right in front of the statement -- a VALU write of an SGPR needs five wait states
+// before a vector-memory instruction reads it, and hipcc does not look inside an asm statement.  tools/check_mfma_hazards.py scans
+// the build for exactly that adjacency, so a reload that turns up in front of a HOT copy fails the build.
+// The HOT form therefore takes the two addresses WITHOUT the piece's offset and adds it as an immediate inside the statement: no
+// per-piece sums for hipcc to hoist out of the phase loop (with three more section forms in round 4 they no longer fitted the scalar
+// registers), two SALU instructions per copy, and the second s_add is the wait state the M0 write needs in front of the LDS-DMA.
+template <bool HOT>
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff, int piece_bytes) {
+    if constexpr (HOT) {
+        unsigned tmp;
+        asm volatile("s_add_i32 m0, %1, %5\n\ts_add_i32 %0, %4, %5\n\tbuffer_load_dwordx4 %2, %3, %0 offen sc1 lds"
+                     : "=&s"(tmp) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff), "i"(piece_bytes) : "memory");
+    } else {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                     :: "s"(lds_addr + (unsigned)piece_bytes), "v"(voff), "s"(rsrc), "s"(soff + (unsigned)piece_bytes) : "memory");
+    }
 }
 
 // A flag look that does NOT stall the MFMA stream: hipcc hoists the comparison of a compiler-visible load up to the load and puts
@@ -93,7 +117,14 @@ __device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
 }
 __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 
-template <int H, int L, int KX>
+// ENDS: the forms for the ends of a launch (step 0 of layer 0 in front of the bulk of the weights, MODE 1 / MODE 2 sections, see there) --
+// the instantiation for SHORT windows (T <= APE_C32_ENDS_MAX_T; every deployed model has T = 6 or 8).  The timeline stamps
+// (tests/tools/timeline_c32.py) show what they do at T = 6: layer 0's second step starts 1.5 us behind the weights instead of a whole
+// exchange behind them, layer 0's third step and layer 1's last one find their slices in LDS (top waits 0.2-0.3 us).  Same-box A/B,
+// 1024 x 6: 83.8 -> 82.3 us (best blocks; 87.2 -> 85.6 medians).  But with these forms in the kernel hipcc's code for the steady-state
+// sections comes out ~0.3-1 % slower per phase (register allocation / layout: 12.24 vs 12.27 us per phase; 1024 x 32: 402 -> 406 us; 1024 x 12: no difference left), so
+// longer windows keep the instantiation without them.
+template <int H, int L, int KX, bool ENDS>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams p) {
     constexpr int UPW = 8;                  // hidden units per wave (x 4 gates = the 32 columns of its tile)
     constexpr int GH = H / (4 * UPW);       // members per cluster
@@ -144,6 +175,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
     const int cluster = (ticket / GH) * 8 + cls, member = ticket % GH;
     const int row0 = cluster * MR;
+    C32_TL(0);
     if (tid == 0)
         __hip_atomic_store(xcc_words + cluster * GH + member, 0x10u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -172,9 +204,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     };
     // f64 z-score, cast f32 (estimator.py:103-104, watch_phone_pocket_nn.py:100): (x - m) / s correctly rounded via the
     // host-rounded reciprocal and one residual step (bit-identical to the division, as in lstm_cluster.hip)
-    const double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
-    const double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
-    const double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;
+    double x_mean = (normalize && xk < I) ? p.xx_m[xk] : 0.0;
+    double x_std = (normalize && xk < I) ? p.xx_s[xk] : 1.0;
+    double x_rstd = (normalize && xk < I) ? p.xx_r[xk] : 1.0;
+    // (opaque from here on: with more section forms in the kernel hipcc preferred to RE-LOAD the three constants inside the staging hook
+    //  of every layer-1 section -- a global-memory round trip in the MFMA stream, 450 -> 950 cycles per section by the stamps)
+    asm volatile("" : "+v"(x_mean), "+v"(x_std), "+v"(x_rstd));
     auto stage_x = [&]() {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -189,22 +224,29 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
 
     // ---- weights: registers, for the whole launch.  Host layout [member][wave][register / 4][lane][4]: register 4 kb + j of
     //      lane (column m = lane & 31, half hh) = W[gate(m) * H + unit(m)][8 kb + 4 hh + j] with m = gate * 8 + local unit
+    //      Only layer 0's input columns (16 registers) are loaded here: step 0 of layer 0 needs nothing else (h_{-1} = 0), and its hand-over
+    //      then travels while the other 384 registers come in (`load_weights`, called behind it).
     float w0[NW0];
     float w1[NW1];
-    {
-        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+    const f32x4* const s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(member * 4 + wave) * (NW0 / 4)) * 64 + lane;
+    const f32x4* const s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < NW0 / 4; ++i) {
+    for (int i = 0; i < BX; ++i) {
+        const f32x4 v = s0[i * 64];
+        w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
+    }
+    auto load_weights = [&]() {
+#pragma unroll
+        for (int i = BX; i < NW0 / 4; ++i) {
             const f32x4 v = s0[i * 64];
             w0[4 * i] = v[0]; w0[4 * i + 1] = v[1]; w0[4 * i + 2] = v[2]; w0[4 * i + 3] = v[3];
         }
-        const f32x4* s1 = reinterpret_cast<const f32x4*>(p.wcl[1]) + ((size_t)(member * 4 + wave) * (NW1 / 4)) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NW1 / 4; ++i) {
             const f32x4 v = s1[i * 64];
             w1[4 * i] = v[0]; w1[4 * i + 1] = v[1]; w1[4 * i + 2] = v[2]; w1[4 * i + 3] = v[3];
         }
-    }
+    };
     // accumulator start values (b_ih + b_hh) of this lane: registers 4 gate + j <-> unit member*32 + wave*8 + 4 hh + j; in LDS,
     // not in 32 more registers
 #pragma unroll
@@ -260,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     }
     __syncthreads();
     if (ctl[0] != 0) return;
+    C32_TL(1);
     const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
 
     // every wave polls for itself: have all member waves published epoch `want` of layer l?
@@ -282,11 +325,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     // a layer-step's 32 KB straight from the exchange buffer into its LDS block: wave w copies KiB w, w + 4, ... (8 of them);
     // piece k of that copy on its own, so that the copy can be spread over the k-blocks of a span
     const unsigned dma_voff = (unsigned)(lane * 16);
-    auto issue_piece = [&](int l, int step, int k) {       // slices of layer l, step `step` -> hb0[step parity] / hb1
-        const unsigned src = hx_base(l, step & 1) + (unsigned)(wave * 1024 + k * 4096);
-        const unsigned dst = (l == 0 ? hb0_lds + (unsigned)((step & 1) * SET_BYTES) : hb1_lds) + (unsigned)(wave * 1024 + k * 4096);
-        dma_1k(dst, dma_voff, hx_desc, src);
+    // (blocking forms: the per-wave offset is laundered through an empty asm at every use, or hipcc hoists the sums of all pieces of all
+    //  section forms out of the loop and runs out of scalar registers -- lstm_upper32.hip)
+    auto opaque = [](unsigned v) -> unsigned { asm volatile("" : "+s"(v)); return v; };
+    const unsigned wave_kib = (unsigned)(wave * 1024);
+    auto issue_piece = [&](auto hot_tag, int l, int step, int k) {       // slices of layer l, step `step` -> hb0[step parity] / hb1
+        constexpr bool HOT = decltype(hot_tag)::value;
+        const unsigned wk = HOT ? wave_kib : opaque(wave_kib);
+        const unsigned src = hx_base(l, step & 1) + wk;
+        const unsigned dst = (l == 0 ? hb0_lds + (unsigned)((step & 1) * SET_BYTES) : hb1_lds) + wk;
+        dma_1k<HOT>(dst, dma_voff, hx_desc, src, k * 4096);
     };
+    constexpr std::true_type HOT{};
+    constexpr std::false_type COLD{};
     // the flag a wave owes for the slice it stored last: raised once that store has drained
     int pend_idx = -1;
     unsigned pend_epoch = 0u;
@@ -297,6 +348,61 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     };
     // workgroup barrier that waits for this wave's LDS traffic only (not for the publish store or a DMA in flight)
     auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
+    // (two cells at a time, the plain arithmetic on float2 values: v_pk_mul / v_pk_add / v_pk_fma_f32 do both cells in one issue
+    //  slot -- VALU work is serial with the MFMAs, tools/experiments/mfma_chain_rate.hip; the transcendentals stay one by one)
+    auto cell_update = [&](const f32x16& acc, float (&c_)[4], float (&hn)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
+            auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
+            const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
+            const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
+            const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
+            const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
+            const f32x2 ov = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ao));
+            const f32x2 c = fv * f32x2{c_[j], c_[j + 1]} + iv * gv;
+            c_[j] = c[0]; c_[j + 1] = c[1];
+            const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
+            hn[j] = h[0]; hn[j + 1] = h[1];
+        }
+    };
+    const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));    // this lane's 16 bytes of a slice set
+
+    // ---- step 0 of layer 0 IN FRONT of the bulk of the weights: its product is the input span alone (4 k-blocks, 16 weight registers),
+    //      and its hand-over -- store, acknowledgement, flag, the peers' flags -- would otherwise be the first thing the launch waits
+    //      for with nothing to do (round 4: ~3 us of the 89 us launch at T = 6).  Phase 0's layer-1 section is idle anyway; the loop
+    //      below starts at phase 1.
+    if constexpr (!ENDS) {
+        load_weights();
+    } else {
+        f32x16 acc;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const f32x4 bv = bias_s[((wave * L + 0) * 4 + gate) * 64 + lane];
+            acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
+        }
+        span32<BX, false, NW0>(acc, xin + n * SX + hh * 4, 8, w0, 0, [&](int) {});
+        mfma_drain(acc);
+        float h0[4];
+        cell_update(acc, cst[0], h0);
+        const u32x4 hv = {__builtin_bit_cast(unsigned, h0[0]), __builtin_bit_cast(unsigned, h0[1]),
+                          __builtin_bit_cast(unsigned, h0[2]), __builtin_bit_cast(unsigned, h0[3])};
+        if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, hx_base(0, 0) + pub_off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, hx_base(0, 0) + pub_off, 0, 16 /* sc1: write-through */);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flags_of + member * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+        load_weights();
+        bar();                                                    // every wave is through with x_0 in LDS
+        if (1 < T) {
+            stage_x();
+            if (2 < T) fetch_x(2);
+        }
+    }
+    C32_TL(2);
 
     // Section (ph, l) = layer l on step t = ph - l.  It reads x_t / h^{l-1}_t and h^l_{t-1}, all published in phase ph - 1,
     // i.e. at least two sections ago; the ONE slice set it is still missing in LDS -- layer 0: h^0_{t-1} (published by the
@@ -318,9 +424,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         return c;
     };
 #endif
-    auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
+    // Two forms for the ends of a launch, where a section has no section in front whose MFMA stream could carry its exchange (round 4:
+    // at the deployed T = 6 four of the launch's exchanges were exposed, ~3 us each of an 89 us launch):
+    //   MODE 1  layer 1 on step 0 runs its input span alone (h_{-1} = 0): 32 k-blocks, so the look at the next section's flags and
+    //           its gather sit at blocks 16 / 20 .. 27 instead of 30 / 34 .. 41, which it never reaches;
+    //   MODE 2  layer 1 on the LAST step behind an idle layer-0 section: h^1_{T-2} was published by the section right in front, so
+    //           nobody could prefetch it.  The input span (h^0_{T-1}, in LDS since the section in front) runs first and carries the
+    //           looks and the gather; the wait for the copies and a second barrier sit between the spans (lstm_cluster16.hip's place
+    //           for the barrier).  Both barriers are unconditional; a wave whose looks both failed blocks in front of the second one.
+    auto section = [&](auto steady_tag, auto layer_tag, auto mode_tag, const int ph) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 1 <= t <= T - 2 for both layers
         constexpr int l = decltype(layer_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
+        static_assert(MODE == 0 || (!ST && l == L - 1), "the end forms are layer 1's");
         const int t = ph - l;
         const bool active = ST || (t >= 0 && t < T);
         // h^l_{t-1} exists and somebody reads it from here on (layer 0 at t == T: no layer-0 step any more, but layer 1's
@@ -330,7 +446,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         const unsigned long long c0 = ST ? now() : 0ull;
 #endif
         // ---- S0: this layer's slices of its last step into LDS ------------------------------------------------------------
-        if (need) {
+        if (MODE == 2) {                                          // (the slices come in under the input span)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            raise_pending();
+        } else if (need) {
             if (!prefetched) {                                    // pipeline fill, a late peer, the final gather
 #ifdef APE_CLUSTER_STAMPS
                 dg_block[l] += 1;
@@ -339,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
                 raise_pending();
                 wait_flags(l, (unsigned)t);
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_piece(l, t - 1, k);
+                for (int k = 0; k < NDMA; ++k) issue_piece(COLD, l, t - 1, k);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the prefetched copy; only the publish store is younger
@@ -354,6 +473,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         const unsigned long long c2 = ST ? now() : 0ull;
 #endif
         const int abort_word = ctl[0];
+        C32_TL(8 + 2 * (2 * ph + l));
         // the next section: layer ln on step tn = its phase - ln; the slice set it is missing is h^{ln}_{tn-1}, epoch tn
         constexpr int ln = (l + 1 < L) ? l + 1 : 0;
         const int tn = (l + 1 < L) ? t - 1 : t + L;
@@ -369,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         constexpr int NBL = (l == 0) ? BX + BH : 2 * BH;
         // (positions swept on MI355X, 1024 x 64: QF 1 / 2 / 3 / 10 / 16 -> 826 / 833 / 819 / 828 / 858 us -- earlier stalls on the store's
         //  acknowledgement, later the peers' look finds nothing; look 12 blocks ahead of the judge instead of 4 -> 840: the flags are not up yet)
-        constexpr int QF = 3, QP = NBL / 2 - 2, QJ = NBL / 2 + 2;
+        constexpr int QF = 3, QP = (MODE == 1) ? 16 : NBL / 2 - 2, QJ = (MODE == 1) ? 20 : NBL / 2 + 2;
         bool staged = false;
 #ifdef APE_CLUSTER_STAMPS
         unsigned long long hk0 = 0, hk_free = 0;
@@ -410,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             }
             if (q >= QJ && q < QJ + NDMA && go) {
                 HK_BEGIN();
-                issue_piece(ln, tn - 1, q - QJ);
+                issue_piece(HOT, ln, tn - 1, q - QJ);
                 HK_END(3);
             }
         };
@@ -427,6 +547,36 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             if constexpr (l == 0) {
                 span32<BX, false, NW0>(acc, xin + n * SX + hh * 4, 8, w0, 0, [&](int q) { mid(q); });
                 if (ST || t > 0) span32<BH, false, NW0>(acc, hb0 + ((t - 1) & 1) * HL + frag, MR * 8, w0, 4 * BX, [&](int q) { mid(BX + q); });
+            } else if constexpr (MODE == 2) {
+                // input span with two looks at the own layer's flags (blocks 1 -> 5, 13 -> 17) and the gather behind the one that succeeds
+                unsigned pk = (unsigned)t;
+                bool got1 = false, got2 = false;
+                span32<BH, true, NW1>(acc, hb0 + (t & 1) * HL + frag, MR * 8, w1, 0, [&](int q) {
+                    if (q == 1) pk = peek_issue(flags_of + l * NFL + (lane & (NFL - 1)));
+                    if (q == 5) {
+                        peek_wait(pk);
+                        got1 = __all((int)(pk >= (unsigned)t)) != 0;
+                    }
+                    if (q >= 5 && q < 5 + NDMA && got1) issue_piece(HOT, l, t - 1, q - 5);
+                    if (q == 13 && !got1) pk = peek_issue(flags_of + l * NFL + (lane & (NFL - 1)));
+                    if (q == 17 && !got1) {
+                        peek_wait(pk);
+                        got2 = __all((int)(pk >= (unsigned)t)) != 0;
+                    }
+                    if (q >= 17 && q < 17 + NDMA && got2) issue_piece(HOT, l, t - 1, q - 17);
+                });
+                if (!got1 && !got2) {
+#ifdef APE_CLUSTER_STAMPS
+                    dg_block[l] += 1;
+#endif
+                    wait_flags(l, (unsigned)t);
+#pragma unroll
+                    for (int k = 0; k < NDMA; ++k) issue_piece(COLD, l, t - 1, k);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar();                                            // every wave's pieces of h^1_{t-1} are in LDS
+                if (ctl[0] != 0) return false;
+                span32<BH, true, NW1>(acc, hb1 + frag, MR * 8, w1, 4 * BH, [&](int) {});
             } else {
                 span32<BH, true, NW1>(acc, hb0 + (t & 1) * HL + frag, MR * 8, w1, 0, [&](int q) { mid(q); });
                 if (ST || t > 0) span32<BH, true, NW1>(acc, hb1 + frag, MR * 8, w1, 4 * BH, [&](int q) { mid(BH + q); });
@@ -436,24 +586,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             if (ST) { dgc[l][0] += c1 - c0; dgc[l][1] += c2 - c1; dgc[l][2] += c3 - c2; }
 #endif
             mfma_drain(acc);
-            // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
-            // (two cells at a time, the plain arithmetic on float2 values: v_pk_mul / v_pk_add / v_pk_fma_f32 do both cells in one issue
-            //  slot -- VALU work is serial with the MFMAs, tools/experiments/mfma_chain_rate.hip; the transcendentals stay one by one)
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                auto exp2_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}; };
-                auto rcp_2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; };
-                const f32x2 ai = {acc[j], acc[j + 1]}, af = {acc[4 + j], acc[5 + j]}, ag = {acc[8 + j], acc[9 + j]}, ao = {acc[12 + j], acc[13 + j]};
-                const f32x2 iv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ai));
-                const f32x2 fv = rcp_2(1.0f + exp2_2(-1.4426950408889634f * af));
-                const f32x2 gv = 2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * ag)) - 1.0f;
-                const f32x2 ov = rcp_2(1.0f + exp2_2(-1.4426950408889634f * ao));
-                const f32x2 c = fv * f32x2{cst[l][j], cst[l][j + 1]} + iv * gv;
-                cst[l][j] = c[0]; cst[l][j + 1] = c[1];
-                const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
-                hnew[j] = h[0]; hnew[j + 1] = h[1];
-            }
+            cell_update(acc, cst[l], hnew);
         }
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         if (!ST && pend_idx >= 0) {                               // (a section too short to reach block QF, or an idle one)
@@ -477,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         {
             const u32x4 hv = {__builtin_bit_cast(unsigned, hnew[0]), __builtin_bit_cast(unsigned, hnew[1]),
                               __builtin_bit_cast(unsigned, hnew[2]), __builtin_bit_cast(unsigned, hnew[3])};
-            const unsigned off = active ? hx_base(l, t & 1) + (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float)) : 0x80000000u;
+            const unsigned off = active ? hx_base(l, t & 1) + pub_off : 0x80000000u;
             if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
             if (active) {
@@ -488,16 +621,31 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
 #ifdef APE_CLUSTER_STAMPS
         if (ST) { dgc[l][3] += now() - c2; dgc[l][4] += 1; }
 #endif
+        C32_TL(9 + 2 * (2 * ph + l));
         return true;
     };
     bool ok = true;
 #pragma unroll 1
-    for (int ph = 0; ph < P && ok; ++ph) {
+    for (int ph = ENDS ? 1 : 0; ph < P && ok; ++ph) {               // (ENDS: phase 0 = step 0 of layer 0, done above)
         // steady state: both layers active with a recurrent span, a next section to prefetch for, x to stage and to fetch
         const bool st0 = ph >= 2 && ph <= T - 3, st1 = st0;
-        ok = st0 ? section(std::true_type{}, std::integral_constant<int, 0>{}, ph) : section(std::false_type{}, std::integral_constant<int, 0>{}, ph);
+        using M0 = std::integral_constant<int, 0>;
+        using L0 = std::integral_constant<int, 0>;
+        using L1 = std::integral_constant<int, 1>;
+        ok = st0 ? section(std::true_type{}, L0{}, M0{}, ph) : section(std::false_type{}, L0{}, M0{}, ph);
         if (!ok) break;
-        ok = st1 ? section(std::true_type{}, std::integral_constant<int, 1>{}, ph) : section(std::false_type{}, std::integral_constant<int, 1>{}, ph);
+        const int t1 = ph - 1;
+        bool done1 = false;
+        if constexpr (ENDS) {
+            if (!st1 && t1 == 0 && T > 1) {
+                ok = section(std::false_type{}, L1{}, std::integral_constant<int, 1>{}, ph);
+                done1 = true;
+            } else if (!st1 && t1 == T - 1 && t1 >= 1 && !prefetched) {
+                ok = section(std::false_type{}, L1{}, std::integral_constant<int, 2>{}, ph);
+                done1 = true;
+            }
+        }
+        if (!done1) ok = st1 ? section(std::true_type{}, L1{}, M0{}, ph) : section(std::false_type{}, L1{}, M0{}, ph);
     }
     if (!ok) return;
     // ---- final gather: h^{L-1}_{T-1} of every member (a section of layer L-1 "on step T": S0 only) -------------------------------
@@ -507,11 +655,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         if (!prefetched) {
             wait_flags(L - 1, (unsigned)T);
 #pragma unroll
-            for (int k = 0; k < NDMA; ++k) issue_piece(L - 1, T - 1, k);
+            for (int k = 0; k < NDMA; ++k) issue_piece(COLD, L - 1, T - 1, k);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar();
         if (ctl[0] != 0) return;
+        C32_TL(4);
     }
 
 #ifdef APE_CLUSTER_STAMPS
@@ -552,6 +701,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             if (p.y != nullptr && live && part == 0 && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
         }
     }
+    C32_TL(5);
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
     __syncthreads();
     if (tid == 0)
@@ -577,7 +727,10 @@ bool ape_cluster32_supported(int H, int L, int KX) { return H == 256 && L == 2 &
 hipError_t ape_prepare_lstm_cluster32(int H, int L, int KX) {
     if (!ape_cluster32_supported(H, L, KX)) return hipSuccess;
     static_assert(smem_bytes32() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
 }
 
@@ -587,6 +740,7 @@ hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const C
     if (!ape_cluster32_supported(H, L, KX)) return hipErrorInvalidValue;
     const int grid_clusters = (clusters + 7) / 8 * 8;
     constexpr size_t smem = smem_bytes32();
-    hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    if (p.T <= APE_C32_ENDS_MAX_T) hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32, true>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    else hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32, false>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
     return hipGetLastError();
 }

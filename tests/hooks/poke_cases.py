@@ -29,7 +29,7 @@ def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
     m, sd, cfg = make_model(name, 0, norm_stats[name])
     poke = _poke(_hip.lib())
     T = cfg["T"] if B < 1024 else 64
-    if B == 1024: assert m.kernel_name(B, T) == {"pocket": "ape_lstm_cluster32<256, 2, 32>", "uarm": "ape_lstm_cluster16<128, 3, 64, 2>"}[name]
+    if B == 1024: assert m.kernel_name(B, T) == {"pocket": "ape_lstm_cluster32<256, 2, 32, false>", "uarm": "ape_lstm_cluster16<128, 3, 64, 2>"}[name]
     x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 3))
     good = m(x, last_step_only=True, normalize_input=True).numpy().copy()
     m.set_kernel("tile16")

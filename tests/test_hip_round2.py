@@ -251,11 +251,14 @@ def test_fp16_second_generation_kernel(norm_stats, name, B, T):
 
 # ---------------- f32 cluster kernel, second generation (32x32x2 MFMA chain, 8-member clusters) ----------------------
 @pytest.mark.parametrize("name,B,T", [("pocket", 1024, 64), ("watch", 700, 8), ("pocket", 513, 3), ("watch", 2081, 6),
-                                      ("pocket", 1024, 1), ("pocket", 1024, 2)])
+                                      ("pocket", 1024, 1), ("pocket", 1024, 2), ("pocket", 600, 4), ("watch", 513, 5),
+                                      ("pocket", 1024, 12), ("watch", 1024, 13)])
 def test_f32_second_generation_cluster_kernel(norm_stats, name, B, T):
     """lstm_cluster32.hip (eval-mode batches above 512 rows of the 2 x 256 models) against the float32 oracle (module
     tolerance 1e-6), the first-generation cluster kernel (other summation order only), ragged and multi-launch batches,
-    the forced any-placement (write-through) exchange (same bits as the in-L2 form) and run-to-run determinism."""
+    the forced any-placement (write-through) exchange (same bits as the in-L2 form) and run-to-run determinism.  Windows of up to 8
+    steps run the instantiation with the end forms of round 4 (step 0 in front of the weights, MODE 1 / MODE 2 sections), T = 8 | 12 sits on either side of
+    the boundary."""
     from wear_mocap_ape_amd import _hip
     st = norm_stats[name]
     model, sd, cfg = make_model(name, 3, st)
@@ -263,7 +266,7 @@ def test_f32_second_generation_cluster_kernel(norm_stats, name, B, T):
     xd = torch.from_numpy(x).cuda()
     xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
     model.set_kernel("cluster")
-    assert model.kernel_name(B, T) == "ape_lstm_cluster32<256, 2, 32>"
+    assert model.kernel_name(B, T) == f"ape_lstm_cluster32<256, 2, 32, {'true' if T <= 8 else 'false'}>"
     y2 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
     model.check()
     y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
