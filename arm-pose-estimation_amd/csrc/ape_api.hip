@@ -1328,6 +1328,16 @@ static hipError_t bank_alloc(ape_streams* b) {
     hipError_t e = hipMalloc((void**)&b->xring, R * b->T * I * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&b->yring, R * b->smooth * O * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&b->y_new, R * O * sizeof(float));
+    // a few streams with tall smoothing stacks: the post-filter deals a stream's stack over several workgroups (one CU each)
+    if (b->post_part) (void)hipFree(b->post_part);
+    b->post_part = nullptr; b->post_cnt = nullptr;
+    const int chunks = ape_stream_post_chunks(b->smooth * b->n_mc);
+    if (e == hipSuccess && chunks > 1 && (long long)b->S * chunks <= b->model->n_cus) {
+        const size_t part_bytes = (size_t)b->S * chunks * 21 * sizeof(double);
+        e = hipMalloc((void**)&b->post_part, part_bytes + (size_t)b->S * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(b->post_part, 0, part_bytes + (size_t)b->S * sizeof(unsigned));
+        if (e == hipSuccess) b->post_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(b->post_part) + part_bytes);
+    }
     return e;
 }
 
@@ -1448,6 +1458,7 @@ int ape_streams_destroy(ape_streams_t* b) {
     if (b->xring) (void)hipFree(b->xring);
     if (b->yring) (void)hipFree(b->yring);
     if (b->y_new) (void)hipFree(b->y_new);
+    if (b->post_part) (void)hipFree(b->post_part);
     if (b->xfrag) (void)hipFree(b->xfrag);
     if (b->ypart) (void)hipFree(b->ypart);
     if (b->xfrag0) (void)hipFree(b->xfrag0);
@@ -1578,6 +1589,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         q.msg_dtype = out_dtype; q.packed = packed ? 1 : 0;
         if (status_out != nullptr && m->cluster_ok) { q.status_in = m->xflags + m->xflag_bytes / sizeof(unsigned); q.status_out = status_out; }
         if (status_out != nullptr && b->h_done != nullptr) { q.done_out = b->h_done; q.done_val = b->h_done_val; }
+        q.part = b->post_part; q.part_cnt = b->post_cnt;
         return q;
     };
     if (b->shared_l0) {

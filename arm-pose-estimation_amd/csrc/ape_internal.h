@@ -215,7 +215,11 @@ struct StreamPostParams {
     unsigned* status_out;        // ... copied here (pinned host memory) by the step's last kernel, or nullptr
     unsigned* done_out;          // host frames: [S] pinned words; stream s's workgroup writes done_val behind its (system-fenced) outputs,
     unsigned done_val;           // so that the host can take the frame the moment it is there instead of waiting for the stream to drain
+    double* part;                // split form (stream_post_device.h): [S][chunks][21] partial sums, or nullptr (one workgroup per stream)
+    unsigned* part_cnt;          // ... and [S] arrival tickets, zero between launches
 };
+// 64-row chunks of a stack of N rows in the split form: rows 0 .. 63, then 63 per chunk (lane 63 repeats row 0)
+static inline int ape_stream_post_chunks(int N) { return N <= 64 ? 1 : 1 + (N - 64 + 62) / 63; }
 
 struct MsgParams {
     const double* est;   // [N,W]

@@ -113,6 +113,8 @@ struct ape_streams {
     float* xring = nullptr;      // [S,n_mc,T,I] feature rows, slot = frame mod T (a stream's n_mc windows are copies)
     float* yring = nullptr;      // [S,smooth,n_mc,O] model outputs, slot = step mod smooth
     float* y_new = nullptr;      // [S,n_mc,O]
+    double* post_part = nullptr; // split post-filter (stream_post_device.h): [S][chunks][21] partial sums + [S] tickets behind them, or
+    unsigned* post_cnt = nullptr; //   nullptr where every stream keeps a workgroup of its own (many streams, or stacks of <= 64 rows)
     // shared-layer-0 route on the weight-stationary upper-layer kernel (lstm_upper32.hip): the sample rows go through it in
     // chunks of `chunk_rows` (a multiple of 32), each expand -> LSTM -> head reduce over the two workspaces below
     bool up32 = false;

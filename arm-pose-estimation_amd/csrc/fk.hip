@@ -199,9 +199,13 @@ __global__ __launch_bounds__(256) void ape_msg_kernel(const MsgParams p) {
 // smooth <= 64); sums over rows by wave shuffles.
 template <typename TMsg>
 __global__ __launch_bounds__(256) void ape_stream_post_kernel(const StreamPostParams p) {
-    stream_post<TMsg>(p, (int)blockIdx.x);
+    stream_post<TMsg, false>(p, (int)blockIdx.x, 0, 1);
 }
-
+// ... a stream's stack dealt over `chunks` workgroups (stream_post, SPLIT): a few streams with tall stacks
+template <typename TMsg>
+__global__ __launch_bounds__(256) void ape_stream_post_split_kernel(const StreamPostParams p, const int chunks) {
+    stream_post<TMsg, true>(p, (int)blockIdx.x / chunks, (int)blockIdx.x % chunks, chunks);
+}
 // ... and the form for banks without stacking: 64 streams per workgroup (stream_post_wide)
 template <typename TMsg>
 __global__ __launch_bounds__(256) void ape_stream_post_wide_kernel(const StreamPostParams p) {
@@ -236,7 +240,13 @@ hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream)
         else hipLaunchKernelGGL(ape_stream_post_wide_kernel<double>, dim3(wide), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
-    const int grid = p.S;                                  // one workgroup (four role waves) per stream
+    const int grid = p.S;                                  // one workgroup (four role waves per row group) per stream
+    const int chunks = ape_stream_post_chunks(p.smooth * p.n_mc);
+    if (p.part != nullptr && chunks > 1) {                 // (ape_api.hip hands the workspace over when the bank is small enough)
+        if (p.msg_dtype == APE_F32) hipLaunchKernelGGL(ape_stream_post_split_kernel<float>, dim3(grid * chunks), dim3(256), 0, stream, p, chunks);
+        else hipLaunchKernelGGL(ape_stream_post_split_kernel<double>, dim3(grid * chunks), dim3(256), 0, stream, p, chunks);
+        return hipGetLastError();
+    }
     if (p.msg_dtype == APE_F32) hipLaunchKernelGGL(ape_stream_post_kernel<float>, dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(ape_stream_post_kernel<double>, dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();

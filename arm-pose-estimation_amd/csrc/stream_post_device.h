@@ -69,16 +69,27 @@ __device__ __forceinline__ double wave_sum(double v) {
 // One workgroup per stream, a wave per chain (as ape_fk3_kernel: one wave computing a whole row is a chain of ~1400 f64
 // instructions): wave 0 the lower arm's 6D -> quaternion chain, its rotated bone and its quaternion mean, wave 1 the upper arm's,
 // wave 2 the hips' and the shoulder origin, wave 3 the copy into the ring, the columns that pass through and -- behind a barrier
-// -- the two sums that join the chains (hand / elbow origins: the 6-float tail of every row).  Sums over rows stay what they
-// were: a lane's rows in order, then the wave shuffle tree.
-template <typename TMsg>
-__device__ inline void stream_post(const StreamPostParams& p, const int s) {
+// -- the two sums that join the chains (hand / elbow origins: the 6-float tail of every row).  Sums over rows: a lane's rows in
+// order, then the wave shuffle tree.
+//
+// SPLIT (round 4): a stream's stack dealt over `C` workgroups, one 64-row chunk each -- for a few streams with tall stacks (one
+// estimator's frame at 60 samples x smooth 5 = 300 rows, the watch-only default 25 x 10 = 250).  The float64 chains keep a SIMD's
+// issue port busy by themselves (~5 cycles per instruction: a second wave on the same SIMD buys nothing -- four row groups in ONE
+// 1024-thread workgroup were measured at 18.1 us per 300-row frame against 15.9 for the plain loop over five chunks), so more rows
+// at once need more CUs.  Chunk 0 holds rows 0 .. 63; chunk c > 0 rows 64 + 63 (c - 1) ... on lanes 0 .. 62 and, on lane 63, row 0
+// once more: its quaternions are the sign reference of the means (transformations.py:44).  Partial sums go to `p.part`, the last
+// workgroup of a stream to arrive (ticket in `p.part_cnt`, release / acquire fences around it) adds them in chunk order and
+// writes the message; the counter is left at zero.
+template <typename TMsg, bool SPLIT>
+__device__ inline void stream_post(const StreamPostParams& p, const int s, const int chunk, const int C) {
 #pragma clang fp contract(off)
 
     __shared__ double rot[64][3][3];                        // per row of a 64-row chunk: rotated lower-arm bone, upper-arm bone, shoulder origin
     __shared__ double e0_s[21];                             // row 0 of the stack (the N == 1 message)
+    __shared__ double ref_s[3][4];                          // row 0's quaternions: the sign reference of the means
     __shared__ double outq_s[3][4];
     __shared__ double omean_s[9];
+    __shared__ int last_s;
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int M = p.n_mc, N = p.smooth * M, O = p.O;
     const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
@@ -87,25 +98,27 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
     const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
     const int c_in[3] = {full ? 3 : 0, full ? 12 : 6, full ? 18 : 12};     // first input column of the role's chain
     const double wgt = 1.0 / (double)N;
-    double ref[4] = {0, 0, 0, 0};                           // row 0's quaternion of this role: the sign reference of the mean
     double acc[4] = {0, 0, 0, 0};
     double osum[6] = {0, 0, 0, 0, 0, 0};
     if (threadIdx.x < 21) e0_s[threadIdx.x] = 0.0;
-    if (threadIdx.x < 12) outq_s[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;
+    if (threadIdx.x < 12) { outq_s[threadIdx.x >> 2][threadIdx.x & 3] = 0.0; ref_s[threadIdx.x >> 2][threadIdx.x & 3] = 0.0; }
     if (threadIdx.x < 9) omean_s[threadIdx.x] = 0.0;
     // host frames: the health of the regressor launch in front of this kernel travels with the datagrams
-    if (p.status_out != nullptr && s == 0 && threadIdx.x == 255)
+    if (p.status_out != nullptr && s == 0 && chunk == 0 && threadIdx.x == 255)
         *p.status_out = __hip_atomic_load(p.status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     // stacked row i = (prediction j of the last `smooth`, oldest first; Monte-Carlo sample k of it): lanes take
-    // rows lane, lane + 64, ... (trip count uniform over the workgroup)
-    for (int base = 0; base < N; base += 64) {
-        const int i = base + lane;
-        const bool act = i < N;
+    // rows lane, lane + 64, ... (trip count uniform over the workgroup); SPLIT: the one chunk of this workgroup
+    const int first = SPLIT ? (chunk == 0 ? 0 : 64 + 63 * (chunk - 1)) : 0;
+    const int past = SPLIT ? min(N, chunk == 0 ? 64 : first + 63) : N;
+    for (int base = first; base < past; base += 64) {
+        const bool refrow = SPLIT && chunk > 0 && lane == 63;       // row 0 once more, for its quaternions only
+        const int i = refrow ? 0 : base + lane;
+        const bool act = i < past && !refrow;
         const float* src = nullptr;
         bool fresh = false;
         int j = 0, k = 0;
-        if (act) {
+        if (act || refrow) {
             j = i / M; k = i - j * M;
             // the newest prediction sits in ring slot `pos`, the oldest one slot further
             fresh = p.cold || j == p.smooth - 1;
@@ -119,7 +132,7 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
         };
         double q[4] = {0, 0, 0, 0};
         if (role < 2) {
-            if (act) {
+            if (act || refrow) {
                 double s6[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) s6[c] = load(c_in[role] + c);
@@ -130,7 +143,7 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
                 q[0] = qq.w; q[1] = qq.x; q[2] = qq.y; q[3] = qq.z;
             }
         } else if (role == 2) {
-            if (act) {
+            if (act || refrow) {
                 Vec3 uo{p.body[6], p.body[7], p.body[8]};
                 if (hips) {
                     const Quat hq = hips_quat(load(c_in[2]), load(c_in[2] + 1));
@@ -138,8 +151,8 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
                     q[0] = hq.w; q[1] = hq.x; q[2] = hq.y; q[3] = hq.z;
                 }
                 rot[lane][2][0] = uo.x; rot[lane][2][1] = uo.y; rot[lane][2][2] = uo.z;
-                if (full) { osum[0] += uo.x; osum[1] += uo.y; osum[2] += uo.z; }
-                if (i == 0 && hips) { e0_s[6] = uo.x; e0_s[7] = uo.y; e0_s[8] = uo.z; }
+                if (full && act) { osum[0] += uo.x; osum[1] += uo.y; osum[2] += uo.z; }
+                if (i == 0 && act && hips) { e0_s[6] = uo.x; e0_s[7] = uo.y; e0_s[8] = uo.z; }
             }
         } else if (act && fresh) {                          // keep the prediction for the next frames
             float* dst = p.yring + (((size_t)s * p.smooth + (p.cold ? j : p.pos)) * M + k) * O;
@@ -147,22 +160,21 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
             for (int c = 0; c < 20; ++c)
                 if (c < O) dst[c] = src[c];
         }
-        if (role < nq) {
-            if (base == 0) {
+        if (role < nq && i == 0 && (act || refrow)) {       // row 0: lane 0 of the first chunk (SPLIT: lane 63 of the others)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ref[c] = __shfl(q[c], 0, 64);
-                if (lane == 0) {
+            for (int c = 0; c < 4; ++c) ref_s[role][c] = q[c];
+            if (act) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) e0_s[qc[role] + c] = q[c];
-                }
-            }
-            if (N > 1) {
-                const double d = fma(q[3], ref[3], fma(q[2], ref[2], fma(q[1], ref[1], q[0] * ref[0])));   // the sign rule of ape_msg_kernel
-                const double sg = !act ? 0.0 : ((i > 0 && d < 0.0) ? -wgt : wgt);
-                acc[0] += q[0] * sg; acc[1] += q[1] * sg; acc[2] += q[2] * sg; acc[3] += q[3] * sg;
+                for (int c = 0; c < 4; ++c) e0_s[qc[role] + c] = q[c];
             }
         }
-        __syncthreads();                                    // the chunk's rotated vectors are in LDS
+        __syncthreads();                                    // the chunk's rotated vectors and row 0's quaternions are in LDS
+        if (role < nq && N > 1) {
+            const double r0 = ref_s[role][0], r1 = ref_s[role][1], r2 = ref_s[role][2], r3 = ref_s[role][3];
+            const double d = fma(q[3], r3, fma(q[2], r2, fma(q[1], r1, q[0] * r0)));   // the sign rule of ape_msg_kernel
+            const double sg = !act ? 0.0 : ((i > 0 && d < 0.0) ? -wgt : wgt);
+            acc[0] += q[0] * sg; acc[1] += q[1] * sg; acc[2] += q[2] * sg; acc[3] += q[3] * sg;
+        }
         if (role == 3 && act) {
             double e6[6];
             if (full) {                                     // hand and lower-arm positions are network outputs (estimate_joints.py:20-45)
@@ -191,18 +203,49 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s) {
         __syncthreads();                                    // ... and read: the next chunk may overwrite them
     }
     if (N > 1) {
-        if (role < nq) {
-            const double a0 = wave_sum(acc[0]), a1 = wave_sum(acc[1]), a2 = wave_sum(acc[2]), a3 = wave_sum(acc[3]);
-            const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
-            if (lane == 0) { outq_s[role][0] = a0 / nrm; outq_s[role][1] = a1 / nrm; outq_s[role][2] = a2 / nrm; outq_s[role][3] = a3 / nrm; }
-        }
-        if (full && role >= 2) {                            // compose_msg.py:26-29: plain means of the three origins
-            const int n_o = (role == 2) ? 3 : 6, o0 = (role == 2) ? 6 : 0;
-            for (int c = 0; c < n_o; ++c) {
-                const double m_c = wave_sum(osum[c]) / (double)N;
-                if (lane == 0) omean_s[o0 + c] = m_c;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (role < nq) { a0 = wave_sum(acc[0]); a1 = wave_sum(acc[1]); a2 = wave_sum(acc[2]); a3 = wave_sum(acc[3]); }
+        double om[6] = {0, 0, 0, 0, 0, 0};
+        const int n_o = (role == 2) ? 3 : 6, o0 = (role == 2) ? 6 : 0;
+        if (full && role >= 2)                              // compose_msg.py:26-29: plain means of the three origins
+            for (int c = 0; c < n_o; ++c) om[c] = wave_sum(osum[c]);
+        if constexpr (SPLIT) {
+            // partial sums out, release, ticket; the last chunk to arrive acquires and adds them in chunk order
+            double* mine = p.part + ((size_t)s * C + chunk) * 21;
+            if (lane == 0 && role < nq) { mine[role * 4] = a0; mine[role * 4 + 1] = a1; mine[role * 4 + 2] = a2; mine[role * 4 + 3] = a3; }
+            if (lane == 0 && full && role >= 2)
+                for (int c = 0; c < n_o; ++c) mine[12 + o0 + c] = om[c];
+            if (p.done_out != nullptr) __threadfence_system();      // (this chunk's tail rows may sit in host memory: out before the ticket)
+            else __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned tk = __hip_atomic_fetch_add(p.part_cnt + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_s = (tk == (unsigned)(C - 1)) ? 1 : 0;
+                if (last_s) {
+                    __hip_atomic_store(p.part_cnt + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence();
+                }
             }
+            __syncthreads();
+            if (!last_s) return;
+            const double* all = p.part + (size_t)s * C * 21;
+            a0 = a1 = a2 = a3 = 0;
+            if (lane == 0 && role < nq)
+                for (int c = 0; c < C; ++c) {
+                    a0 += all[c * 21 + role * 4]; a1 += all[c * 21 + role * 4 + 1]; a2 += all[c * 21 + role * 4 + 2]; a3 += all[c * 21 + role * 4 + 3];
+                }
+            if (lane == 0 && full && role >= 2)
+                for (int k = 0; k < n_o; ++k) {
+                    om[k] = 0;
+                    for (int c = 0; c < C; ++c) om[k] += all[c * 21 + 12 + o0 + k];
+                }
         }
+        if (lane == 0 && role < nq) {
+            const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+            outq_s[role][0] = a0 / nrm; outq_s[role][1] = a1 / nrm; outq_s[role][2] = a2 / nrm; outq_s[role][3] = a3 / nrm;
+        }
+        if (lane == 0 && full && role >= 2)
+            for (int c = 0; c < n_o; ++c) omean_s[o0 + c] = om[c] / (double)N;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

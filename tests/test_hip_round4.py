@@ -415,3 +415,32 @@ def test_wide_post_kernel_equals_the_per_stream_one(norm_stats, name, dtype):
             assert np.array_equal(dw[:S_narrow], dn) and np.isfinite(dw).all(), f
             assert np.array_equal(dw[:, 4:7], dw[:, 25:28]) and np.array_equal(dw[:, 11:14], dw[:, 28:31])
     m.check()
+
+
+@pytest.mark.parametrize("name,n_mc,smooth", [("pocket", 13, 6), ("uarm", 50, 3), ("watch", 25, 10)])
+def test_split_post_kernel_equals_the_per_stream_one(norm_stats, name, n_mc, smooth):
+    """stacks of more than 64 rows of a FEW streams are dealt over several workgroups (`ape_stream_post_split_kernel`: 64-row chunks,
+    partial sums joined by the last workgroup to arrive, in chunk order); a bank too large for that (streams x chunks > CUs) keeps one
+    workgroup per stream.  Same rows, same Philox rows (global row = stream * n_mc + sample) -> the first streams of a 140-stream bank
+    against a 2-stream bank, both on the batch-tile kernel (row-independent: the same targets bit for bit): tails bit-equal (row-local
+    arithmetic), messages to 1e-12 (the means' summation order differs), cold start and ring wrap-around included."""
+    from tests.test_hip_parity import make_model, _synthetic_windows
+    from wear_mocap_ape_amd.streams import StreamBank
+    st = norm_stats[name]
+    m, sd, cfg = make_model(name, 8, st)
+    m.set_body(orc.DEFAULT_BODY)
+    m.set_kernel("tile16")
+    T, I = cfg["T"], cfg["I"]
+    S_big, S_small = 140, 2
+    feats = _synthetic_windows(st, S_big, smooth + 3, I, 91)
+    big = StreamBank(m, S_big, T, smooth=smooth, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=77)
+    small = StreamBank(m, S_small, T, smooth=smooth, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=77)
+    for f in range(smooth + 3):
+        fw = torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda()
+        big.push_features(fw)
+        small.push_features(fw[:S_small].contiguous())
+        mb, tb = (v.cpu().numpy().copy() for v in big.step(with_tail=True))
+        ms, ts = (v.cpu().numpy().copy() for v in small.step(with_tail=True))
+        assert np.array_equal(tb[:S_small], ts), f
+        assert np.abs(mb[:S_small] - ms).max() < 1e-12, (f, float(np.abs(mb[:S_small] - ms).max()))
+    m.check()
