@@ -324,8 +324,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         // one flag per (cluster, layer, member, wave) -- or, fp16 v2 kernel, per (32-row cluster, row set, member wave) --
         // + the ticket / departure words
         size_t flag_words = (size_t)max_clusters * L * GH * 4;
-        if (ape_cluster_f16v2_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * 2 * 32 > flag_words)
-            flag_words = (size_t)f16v2_capacity(m->n_cus) * 2 * 32;
+        if (ape_cluster_f16v2_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * 2 * 64 > flag_words)
+            flag_words = (size_t)f16v2_capacity(m->n_cus) * 2 * 64;      // (64 flags per cluster and set in the 16-member form)
         // (second-generation kernel of the 3 x 128 model: one flag per (32-row cluster, layer, member, one of eight waves))
         if (ape_cluster16_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * L * 64 > flag_words)
             flag_words = (size_t)f16v2_capacity(m->n_cus) * L * 64;
@@ -973,7 +973,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
                 m->last_kernel = "ape_lstm_cluster_f16v2";
-                hipError_t e = ape_launch_lstm_cluster_f16v2(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
+                // (APE_FLAG_ALT_FORM: the 16-unit-member form, two workgroups per CU -- needs 2 x 16 x clusters workgroups resident)
+                const bool duo = (flags & APE_FLAG_ALT_FORM) != 0 && m->n_cus * 2 >= 16 * (((nb + 31) / 32 + 7) / 8 * 8);
+                if (duo) m->last_kernel = "ape_lstm_cluster_f16v2<duo>";
+                hipError_t e = ape_launch_lstm_cluster_f16v2(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream, duo);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "fp16 cluster lstm launch failed: %s", hipGetErrorString(e));
             }
             return APE_OK;

@@ -59,8 +59,9 @@ __device__ __forceinline__ void mfma_wa(f32x4& acc, const f32x4 w, const f32x4 a
 // (the accumulators are in/out operands of the drain: the gate math, which reads them, cannot be scheduled above it)
 template <int NTW>
 __device__ __forceinline__ void mfma_drain(f32x4 (&acc)[NTW]) {
-    static_assert(NTW == 2, "two tiles per wave");
-    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+    static_assert(NTW == 1 || NTW == 2, "one or two tiles per wave");
+    if constexpr (NTW == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
 }
 
 // NQ 32-deep k-blocks of LDS activations (16 rows x 32 k each) into registers; `stride` halves between k-blocks
@@ -107,9 +108,13 @@ __device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
 }
 __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 
-template <int H, int L, int KX>
-__global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterParams p) {
-    constexpr int UPW = 8;                  // hidden units per wave
+// UPW = 4 (round 4, "duo"): 16-unit members -- a wave owns 4 units = ONE tile, 100 weight registers -- so that a workgroup fits twice on a
+// CU (<= 256 registers per wave, 47 KB of LDS): 16-member clusters of 32 rows, 512 workgroups for 1024 windows, TWO independent
+// workgroups per CU with a barrier each.  A section of this kernel is ~48 % compute and ~52 % hand-over waits (profiles/r03_f16v2_stamps.md);
+// a second, independent wave per SIMD can run under the first one's waits.  The pieces of the exchange are 8 bytes per wave then (two
+// waves share a 16-byte k-group of the fragment order); everything else is the same code.
+template <int H, int L, int KX, int UPW>
+__global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v2(const ClusterParams p) {
     constexpr int NTW = UPW / 4;            // 16-column MFMA tiles per wave (column = unit * 4 + gate)
     constexpr int GH = H / (4 * UPW);       // members per cluster
     constexpr int SR = 16, NS = 2;          // rows per set, sets per cluster
@@ -117,10 +122,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     constexpr int QX = KX / 32, QH = H / 32;
     constexpr int NB0 = QX + QH, NB1 = 2 * QH;
     constexpr int NFL = 4 * GH;             // flags per (cluster, set): one per member wave
-    constexpr int PIECES = L * GH * 4 * SR; // 16-byte pieces of one set's gathered slices
+    constexpr int KG = 4 * UPW / 8;         // 16-byte k-groups (8 units) per member: 4 (one per wave) or 2 (one per pair of waves)
+    constexpr int PIECES = L * GH * KG * SR; // 16-byte pieces of one set's gathered slices
     constexpr int NDMA = PIECES / 256;      // LDS-DMA instructions per wave and gather
-    constexpr int HL = GH * 4 * SR * 8;     // halves of one (set, layer) block: [member][wave][row][8 units]
-    static_assert(GH == 8 && QH == GH && L == 2 && PIECES % 256 == 0, "built for 8-member clusters of the 2 x 256 models");
+    constexpr int HL = GH * KG * SR * 8;    // halves of one (set, layer) block: [member][k-group][row][8 units]
+    static_assert((UPW == 8 || UPW == 4) && GH * KG == 4 * QH && L == 2 && PIECES % 256 == 0 && NFL <= 64, "built for the 2 x 256 models");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
 #endif
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
-    _Float16* hbuf = smem16;                              // [NS][L][member][wave][row][8]: gathered h of the set's last phase, in
+    _Float16* hbuf = smem16;                              // [NS][L][member][k-group][row][8]: gathered h of the set's last phase, in
                                                           //  the exchange order = MFMA fragment order (k-block = member, k-group = wave)
     _Float16* xin = hbuf + NS * L * HL;                   // [NS][2 parity][SR][SX]
     _Float16* own = xin + NS * 2 * SR * SX;               // [wave 4][L][SR][UPW]  fresh slice of this wave (wave-private)
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     f32x4 w1[NTW][NB1];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int m16 = 2 * member + (wave >> 1), w16 = 2 * (wave & 1) + t;
+        const int m16 = (UPW == 8) ? 2 * member + (wave >> 1) : member, w16 = (UPW == 8) ? 2 * (wave & 1) + t : wave;
         const f32x4* s0 = reinterpret_cast<const f32x4*>(p.wcl[0]) + ((size_t)(m16 * 4 + w16) * NB0) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NB0; ++i) w0[t][i] = s0[i * 64];
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         for (int t = 0; t < NTW; ++t) {
             f32x4 bv;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bv[k] = p.bias[l][k * H + member * 32 + wave * 8 + t * 4 + g];
+            for (int k = 0; k < 4; ++k) bv[k] = p.bias[l][k * H + member * (4 * UPW) + wave * UPW + t * 4 + g];
             bias_s[((wave * L + l) * NTW + t) * 64 + lane] = bv;
         }
     // per-set register state is kept as "this section's set" / "the other set" and swapped at the end of every section,
@@ -460,11 +466,21 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
         {
             const int l = lane >> 4, row = lane & 15, t = ph - l;
             const bool live = lane < 16 * L && (ST || (t >= 0 && t < T));
-            const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
             // dead lanes aim outside the buffer descriptor: the store instruction is issued by every wave, writes nothing there
-            const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16) : 0x80000000u;
-            if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            if constexpr (UPW == 8) {
+                const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
+                const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16) : 0x80000000u;
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            } else {
+                // this wave's 4 units are half of a 16-byte k-group: 8 bytes at (wave & 1) * 8 inside the piece of (member, wave >> 1, row)
+                typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+                const u32x2 hv = *reinterpret_cast<const u32x2*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
+                const unsigned off = (live && !d_noex)
+                    ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * KG + (wave >> 1)) * SR + row) * 16 + (wave & 1) * 8) : 0x80000000u;
+                if (in_l2) __builtin_amdgcn_raw_buffer_store_b64(hv, hx_rsrc, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
+            }
             pend_set = s;
             pend_epoch = (unsigned)(ph + 1);
         }
@@ -524,10 +540,10 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_f16v2(const ClusterPa
     }
 }
 
-template <int H, int L, int KX>
+template <int H, int L, int KX, int UPW>
 constexpr size_t smem_bytes() {
-    return ((size_t)2 * L * 16 * H + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * 8) * sizeof(_Float16) +
-           (size_t)4 * L * 2 * 64 * 16 + 16;
+    return ((size_t)2 * L * 16 * H + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * UPW) * sizeof(_Float16) +
+           (size_t)4 * L * (UPW / 4) * 64 * 16 + 16;
 }
 
 }  // namespace
@@ -536,16 +552,26 @@ bool ape_cluster_f16v2_supported(int H, int L, int KX) { return H == 256 && L ==
 
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX) {
     if (!ape_cluster_f16v2_supported(H, L, KX)) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster_f16v2<256, 2, 32>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster_f16v2<256, 2, 32, 8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    static_assert(2 * smem_bytes<256, 2, 32, 4>() <= APE_LDS_BYTES, "two workgroups of the 16-unit-member form per CU");
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster_f16v2<256, 2, 32, 4>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<256, 2, 32, 4>());
 }
 
 // `clusters` = 32-row clusters needed; the grid is rounded up to whole block-index classes (8 clusters), the extra
-// clusters own rows past the batch and only take part in the formation
-hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream) {
+// clusters own rows past the batch and only take part in the formation.  `duo`: the 16-unit-member form, 16 workgroups per cluster,
+// two per CU.
+hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream, bool duo) {
     if (!ape_cluster_f16v2_supported(H, L, KX)) return hipErrorInvalidValue;
     const int grid_clusters = (clusters + 7) / 8 * 8;
-    constexpr size_t smem = smem_bytes<256, 2, 32>();
-    hipLaunchKernelGGL((ape_lstm_cluster_f16v2<256, 2, 32>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    if (duo) {
+        constexpr size_t smem = smem_bytes<256, 2, 32, 4>();
+        hipLaunchKernelGGL((ape_lstm_cluster_f16v2<256, 2, 32, 4>), dim3(grid_clusters * 16), dim3(256), smem, stream, p);
+    } else {
+        constexpr size_t smem = smem_bytes<256, 2, 32, 8>();
+        hipLaunchKernelGGL((ape_lstm_cluster_f16v2<256, 2, 32, 8>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
+    }
     return hipGetLastError();
 }

@@ -238,6 +238,15 @@ def test_fp16_second_generation_kernel(norm_stats, name, B, T):
     torch.cuda.synchronize()
     model.check()
     assert np.array_equal(y_wt.cpu().numpy(), y2)
+    # round 4: the 16-unit-member form of the same kernel (APE_FLAG_ALT_FORM: 16-member clusters, two workgroups per CU) -- measured
+    # slower and not the default, kept selectable; same arithmetic up to the summation order inside the exchange's k-groups
+    y_duo = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | _hip.FLAG_ALT_FORM,
+                                           None, 0.0, 0, C.c_void_p(y_duo.data_ptr()), None), "ape_lstm_forward")
+    torch.cuda.synchronize()
+    model.check()
+    assert model.last_kernel() == "ape_lstm_cluster_f16v2<duo>"
+    assert float(np.abs(y_duo.cpu().numpy() - y2).max()) < 3e-5
     model.set_precision("f16_gen1")
     assert model.kernel_name(B, T) == "ape_lstm_cluster_f16"
     y1 = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
