@@ -109,7 +109,8 @@ enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1, APE_PRECISION_F16_GEN1 = 2 
 #define APE_FLAG_NO_XCD_CLASSES  0x02000000u /* first-generation cluster kernel: clusters by global arrival ticket instead of within
                                                block-index classes (one XCD each) */
 #define APE_FLAG_ALT_FORM        0x01000000u /* the alternative decomposition where a kernel has two: the latency kernel's H/16-member form,
-                                               lstm_cluster16's one-workgroup-per-CU form */
+                                               lstm_cluster16's one-workgroup-per-CU form, the fp16 kernel's 16-unit-member form (two
+                                               workgroups per CU; measured slower) */
 
 typedef struct ape_model ape_model_t;
 
