@@ -590,7 +590,7 @@ def other_paths():
                                                            C.c_void_p(y.data_ptr()), None), "fwd"), 10, 50)
         out["mlp_regressor"] = {"rows": N, "us_per_launch": us, "rows_per_s": N / us * 1e6,
                                 "tflops": m.flops_per_window(1) * N / us / 1e6, "kernel": m.kernel_name(N, 1),
-                                "profile": "profiles/r03_mlp_pipe.md"}
+                                "profile": "profiles/r04_mlp_pipe.md"}
         m.check()
         del m, x, y
     except Exception as exc:
@@ -605,7 +605,7 @@ def other_paths():
         m.check()
         out["imupose_lstm"] = {"windows": B, "frames": T, "us_per_call": us, "windows_per_s": B / us * 1e6,
                                "tflops": m.flops_per_window(T) * B / us / 1e6, "kernel": m.kernel_name(B, T),
-                               "profile": "profiles/r03_imupose_cluster.md"}
+                               "profile": "profiles/r04_imupose_cluster.md"}
         del m, x, y
     except Exception as exc:
         out["imupose_lstm"] = {"error": str(exc)[:200]}
@@ -622,7 +622,7 @@ def other_paths():
             res[f"T{T}"] = {"us_per_launch": us, "windows_per_s": B / us * 1e6, "tflops": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
                             "kernel": m.kernel_name(B, T)}
         m.check()
-        out["uarm_lstm"] = dict(res, windows=B, profile="profiles/r03_uarm_T64.md")
+        out["uarm_lstm"] = dict(res, windows=B, profile="profiles/r04_uarm_T64.md")
         del m, x, y
     except Exception as exc:
         out["uarm_lstm"] = {"error": str(exc)[:200]}

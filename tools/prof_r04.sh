@@ -1,5 +1,5 @@
 # rocprofv3 passes behind profiles/r04_*.md (run on the GPU box: bash tools/prof_r04.sh <what>); the trace databases are summarised
-# here because they are too big to travel back.  <what> = cluster32 | bank_mc | bank_uarm | bank_watch | mc_small | frame
+# here because they are too big to travel back.  <what> = cluster32 | bank_mc | bank_uarm | bank_watch | mc_small | pipe | uarm | imupose
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -74,6 +74,18 @@ mc_small)
   rm -rf $P/trace
   trace python3 tests/tools/frame_trace.py 60 5 400 host
   kernels > gpurun_out/prof_mc_small_host60_kernels.txt
+  ;;
+pipe)
+  passes python3 tests/tools/time_mlp.py 262144
+  python3 tools/summarize_prof.py r04_mlp_pipe $P/trace $P/fetch $P/write ape_mlp_pipe 65536 262144 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/mlp_pipe.hip --lds 148544 --flop-per-launch 7.35513e10 --peak-tflops 157.3 --skip-first 20 --note "DropoutFF 22 -> 256 -> 256 -> 256 -> 14, eval mode, 262 144 rows = 8192 tiles of 32 rows over 128 pairs of workgroups (64 tiles per pair); grid 256 workgroups x 256 threads; \`python3 tests/tools/time_mlp.py 262144\`; recipe \`tools/prof_r04.sh pipe\`."
+  ;;
+uarm)
+  passes python3 tests/tools/time_uarm.py
+  python3 tools/summarize_prof.py r04_uarm_T64 $P/trace $P/fetch $P/write "ape_lstm_cluster16<128, 3, 64, 2>" 131072 1024 --wg-threads 512 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster16.hip --lds 92944 --flop-per-launch 4.5502955520e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "WatchPhoneUarmNN's regressor (I = 38, H = 128, L = 3, O = 12; watch_phone_uarm_nn.py:13-41), 1024 windows x 64 frames, eval mode, on the second-generation kernel of that shape (DESIGN.md 4.14; the first generation ran this at 532 us under rocprofv3, 284 MB per launch); \`python3 tests/tools/time_uarm.py\`; recipe \`tools/prof_r04.sh uarm\`."
+  ;;
+imupose)
+  passes python3 tests/tools/time_imupose.py
+  python3 tools/summarize_prof.py r04_imupose_cluster $P/trace $P/fetch $P/write "ape_lstm_cluster<256, 2, 256, 2, false>" 65536 512 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster.hip --flop-per-launch 6.8723671040e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "ImuPoseLSTM (nn_models.py:210-249: Linear 22 -> 256 + ReLU, 2 x 256 LSTM with a 256-wide layer-0 input, Linear 256 -> 14), 1024 windows x 64 frames = TWO launches of 512 windows (16 clusters x 16 members x 32 rows) of the first-generation kernel, this round with XCD-local clusters (DESIGN 4.1); algorithmic FLOP of one launch = 512 x (64 x 2 x 4H x (512 + 512) + 2 x 14 x 256); \`python3 tests/tools/time_imupose.py\`; recipe \`tools/prof_r04.sh imupose\`."
   ;;
 esac
 cp profiles/r04_*.md gpurun_out/ 2>/dev/null || true
