@@ -733,7 +733,7 @@ static int mc_small_launch(ape_model_t* m, const float* x, size_t x_stream_strid
     q.rows = n_streams * n_mc; q.n_mc = n_mc; q.n_streams = n_streams;
     q.cps = 8 / n_streams; q.R = (n_mc + q.cps - 1) / q.cps;
     q.T = T; q.I = I; q.O = O; q.x_ring = x_ring;
-    q.flags = flags & (APE_FLAG_NORMALIZE_INPUT | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX | APE_DIAG_WRITE_THROUGH);
+    q.flags = flags & (APE_FLAG_NORMALIZE_INPUT | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX | APE_FLAG_ANY_PLACEMENT);
     q.dropout_p = (flags & APE_FLAG_DROPOUT_PHILOX) ? dropout_p : 0.0f; q.seed = seed;
     q.dbg_wg = m->dbg_wg;
     q.xg = m->gxm + 256 + 8 * m->gxm_cluster_bytes;
@@ -756,10 +756,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
     flags &= ~(uint32_t)APE_FLAG_XCD_CLASSES;            // (the launcher's own bit)
 #if !defined(APE_ABLATE) && !defined(APE_CLUSTER_STAMPS)
-    // the product library knows the documented flags and the three exchange-form selectors of include/ape_hip.h; the timing-only
+    // the product library knows the documented flags and the four exchange-form selectors of include/ape_hip.h; the timing-only
     // ablation bits (results are garbage) exist in the diagnostic builds alone
     if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_ALL_STEPS | APE_FLAG_DROPOUT_MASKS | APE_FLAG_DROPOUT_PHILOX | APE_FLAG_BROADCAST_X |
-                            APE_FLAG_ANY_PLACEMENT | APE_FLAG_NO_XCD_CLASSES | APE_FLAG_ALT_FORM))
+                            APE_FLAG_ANY_PLACEMENT | APE_FLAG_IN_XCD_PLAIN | APE_FLAG_NO_XCD_CLASSES | APE_FLAG_ALT_FORM))
         return fail(APE_ERR_INVALID_ARG, "lstm_forward: unknown flag bits 0x%x", flags);
 #endif
     if (!m->has_weights) return fail(APE_ERR_NOT_READY, "lstm_forward: weights not loaded");
@@ -901,7 +901,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int nmt = cluster_nmt(m->n_cus, H, B - n16, cdrop || m->wide_cluster);      // (wide: at most two row tiles, like dropout)
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path && !m->wide_cluster;   // latency path: VALU GEMV, one exchange per phase
-        const int small_uw = (flags & APE_DIAG_SMALL_UW4) ? 4 : m->small_uw;
+        const int small_uw = (flags & APE_FLAG_ALT_FORM) ? 4 : m->small_uw;
         const int rest_plan = (f16 || small) ? PLAN_NONE : rest_kernel(B - n16, T, (!cdrop && !drop && !all_steps) ? gen2_of(m) : 0);
         if (rest_plan == PLAN_C32) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
@@ -1036,7 +1036,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
             int clusters = (nb + 16 * nmt - 1) / (16 * nmt);
             // f32 first-generation kernel: whole groups of 8 clusters (if the device holds them) form XCD-local clusters and hand
             // their slices over inside that XCD's L2 (lstm_cluster.hip, APE_FLAG_XCD_CLASSES); the extra clusters own no rows
-            if (!small && !f16 && m->gen1_classes && !(flags & APE_DIAG_NO_XSTAGE)) {        // (diagnostic bit: A/B on one box)
+            if (!small && !f16 && m->gen1_classes && !(flags & APE_FLAG_NO_XCD_CLASSES)) {   // (selector: A/B on one box)
                 const int c8 = (clusters + 7) / 8 * 8;
                 // (a launch of fewer than four clusters -- one stream's 25 Monte-Carlo rows -- stays as it is: there the rendezvous costs
                 //  more than the shorter hops save, 44.7 vs 43.8 us)
@@ -1553,11 +1553,12 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
     if (!b->xring || !b->yring || !b->y_new)
         return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
     if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
-    // (APE_DIAG_WRITE_THROUGH: internal, tests only -- the cluster kernels take their any-placement exchange form, same bits)
-    const uint32_t diag_wt = flags & (APE_DIAG_WRITE_THROUGH | APE_DIAG_NO_XSTAGE);     // (+ the A/B bit of the first generation's classes)
-    flags &= ~(uint32_t)(APE_DIAG_WRITE_THROUGH | APE_DIAG_NO_XSTAGE);
+    // the exchange-form selectors of include/ape_hip.h travel to the frame's LSTM launches unchanged (same bits whichever is set)
+    const uint32_t diag_wt = flags & (APE_FLAG_ANY_PLACEMENT | APE_FLAG_IN_XCD_PLAIN | APE_FLAG_NO_XCD_CLASSES);
+    flags &= ~diag_wt;
     if (flags & ~(uint32_t)(APE_FLAG_NORMALIZE_INPUT | APE_FLAG_PACKED_MSG))
-        return fail(APE_ERR_INVALID_ARG, "streams_step: only NORMALIZE_INPUT and PACKED_MSG are accepted");
+        return fail(APE_ERR_INVALID_ARG, "streams_step: NORMALIZE_INPUT, PACKED_MSG and the exchange-form selectors ANY_PLACEMENT, "
+                    "IN_XCD_PLAIN, NO_XCD_CLASSES are accepted");
     if (out_dtype != APE_F32 && out_dtype != APE_F64) return fail(APE_ERR_INVALID_ARG, "streams_step: unknown dtype selector");
     const bool packed = (flags & APE_FLAG_PACKED_MSG) != 0;
     if (packed && tail_dev)

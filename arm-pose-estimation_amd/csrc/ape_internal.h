@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/ape_hip.h"
 
 #define APE_MAX_LAYERS 3
 #define APE_MAX_INPUT 64
@@ -10,20 +11,20 @@
 #define APE_XCC_WORDS 1024
 #define APE_C32_ENDS_MAX_T 8      // lstm_cluster32.hip: windows of up to this many steps run the instantiation with the end forms
 #define APE_LDS_BYTES (160 * 1024) // LDS of a gfx950 CU: the dynamic-LDS limit every kernel instantiation is raised to, once
-// internal timing-only diagnostics (never set by the public API's documented flags; outputs are wrong)
+// internal timing-only ablation switches: the diagnostic builds alone (make diag / make ablate) read them, outputs are wrong.  Their bit
+// values overlap with NO public flag or selector of include/ape_hip.h (round 5: two of them used to).
 #define APE_DIAG_NO_EXCHANGE 0x40000000u
 #define APE_DIAG_NO_ACT      0x20000000u
 #define APE_DIAG_STAMP       0x10000000u
-#define APE_DIAG_NO_MFMA     0x04000000u   // diagnostic builds of the fp16 v2 kernel only: skip the matrix work
-#define APE_DIAG_NO_XSTAGE   0x02000000u   // ... skip the staging / fetch of the next step's inputs (product: = APE_FLAG_NO_XCD_CLASSES, include/ape_hip.h)
-                                             // (product dispatch: the same bit keeps a first-generation launch on any-placement clusters -- A/B runs
-                                             //  and tests/test_hip_round3.py; same results either way)
-#define APE_DIAG_WRITE_THROUGH 0x08000000u   // small-batch kernel: use the any-placement (sc1) exchange even when the
-                                            // members share an XCD -- results are the same; lets tests run that path
+#define APE_DIAG_NO_MFMA     0x04000000u   // fp16 v2 / upper-layer kernel: skip the matrix work
+#define APE_DIAG_NO_XSTAGE   0x00200000u   // ... skip the staging / fetch of the next step's inputs
+#define APE_DIAG_NO_BARRIER  0x00100000u   // upper-layer kernel: no workgroup barrier at a section's top
 
 #define APE_FLAG_XCD_CLASSES 0x00800000u   // internal (set by the launcher): the first-generation kernel forms its clusters within block-index classes
-#define APE_DIAG_SMALL_UW4   0x01000000u   // small-batch kernel: the H/16-member form also where the H/8-member one is available
-                                            // (same results up to f32 summation order; lets tests run that form)
+
+// Hand-over form of a flag-based kernel, in one place: plain (write-back) payload stores ONLY when the caller opted in with
+// APE_FLAG_IN_XCD_PLAIN AND the cluster verified at run time that all its members share an XCD (`same_xcd`); otherwise write-through.
+#define APE_HANDOVER_IN_L2(flags, same_xcd) ((same_xcd) && ((flags) & APE_FLAG_IN_XCD_PLAIN) != 0u && ((flags) & APE_FLAG_ANY_PLACEMENT) == 0u)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -115,7 +116,7 @@ struct UpperParams {
     float* hseq;                        // layer-0 form only: [n_tiles][T][32 KB] every step's slices (fragment order)
     size_t hseq_bytes;
     int T, O, n_tiles;
-    unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
+    unsigned flags;                     // APE_FLAG_IN_XCD_PLAIN / APE_FLAG_ANY_PLACEMENT only
 };
 
 // Kernel arguments of the weight-stationary kernel for layers 1 and 2 of the 3 x 128 model in a Monte-Carlo stream bank
@@ -135,7 +136,7 @@ struct Upper128Params {
     unsigned* status;
     unsigned* xcc_slots;
     int T, O, n_tiles;
-    unsigned flags;                     // APE_DIAG_WRITE_THROUGH only
+    unsigned flags;                     // APE_FLAG_IN_XCD_PLAIN / APE_FLAG_ANY_PLACEMENT only
     float dropout_p;
     unsigned long long* dbg_wg;         // diagnostic build only (APE_CLUSTER_STAMPS): shader-clock sums of cluster 0 / member 0 / wave 0
 };
@@ -255,7 +256,7 @@ struct McSmallParams {
     int cps;                            // clusters per stream
     int R;                              // sample rows per cluster (<= 16)
     int T, I, O, x_ring;
-    unsigned flags;                     // NORMALIZE_INPUT, DROPOUT_MASKS | DROPOUT_PHILOX, APE_DIAG_WRITE_THROUGH
+    unsigned flags;                     // NORMALIZE_INPUT, DROPOUT_MASKS | DROPOUT_PHILOX, APE_FLAG_ANY_PLACEMENT
     float dropout_p;
     unsigned long long seed;
     unsigned long long* dbg_wg;         // diagnostic builds only

@@ -358,7 +358,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     }
     bar();
     if (ctl[0] != 0) return;
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;      // uniform over the cluster
+        // hand-over form (ape_internal.h): write-through (`sc1`) payload stores unless the caller opted into the plain in-XCD form AND the
+    // members were verified to share an XCD; uniform over the cluster
+    const bool in_l2 = APE_HANDOVER_IN_L2(p.flags, ctl[3] != 0);
 
     // The flag a wave owes for the slice it stored last: raised once those stores have drained -- a few k-blocks
     // into the NEXT section's MFMAs (the write-through latency hides there), or at the latest before this wave

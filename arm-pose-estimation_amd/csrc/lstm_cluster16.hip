@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     }
     __syncthreads();
     if (ctl[0] != 0) return;
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
+        // hand-over form (ape_internal.h): write-through (`sc1`) payload stores unless the caller opted into the plain in-XCD form AND the
+    // members were verified to share an XCD; uniform over the cluster
+    const bool in_l2 = APE_HANDOVER_IN_L2(p.flags, ctl[3] != 0);
 
     auto wait_flags = [&](int l, unsigned want) {
         unsigned spins = 0;
@@ -595,12 +597,12 @@ hipError_t ape_prepare_lstm_cluster16(int H, int L, int KX) {
 }
 
 // `rows` windows (at most 1024 on a whole MI355X); the grid is rounded up to whole block-index classes (8 clusters x GH members).
-// Default form: 32-window clusters, one eight-wave workgroup per CU.  APE_DIAG_SMALL_UW4 (diagnostic flag, re-used): 16-window clusters,
+// Default form: 32-window clusters, one eight-wave workgroup per CU.  APE_FLAG_ALT_FORM (include/ape_hip.h): 16-window clusters,
 // two four-wave workgroups per CU, each with its own barrier -- built to see whether two cluster members that drift freely on a CU overlap
 // better than two row tiles behind one barrier: they do not (1024 x 64 on one box: 456 vs 450 us)
 hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int rows, const ClusterParams& p, hipStream_t stream) {
     if (!ape_cluster16_supported(H, L, KX)) return hipErrorInvalidValue;
-    if (!(p.flags & APE_DIAG_SMALL_UW4)) {
+    if (!(p.flags & APE_FLAG_ALT_FORM)) {
         const int grid_clusters = ((rows + 31) / 32 + 7) / 8 * 8;
         constexpr size_t smem = smem16<128, 3, 64, 2>();
         hipLaunchKernelGGL((ape_lstm_cluster16<128, 3, 64, 2>), dim3(grid_clusters * 8), dim3(512), smem, stream, p);

@@ -124,6 +124,14 @@ __device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt
 // 1024 x 6: 83.8 -> 82.3 us (best blocks; 87.2 -> 85.6 medians).  But with these forms in the kernel hipcc's code for the steady-state
 // sections comes out ~0.3-1 % slower per phase (register allocation / layout: 12.24 vs 12.27 us per phase; 1024 x 32: 402 -> 406 us; 1024 x 12: no difference left), so
 // longer windows keep the instantiation without them.
+// hook positions of a steady-state section (k-block indices; see `mid` in the kernel): QF = where the flag owed for the section in front's publish
+// store goes up, QPD = shift of the look / judge / gather positions from the middle of the section
+#ifndef C32_QF
+#define C32_QF 3
+#endif
+#ifndef C32_QPD
+#define C32_QPD 0
+#endif
 template <int H, int L, int KX, bool ENDS>
 __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams p) {
     constexpr int UPW = 8;                  // hidden units per wave (x 4 gates = the 32 columns of its tile)
@@ -303,7 +311,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     __syncthreads();
     if (ctl[0] != 0) return;
     C32_TL(1);
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
+        // hand-over form (ape_internal.h): write-through (`sc1`) payload stores unless the caller opted into the plain in-XCD form AND the
+    // members were verified to share an XCD; uniform over the cluster
+    const bool in_l2 = APE_HANDOVER_IN_L2(p.flags, ctl[3] != 0);
 
     // every wave polls for itself: have all member waves published epoch `want` of layer l?
     auto wait_flags = [&](int l, unsigned want) {
@@ -414,6 +424,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     // barrier the store itself is waited for and its flag goes up.
     const int P = T + L - 1;                 // phases 0 .. P-1 compute; "phase" P: the final gather for the head
     bool prefetched = false;
+#ifdef APE_C32_COUNTS
+    // light counters of a product-like build (tests/tools/counts_c32.py): per workgroup (wave 0), per layer -- sections whose gather took the
+    // blocking form / was prefetched, shader clocks between a section's entry and the exit of its top barrier
+    unsigned lc_block[2] = {0u, 0u}, lc_go[2] = {0u, 0u}, lc_n[2] = {0u, 0u};
+    unsigned long long lc_top[2] = {0ull, 0ull}, lc_t0 = 0ull;
+    const unsigned long long lc_start = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef APE_CLUSTER_STAMPS
     unsigned long long dg_block[2] = {0, 0}, dg_go[2] = {0, 0};      // diagnostic counters per layer (cluster 0, member 0)
     unsigned long long dgh[2][6] = {};       // ... and inside the spans: store drain + flag, x staging, judge, gather issue, (unused), eight hook-free blocks
@@ -428,15 +445,22 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     // at the deployed T = 6 four of the launch's exchanges were exposed, ~3 us each of an 89 us launch):
     //   MODE 1  layer 1 on step 0 runs its input span alone (h_{-1} = 0): 32 k-blocks, so the look at the next section's flags and
     //           its gather sit at blocks 16 / 20 .. 27 instead of 30 / 34 .. 41, which it never reaches;
-    //   MODE 2  layer 1 on the LAST step behind an idle layer-0 section: h^1_{T-2} was published by the section right in front, so
-    //           nobody could prefetch it.  The input span (h^0_{T-1}, in LDS since the section in front) runs first and carries the
-    //           looks and the gather; the wait for the copies and a second barrier sit between the spans (lstm_cluster16.hip's place
-    //           for the barrier).  Both barriers are unconditional; a wave whose looks both failed blocks in front of the second one.
+    // and ONE form for every layer-1 section with a recurrent span (round 5; round 4 had it for the last step of a short window only):
+    //   MODE 3  layer 1 on step t >= 1 gathers its OWN missing slice set h^1_{t-1} under its input span: that span reads h^0_t, in LDS since
+    //           the layer-0 section in front, so the section starts without a wait and WITHOUT a barrier; the look at the own layer's flags
+    //           sits at block QF + 1 -- a whole layer-0 section (>= 4 us) behind the publish, where round 4's look from inside that
+    //           layer-0 section came 1.4 us behind the flag and, with write-through stores, found it down in one section of ten
+    //           (6.5 blocking gathers per 1024 x 64 launch and member against 1.0 with plain stores; tests/tools/counts_c32.py) --
+    //           the eight pieces follow it, and the wait for them and the section's ONE barrier sit between the spans
+    //           (lstm_cluster16.hip's place for it): 16+ k-blocks for the copies to land in instead of 8.  x staging moves behind that
+    //           barrier; layer-0 sections no longer carry a look or a gather.  Outside the steady state (the last step of a short
+    //           window sits behind an idle, i.e. empty, layer-0 section) a second look follows at block QF + 13; a wave whose looks
+    //           failed blocks in front of the barrier.
     auto section = [&](auto steady_tag, auto layer_tag, auto mode_tag, const int ph) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 1 <= t <= T - 2 for both layers
         constexpr int l = decltype(layer_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
-        static_assert(MODE == 0 || (!ST && l == L - 1), "the end forms are layer 1's");
+        static_assert(MODE == 0 || (l == L - 1 && (MODE == 3 || !ST)), "the special forms are layer 1's");
         const int t = ph - l;
         const bool active = ST || (t >= 0 && t < T);
         // h^l_{t-1} exists and somebody reads it from here on (layer 0 at t == T: no layer-0 step any more, but layer 1's
@@ -445,14 +469,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c0 = ST ? now() : 0ull;
 #endif
+#ifdef APE_C32_COUNTS
+        lc_t0 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- S0: this layer's slices of its last step into LDS ------------------------------------------------------------
-        if (MODE == 2) {                                          // (the slices come in under the input span)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            raise_pending();
+        if (MODE == 3) {                                          // (the slices come in under the input span: nothing to wait for here)
         } else if (need) {
             if (!prefetched) {                                    // pipeline fill, a late peer, the final gather
 #ifdef APE_CLUSTER_STAMPS
                 dg_block[l] += 1;
+#endif
+#ifdef APE_C32_COUNTS
+                lc_block[l] += 1u;
 #endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
@@ -468,16 +496,20 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c1 = ST ? now() : 0ull;
 #endif
-        bar();
+        if constexpr (MODE != 3) bar();
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c2 = ST ? now() : 0ull;
 #endif
-        const int abort_word = ctl[0];
+#ifdef APE_C32_COUNTS
+        if (ST && MODE != 3) { lc_top[l] += __builtin_amdgcn_s_memtime() - lc_t0; lc_n[l] += 1u; }
+#endif
+        const int abort_word = (MODE == 3) ? 0 : ctl[0];          // (MODE 3 looks behind its own barrier, between the spans)
         C32_TL(8 + 2 * (2 * ph + l));
         // the next section: layer ln on step tn = its phase - ln; the slice set it is missing is h^{ln}_{tn-1}, epoch tn
         constexpr int ln = (l + 1 < L) ? l + 1 : 0;
         const int tn = (l + 1 < L) ? t - 1 : t + L;
-        const bool pre = ST || (tn >= 1 && tn <= T);
+        // (layer 1 gathers for itself, MODE 3: only layer-1 sections prefetch, for the layer-0 section behind them)
+        const bool pre = (l == L - 1) && (ST || (tn >= 1 && tn <= T));
         unsigned peek = (unsigned)tn;
         bool go = false;
         // exchange work hung into the MFMA stream (k-block q of the whole layer-step, a constant after unrolling):
@@ -489,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         constexpr int NBL = (l == 0) ? BX + BH : 2 * BH;
         // (positions swept on MI355X, 1024 x 64: QF 1 / 2 / 3 / 10 / 16 -> 826 / 833 / 819 / 828 / 858 us -- earlier stalls on the store's
         //  acknowledgement, later the peers' look finds nothing; look 12 blocks ahead of the judge instead of 4 -> 840: the flags are not up yet)
-        constexpr int QF = 3, QP = (MODE == 1) ? 16 : NBL / 2 - 2, QJ = (MODE == 1) ? 20 : NBL / 2 + 2;
+        constexpr int QF = C32_QF, QP = (MODE == 1) ? 16 : NBL / 2 - 2 + C32_QPD, QJ = (MODE == 1) ? 20 : NBL / 2 + 2 + C32_QPD;
         bool staged = false;
 #ifdef APE_CLUSTER_STAMPS
         unsigned long long hk0 = 0, hk_free = 0;
@@ -514,24 +546,26 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             // x of the next layer-0 step: registers -> LDS (layer 0's readers of xin finished before this section's barrier), and
             // the fetch of the step after it EARLY in the section: issued at its end the loads were the youngest entries but one of
             // the memory queue, and the counted wait at the top of the next section sat out their whole latency (13 us per launch)
-            if (l == L - 1 && q == QF + 1 && (ST || ph + 1 < T)) {
+            if (l == L - 1 && q == ((MODE == 3) ? BH + 1 : QF + 1) && (ST || ph + 1 < T)) {
                 HK_BEGIN();
                 stage_x();
                 if (ST || ph + 2 < T) fetch_x(ph + 2);
                 staged = true;
                 HK_END(1);
             }
-            if (q == QP) peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));     // (always: no branch around it)
-            if (q == QJ) {
-                HK_BEGIN();
-                peek_wait(peek);
-                go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
-                HK_END(2);
-            }
-            if (q >= QJ && q < QJ + NDMA && go) {
-                HK_BEGIN();
-                issue_piece(HOT, ln, tn - 1, q - QJ);
-                HK_END(3);
+            if constexpr (l == L - 1) {
+                if (q == QP) peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));     // (always: no branch around it)
+                if (q == QJ) {
+                    HK_BEGIN();
+                    peek_wait(peek);
+                    go = pre && __all((int)(peek >= (unsigned)tn)) != 0;
+                    HK_END(2);
+                }
+                if (q >= QJ && q < QJ + NDMA && go) {
+                    HK_BEGIN();
+                    issue_piece(HOT, ln, tn - 1, q - QJ);
+                    HK_END(3);
+                }
             }
         };
         float hnew[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -547,36 +581,53 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             if constexpr (l == 0) {
                 span32<BX, false, NW0>(acc, xin + n * SX + hh * 4, 8, w0, 0, [&](int q) { mid(q); });
                 if (ST || t > 0) span32<BH, false, NW0>(acc, hb0 + ((t - 1) & 1) * HL + frag, MR * 8, w0, 4 * BX, [&](int q) { mid(BX + q); });
-            } else if constexpr (MODE == 2) {
-                // input span with two looks at the own layer's flags (blocks 1 -> 5, 13 -> 17) and the gather behind the one that succeeds
+            } else if constexpr (MODE == 3) {
+                // input span: the common hooks (flag owed at QF, the look for the NEXT section at QP) + the look at the OWN layer's flags at
+                // QO, the judge four blocks on, the gather behind it; outside the steady state a second look twelve blocks after the first
+                constexpr int QO = QF + 1, QO2 = QO + 12;
+                static_assert(QO2 + 4 + NDMA <= QP && QP < BH, "the own gather's hooks sit in front of the look for the next section");
                 unsigned pk = (unsigned)t;
                 bool got1 = false, got2 = false;
                 span32<BH, true, NW1>(acc, hb0 + (t & 1) * HL + frag, MR * 8, w1, 0, [&](int q) {
-                    if (q == 1) pk = peek_issue(flags_of + l * NFL + (lane & (NFL - 1)));
-                    if (q == 5) {
+                    mid(q);
+                    if (q == QO) pk = peek_issue(flags_of + l * NFL + (lane & (NFL - 1)));
+                    if (q == QO + 4) {
                         peek_wait(pk);
                         got1 = __all((int)(pk >= (unsigned)t)) != 0;
                     }
-                    if (q >= 5 && q < 5 + NDMA && got1) issue_piece(HOT, l, t - 1, q - 5);
-                    if (q == 13 && !got1) pk = peek_issue(flags_of + l * NFL + (lane & (NFL - 1)));
-                    if (q == 17 && !got1) {
-                        peek_wait(pk);
-                        got2 = __all((int)(pk >= (unsigned)t)) != 0;
+                    if (q >= QO + 4 && q < QO + 4 + NDMA && got1) issue_piece(HOT, l, t - 1, q - (QO + 4));
+                    if constexpr (!ST) {
+                        if (q == QO2 && !got1) pk = peek_issue(flags_of + l * NFL + (lane & (NFL - 1)));
+                        if (q == QO2 + 4 && !got1) {
+                            peek_wait(pk);
+                            got2 = __all((int)(pk >= (unsigned)t)) != 0;
+                        }
+                        if (q >= QO2 + 4 && q < QO2 + 4 + NDMA && got2) issue_piece(HOT, l, t - 1, q - (QO2 + 4));
                     }
-                    if (q >= 17 && q < 17 + NDMA && got2) issue_piece(HOT, l, t - 1, q - 17);
                 });
+#ifdef APE_C32_COUNTS
+                lc_t0 = __builtin_amdgcn_s_memtime();
+#endif
                 if (!got1 && !got2) {
 #ifdef APE_CLUSTER_STAMPS
                     dg_block[l] += 1;
 #endif
+#ifdef APE_C32_COUNTS
+                    lc_block[l] += 1u;
+#endif
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    raise_pending();                              // (a section entered with its flag still owed: T = 2's only one)
                     wait_flags(l, (unsigned)t);
 #pragma unroll
                     for (int k = 0; k < NDMA; ++k) issue_piece(COLD, l, t - 1, k);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                bar();                                            // every wave's pieces of h^1_{t-1} are in LDS
+                bar();                                            // every wave's pieces of h^1_{t-1} are in LDS; xin's readers are through
+#ifdef APE_C32_COUNTS
+                if (ST) { lc_top[l] += __builtin_amdgcn_s_memtime() - lc_t0; lc_n[l] += 1u; }
+#endif
                 if (ctl[0] != 0) return false;
-                span32<BH, true, NW1>(acc, hb1 + frag, MR * 8, w1, 4 * BH, [&](int) {});
+                span32<BH, true, NW1>(acc, hb1 + frag, MR * 8, w1, 4 * BH, [&](int q) { mid(BH + q); });
             } else {
                 span32<BH, true, NW1>(acc, hb0 + (t & 1) * HL + frag, MR * 8, w1, 0, [&](int q) { mid(q); });
                 if (ST || t > 0) span32<BH, true, NW1>(acc, hb1 + frag, MR * 8, w1, 4 * BH, [&](int q) { mid(BH + q); });
@@ -597,6 +648,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         if (go) prefetched = true;
 #ifdef APE_CLUSTER_STAMPS
         if (go) dg_go[ln] += 1;
+#endif
+#ifdef APE_C32_COUNTS
+        if (go) lc_go[ln] += 1u;
 #endif
         if constexpr (l == L - 1) {
             // (an idle section, whose hooks did not run: the same here)
@@ -640,12 +694,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             if (!st1 && t1 == 0 && T > 1) {
                 ok = section(std::false_type{}, L1{}, std::integral_constant<int, 1>{}, ph);
                 done1 = true;
-            } else if (!st1 && t1 == T - 1 && t1 >= 1 && !prefetched) {
-                ok = section(std::false_type{}, L1{}, std::integral_constant<int, 2>{}, ph);
-                done1 = true;
             }
         }
-        if (!done1) ok = st1 ? section(std::true_type{}, L1{}, M0{}, ph) : section(std::false_type{}, L1{}, M0{}, ph);
+        // (a step with a recurrent span: the section gathers h^1_{t-1} for itself, MODE 3; idle sections and step 0 of the long-window
+        //  instantiation: the plain form)
+        using M3 = std::integral_constant<int, 3>;
+        if (!done1 && t1 >= 1 && t1 < T) {
+            ok = st1 ? section(std::true_type{}, L1{}, M3{}, ph) : section(std::false_type{}, L1{}, M3{}, ph);
+            done1 = true;
+        }
+        if (!done1) ok = section(std::false_type{}, L1{}, M0{}, ph);
     }
     if (!ok) return;
     // ---- final gather: h^{L-1}_{T-1} of every member (a section of layer L-1 "on step T": S0 only) -------------------------------
@@ -672,6 +730,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     if (p.dbg_wg != nullptr && lane == 0 && cluster == 0 && member == 0)
         for (int l = 0; l < 2; ++l)
             for (int k = 0; k < 6; ++k) p.dbg_wg[128 + wave * 16 + l * 6 + k] = dgh[l][k];
+#endif
+#ifdef APE_C32_COUNTS
+    if (p.dbg_wg != nullptr && tid == 0 && cluster < 24) {
+        unsigned long long* o = p.dbg_wg + 512 + (cluster * GH + member) * 8;
+        o[0] = lc_block[0]; o[1] = lc_block[1]; o[2] = lc_go[0]; o[3] = lc_go[1];
+        o[4] = lc_top[0]; o[5] = lc_top[1]; o[6] = lc_n[0]; o[7] = __builtin_amdgcn_s_memtime() - lc_start;
+    }
 #endif
     // ---- head: member m finishes windows 4m .. 4m+3 of the cluster's 32 ----------------------------------------------------------------
     {

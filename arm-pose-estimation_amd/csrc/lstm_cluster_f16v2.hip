@@ -298,7 +298,9 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     }
     __syncthreads();
     if (ctl[0] != 0) return;
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;     // uniform over the cluster
+        // hand-over form (ape_internal.h): write-through (`sc1`) payload stores unless the caller opted into the plain in-XCD form AND the
+    // members were verified to share an XCD; uniform over the cluster
+    const bool in_l2 = APE_HANDOVER_IN_L2(p.flags, ctl[3] != 0);
 
     // every wave polls for itself: have all member waves published epoch `want` of set s?
     auto wait_flags = [&](int s, unsigned want) {

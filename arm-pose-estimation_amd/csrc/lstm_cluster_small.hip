@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster_small(const ClusterPa
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ctl[0] != 0) return;
     // uniform over the cluster: every member read the same GH words
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_FLAG_ANY_PLACEMENT) == 0;
 
     const int P = T + L - 1;
 #pragma unroll

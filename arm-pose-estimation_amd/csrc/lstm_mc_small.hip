@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_mc_small(const McSmallParams 
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ctl[0] != 0) return;
-    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_DIAG_WRITE_THROUGH) == 0;
+    const bool in_l2 = ctl[3] != 0 && (p.flags & APE_FLAG_ANY_PLACEMENT) == 0;
     auto store_granule = [&](float val, unsigned tag, unsigned off) {
         u32x2 gran;
         gran[0] = __builtin_bit_cast(unsigned, val);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     constexpr unsigned ab = 0u;
 #endif
     const bool ab_noex = (ab & APE_DIAG_NO_EXCHANGE) != 0, ab_noact = (ab & APE_DIAG_NO_ACT) != 0, ab_nox = (ab & APE_DIAG_NO_XSTAGE) != 0,
-               ab_nomfma = (ab & APE_DIAG_NO_MFMA) != 0, ab_nobar = (ab & APE_DIAG_SMALL_UW4) != 0;
+               ab_nomfma = (ab & APE_DIAG_NO_MFMA) != 0, ab_nobar = (ab & APE_DIAG_NO_BARRIER) != 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xb = smem;                            // [set 2][HL]  masked input of the set's current step, fragment order

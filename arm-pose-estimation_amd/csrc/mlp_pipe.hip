@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             ctl_s[3] = (peer == my_xcc) ? 1 : 0;
         }
         __syncthreads();
-        const bool same = ctl_s[3] != 0 && !(pp.diag & 32u);     // (APE_PIPE_DIAG & 32: take the write-through path anyway)
+        // ring stores: write-through (`sc1`) unless the caller opted into the plain in-XCD form AND the pair shares an XCD (ape_internal.h,
+        // DESIGN.md 4.17); APE_PIPE_DIAG & 32: the write-through path whatever the flags
+        const bool same = APE_HANDOVER_IN_L2(p.flags, ctl_s[3] != 0) && !(pp.diag & 32u);
         if ((pp.diag & 8u) && tid == 0 && pair < 8) pp.ctl[240 + pair * 2 + role] = 0x100u | (same ? 1u : 0u);      // (stamps: the first pairs' verdict)
         return same;
     };
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
         lds_st(tile_addr + lane_off, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, 4 + q);
     };
     const unsigned lane_off_hi = lane_off + 4096u;
-    // (wt_tag: the pair's two workgroups do NOT share an XCD -- the stores then write through to memory, `sc1`, 1 % slower)
+    // (wt_tag: the default -- the stores write through to memory, `sc1`; false only with APE_FLAG_IN_XCD_PLAIN on a pair inside one XCD)
     auto put_ring = [&](const f32x16& c0, const f32x16& c1, int q, unsigned base, auto wt_tag) {
         ring_st(lane_off, f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]}, base, q, wt_tag);
         ring_st(lane_off_hi, f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]}, base, q, wt_tag);

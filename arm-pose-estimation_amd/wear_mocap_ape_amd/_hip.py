@@ -25,6 +25,7 @@ FLAG_DROPOUT_PHILOX = 0x8
 FLAG_PACKED_MSG = 0x20
 FLAG_BROADCAST_X = 0x10
 FLAG_ANY_PLACEMENT, FLAG_NO_XCD_CLASSES, FLAG_ALT_FORM = 0x08000000, 0x02000000, 0x01000000    # exchange-form selectors (A/B runs, tests)
+FLAG_IN_XCD_PLAIN = 0x00400000      # opt-in: plain hand-over stores inside an XCD-pure cluster (the default is write-through)
 KERNEL_AUTO, KERNEL_TILE16, KERNEL_CLUSTER, KERNEL_CLUSTER_GEN1, KERNEL_AUTO_GEN1 = 0, 1, 2, 3, 4
 PRECISION_F32, PRECISION_F16, PRECISION_F16_GEN1 = 0, 1, 2
 MODEL_LSTM, MODEL_FF, MODEL_IMUPOSE = 0, 1, 2

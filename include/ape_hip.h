@@ -101,11 +101,19 @@ enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1, APE_PRECISION_F16_GEN1 = 2 
 #define APE_FLAG_BROADCAST_X     0x10u /* x_dev is ONE window [1,T,I] shared by all B rows: the x.repeat((n,1,1)) of
                                          monte_carlo_predictions (nn_models.py:206) without materialising it    */
 
-/* Exchange-form selectors of the weight-stationary kernels, for A/B runs and tests (ape_lstm_forward, ape_streams_step).  They change
- * HOW the workgroups of a cluster hand their slices over, never the arithmetic: results are bit-equal (ALT_FORM: equal up to float32
- * summation order).  Every other undeclared bit is refused. */
-#define APE_FLAG_ANY_PLACEMENT   0x08000000u /* hand-over by write-through stores: the form that is valid wherever the workgroups of a
-                                               cluster run (what a cluster takes by itself when its members do not share an XCD) */
+/* Exchange-form selectors of the weight-stationary kernels, for A/B runs and tests (ape_lstm_forward, ape_infer, ape_streams_step).  They
+ * change HOW the workgroups of a cluster hand their slices over, never the arithmetic: results are bit-equal (ALT_FORM: equal up to
+ * float32 summation order).  Every other undeclared bit is refused.
+ * DEFAULT hand-over of every flag-based kernel (round 5): payload by write-through (`sc1`) stores, every storing wave waits for its
+ * stores, then its flag (an agent-scope store); every load of handed-off bytes is an `sc1` load -- the form the MI355X guide lists as
+ * valid wherever the workgroups run. */
+#define APE_FLAG_ANY_PLACEMENT   0x08000000u /* the two tagged-granule latency kernels (lstm_cluster_small / lstm_mc_small): write-through
+                                               granule stores also where the members share an XCD.  A no-op for the flag-based kernels,
+                                               whose default it names since round 5 */
+#define APE_FLAG_IN_XCD_PLAIN    0x00400000u /* OPT-IN, A/B runs and tests only: payload by plain (write-back) stores where all members of a
+                                               cluster were verified to share an XCD (the default until round 4; 1-2 % faster in float32,
+                                               10 % in fp16).  OUTSIDE the guide's table of valid forms: a plain store behind
+                                               `s_waitcnt vmcnt(0)` is no agent-scope release.  Same bits when it holds */
 #define APE_FLAG_NO_XCD_CLASSES  0x02000000u /* first-generation cluster kernel: clusters by global arrival ticket instead of within
                                                block-index classes (one XCD each) */
 #define APE_FLAG_ALT_FORM        0x01000000u /* the alternative decomposition where a kernel has two: the latency kernel's H/16-member form,

@@ -233,7 +233,8 @@ def test_fp16_second_generation_kernel(norm_stats, name, B, T):
     y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
     assert np.array_equal(y2, y2b)
     y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
-    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | 0x08000000,
+    # (the default hand-over is write-through since round 5; the opt-in plain in-XCD form must give the same bits)
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | _hip.FLAG_IN_XCD_PLAIN,
                                            None, 0.0, 0, C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
     torch.cuda.synchronize()
     model.check()
@@ -265,7 +266,7 @@ def test_fp16_second_generation_kernel(norm_stats, name, B, T):
 def test_f32_second_generation_cluster_kernel(norm_stats, name, B, T):
     """lstm_cluster32.hip (eval-mode batches above 512 rows of the 2 x 256 models) against the float32 oracle (module
     tolerance 1e-6), the first-generation cluster kernel (other summation order only), ragged and multi-launch batches,
-    the forced any-placement (write-through) exchange (same bits as the in-L2 form) and run-to-run determinism.  Windows of up to 8
+    the opt-in plain in-XCD exchange (same bits as the default write-through form) and run-to-run determinism.  Windows of up to 8
     steps run the instantiation with the end forms of round 4 (step 0 in front of the weights, MODE 1 / MODE 2 sections), T = 8 | 12 sits on either side of
     the boundary."""
     from wear_mocap_ape_amd import _hip
@@ -281,7 +282,8 @@ def test_f32_second_generation_cluster_kernel(norm_stats, name, B, T):
     y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
     assert np.array_equal(y2, y2b)
     y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
-    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | 0x08000000,
+    # (the default hand-over is write-through since round 5; the opt-in plain in-XCD form must give the same bits)
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | _hip.FLAG_IN_XCD_PLAIN,
                                            None, 0.0, 0, C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
     torch.cuda.synchronize()
     model.check()
@@ -481,12 +483,13 @@ def test_mc_bank_cluster_route_against_batch_tile_route(golden, norm_stats, name
         m.check()
         outs[kern] = res
         del bank
-    # the any-placement exchange form of the cluster kernels (write-through stores: what a cluster whose members do not share an
-    # XCD runs), forced by the internal flag: the same bits as the in-L2 form
+    # the opt-in plain in-XCD exchange form of the first-generation cluster kernel (APE_FLAG_IN_XCD_PLAIN; the bank kernels themselves
+    # hand over write-through whatever the flag): the same bits as the default write-through form
     m, sd, _ = make_model(name, 21, stats)
     m.set_body(orc.DEFAULT_BODY)
     bank = StreamBank(m, S, T, smooth=2, normalize=True, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=4242)
-    bank._flags |= 0x08000000                      # APE_DIAG_WRITE_THROUGH (csrc/ape_internal.h)
+    from wear_mocap_ape_amd import _hip
+    bank._flags |= _hip.FLAG_IN_XCD_PLAIN
     for f in range(T + 3):
         bank.push_features(torch.from_numpy(np.ascontiguousarray(feats[:, f])).cuda())
         msg, tail = bank.step(with_tail=True)

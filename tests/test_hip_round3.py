@@ -25,7 +25,7 @@ def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
     watch_phone_uarm_nn.py:13-41)
     against the float32 oracle (module tolerance 1e-6), the first-generation cluster kernel and the batch-tile kernel (other
     summation orders only); window lengths around the depth of its three-layer software pipeline (fill and drain sections),
-    ragged and multi-launch batches, the forced any-placement (write-through) exchange and run-to-run determinism."""
+    ragged and multi-launch batches, the opt-in plain in-XCD exchange (same bits as the default write-through form) and run-to-run determinism."""
     from wear_mocap_ape_amd import _hip
     name = "uarm"
     st = norm_stats[name]
@@ -40,7 +40,7 @@ def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
     y2b = model(xd, last_step_only=True, normalize_input=True).cpu().numpy()[:, 0]
     assert np.array_equal(y2, y2b)
     y_wt = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
-    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | 0x08000000,
+    _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | _hip.FLAG_IN_XCD_PLAIN,
                                            None, 0.0, 0, C.c_void_p(y_wt.data_ptr()), None), "ape_lstm_forward")
     torch.cuda.synchronize()
     model.check()
@@ -59,10 +59,10 @@ def test_uarm_second_generation_cluster_kernel(norm_stats, B, T):
 @pytest.mark.parametrize("name,B,T,drop", [("uarm", 1024, 6, False), ("pocket", 512, 8, False), ("pocket", 300, 6, True), ("watch", 64, 8, True),
                                            ("pocket", 77, 3, False), ("uarm", 2100, 5, True)])
 def test_first_generation_kernel_forms_xcd_local_clusters(norm_stats, name, B, T, drop):
-    """lstm_cluster.hip from four clusters on: clusters formed within block-index classes (one XCD each, verified at run time) hand their
-    slices over by plain stores inside that XCD's L2.  The same bits as the any-placement formation (internal A/B bit 0x02000000: global
-    tickets, write-through stores) and as the class formation with write-through stores forced (0x08000000); eval mode also against the
-    oracle; repeat launches bit-equal (the class tickets and XCD words are self-cleaning)."""
+    """lstm_cluster.hip from four clusters on: clusters formed within block-index classes (one XCD each, verified at run time), slices handed
+    over by write-through stores (round 5).  The same bits as the any-placement formation (APE_FLAG_NO_XCD_CLASSES: global tickets) and as
+    the class formation with the opt-in plain in-XCD stores (APE_FLAG_IN_XCD_PLAIN); eval mode also against the oracle; repeat launches
+    bit-equal (the class tickets and XCD words are self-cleaning)."""
     from wear_mocap_ape_amd import _hip
     st = norm_stats[name]
     model, sd, cfg = make_model(name, 9, st)
@@ -72,7 +72,7 @@ def test_first_generation_kernel_forms_xcd_local_clusters(norm_stats, name, B, T
     assert "ape_lstm_cluster<" in model.kernel_name(B, T)
     base = _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_DROPOUT_PHILOX if drop else 0)
     outs = []
-    for extra in (0, 0, 0x02000000, 0x08000000):
+    for extra in (0, 0, _hip.FLAG_NO_XCD_CLASSES, _hip.FLAG_IN_XCD_PLAIN):
         y = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
         _hip.check(_hip.lib().ape_lstm_forward(model.handle, C.c_void_p(xd.data_ptr()), B, T, base | extra, None, 0.2 if drop else 0.0, 11,
                                                C.c_void_p(y.data_ptr()), None), "ape_lstm_forward")

@@ -330,9 +330,9 @@ def test_undeclared_flag_bits_are_refused(norm_stats):
     x = torch.zeros((8, 6, cfg["I"]), device="cuda")
     y = torch.zeros((8, cfg["O"]), device="cuda")
     lib = _hip.lib()
-    for bit in (0x40000000, 0x20000000, 0x10000000, 0x04000000, 0x100):
+    for bit in (0x40000000, 0x20000000, 0x10000000, 0x04000000, 0x00200000, 0x00100000, 0x100):
         assert lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), 8, 6, bit, None, 0.0, 0, C.c_void_p(y.data_ptr()), None) != 0, hex(bit)
-    for bit in (_hip.FLAG_ANY_PLACEMENT, _hip.FLAG_NO_XCD_CLASSES, _hip.FLAG_ALT_FORM):
+    for bit in (_hip.FLAG_ANY_PLACEMENT, _hip.FLAG_IN_XCD_PLAIN, _hip.FLAG_NO_XCD_CLASSES, _hip.FLAG_ALT_FORM):
         assert lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), 8, 6, bit, None, 0.0, 0, C.c_void_p(y.data_ptr()), None) == 0, hex(bit)
     m.check()
 

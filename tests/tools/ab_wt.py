@@ -1,5 +1,6 @@
-"""What does the write-through (sc1) hand-over cost each flag-based cluster kernel?  Same process, interleaved blocks of launches with
-and without APE_FLAG_ANY_PLACEMENT (include/ape_hip.h): python tests/tools/ab_wt.py"""
+"""What does the write-through (sc1) hand-over -- the default since round 5 -- cost each flag-based cluster kernel against the opt-in plain
+in-XCD form?  Same process, interleaved blocks of launches with and without APE_FLAG_IN_XCD_PLAIN (include/ape_hip.h):
+python tests/tools/ab_wt.py"""
 import ctypes as C, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arm-pose-estimation_amd"))
@@ -41,7 +42,7 @@ for name, B, T, prec in (("pocket", 1024, 64, "f32"), ("pocket", 1024, 6, "f32")
     x = torch.randn(B, T, cfg["I"], device="cuda")
     y = torch.empty(B, cfg["O"], device="cuda")
     def fwd(f):
-        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_ANY_PLACEMENT if f else 0),
+        _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | (0 if f else _hip.FLAG_IN_XCD_PLAIN),
                                         None, 0.0, 0, C.c_void_p(y.data_ptr()), None), "fwd")
     ab(f"{name} {B} x {T} {prec} [{m.kernel_name(B, T)}]", fwd)
     m.check()
@@ -53,7 +54,7 @@ for name, S, n_mc, smooth, kind in (("pocket", 1024, 25, 1, _hip.PARSE_WATCH_PHO
     bank = StreamBank(m, S, T, smooth=smooth, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc, dropout=0.2)
     base = bank._flags
     def frame(f):
-        bank._flags = base | (_hip.FLAG_ANY_PLACEMENT if f else 0)
+        bank._flags = base | (0 if f else _hip.FLAG_IN_XCD_PLAIN)
         bank.push_rows(rows, kind); bank.step_datagrams()
     ab(f"bank {name} S={S} mc={n_mc} T={T} smooth={smooth}", frame, n=8)
     m.check()

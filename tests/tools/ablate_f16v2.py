@@ -16,7 +16,7 @@ m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], device=0); m.l
 m.set_precision("f16")
 x = torch.randn(B, T, cfg["I"], device="cuda"); y = torch.empty(B, cfg["O"], device="cuda")
 lib = _hip.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-NOEX, NOACT, NOMFMA, NOX, WT = 0x40000000, 0x20000000, 0x04000000, 0x02000000, 0x08000000
+NOEX, NOACT, NOMFMA, NOX, WT = 0x40000000, 0x20000000, 0x04000000, 0x00200000, 0x08000000
 
 def run(n, flags):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

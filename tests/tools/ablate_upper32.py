@@ -4,7 +4,7 @@ construction).  python tests/tools/ablate_upper32.py [S] [n_mc]  (spawns one pro
 import os, subprocess, sys
 S = sys.argv[1] if len(sys.argv) > 1 else "1024"
 n_mc = sys.argv[2] if len(sys.argv) > 2 else "32"
-NOEX, NOACT, NOMFMA, NOX, NOBAR = 0x40000000, 0x20000000, 0x04000000, 0x02000000, 0x01000000
+NOEX, NOACT, NOMFMA, NOX, NOBAR = 0x40000000, 0x20000000, 0x04000000, 0x00200000, 0x00100000
 lib = "/root/repo/arm-pose-estimation_amd/lib/diag/libape_hip_ablate.so"
 for tag, fl in (("everything on", 0), ("no h exchange (publish, flags, gather)", NOEX), ("no gate transcendentals", NOACT),
                 ("no x copies", NOX), ("no exchange, no x copies", NOEX | NOX), ("no exchange / x / section barrier + wait", NOEX | NOX | NOBAR),

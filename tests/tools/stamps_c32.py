@@ -1,6 +1,6 @@
 """Per-section cycle accounting of lstm_cluster32.hip (diagnostic build, make diag): steady-state sections of cluster 0 / member 0, per wave and
 layer: top wait, barrier, MFMA spans (with the exchange hooks), everything behind the barrier (spans + drain + cell update + publish).
-python tests/tools/stamps_c32.py [B] [T]"""
+python tests/tools/stamps_c32.py [B] [T] [extra flags, e.g. 0x00400000 = the opt-in plain in-XCD hand-over]"""
 import ctypes as C, os, sys
 os.environ.setdefault("APE_HIP_LIB", "/root/repo/arm-pose-estimation_amd/lib/diag/libape_hip_diag.so")
 import numpy as np
@@ -16,13 +16,17 @@ m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, d
 m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 0))
 m.set_kernel("cluster")
 x = torch.randn(B, T, cfg["I"], device="cuda")
-for _ in range(5): m(x, last_step_only=True)
+EXTRA = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
+lib = _hip.lib()
+y = torch.empty(B, cfg["O"], device="cuda")
+for _ in range(5):
+    _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, EXTRA, None, 0.0, 0, C.c_void_p(y.data_ptr()), None), "fwd")
 torch.cuda.synchronize(); m.check()
-lib = _hip.lib(); buf = (C.c_ulonglong * 2048)()
+buf = (C.c_ulonglong * 2048)()
 lib.ape_debug_read_wg.argtypes = [C.c_void_p, C.c_void_p]
 lib.ape_debug_read_wg(m.handle, buf)
 d = np.frombuffer(buf, dtype=np.uint64)[32:32 + 64].reshape(4, 16)[:, :10].reshape(4, 2, 5).astype(np.float64)
-print(f"{m.kernel_name(B, T)}  B={B} T={T}: shader cycles per steady-state section; MFMA content: layer 0 {(4 + 32) * 4 * 64}, layer 1 {64 * 4 * 64}")
+print(f"{m.kernel_name(B, T)}  B={B} T={T} flags {EXTRA:#x}: shader cycles per steady-state section; MFMA content: layer 0 {(4 + 32) * 4 * 64}, layer 1 {64 * 4 * 64}")
 for w in range(4):
     for l in range(2):
         n = max(d[w, l, 4], 1)
