@@ -78,7 +78,14 @@ __device__ __forceinline__ void words_wait(u32x4& v) { asm volatile("s_waitcnt v
 __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
     // (s_nop 4: the descriptor may have been reloaded from a spill lane by v_readlane_b32 right in front -- a VALU write of an SGPR needs
     //  five wait states before a vector-memory instruction reads it, and hipcc does not look inside an asm statement)
+#if defined(UP128_PLAIN_STORES)
+#if !defined(APE_UP128_ASSERT)
+#error "UP128_PLAIN_STORES rebuilds round 4's faulty hand-over: for the asserting diagnostic build (tests/tools/assert_up128.py) only"
+#endif
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+#else
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+#endif
 }
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer to 1 KiB of LDS at the wave-uniform byte address `lds_addr`
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
@@ -323,6 +330,24 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         else copy_piece(h2b_lds, s, hx_desc, (go && b_act[s] && b_t[s] != 0) ? hx_rec : 0u, ex_base(s, 2, par), k);
     };
 
+#ifdef APE_UP128_ASSERT
+    // Asserting diagnostic build (tests/tools/assert_up128.py; never shipped): the tool loads weights under which a layer's fresh h is the
+    // same number for every unit and row and depends on the step alone (W = 0, per-gate constant biases), so every float a section finds in
+    // its gathered operands must equal what THIS lane computed in the set's section in front -- existing state, no tags, no extra traffic.
+    // Wave 0 checks all 3 x 16 KB behind the top barrier (phase 0) and again at the section's end (phase 1: a copy that landed late shows
+    // as bad in phase 0 only); a mismatch leaves a record {who, where, found, expected, clock} in dbg_wg[1024 ...].
+    float chkA[2] = {0.0f, 0.0f}, chkB[2] = {0.0f, 0.0f};
+    auto chk_record = [&](unsigned s_, unsigned k_, unsigned kind, unsigned kb, unsigned phase, float found, float expect) {
+        const unsigned slot = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.dbg_wg + 1024), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < 120u) {
+            unsigned long long* o = p.dbg_wg + 1032 + slot * 4;
+            o[0] = ((unsigned long long)cluster << 48) | ((unsigned long long)member << 40) | ((unsigned long long)s_ << 32) | k_;
+            o[1] = ((unsigned long long)phase << 48) | ((unsigned long long)kind << 32) | (kb << 8) | (unsigned)lane;
+            o[2] = ((unsigned long long)__builtin_bit_cast(unsigned, found) << 32) | __builtin_bit_cast(unsigned, expect);
+            o[3] = __builtin_amdgcn_s_memtime();
+        }
+    };
+#endif
 #ifdef APE_CLUSTER_STAMPS
     // diagnostic counters and shader-clock sums (cluster 0, member 0, wave 0): sections, blocking tops, cycles in the top of a section
     // (wait + barrier), its MFMA chains, the gate math (+ head), the publish
@@ -362,6 +387,34 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         bar();                                                      // (unconditional: lstm_upper32.hip on why)
         UP_STAMP(dg_top);
         const int abort_word = ctl[0];
+#ifdef APE_UP128_ASSERT
+        auto chk_all = [&](unsigned phase) {
+            if (wave != 0 || p.dbg_wg == nullptr) return;
+            const float* chk_base = smem;
+            asm volatile("" : "+v"(chk_base));
+            int bad = -1;                                          // first (kind, k-block) of this lane whose 16 bytes are not what they must be
+            float bad_v = 0.0f;
+#pragma unroll 1
+            for (int idx = 0; idx < 3 * BH; ++idx) {
+                const int kind = idx / BH, kb = idx - kind * BH;
+                const bool on = (kind == 0) ? recA : (kind == 1) ? actB : recB;
+                if (!on) continue;
+                const float expect = (kind == 2) ? chkB[s] : chkA[s];
+                // (h1b / m1b / h2b = smem + 2 HL, + 4 HL, + 6 HL; through a vector-register copy of the base, or the scalar LDS addresses
+                //  of the copies end up in vector registers with it)
+                const f32x4 v = *reinterpret_cast<const f32x4*>(chk_base + (2 + 2 * kind + s) * HL + frag + kb * (MR * 8));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // (the masked slice: 0 or keep x h_1, to an ulp -- the steps of a layer's sequence lie 1e-3 and more apart)
+                    const bool fine = (kind == 1) ? (v[j] == 0.0f || __builtin_fabsf(v[j] - expect * keep) <= 1e-6f * __builtin_fabsf(v[j]))
+                                                  : (__builtin_bit_cast(unsigned, v[j]) == __builtin_bit_cast(unsigned, expect));
+                    if (!fine && bad < 0) { bad = idx; bad_v = v[j]; }
+                }
+            }
+            if (bad >= 0) chk_record((unsigned)s, k, (unsigned)(bad / BH), (unsigned)(bad % BH), phase, bad_v, (bad / BH == 2) ? chkB[s] : chkA[s]);
+        };
+        chk_all(0u);
+#endif
         // the NEXT section is the other set's (if it has one left)
         const bool o_more = a_act[o] || b_act[o];
         const unsigned want = ksec[o];
@@ -433,6 +486,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
         };
         if (actA) gates(accA, cst[s][0], hA);
         if (actB) gates(accB, cst[s][1], hB);
+#ifdef APE_UP128_ASSERT
+        chk_all(1u);
+        chkA[s] = hA[0]; chkB[s] = hB[0];
+        if (p.dbg_wg != nullptr && s == 0 && cluster == 0 && member == 0 && tid == 0 && k < 32u) {      // the value table: h_1, h_2 by section
+            p.dbg_wg[1600 + 2 * k] = __builtin_bit_cast(unsigned, hA[0]);
+            p.dbg_wg[1601 + 2 * k] = __builtin_bit_cast(unsigned, hB[0]);
+        }
+#endif
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         pre[o] = go;
 #ifdef APE_CLUSTER_STAMPS
