@@ -1671,13 +1671,13 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         } else if (b->up128 && coop) {
             // the 3 x 128 model: layers 1 and 2 on the four-member weight-stationary clusters (lstm_upper128.hip), per chunk of sample
             // rows: masked input + layer-1 keep bits, the persistent kernel, the head reduce
-            if (b->inj_masks) return fail(APE_ERR_UNSUPPORTED, "streams_step: injected masks (test hook) on the 3 x 128 weight-stationary route");
             const long long total = (long long)b->S * b->n_mc;
             for (long long r0 = 0; r0 < total; r0 += b->chunk_rows) {
                 const int rows = (int)((total - r0 < b->chunk_rows) ? total - r0 : b->chunk_rows);
                 ExpandParams xq{};
                 xq.hseq = m->hseq_ws; xq.hseq_frag = 0; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
                 xq.layer = 0; xq.dropout_p = b->dropout_p; xq.seed = b->seed + b->mc_calls;
+                xq.masks = b->inj_masks; xq.masks_rows = total;      // (test hooks: the caller's masks for both mask layers)
                 Upper128Params u{};
                 u.xfrag = b->xfrag; u.xfrag_bytes = ape_upper128_xfrag_bytes(rows, b->T); u.maskbits = b->maskbits; u.ypart = b->ypart;
                 u.w[0] = m->wup128[1]; u.w[1] = m->wup128[2]; u.bias[0] = m->bias[1]; u.bias[1] = m->bias[2]; u.w_out = m->w_out;

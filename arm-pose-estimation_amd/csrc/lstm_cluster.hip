@@ -32,6 +32,7 @@
 //     columns ordered unit*4 + gate: every lane then holds i,f,g,o of ONE (unit, batch row) in its four
 //     accumulator registers, so activations and the c/h update are lane-local and spread over all 64 lanes.
 #include "ape_internal.h"
+#include "async_look.h"
 #include "../../include/ape_hip.h"
 
 // k-block schedule of the exchange work under the MFMAs (see the phase loop); tunable at build time
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     float* xin = hbuf + L * MR * SH;              // [MR][SX]
     float* own = xin + MR * SX;                   // [NV][MR][SO] this member's fresh slice (raw, masked)
     float* dbuf = own + NV * MR * SO;             // [L-1][MR][SH] gathered MASKED h (DROP only)
-    int* ctl = reinterpret_cast<int*>(dbuf + (DROP ? (L - 1) * MR * SH : 0));   // [0] abort flag, [1] arrival ticket, [2] last-out
+    unsigned* look_s = reinterpret_cast<unsigned*>(dbuf + (DROP ? (L - 1) * MR * SH : 0));   // [wave 4][64]: landing zones of the flag looks (async_look.h)
+    int* ctl = reinterpret_cast<int*>(look_s + 4 * 64);         // [0] abort flag, [1] arrival ticket, [2] last-out
     // A launch that finds the sticky status word set -- an earlier launch on this model aborted and skipped its
     // self-cleaning, so tickets, flags and counters are stale -- leaves without touching anything (status 2 tells
     // ape_model_check that later launches ran into it), and so does a workgroup whose ticket lies outside the grid.
@@ -156,6 +158,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     const __amdgpu_buffer_rsrc_t hx_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
     constexpr int NFL = 4 * GH;                  // flags per (cluster, layer): one per member WAVE
+    const ape_desc_t fl_desc = ape_make_desc(p.xflags, (unsigned)((gridDim.x / GH) * L * NFL * sizeof(unsigned)));
+    const unsigned fl_off = (unsigned)(cluster * L * NFL * sizeof(unsigned));
+    const unsigned look_voff = (unsigned)((lane & (NFL - 1)) * sizeof(unsigned));
+    const unsigned look_lds = (unsigned)reinterpret_cast<unsigned long long>(look_s) + (unsigned)(wave * 256);
+    const unsigned* const look_mine = look_s + wave * 64 + lane;
     unsigned* const myflags = p.xflags + (size_t)cluster * L * NFL;
 
     // ---- exchange helpers ------------------------------------------------------------------------------
@@ -165,7 +172,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
 
     // every wave polls for itself (no barrier on the way): all members published epoch `want` of layer l?
     // bounded; on give-up raises the sticky status word and the workgroup abort flag
-    // non-blocking look: the load only.  Eval-mode instantiations issue it by inline asm and first touch it at the judge
+    // non-blocking look: the load only.  Eval-mode instantiations issue it as LDS-DMA into the wave's landing zone (async_look.h; rounds 3-4:
+    // an asm load with a register destination, which hipcc is free to copy or re-use while the load is in flight) and read it back at the judge
     // (peek_wait): hipcc hoists the comparison of a compiler-visible load up to the load and waits `vmcnt(0)` right behind it, an
     // L2 round trip exposed in every section (round 3, found in the disassembly; lstm_cluster32.hip).  Measured on this kernel:
     // upper-arm model 1024 x 64 530 -> 513 us, ImuPoseLSTM neutral -- but the dropout instantiations (the estimators' 25-sample
@@ -176,13 +184,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             if (diag_noex || lane >= NFL) return want;
             return __hip_atomic_load(myflags + l * NFL + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            unsigned v;
-            const unsigned* addr = myflags + l * NFL + (lane & (NFL - 1));
-            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
-            return v;
+            look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(l * NFL * sizeof(unsigned)));
+            return 0u;                                   // (the value comes out of peek_wait)
         }
     };
-    auto peek_wait = [&](unsigned& v) { if constexpr (!DROP) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); };
+    auto peek_wait = [&](unsigned& v) {
+        if constexpr (!DROP) {
+            look_landed();
+            v = *look_mine;
+        }
+    };
     auto wait_flags = [&](int l, unsigned want, unsigned peeked) {
         if (diag_noex) return;
         if (__all((int)(peeked >= want))) return;                  // the prefetched look was enough
@@ -701,7 +712,7 @@ template <int H, int L, int KX, int NMT, bool DROP>
 size_t smem_bytes() {
     constexpr int MR = 16 * NMT, NV = DROP ? 2 : 1;
     return ((size_t)L * MR * (H + 8) + (size_t)MR * (KX + 8) + (size_t)NV * MR * 20 +
-            (size_t)(DROP ? (L - 1) * MR * (H + 8) : 0) + 4) * sizeof(float);
+            (size_t)(DROP ? (L - 1) * MR * (H + 8) : 0) + 4 * 64 + 4) * sizeof(float);
 }
 
 template <int H, int L, int KX, int NMT, bool DROP>

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "ape_internal.h"
+#include "async_look.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -85,12 +86,7 @@ __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
     if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
     else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
-__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+// (the flag looks: LDS-DMA into the wave's landing zone, async_look.h -- no destination register)
 
 template <int H, int L, int KX, int RT>
 __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const ClusterParams p) {
@@ -128,7 +124,8 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     float* xin = hbase + (2 * (L - 1) + 1) * HL;          // [XL]
     float* patch = xin + XL;                              // [wave 8][window 16][4]: the publish transpose
     f32x4* bias_s = reinterpret_cast<f32x4*>(patch + 4 * MR * 4);     // [wave 4][L][g 4]: start values of unit g's four gates
-    int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * 4);            // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    unsigned* look_s = reinterpret_cast<unsigned*>(bias_s + 4 * L * 4);   // [wave NWV][64]: landing zones of the flag looks (async_look.h)
+    int* ctl = reinterpret_cast<int*>(look_s + NWV * 64);             // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
     auto hb = [&](int l, int par) -> float* { return hbase + (l < L - 1 ? 2 * l + par : 2 * (L - 1)) * HL; };
 
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -238,6 +235,11 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
     hx_desc[3] = 0x00020000u;
     unsigned* const flags_of = p.xflags + (size_t)cluster * L * NFL;
+    const ape_desc_t fl_desc = ape_make_desc(p.xflags, (unsigned)((gridDim.x / GH) * L * NFL * sizeof(unsigned)));
+    const unsigned fl_off = (unsigned)(cluster * L * NFL * sizeof(unsigned));
+    const unsigned look_voff = (unsigned)((lane & (NFL - 1)) * sizeof(unsigned));
+    const unsigned look_lds = (unsigned)reinterpret_cast<unsigned long long>(look_s) + (unsigned)(wave * 256);
+    const unsigned* const look_mine = look_s + wave * 64 + lane;
     auto hx_base = [&](int l, int par) -> unsigned { return (unsigned)((((size_t)cluster * L + l) * 2 + par) * SET_BYTES); };
     const unsigned hbase_lds = (unsigned)reinterpret_cast<unsigned long long>(hbase);
 
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
             }
         };
         // ---- work behind the barrier, item k: 0 flag of the store above, x; 1 look at the next section's flags; 2 judge;
-        //      3 .. 2 + NDMA the next section's gather.  (The look and its judgement stay in one straight run of code: the register the
-        //      load lands in must not be copied by the compiler in between.)
+        //      3 .. 2 + NDMA the next section's gather.  (The look lands in the wave's LDS zone, async_look.h: rounds 3-4 had it land in a
+        //      register that the compiler "must not copy in between" -- nothing could have stopped it.)
         auto post = [&](int k) {
             if (k == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the publish store has drained
@@ -407,9 +409,10 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
                     if (ph + 1 < T) stage_x();
                 }
             } else if (k == 1) {
-                peek = peek_issue(flags_of + ln * NFL + (lane & (NFL - 1)));                     // (always: no branch around it)
+                look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(ln * NFL * sizeof(unsigned)));     // (always: no branch around it)
             } else if (k == 2) {
-                peek_wait(peek);
+                look_landed();
+                peek = *look_mine;
                 go = pre_ok && __all((int)(peek >= (unsigned)tn)) != 0;
                 if constexpr (l == 1) {
                     // the fetch of the step after it: the oldest entries of the memory queue when the next counted wait comes
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
 
 template <int H, int L, int KX, int RT>
 constexpr size_t smem16() {
-    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 256 * RT + (size_t)(KX / 16) * 256 * RT + 4 * RT * 64) * sizeof(float) + (size_t)4 * L * 4 * 16 + 16;
+    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 256 * RT + (size_t)(KX / 16) * 256 * RT + 4 * RT * 64) * sizeof(float) + (size_t)4 * L * 4 * 16 + (size_t)4 * RT * 64 * sizeof(unsigned) + 16;
 }
 
 }  // namespace

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "ape_internal.h"
+#include "async_look.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -101,12 +102,7 @@ __device__ __forceinline__ void span(f32x4 (&acc)[NTW], const f32x4 (&a)[NQ], co
 #define V2_STAMP(k) do {} while (0)
 #endif
 
-__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+// (the flag looks: LDS-DMA into the wave's landing zone, async_look.h -- no destination register)
 
 // UPW = 4 (round 4, "duo"): 16-unit members -- a wave owns 4 units = ONE tile, 100 weight registers -- so that a workgroup fits twice on a
 // CU (<= 256 registers per wave, 47 KB of LDS): 16-member clusters of 32 rows, 512 workgroups for 1024 windows, TWO independent
@@ -150,7 +146,8 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     _Float16* xin = hbuf + NS * L * HL;                   // [NS][2 parity][SR][SX]
     _Float16* own = xin + NS * 2 * SR * SX;               // [wave 4][L][SR][UPW]  fresh slice of this wave (wave-private)
     f32x4* bias_s = reinterpret_cast<f32x4*>(own + 4 * L * SR * UPW);   // [wave 4][L][NTW][lane 64]: the accumulators' start values
-    int* ctl = reinterpret_cast<int*>(bias_s + 4 * L * NTW * 64);   // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    unsigned* look_s = reinterpret_cast<unsigned*>(bias_s + 4 * L * NTW * 64);   // [wave 4][64]: landing zones of the flag looks (async_look.h)
+    int* ctl = reinterpret_cast<int*>(look_s + 4 * 64);             // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
 
     // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words][done]
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -220,6 +217,11 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     hx_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.hx_bytes);
     hx_desc[3] = 0x00020000u;
     unsigned* const flags_of = p.xflags + (size_t)cluster * NS * NFL;      // [set][member*4 + wave] epoch = phases published
+    const ape_desc_t fl_desc = ape_make_desc(p.xflags, (unsigned)((gridDim.x / GH) * NS * NFL * sizeof(unsigned)));
+    const unsigned fl_off = (unsigned)(cluster * NS * NFL * sizeof(unsigned));
+    const unsigned look_voff = (unsigned)((lane & (NFL - 1)) * sizeof(unsigned));
+    const unsigned look_lds = (unsigned)reinterpret_cast<unsigned long long>(look_s) + (unsigned)(wave * 256);
+    const unsigned* const look_mine = look_s + wave * 64 + lane;
     constexpr unsigned SET_BYTES = PIECES * 16;                            // one (set, parity): [layer][member][wave][row][8 halves]
     auto hx_base = [&](int s, int par) -> unsigned { return (unsigned)((((size_t)cluster * NS + s) * 2 + par) * SET_BYTES); };
     const unsigned hbuf_lds = (unsigned)reinterpret_cast<unsigned long long>(hbuf);     // LDS byte address (low half of the flat one)
@@ -429,11 +431,10 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                     if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
                 }
             } else {
-                // [B0] look at the flags the next section needs; the load flies under the gate math below.  Issued by inline asm and
-                // first touched at [B]: hipcc hoists the comparison of a compiler-visible load up to the load and waits `vmcnt(0)`
-                // right behind it -- the L2 round trip it was meant to hide (round 3, found in the disassembly).  All 64 lanes,
-                // unconditionally: no exec juggling, no merge of its result with another value.
-                peek = peek_issue(flags_of + sn * NFL + (lane & (NFL - 1)));
+                // [B0] look at the flags the next section needs; the load flies under the gate math below.  Issued as LDS-DMA into the wave's
+                // landing zone (async_look.h) and read back at [B]: hipcc hoists the comparison of a compiler-visible load up to the load and
+                // waits `vmcnt(0)` right behind it -- the L2 round trip it was meant to hide (round 3, found in the disassembly).
+                look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
                 peeked = true;
             }
             V2_STAMP(2);
@@ -458,7 +459,10 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
         }
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         // [B] every peer wave has published what the next section needs: its whole gather goes into flight now
-        if (peeked) peek_wait(peek);
+        if (peeked) {
+            look_landed();
+            peek = *look_mine;
+        }
         if ((ST || want > 0u) && !d_noex && __all((int)(peek >= want))) {
             issue_gather(sn, (phn - 1) & 1);
             prefetched = true;
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
 template <int H, int L, int KX, int UPW>
 constexpr size_t smem_bytes() {
     return ((size_t)2 * L * 16 * H + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * UPW) * sizeof(_Float16) +
-           (size_t)4 * L * (UPW / 4) * 64 * 16 + 16;
+           (size_t)4 * L * (UPW / 4) * 64 * 16 + (size_t)4 * 64 * sizeof(unsigned) + 16;
 }
 
 }  // namespace

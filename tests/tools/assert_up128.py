@@ -3,7 +3,7 @@ section find in its gathered operands?  Weights under which a layer's fresh h is
 float of a gathered slice must equal what the checking lane itself computed in the set's section in front; a mismatch is classified by where
 its value sits in the layer's sequence: an OLDER step (the slice had not arrived: visibility / a copy counted as landed too early), a NEWER
 step (overwritten by a fast producer: protocol), zero (never written).  The process's FIRST launch is the one that counts.
-    APE_HIP_LIB=.../lib/ab/libape_<variant>.so python tests/tools/assert_up128.py [S] [n_mc]"""
+    APE_HIP_LIB=.../lib/ab/libape_<variant>.so python tests/tools/assert_up128.py [S] [n_mc] [frames] [device copies per frame on a second stream]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arm-pose-estimation_amd"))
@@ -15,6 +15,8 @@ from wear_mocap_ape_amd.estimate import nn_models
 from wear_mocap_ape_amd.streams import StreamBank
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_mc = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+FRAMES = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+NCOPY = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 cfg = orc.MODEL_CONFIGS["uarm"]
 T, H = cfg["T"], cfg["H"]
 sd = orc.make_state_dict(cfg["I"], H, cfg["L"], cfg["O"], 5)
@@ -31,8 +33,17 @@ lib.ape_debug_read_wg.restype, lib.ape_debug_read_wg.argtypes = C.c_int, [C.c_vo
 rows = torch.randn(S, 55, device="cuda")
 bank = StreamBank(m, S, T, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc, dropout=0.2)
 f32 = lambda bits: float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
-for frame in range(3):                                   # frame 0 = the process's cold launch
-    bank.push_rows(rows, _hip.PARSE_WATCH_PHONE_UARM); bank.step_datagrams()
+side = torch.cuda.Stream()
+if NCOPY:
+    ca = torch.full((64 << 20,), 1.0, dtype=torch.float32, device="cuda"); cb = torch.empty_like(ca)
+last_n = 0
+for frame in range(FRAMES):                              # frame 0 = the process's cold launch
+    bank.push_rows(rows, _hip.PARSE_WATCH_PHONE_UARM)
+    torch.cuda.synchronize()
+    if NCOPY:
+        with torch.cuda.stream(side):
+            for _ in range(NCOPY): cb.copy_(ca, non_blocking=True)
+    bank.step_datagrams()
     torch.cuda.synchronize(); m.check()
     assert m.last_kernel() == "ape_lstm_upper128", m.last_kernel()
     buf = (C.c_ulonglong * (256 * 8))()
@@ -43,7 +54,8 @@ for frame in range(3):                                   # frame 0 = the process
     for k in range(2 * T + 1):
         seq[0].append(int(d[1600 + 2 * k]) & 0xFFFFFFFF); seq[2].append(int(d[1601 + 2 * k]) & 0xFFFFFFFF)
     tag = "COLD " if frame == 0 else "warm "
-    print(f"{tag}frame {frame}: {n} mismatching (lane, section, kind) records" + ("" if n else "  -- every gathered float was the expected one"))
+    print(f"{tag}frame {frame}: {n - last_n} new mismatching (lane, section, kind) records (cumulative {n})" + ("" if n else "  -- every gathered float was the expected one"))
+    last_n = n
     by = {}
     for r in range(min(n, 120)):
         o = d[1032 + 4 * r: 1036 + 4 * r]

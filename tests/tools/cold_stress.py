@@ -1,5 +1,8 @@
-"""First launch of a fresh process (cold clocks, cold caches) of one cooperative kernel against the batch-tile kernel on the same input:
-python tests/tools/cold_stress.py <pocket|uarm|watch> <B> <T> <f32|f16> [any]   -> one line, 'OFF' when a row differs beyond the budget"""
+"""First launch of a fresh process (cold clocks, cold caches) of one cooperative kernel against the ORACLE (numpy restatement of the
+reference's LSTM, seeded weights) and, beside it, the batch-tile kernel on the same input -- the check must not depend on a second HIP
+kernel being right on a cold chip:
+python tests/tools/cold_stress.py <pocket|uarm|watch> <B> <T> <f32|f16> [plain]   -> one line, 'OFF' when a row differs beyond the budget
+([plain]: the opt-in APE_FLAG_IN_XCD_PLAIN hand-over instead of the default write-through one)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "arm-pose-estimation_amd"))
@@ -9,18 +12,20 @@ from oracle import ape_oracle as orc
 from wear_mocap_ape_amd import _hip
 from wear_mocap_ape_amd.estimate import nn_models
 name, B, T, prec = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-anyp = len(sys.argv) > 5 and sys.argv[5] == "any"
+plain = len(sys.argv) > 5 and sys.argv[5] == "plain"
 cfg = orc.MODEL_CONFIGS[name]
 m = nn_models.DropoutLSTM(cfg["I"], cfg["H"], cfg["L"], cfg["O"], dropout=0.2, device=0)
-m.load_state_dict(orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5))
+sd = orc.make_state_dict(cfg["I"], cfg["H"], cfg["L"], cfg["O"], 5)
+m.load_state_dict(sd)
 m.set_norm_stats(np.zeros(cfg["I"]), np.ones(cfg["I"]), np.zeros(cfg["O"]), np.ones(cfg["O"]))
 if prec == "f16": m.set_precision("f16")
 lib = _hip.lib()
-x = torch.from_numpy(np.random.default_rng(2).normal(size=(B, T, cfg["I"])).astype(np.float32)).cuda()
+x_host = np.random.default_rng(2).normal(size=(B, T, cfg["I"])).astype(np.float32)
+x = torch.from_numpy(x_host).cuda()
 ys = []
 for launch in range(3):                        # the cold one, then two warm ones
     y = torch.empty(B, cfg["O"], device="cuda")
-    _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_ANY_PLACEMENT if anyp else 0),
+    _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT | (_hip.FLAG_IN_XCD_PLAIN if plain else 0),
                                     None, 0.0, 0, C.c_void_p(y.data_ptr()), None), "fwd")
     torch.cuda.synchronize(); ys.append(y.cpu().numpy())
 kern = m.last_kernel()
@@ -34,4 +39,10 @@ tol = 5e-3 if prec == "f16" else 2e-5
 d = [float(np.abs(v - ref).max()) for v in ys]
 rows = int((np.abs(ys[0] - ref).max(axis=1) > tol).sum())
 same = all(np.array_equal(ys[0], v) for v in ys[1:])
-print(f"{name} {B}x{T} {prec} {kern}{' any' if anyp else ''}: cold {d[0]:.2e} warm {d[1]:.2e} {d[2]:.2e}; cold == warm bits: {same}" + (f"  OFF ({rows} rows)" if (rows or not same) else ""))
+# the oracle on the same windows (zero-mean / unit-variance statistics: the z-score is the identity); fp16: the f16-storage emulation
+y_orc = orc.lstm_forward(sd, x_host, storage="f16")[:, -1] if prec == "f16" else orc.lstm_forward(sd, x_host)[:, -1]
+tol_o = 3e-4 if prec == "f16" else 1e-6
+d_o = float(np.abs(ys[0] - y_orc).max())
+rows_o = int((np.abs(ys[0] - y_orc).max(axis=1) > tol_o).sum())
+print(f"{name} {B}x{T} {prec} {kern}{' plain' if plain else ''}: cold vs oracle {d_o:.2e}; vs batch-tile: cold {d[0]:.2e} warm {d[1]:.2e} {d[2]:.2e}; cold == warm bits: {same}"
+      + (f"  OFF ({rows} rows vs batch-tile, {rows_o} vs oracle)" if (rows or rows_o or not same) else ""))

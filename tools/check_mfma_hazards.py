@@ -6,6 +6,13 @@ next `window` instructions, an MFMA, reads as a source.
 A third pattern, found in round 4 (lstm_mc_small.hip's diagnostic build: every launch aborted): a VALU instruction that writes a SCALAR
 register (v_readlane_b32 reloading a spilled buffer descriptor, v_readfirstlane_b32, a v_cmp with an SGPR destination) needs 5 wait states
 before a vector-memory instruction reads that register; hipcc pads its own loads and stores, not the ones inside an asm statement.
+A fourth pattern, found in round 5 (lstm_upper128.hip: whole 32-row tiles off by 1e-4 .. 1e-3 on a cold start or beside a memory-bound
+kernel): a vector-memory LOAD issued inside an asm statement with a compiler-allocated destination ("=v") so that it can stay in flight
+under the MFMA stream, its value first touched by a later asm `s_waitcnt vmcnt(0)`.  hipcc takes the asm's output for valid at once and is
+free to COPY the destination registers (a phi move at a branch merge did) or, where it can prove the value dead, to RE-USE them, in front
+of that wait: the copy then holds what the registers held before, and a late-landing load clobbers the re-user's data.  The scan walks
+the code from every such load (following branches, up to the first `s_waitcnt vmcnt(0)` on each path) and reports any instruction that
+reads or writes a destination register.
     tools/check_mfma_hazards.py file.hip [extra hipcc flags]     exit code 1 when a hazard is found"""
 import re, subprocess, sys, tempfile
 
@@ -50,7 +57,7 @@ def scan_sgpr_into_asm_vmem(path, need=5):
         t = line.strip()
         if t.startswith(";;#ASMSTART"): in_asm = True; continue
         if t.startswith(";;#ASMEND"): in_asm = False; continue
-        if t.endswith(":") and not t.startswith(";"):
+        if t.split(";")[0].strip().endswith(":") and not t.startswith(";"):
             ins.append((n, "LABEL", False)); continue
         if not t or t.startswith((";", ".", "//")): continue
         ins.append((n, t.split(";")[0].strip(), in_asm))
@@ -77,11 +84,12 @@ def scan_early_reads(path, window=12):
     ins, labels = [], {}
     for n, line in enumerate(open(path), 1):
         t = line.strip()
-        if t.endswith(":") and not t.startswith(";"):
-            labels[t[:-1]] = len(ins)
+        c = t.split(";")[0].strip()                    # (a label inside a loop carries a trailing comment: `.LBB0_104:   ; in Loop: ...`)
+        if c.endswith(":") and not t.startswith(";"):
+            labels[c[:-1]] = len(ins)
             continue
         if not t or t.startswith((";", ".", "//")): continue
-        ins.append((n, t.split(";")[0].strip()))
+        ins.append((n, c))
     bad = set()
     def walk(i, left, dst, origin):
         while left > 0 and i < len(ins):
@@ -103,6 +111,47 @@ def scan_early_reads(path, window=12):
         if t.startswith("v_mfma"): walk(i + 1, window, regs(t.split(None, 1)[1].split(",")[0].strip()), (n, t))
     return sorted(bad)
 
+def vregs_all(text):
+    out = set()
+    for a, b, c in re.findall(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        out |= {int(c)} if c else set(range(int(a), int(b) + 1))
+    return out
+
+def scan_async_asm_loads(path, limit=6000):
+    """asm-issued VMEM loads with a VGPR destination (not LDS-DMA): every instruction between the load and the first `s_waitcnt vmcnt(0)` on
+    each path that touches a destination register"""
+    ins, labels, in_asm = [], {}, False
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"): in_asm = True; continue
+        if t.startswith(";;#ASMEND"): in_asm = False; continue
+        c = t.split(";")[0].strip()
+        if c.endswith(":") and not t.startswith(";"):
+            labels[c[:-1]] = len(ins); continue
+        if not t or t.startswith((";", ".", "//")): continue
+        ins.append((n, c, in_asm))
+    bad = set()
+    for i, (n, t, a) in enumerate(ins):
+        if not a or not t.startswith(("global_load", "buffer_load", "flat_load")) or t.rstrip().endswith(" lds") or " lds " in t: continue
+        dst = regs(t.split(None, 1)[1].split(",")[0].strip())
+        if not dst: continue
+        seen, stack = set(), [(i + 1, limit)]
+        while stack:
+            j, left = stack.pop()
+            while left > 0 and j < len(ins) and j not in seen:
+                seen.add(j)
+                qn, qt, qa = ins[j]
+                if qt.startswith("s_waitcnt") and "vmcnt(0)" in qt: break
+                if qt.startswith(("s_endpgm", "s_setpc")): break
+                if qt.startswith("s_branch"):
+                    j = labels.get(qt.split()[1], len(ins)); continue
+                if qt.startswith("s_cbranch"):
+                    stack.append((labels.get(qt.split()[1], len(ins)), left - 1))
+                elif " " in qt and not qt.startswith("s_") and vregs_all(qt.split(None, 1)[1]) & dst:
+                    bad.add((n, t, qn, qt))
+                j += 1; left -= 1
+    return sorted(bad)
+
 if __name__ == "__main__":
     src = sys.argv[1]
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
@@ -112,9 +161,11 @@ if __name__ == "__main__":
         bad = scan(f.name) if asm_mfma else []
         early = scan_early_reads(f.name) if asm_mfma else []
         sg = scan_sgpr_into_asm_vmem(f.name)
+        al = scan_async_asm_loads(f.name)
     for pn, pt, n, t in bad: print(f"{src}: line {pn}: {pt}   ->   line {n}: {t}")
     for n, t, qn, qt in early: print(f"{src}: line {n}: {t}   read early by   line {qn}: {qt}")
     for pn, pt, n, t, st in sg: print(f"{src}: line {pn}: {pt}   ->   asm line {n}: {t}   ({st} wait states, 5 needed)")
+    for n, t, qn, qt in al: print(f"{src}: asm load line {n}: {t}   destination touched in front of its wait by   line {qn}: {qt}")
     print(f"{src}: {len(bad)} VALU-write -> MFMA SrcA/SrcB adjacencies, {len(early)} early reads of an MFMA result, "
-          f"{len(sg)} VALU-written SGPRs read early by an asm vector-memory instruction")
-    sys.exit(1 if bad or early or sg else 0)
+          f"{len(sg)} VALU-written SGPRs read early by an asm vector-memory instruction, {len(al)} touches of an in-flight asm load's destination")
+    sys.exit(1 if bad or early or sg or al else 0)
