@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1751,6 +1752,14 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
 // The raw rows are copied into pinned, device-visible staging the feature builder reads directly; the post kernel writes the
 // datagram rows and the model's status word straight into pinned host memory: the frame holds no copy command, just the
 // step's kernels and one stream synchronisation.  An aborted cooperative launch is recovered here (ape_model_recover).
+// The frame call polls words the device writes into pinned memory (h_done, h_status) and reads h_out without a stream synchronisation:
+// the buffers are allocated COHERENT (fine-grained) and mapped explicitly -- with hipHostMallocDefault that property hangs on the
+// HIP_HOST_COHERENT environment variable, and non-coherent pinned memory shows the host a kernel's writes only at its end.
+#define APE_PINNED (hipHostMallocCoherent | hipHostMallocMapped)
+static inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_host, uint32_t flags, void* out_host,
                            int32_t out_dtype, void* stream) {
     if (!b || !rows_host || !out_host) return fail(APE_ERR_INVALID_ARG, "streams_frame_host: NULL argument");
@@ -1765,26 +1774,27 @@ int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_hos
     const size_t out_bytes = (size_t)b->S * (25 + 6 * N) * (out_dtype == APE_F64 ? sizeof(double) : sizeof(float));
     if (rows_bytes > b->h_rows_bytes) {
         if (b->h_rows) { HIP_TRY(hipHostFree(b->h_rows)); b->h_rows = nullptr; b->h_rows_bytes = 0; }
-        HIP_TRY(hipHostMalloc((void**)&b->h_rows, rows_bytes, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&b->h_rows, rows_bytes, APE_PINNED));
         b->h_rows_bytes = rows_bytes;
     }
     if (out_bytes > b->h_out_bytes) {
         if (b->h_out) { HIP_TRY(hipHostFree(b->h_out)); b->h_out = nullptr; b->h_out_bytes = 0; }
-        HIP_TRY(hipHostMalloc(&b->h_out, out_bytes, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&b->h_out, out_bytes, APE_PINNED));
         b->h_out_bytes = out_bytes;
     }
     if (!b->h_status) {
-        HIP_TRY(hipHostMalloc((void**)&b->h_status, 64, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&b->h_status, 64, APE_PINNED));
         *b->h_status = 0u;
     }
     // up to 64 streams: a word per stream that the post kernel's workgroup writes behind its outputs -- the host takes the frame when
     // all are there instead of waiting for the stream's completion signal to travel (a larger bank waits for the stream)
     if (!b->h_done && b->S <= 64) {
-        HIP_TRY(hipHostMalloc((void**)&b->h_done, 64 * sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&b->h_done, 64 * sizeof(unsigned), APE_PINNED));
         memset(b->h_done, 0, 64 * sizeof(unsigned));
     }
     b->h_done_val += 1;
     if (b->h_done_val == 0) b->h_done_val = 1;
+    const double t_begin = now_us();
     memcpy(b->h_rows, rows_host, rows_bytes);
     // (a sentinel, not zero: in the single-launch frame an aborted launch never reaches the tail that writes the word)
     *b->h_status = m->cluster_ok ? 0xFFFFFFFFu : 0u;       // (no cooperative kernel on this model: nothing writes the word, nothing can abort)
@@ -1804,7 +1814,8 @@ int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_hos
         if (int rc = ape_streams_push_rows(b, kind, b->h_rows, stream)) return rc;
         if (int rc = streams_step_impl(b, flags | APE_FLAG_PACKED_MSG, b->h_out, nullptr, out_dtype, stream, b->h_status)) return rc;
     }
-    bool seen = false;
+    const double t_launched = now_us();
+    bool seen = false, recovered = false;
     if (b->h_done) {
         // ~50 ms of looking (a frame is tens of microseconds; a launch that gives up takes seconds: the stream wait below covers it)
         volatile unsigned* dw = b->h_done;
@@ -1815,8 +1826,10 @@ int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_hos
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
+    const bool fell_through = !seen && b->h_done != nullptr;
     if (!seen) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (*(volatile unsigned*)b->h_status != 0u) {
+        recovered = true;
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         // the regressor launch gave up (bounded spins): the step is still the bank's newest one, so it can be issued again on
         // the kernels that need no co-residency -- into the same pinned rows.  (Single-launch frame: the builder workgroup may not
@@ -1832,7 +1845,32 @@ int ape_streams_frame_host(ape_streams_t* b, int32_t kind, const float* rows_hos
         // stream: nothing aborted since the last check, what the journal holds is done
         journal_clear(m);
     }
+    const double t_there = now_us();
     memcpy(out_host, b->h_out, out_bytes);
+    const double t_end = now_us();
+    if (b->fs_trace.empty()) b->fs_trace.resize(4096 * 3, 0.0f);
+    float* tr = b->fs_trace.data() + (b->fs_frames % 4096) * 3;
+    tr[0] = (float)(t_launched - t_begin); tr[1] = (float)(t_there - t_launched); tr[2] = (float)(t_end - t_there);
+    b->fs_frames += 1;
+    b->fs_fallback += fell_through ? 1 : 0;
+    b->fs_recovered += recovered ? 1 : 0;
+    return APE_OK;
+}
+
+int ape_streams_frame_stats(ape_streams_t* b, ape_frame_stats_t* out, float* trace_us, int32_t capacity_frames, int32_t* n_out, int32_t reset) {
+    if (!b || !out) return fail(APE_ERR_INVALID_ARG, "streams_frame_stats: NULL argument");
+    out->frames = b->fs_frames; out->fallback_syncs = b->fs_fallback; out->recovered = b->fs_recovered;
+    int32_t n = 0;
+    if (trace_us && capacity_frames > 0 && !b->fs_trace.empty()) {
+        const uint64_t have = b->fs_frames < 4096 ? b->fs_frames : 4096;
+        n = (int32_t)(have < (uint64_t)capacity_frames ? have : (uint64_t)capacity_frames);
+        for (int32_t i = 0; i < n; ++i) {
+            const uint64_t frame = b->fs_frames - (uint64_t)n + (uint64_t)i;
+            memcpy(trace_us + 3 * (size_t)i, b->fs_trace.data() + (frame % 4096) * 3, 3 * sizeof(float));
+        }
+    }
+    if (n_out) *n_out = n;
+    if (reset) { b->fs_frames = b->fs_fallback = b->fs_recovered = 0; }
     return APE_OK;
 }
 

@@ -139,4 +139,7 @@ struct ape_streams {
     unsigned* h_done = nullptr;  // [64] pinned: the post kernel's per-stream "outputs are there" words of a host frame
     unsigned h_done_val = 0;     // ... and the value this frame's are awaited with
     size_t h_rows_bytes = 0, h_out_bytes = 0;
+    // where a host frame's time goes (ape_streams_frame_stats): a ring of the last 4096 frames' {launch, wait, copy} microseconds
+    std::vector<float> fs_trace;
+    uint64_t fs_frames = 0, fs_fallback = 0, fs_recovered = 0;
 };

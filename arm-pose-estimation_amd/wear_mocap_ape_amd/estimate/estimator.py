@@ -56,6 +56,22 @@ class _DeviceFrame:
     def reset(self):
         self._hip.check(self._lib.ape_streams_reset(self._bank), "ape_streams_reset")
 
+    def frame_stats(self, reset: bool = False) -> dict:
+        """where the frames' host time went (ape_streams_frame_stats, ABI 7): per-frame microseconds of the last <= 4096 frames in
+        `launch` (rows into pinned staging + the launch calls), `wait` (last launch call returned -> completion words seen) and `copy`
+        (pinned output -> the caller's buffer), and the number of frames that fell through to a stream synchronisation"""
+        C = self._C
+
+        class _FS(C.Structure):
+            _fields_ = [("frames", C.c_uint64), ("fallback_syncs", C.c_uint64), ("recovered", C.c_uint64)]
+        fs, n = _FS(), C.c_int32(0)
+        trace = np.zeros((4096, 3), dtype=np.float32)
+        self._hip.check(self._lib.ape_streams_frame_stats(self._bank, C.byref(fs), C.c_void_p(trace.ctypes.data), 4096, C.byref(n),
+                                                          1 if reset else 0), "ape_streams_frame_stats")
+        t = trace[:n.value]
+        return {"frames": int(fs.frames), "fallback_syncs": int(fs.fallback_syncs), "recovered": int(fs.recovered),
+                "launch_us": t[:, 0].copy(), "wait_us": t[:, 1].copy(), "copy_us": t[:, 2].copy()}
+
     def frame(self, row) -> np.ndarray:
         """raw message -> float64 [25 + 6N]: the message followed by hand / elbow xyz of the N stacked rows (a view of
         this object's buffer, overwritten by the next frame)"""

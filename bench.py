@@ -361,6 +361,27 @@ def estimator_loop(sd, n_frames=1000):
                                                  "msg_from_pred": float(np.median(tt[:, 2]) * 1e6)}
                 else:
                     ent[form]["aborted_checks"] = est._hip_model().stats()["aborted_checks"]
+                    # where a frame's wall time goes, frame by frame (ape_streams_frame_stats, ABI 7): inside the C call -- launch calls,
+                    # wait for the completion words, output copy -- and what is left for the Python side of process_row; the frames at and
+                    # above the wall-clock p99 are looked at on their own: is the tail the device's or the host's?
+                    fs = est._frame_runner().frame_stats()
+                    k = min(len(fs["wait_us"]), n)
+                    inside = fs["launch_us"][-k:] + fs["wait_us"][-k:] + fs["copy_us"][-k:]
+                    wall = us[-k:]
+                    tail = wall >= np.percentile(wall, 99)
+                    pct = lambda a, q: float(np.percentile(a, q))
+                    ent[form]["p99_over_p50"] = ent[form]["p99_us"] / ent[form]["p50_us"]
+                    ent[form]["fallback_syncs"] = fs["fallback_syncs"]
+                    ent[form]["split_us"] = {
+                        "launch_calls": {"p50": pct(fs["launch_us"][-k:], 50), "p99": pct(fs["launch_us"][-k:], 99)},
+                        "wait_for_completion_words": {"p50": pct(fs["wait_us"][-k:], 50), "p99": pct(fs["wait_us"][-k:], 99)},
+                        "copy_out": {"p50": pct(fs["copy_us"][-k:], 50), "p99": pct(fs["copy_us"][-k:], 99)},
+                        "python_side": {"p50": pct(wall - inside, 50), "p99": pct(wall - inside, 99)},
+                        "frames_at_or_above_wall_p99": {"n": int(tail.sum()), "wall_mean": float(wall[tail].mean()),
+                                                        "launch_calls_mean": float(fs["launch_us"][-k:][tail].mean()),
+                                                        "wait_mean": float(fs["wait_us"][-k:][tail].mean()),
+                                                        "copy_out_mean": float(fs["copy_us"][-k:][tail].mean()),
+                                                        "python_side_mean": float((wall - inside)[tail].mean())}}
                 del est
             out[f"mc{mc}_smooth{smooth}"] = ent
     except Exception as exc:                # reported, never fatal for the headline line

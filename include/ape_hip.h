@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 6
+#define APE_ABI_VERSION 7
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -278,6 +278,18 @@ int ape_streams_step(ape_streams_t* bank, uint32_t flags, void* msg_dev, void* t
  * ape_model_recover before the call returns, and a clean frame clears the handle's journal. */
 int ape_streams_frame_host(ape_streams_t* bank, int32_t kind, const float* rows_host, uint32_t flags, void* out_host,
                            int32_t out_dtype, void* stream);
+/* where a host frame's time goes (ABI 7; bench.py `batch1.estimator_loop`): ape_streams_frame_host keeps, for the last 4096 frames, the
+ * host time spent (us) in [0] the rows' copy into pinned staging + the frame's launch calls, [1] the wait from the last launch call's
+ * return to all completion words seen (or the stream synchronised), [2] the copy of the pinned output into out_host; and counts the frames
+ * whose completion words were NOT seen within the poll budget and fell through to hipStreamSynchronize.  `trace_us` (may be NULL):
+ * [n][3] floats, oldest frame first, n = min(frames since the last reset, capacity_frames, 4096) -> *n_out.  reset != 0 clears. */
+typedef struct ape_frame_stats {
+    uint64_t frames;           /* ape_streams_frame_host calls since the last reset        */
+    uint64_t fallback_syncs;   /* ... of them, frames that ended in hipStreamSynchronize   */
+    uint64_t recovered;        /* ... frames whose cooperative launch gave up and was re-issued */
+} ape_frame_stats_t;
+int ape_streams_frame_stats(ape_streams_t* bank, ape_frame_stats_t* out, float* trace_us, int32_t capacity_frames, int32_t* n_out,
+                            int32_t reset);
 /* measurement aid (bench.py `stream_bank_T6.*.roofline`): with profiling on, every launch of the step's dominant kernel (the
  * regressor: ape_lstm_upper32 in a Monte-Carlo bank, else the LSTM launch) is bracketed by a pair of HIP events on the
  * step's own stream; ape_streams_profile_read synchronises, returns the summed duration and the number of launches since

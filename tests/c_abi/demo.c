@@ -1,6 +1,6 @@
 /* A caller of libape_hip.so that is neither Python nor PyTorch: plain C against include/ape_hip.h and the HIP runtime.
  * Builds the pocket regressor from a seeded weight blob, pushes seeded windows through ape_infer (z-score + LSTM +
- * head + de-normalise + FK) and through the stream bank, and writes the results to a file that
+ * head + de-normalise + FK), through the stream bank and through the one-call host frame (ABI 6, with its ABI-7 statistics), and writes the results to a file that
  * tests/test_hip_parity.py::test_c_caller compares with the Python binding on the same numbers.
  *
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c_abi/demo.c \
@@ -97,12 +97,44 @@ int main(int argc, char** argv) {
     double msg[S * 25];
     CHECK_HIP(hipMemcpy(msg, msg_dev, sizeof(msg), hipMemcpyDeviceToHost));
 
+    /* ABI 6 / 7: ONE estimator's frame with host buffers -- estimator.py:174-177 (parse_row_to_xx -> add_xx_to_row_hist_and_make_prediction
+     * -> msg_from_pred) as one blocking call per frame -- and where the frames' host time went.  The features the rows parse to are
+     * written out too (ape_parse_rows): the checker feeds THEM to the oracle's window + model + message. */
+    enum { F = 9, RW = 55, DG = 25 + 6 * SMOOTH };
+    ape_streams_t* one = NULL;
+    CHECK_APE(ape_streams_create(model, 1, T, SMOOTH, &one));
+    static float rows[F][RW], feats[F][I], dgram[F][DG];
+    lcg_state = 4242u;
+    for (int fr = 0; fr < F; ++fr)
+        for (int k = 0; k < RW; ++k) rows[fr][k] = lcg_uniform();
+    float *rows_dev, *feats_dev;
+    CHECK_HIP(hipMalloc((void**)&rows_dev, sizeof(rows)));
+    CHECK_HIP(hipMalloc((void**)&feats_dev, sizeof(feats)));
+    CHECK_HIP(hipMemcpy(rows_dev, rows, sizeof(rows), hipMemcpyHostToDevice));
+    CHECK_APE(ape_parse_rows(APE_PARSE_WATCH_PHONE_POCKET, rows_dev, F, feats_dev, APE_F32, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(feats, feats_dev, sizeof(feats), hipMemcpyDeviceToHost));
+    for (int fr = 0; fr < F; ++fr)
+        CHECK_APE(ape_streams_frame_host(one, APE_PARSE_WATCH_PHONE_POCKET, rows[fr], APE_FLAG_NORMALIZE_INPUT, dgram[fr], APE_F32, stream));
+    ape_frame_stats_t fs;
+    float trace[F * 3];
+    int32_t n_tr = 0;
+    CHECK_APE(ape_streams_frame_stats(one, &fs, trace, F, &n_tr, 0));
+    if (fs.frames != F || n_tr != F || fs.recovered != 0) { fprintf(stderr, "frame stats: %llu frames, %d traced, %llu recovered\n",
+                                                                      (unsigned long long)fs.frames, (int)n_tr, (unsigned long long)fs.recovered); return 5; }
+    for (int fr = 0; fr < F; ++fr)
+        if (!(trace[3 * fr] >= 0.0f && trace[3 * fr + 1] >= 0.0f && trace[3 * fr + 2] >= 0.0f)) { fprintf(stderr, "frame trace %d\n", fr); return 5; }
+    CHECK_APE(ape_model_check(model));
+
     FILE* f = fopen(out_path, "wb");
     if (!f) { perror(out_path); return 4; }
     fwrite(y, sizeof(float), (size_t)B * O, f);
     fwrite(est, sizeof(double), (size_t)B * 21, f);
     fwrite(msg, sizeof(double), (size_t)S * 25, f);
+    fwrite(feats, sizeof(float), (size_t)F * I, f);
+    fwrite(dgram, sizeof(float), (size_t)F * DG, f);
     fclose(f);
+    CHECK_APE(ape_streams_destroy(one));
     CHECK_APE(ape_streams_destroy(bank));
     CHECK_APE(ape_model_destroy(model));
     printf("ok: %d windows -> %s (kernel %s)\n", B, out_path, "libape_hip");

@@ -976,7 +976,11 @@ def test_c_caller(tmp_path):
     raw = np.fromfile(out, dtype=np.uint8)
     y = raw[:B * O * 4].view(np.float32).reshape(B, O)
     est = raw[B * O * 4:B * O * 4 + B * 21 * 8].view(np.float64).reshape(B, 21)
-    msg = raw[B * O * 4 + B * 21 * 8:].view(np.float64).reshape(S, 25)
+    o_msg = B * O * 4 + B * 21 * 8
+    msg = raw[o_msg:o_msg + S * 25 * 8].view(np.float64).reshape(S, 25)
+    F, DG = 9, 25 + 6 * SMOOTH
+    feats = raw[o_msg + S * 25 * 8:o_msg + S * 25 * 8 + F * I * 4].view(np.float32).reshape(F, I)
+    dgram = raw[o_msg + S * 25 * 8 + F * I * 4:].view(np.float32).reshape(F, DG)
     y_ref, est_ref = orc.infer_windows(sd, stats, orc.DEFAULT_BODY, 0, x, route="eigh")
     assert np.abs(y - y_ref).max() < TOL_Y_SHORT
     assert np.abs(est - est_ref).max() < TOL_EST_E2E
@@ -988,6 +992,15 @@ def test_c_caller(tmp_path):
             pred = win.push(x[s, t])
         ref = orc.msg_from_est(orc.arm_pose_from_targets(pred, orc.DEFAULT_BODY, 0, "eigh"), orc.DEFAULT_BODY, 0)
         assert np.abs(msg[s] - ref).max() < 5e-6
+    # ape_streams_frame_host (ABI 6): one estimator, F frames, host rows in / host datagrams out; the rows' features (ape_parse_rows,
+    # pinned to the reference by the parse goldens) through the oracle's window, model, smoothing stack and message + tail
+    assert np.isfinite(feats).all() and np.isfinite(dgram).all()
+    win = orc.WindowOracle(T, SMOOTH, stats, predict)
+    for fr in range(F):
+        pred = win.push(feats[fr])
+        est = orc.arm_pose_from_targets(pred, orc.DEFAULT_BODY, 0, "eigh")
+        ref = np.asarray(orc.msg_with_mc_samples(orc.msg_from_est(est, orc.DEFAULT_BODY, 0), est, True), dtype=np.float64)
+        assert ref.shape == (DG,) and np.abs(dgram[fr] - ref).max() < 1e-5, (fr, float(np.abs(dgram[fr] - ref).max()))
 
 
 def test_two_models_on_two_streams_concurrently(norm_stats):
