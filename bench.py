@@ -43,6 +43,7 @@ import torch.distributed as dist  # noqa: E402
 WINDOWS_PER_GPU = 1024
 T_FRAMES = 64
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0             # same guide: HBM3E ~8 TB/s
 PEAK_F16_MFMA_TFLOPS = 2500.0      # same table, "Peak BF16/FP16 MFMA": ~2.5 PF dense (never the 2:1-sparsity figure)
 POCKET = dict(I=22, H=256, L=2, O=14, layout=0)
 
@@ -473,9 +474,13 @@ def stream_bank_numbers(model, stats, cases=None):
                 alg_bytes = rows_total * (T * I * 4 + O * 4)
             k_ms = kms / frames                  # all launches of the kernel in one frame (8192 x 25: five chunks)
             tf = flop / (k_ms * 1e-3) / 1e12
-            traffic, ttag, stale = load_traffic(kname, rows_total)
+            traffic, ttag, stale = load_traffic(kname, rows_total, model=name, T=T)
             ent["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag, "traffic_stale": stale,
+                               # the memory side beside the matrix cores: counter bytes per launch over this run's launch time, against
+                               # the 8 TB/s of HBM3E (the banks' write-through hand-over puts every slice on the memory side)
+                               "hbm_counter_GBps": (traffic * (launches / frames) / (k_ms * 1e-3) / 1e9) if traffic else None,
+                               "hbm_counter_frac_of_peak": (traffic * (launches / frames) / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS) if traffic else None,
                                "kernel": kname, "kernel_ms": k_ms, "launches_per_frame": launches / frames,
                                "flop_per_frame": flop, "hbm_algorithmic_bytes_per_frame": alg_bytes,
                                "kernel_share_of_frame": k_ms / ms}
@@ -681,18 +686,26 @@ def other_paths():
     return out
 
 
-def load_traffic(kernel_name, windows):
+def load_traffic(kernel_name, windows, model=None, T=None):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (profiles/traffic_latest.json, written by tools/summarize_prof.py from separate counter runs of this very
-    command; counters cannot be collected from inside the timed run)"""
+    command; counters cannot be collected from inside the timed run).  Entries are keyed on (kernel instantiation, windows per launch,
+    model, T): an entry that names a model / a window length serves only the caller that asks for the same one."""
     tfile = REPO / "profiles" / "traffic_latest.json"
     try:
         tj = json.loads(tfile.read_text())
         best = None
         for ent in tj.get("kernels", [tj]):
             a = ent.get("kernel", "")
-            if a and (a in kernel_name or kernel_name in a) and ent.get("windows") == windows:
-                best = ent                                   # the newest matching entry wins (the file is append-ordered)
+            if not (a and (a in kernel_name or kernel_name in a) and ent.get("windows") == windows):
+                continue
+            if ent.get("model") is not None and model is not None and ent["model"] != model:
+                continue
+            if ent.get("T") is not None and T is not None and ent["T"] != T:
+                continue
+            if (model is not None or T is not None) and ent.get("model") is None and ent.get("T") is None and best is not None:
+                continue                                     # (an unkeyed entry of an earlier round never displaces a keyed one)
+            best = ent                                       # the newest matching entry wins (the file is append-ordered)
         if best is not None:
             # stale = the entry was measured on another build of the kernel: tools/summarize_prof.py stamps every entry with
             # the SHA-256 of the kernel's object file (lib/build_info.json, written at link time); an entry without a stamp
@@ -966,17 +979,22 @@ def main():
     # BASELINE configs[3] literally: 8192 independent streams, one shard of 1024 per GPU, in the estimators' default Monte-Carlo mode --
     # in an N-rank run every rank also steps ITS 1024-stream x 25-sample bank (device-side frame: rows in, datagram rows out) and
     # reports the frame time, so that the per-node load of configs[3] is in the line rank by rank
-    bank_ms = float("nan")
+    # (round 5: all three deployed estimators' shards -- pocket 25 samples, upper-arm 50 samples, watch-only 25 samples / smooth 10)
+    bank_ms = bank_uarm_ms = bank_watch_ms = float("nan")
     if use_dist:
-        bk = stream_bank_numbers(model, stats, cases=[("S1024_mc25", "pocket", 1024, 25, 1, 20)])
+        bk = stream_bank_numbers(model, stats, cases=[("S1024_mc25", "pocket", 1024, 25, 1, 20), ("uarm_S1024_mc50_T6", "uarm", 1024, 50, 1, 10),
+                                                      ("watch_S1024_mc25_T8", "watch", 1024, 25, 10, 10)])
         bank_ms = float(bk.get("S1024_mc25", {}).get("ms_per_frame_of_all_streams", float("nan")))
+        bank_uarm_ms = float(bk.get("uarm_S1024_mc50_T6", {}).get("ms_per_frame_of_all_streams", float("nan")))
+        bank_watch_ms = float(bk.get("watch_S1024_mc25_T8", {}).get("ms_per_frame_of_all_streams", float("nan")))
     # every rank's own numbers travel to rank 0 (a straggler GPU must be visible in the one line the driver gets)
-    mine_t = torch.tensor([rank, kernel_ms, own_elapsed / args.steps * 1e3, bank_ms], dtype=torch.float64, device=comm_dev)
+    mine_t = torch.tensor([rank, kernel_ms, own_elapsed / args.steps * 1e3, bank_ms, bank_uarm_ms, bank_watch_ms], dtype=torch.float64, device=comm_dev)
     rank_times = [mine_t]
     if use_dist:
         rank_times = [torch.empty_like(mine_t) for _ in range(world)]
         dist.all_gather(rank_times, mine_t)
-    rank_times = {int(t_[0].item()): (float(t_[1].item()), float(t_[2].item()), float(t_[3].item())) for t_ in rank_times}
+    rank_times = {int(t_[0].item()): tuple(float(t_[k].item()) for k in range(1, 6)) for t_ in rank_times}
+    nn_ = lambda v: None if v != v else v           # (NaN = not measured: a 1-rank run, where stream_bank_T6 carries the frames)
     flop_per_launch = model.flops_per_window(T_FRAMES) * B
     achieved_tf = flop_per_launch / (kernel_ms * 1e-3) / 1e12
 
@@ -998,10 +1016,12 @@ def main():
                                     "per_rank": [{"rank": int(s_[0]), "streams": [int(s_[1]), int(s_[2])], "device": int(s_[3]),
                                                   "weight_blob_sum": s_[4], "kernel_ms": rank_times[int(s_[0])][0],
                                                   "ms_per_step": rank_times[int(s_[0])][1],
-                                                  "bank_S1024_mc25_T6_ms_per_frame": (None if rank_times[int(s_[0])][2] != rank_times[int(s_[0])][2]
-                                                                                      else rank_times[int(s_[0])][2])} for s_ in shards],
-                                    "bank_note": "per rank: one frame of its 1024-stream x 25-sample Monte-Carlo bank (configs[3]'s shard in the "
-                                                 "estimators' default mode); null in a 1-rank run, where stream_bank_T6 carries it"},
+                                                  "bank_S1024_mc25_T6_ms_per_frame": nn_(rank_times[int(s_[0])][2]),
+                                                  "bank_uarm_S1024_mc50_T6_ms_per_frame": nn_(rank_times[int(s_[0])][3]),
+                                                  "bank_watch_S1024_mc25_T8_smooth10_ms_per_frame": nn_(rank_times[int(s_[0])][4])} for s_ in shards],
+                                    "bank_note": "per rank: one frame of its 1024-stream Monte-Carlo bank for each of the three deployed estimators in "
+                                                 "their default modes (configs[3]'s shard: pocket 25 samples, upper-arm 50 samples, watch-only 25 samples "
+                                                 "with smooth 10); null in a 1-rank run, where stream_bank_T6 carries them"},
                        "preroll_steps": PREROLL},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag,

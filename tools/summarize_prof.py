@@ -41,6 +41,8 @@ ap.add_argument("--note", default="")
 ap.add_argument("--wg-threads", type=int, default=256)
 ap.add_argument("--skip-first", type=int, default=0, help="leave the first N matching launches out of the duration mean (clock ramp)")
 ap.add_argument("--min-us", type=float, default=0.0, help="only launches at least this long (the same instantiation also serves shorter windows)")
+ap.add_argument("--model", default=None, help="pocket | watch | uarm | ff | imupose: part of the traffic entry's key (the same kernel serves several models)")
+ap.add_argument("--T", type=int, default=None, help="window length of the profiled launches: part of the traffic entry's key")
 args = ap.parse_args()
 
 
@@ -187,8 +189,10 @@ if hbm is not None:
         ents = cur.get("kernels", [cur])
     except Exception:
         ents = []
-    ents = [e for e in ents if not (e.get("kernel") == args.kname and e.get("windows") == args.windows)]
-    ent = {"tag": args.tag, "kernel": args.kname, "windows": args.windows, "hbm_bytes_per_launch": hbm,
+    # one entry per (kernel instantiation, windows, model, T): the pocket bank must not quote the watch bank's bytes
+    same = lambda e: (e.get("kernel") == args.kname and e.get("windows") == args.windows and e.get("model") == args.model and e.get("T") == args.T)
+    ents = [e for e in ents if not same(e)]
+    ent = {"tag": args.tag, "kernel": args.kname, "windows": args.windows, "model": args.model, "T": args.T, "hbm_bytes_per_launch": hbm,
            "fetch_kib_raw": fetch_kib, "write_kib_raw": write_kib, "kernel_us_mean": mean_us}
     # which build was measured: the commit the library was built from and the SHA-256 of the kernel's object file
     # (lib/build_info.json, written by csrc/Makefile at link time); bench.py compares the hash with the library it runs
