@@ -103,6 +103,17 @@ __device__ __forceinline__ void span(f32x4 (&acc)[NTW], const f32x4 (&a)[NQ], co
 #endif
 
 // (the flag looks: LDS-DMA into the wave's landing zone, async_look.h -- no destination register)
+// sweep positions of a section's hooks (tests/tools): where the flag owed for the other set's publish goes up (0: right behind the barrier,
+// 1: behind layer 0's MFMAs) and where the look at the next section's flags is issued (0: behind layer 1's MFMAs, 1: behind layer 0's gate
+// math, 2: behind layer 0's MFMAs, 3: between layer 1's two spans -- the default since round 5: the look now lands in LDS and is read back
+// from there, one LDS hop more than the register destination it had; swept under the write-through hand-over at 1024 x 64:
+// 0 241.3 us, 1 243.3, 2 288.0, 3 235.1; flag raise behind layer 0's MFMAs instead of behind the barrier 255.7)
+#ifndef F16_RAISE_AT
+#define F16_RAISE_AT 0
+#endif
+#ifndef F16_LOOK_AT
+#define F16_LOOK_AT 3
+#endif
 
 // UPW = 4 (round 4, "duo"): 16-unit members -- a wave owns 4 units = ONE tile, 100 weight registers -- so that a workgroup fits twice on a
 // CU (<= 256 registers per wave, 47 KB of LDS): 16-member clusters of 32 rows, 512 workgroups for 1024 windows, TWO independent
@@ -384,8 +395,10 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
         // barrier, so that the peers' look at these words (after THEIR layer-1 MFMAs) finds it.  Measured on configs[4]:
         // here 244 us; after the layer-0 MFMAs (the store certainly drained, nothing waits) 252 us; after layer 0's gate
         // math 292 us -- the later the flag, the more gathers miss their prefetch and fall back to the blocking form
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!d_noex) raise_pending();
+        if (F16_RAISE_AT == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!d_noex) raise_pending();
+        }
         const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
         // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
         // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
@@ -417,11 +430,23 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                     if (ST || t > 0) span<NTW, QH, NB0>(acc, a0r, w0, QX);
                 } else {
                     span<NTW, QH, NB1>(acc, a1i, w1, 0);
+                    if (F16_LOOK_AT == 3) {                           // (sweep position: between layer 1's two spans)
+                        look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
+                        peeked = true;
+                    }
                     if (ST || t > 0) span<NTW, QH, NB1>(acc, a1r, w1, QH);
                 }
                 mfma_drain<NTW>(acc);
             }
             V2_STAMP(4);                                          // 4: MFMA spans (incl. the wait for the LDS reads feeding them)
+            if (l == 0 && F16_RAISE_AT == 1) {                    // (sweep position: the flag owed goes up behind layer 0's MFMAs)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!d_noex) raise_pending();
+            }
+            if (l == 0 && F16_LOOK_AT == 2) {
+                look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
+                peeked = true;
+            }
             if (l == 0) {
                 if (ST || ph >= 1) load_frags<QH>(a1i, hset, 512);
                 if (ST || ph > 1) load_frags<QH>(a1r, hset + HL, 512);
@@ -430,8 +455,8 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                     stage_x(xr, s, ph + 1);
                     if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
                 }
-            } else {
-                // [B0] look at the flags the next section needs; the load flies under the gate math below.  Issued as LDS-DMA into the wave's
+            } else if (!peeked) {
+                // [B0] look at the flags the next section needs (if the section has not issued it yet: F16_LOOK_AT, or a layer-1 part that did not run); the load flies under the gate math below.  Issued as LDS-DMA into the wave's
                 // landing zone (async_look.h) and read back at [B]: hipcc hoists the comparison of a compiler-visible load up to the load and
                 // waits `vmcnt(0)` right behind it -- the L2 round trip it was meant to hide (round 3, found in the disassembly).
                 look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
@@ -456,13 +481,18 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                 own[((wave * L + l) * SR + r) * UPW + tt * 4 + g] = (_Float16)hval;
             }
             V2_STAMP(5);                                          // 5: gates + cell update + own-slice staging
+            if (l == 0 && F16_LOOK_AT == 1) {                     // (sweep position: behind layer 0's gate math)
+                look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
+                peeked = true;
+            }
         }
         if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
         // [B] every peer wave has published what the next section needs: its whole gather goes into flight now
-        if (peeked) {
-            look_landed();
-            peek = *look_mine;
-        }
+        // (the landed look and this wave's fresh slices are read out of LDS together: one LDS latency in front of the judge, not two)
+        u32x4 pub_v = {0u, 0u, 0u, 0u};
+        if (peeked) look_landed();
+        if constexpr (UPW == 8) pub_v = *reinterpret_cast<const u32x4*>(own + ((wave * L + ((lane >> 4) & (L - 1))) * SR + (lane & 15)) * UPW);
+        if (peeked) peek = *look_mine;
         if ((ST || want > 0u) && !d_noex && __all((int)(peek >= want))) {
             issue_gather(sn, (phn - 1) & 1);
             prefetched = true;
@@ -474,7 +504,7 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
             const bool live = lane < 16 * L && (ST || (t >= 0 && t < T));
             // dead lanes aim outside the buffer descriptor: the store instruction is issued by every wave, writes nothing there
             if constexpr (UPW == 8) {
-                const u32x4 hv = *reinterpret_cast<const u32x4*>(own + ((wave * L + (l & (L - 1))) * SR + row) * UPW);
+                const u32x4 hv = pub_v;
                 const unsigned off = (live && !d_noex) ? hx_base(s, ph & 1) + (unsigned)((((l * GH + member) * 4 + wave) * SR + row) * 16) : 0x80000000u;
                 if (in_l2) __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 0);
                 else __builtin_amdgcn_raw_buffer_store_b128(hv, hx_rsrc, off, 0, 16 /* sc1: write-through */);
