@@ -616,7 +616,7 @@ def other_paths():
                                                            C.c_void_p(y.data_ptr()), None), "fwd"), 10, 50)
         out["mlp_regressor"] = {"rows": N, "us_per_launch": us, "rows_per_s": N / us * 1e6,
                                 "tflops": m.flops_per_window(1) * N / us / 1e6, "kernel": m.kernel_name(N, 1),
-                                "profile": "profiles/r04_mlp_pipe.md"}
+                                "profile": "profiles/r05_mlp_pipe.md"}
         m.check()
         del m, x, y
     except Exception as exc:
@@ -631,7 +631,7 @@ def other_paths():
         m.check()
         out["imupose_lstm"] = {"windows": B, "frames": T, "us_per_call": us, "windows_per_s": B / us * 1e6,
                                "tflops": m.flops_per_window(T) * B / us / 1e6, "kernel": m.kernel_name(B, T),
-                               "profile": "profiles/r04_imupose_cluster.md"}
+                               "profile": "profiles/r05_imupose_cluster.md"}
         del m, x, y
     except Exception as exc:
         out["imupose_lstm"] = {"error": str(exc)[:200]}
@@ -648,7 +648,7 @@ def other_paths():
             res[f"T{T}"] = {"us_per_launch": us, "windows_per_s": B / us * 1e6, "tflops": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS,
                             "kernel": m.kernel_name(B, T)}
         m.check()
-        out["uarm_lstm"] = dict(res, windows=B, profile="profiles/r04_uarm_T64.md")
+        out["uarm_lstm"] = dict(res, windows=B, profile="profiles/r05_uarm_T64.md")
         del m, x, y
     except Exception as exc:
         out["uarm_lstm"] = {"error": str(exc)[:200]}
@@ -756,7 +756,7 @@ def fp16_config4(stats_watch, n_iter=20):
     m.check()
     flop = m.flops_per_window(T_FRAMES) * WINDOWS_PER_GPU
     tf16 = flop / (out["f16"] * 1e-3) / 1e12
-    traffic, ttag, tstale = load_traffic(names["f16"], WINDOWS_PER_GPU)
+    traffic, ttag, tstale = load_traffic(names["f16"], WINDOWS_PER_GPU, model="watch", T=T_FRAMES)
     alg_bytes = WINDOWS_PER_GPU * (T_FRAMES * cfg["I"] * 4 + cfg["O"] * 4)
     return {"workload": "configs[4]: watch-only (I=20,H=256,L=2,O=12), 1024 windows x 64 frames, fp16 W/x/h, fp32 accumulate",
             "kernel_ms_f16": out["f16"], "kernel_ms_f32": out["f32"], "windows_per_s_f16": WINDOWS_PER_GPU / out["f16"] * 1e3,
@@ -766,10 +766,15 @@ def fp16_config4(stats_watch, n_iter=20):
                          "frac": tf16 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_from": ttag, "traffic_stale": tstale,
                          "kernel": names["f16"], "kernel_ms": out["f16"], "flop_per_launch": flop,
                          "hbm_algorithmic_bytes_per_launch": alg_bytes,
-                         # the bound that binds: 2 (T + 2) = 132 dependent sections, each MFMA spans + gate math + ONE hop
-                         # through the XCD's L2 (cycles from profiles/r03_f16v2_stamps.md / r03_small_stamps.md at 2.31 GHz)
-                         "latency_floor_us": 2 * (T_FRAMES + 2) * (1140 + 898 + 546) / 2310.0,
-                         "frac_of_latency_floor": 2 * (T_FRAMES + 2) * (1140 + 898 + 546) / 2310.0 / (out["f16"] * 1e3),
+                         # the bound that binds: 2 (T + 2) = 132 dependent sections, each MFMA spans + gate math + ONE hop of the
+                         # exchange (cycles of the round-4 stamps, profiles/r04_f16_duo_ab.md, shipped form: MFMA spans 1132, gates + own
+                         # staging 905, flag poll 88 + gather landed 482; at 2.31 GHz).  Round 5: the hand-over is write-through by default
+                         # (the guide's valid form): the two row sets of a cluster take turns, so a phase lasts max(2 C, C + E) with C one
+                         # section's own work (~1.5 us) and E the exchange from publish to landed (~1.5 us plain in-XCD, ~2.1 us
+                         # write-through) -- C + E binds, DESIGN.md 4.11
+                         "latency_floor_us": 2 * (T_FRAMES + 2) * (1132 + 905 + 88 + 482) / 2310.0,
+                         "frac_of_latency_floor": 2 * (T_FRAMES + 2) * (1132 + 905 + 88 + 482) / 2310.0 / (out["f16"] * 1e3),
+                         "hand_over": "write-through (sc1) stores: the default since round 5; APE_FLAG_IN_XCD_PLAIN measures ~8 % faster",
                          "note": "latency-bound, not matrix-bound: per layer-step a wave has 2 x 16 f16 MFMAs (~0.5K cycles) "
                                  "between two cluster-wide exchanges of h; the f16 dense MFMA peak is the stated roofline, "
                                  "latency_floor_us = sections x (MFMA spans + gates + one in-XCD hop) the one that binds"}}
@@ -1001,7 +1006,7 @@ def main():
     if rank == 0:
         total_windows = sum(int(s_[2] - s_[1]) for s_ in shards) * args.steps
         kname = model.kernel_name(B, T_FRAMES)
-        traffic, ttag, tstale = load_traffic(kname, B)
+        traffic, ttag, tstale = load_traffic(kname, B, model="pocket", T=T_FRAMES)
         out = {
             "metric": "IMU windows/sec", "value": total_windows / elapsed, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
