@@ -703,8 +703,8 @@ def load_traffic(kernel_name, windows, model=None, T=None):
                 continue
             if ent.get("T") is not None and T is not None and ent["T"] != T:
                 continue
-            if (model is not None or T is not None) and ent.get("model") is None and ent.get("T") is None and best is not None:
-                continue                                     # (an unkeyed entry of an earlier round never displaces a keyed one)
+            if (model is not None or T is not None) and ent.get("model") is None and ent.get("T") is None:
+                continue                                     # (an unkeyed entry of an earlier round answers no keyed question: null, not another shape's bytes)
             best = ent                                       # the newest matching entry wins (the file is append-ordered)
         if best is not None:
             # stale = the entry was measured on another build of the kernel: tools/summarize_prof.py stamps every entry with
