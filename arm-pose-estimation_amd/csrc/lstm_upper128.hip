@@ -239,11 +239,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     }
     __syncthreads();
     if (ctl[0] != 0) return;
-    // The slices are handed over by WRITE-THROUGH (sc1) stores even though all members of a cluster share an XCD's L2.  Round 4, found
-    // with this kernel: behind a plain store, `s_waitcnt vmcnt(0)` does not mean that an sc1 load of another CU sees the data -- with
-    // the look at the flags moved forward (copies starting ~1.9 us behind the stores instead of ~2.6 us) the first launch of a fresh
-    // process read stale slices in 7 of 8 runs (whole 32-row tiles off by 1e-3 .. 1e-2), with sc1 stores in 0 of 8; and here, with two
-    // tiles in flight per cluster, the later acknowledgement costs nothing (1.181 vs 1.183 ms per launch).  profiles/r04_bank_uarm.md.
+    // The slices are handed over by WRITE-THROUGH (sc1) stores although all members of a cluster share an XCD's L2: the form the MI355X guide
+    // lists as valid wherever the workgroups run, and with two tiles in flight per cluster the later acknowledgement costs nothing (1.181 vs
+    // 1.183 ms per launch).  (Round 4 made this change in the belief that plain stores had caused this kernel's cold-start fault -- whole
+    // 32-row tiles off on a fresh process's first launch; round 5 found the real cause, the mask words' asm load whose destination hipcc
+    // copied in front of its wait -- see the note above look_issue_plain's use below and DESIGN.md 4.17 -- and that the hand-over had been
+    // sound in both flavours.)
     // per-lane addresses of the hooks' loads, computed once: the look at a set's flags (+ the set's 2 * NFL words; all four quarter-waves
     // read the same sixteen), the mask words of this lane's four units (+ (tile * T + t) * 128 words)
     const ape_desc_t fl_desc = ape_make_desc(p.xflags, (unsigned)(NC * 2 * 2 * NFL * sizeof(unsigned)));

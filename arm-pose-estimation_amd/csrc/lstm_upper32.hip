@@ -231,10 +231,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     }
     __syncthreads();
     if (ctl[0] != 0) return;
-    // Round 4 (found with lstm_upper128.hip, see there): behind a PLAIN store `s_waitcnt vmcnt(0)` does not guarantee that another CU's sc1
-    // load sees the data, so a flag raised after it can overtake the slice; the hand-over is by write-through (sc1) stores whatever the
-    // placement.  With two tiles in flight per cluster the later acknowledgement is free (tests/tools/ab_wt.py: 1202.1 vs 1200.7 us per
-    // frame of the 1024 x 25 bank, 1626.2 vs 1621.3 us of the watch-only bank).
+    // The hand-over is by write-through (sc1) stores whatever the placement: the form the MI355X guide lists as valid wherever the workgroups
+    // run, and with two tiles in flight per cluster the later acknowledgement is free (tests/tools/ab_wt.py: 1202.1 vs 1200.7 us per frame of
+    // the 1024 x 25 bank, 1626.2 vs 1621.3 us of the watch-only bank).  (Round 4 made this change in the belief that plain stores had caused
+    // lstm_upper128.hip's cold-start fault; round 5 found the real cause -- an asm load's destination copied in front of its wait,
+    // async_look.h -- and that the hand-over had been sound in both flavours: DESIGN.md 4.17.)
     constexpr bool in_l2 = false;
 
     // every wave polls for itself: have all member waves published epoch `want` of set s?
