@@ -64,4 +64,22 @@ int ape_debug_bank_targets(ape_streams_t* b, float* out_host) {
     return APE_OK;
 }
 
+// one of the bank's device buffers -> host, for localising a wrong frame: 0 the feature ring [S, n_mc, T, I], 1 layer 0's input tiles
+// (fragment order, ape_lower32_xfrag_bytes), 2 layer 0's output sequence (fragment order), 3 the masked input of the last chunk of launch B.
+// `bytes` = what the caller's buffer holds; the copy is the smaller of that and the buffer (returned in *copied)
+int ape_debug_bank_buffer(ape_streams_t* b, int which, void* out_host, size_t bytes, size_t* copied) {
+    if (!b || !out_host || which < 0 || which > 3) return APE_ERR_INVALID_ARG;
+    const int I = b->model->dims.input_size;
+    const size_t tiles = (size_t)(b->S + 31) / 32, ctiles = (size_t)(b->chunk_rows + 31) / 32;
+    const void* src = which == 0 ? (const void*)b->xring : which == 1 ? (const void*)b->xfrag0 : which == 2 ? (const void*)b->hfrag : (const void*)b->xfrag;
+    size_t have = which == 0 ? (size_t)b->S * b->n_mc * b->T * I * sizeof(float) : which == 1 ? tiles * b->T * 4096 : which == 2 ? tiles * b->T * 32768 : ctiles * b->T * 32768;
+    if (!src) return APE_ERR_NOT_READY;
+    if (have > bytes) have = bytes;
+    APE_DBG_TRY(hipSetDevice(b->model->dims.device));
+    APE_DBG_TRY(hipDeviceSynchronize());
+    APE_DBG_TRY(hipMemcpy(out_host, src, have, hipMemcpyDeviceToHost));
+    if (copied) *copied = have;
+    return APE_OK;
+}
+
 }  // extern "C"

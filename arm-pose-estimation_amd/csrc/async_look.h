@@ -44,3 +44,12 @@ __device__ __forceinline__ void look_issue_plain(unsigned zone_lds, unsigned vof
 }
 // everything this wave has in flight has arrived -- the look in its zone, and whatever else the caller has issued
 __device__ __forceinline__ void look_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The same blindness on the STORE side (round 5, lstm_upper32.hip's layer-0 form: DESIGN.md 4.18): a vector-memory store of more than 64 bits
+// reads its data registers up to two wait states AFTER it issues (gfx940 and later; LLVM's GCNHazardRecognizer pads the stores hipcc emits
+// itself -- "VMEM store-data hazard" -- and skips buffer stores whose soffset is an SGPR).  An asm statement is opaque to that pass: hipcc
+// gave the publish store's data registers to the epoch counter (`v_add_u32 v2, 1, v51` one instruction behind `buffer_store_dwordx4 v[2:5]`),
+// and beside a memory-bound neighbour sixteen lanes of a wave published the integer epoch in place of a hidden value, once in ~2000 frames.
+// Every asm store of the kernels therefore carries its two wait states inside the statement (APE_STORE_TAIL); tools/check_mfma_hazards.py
+// scans for a wide asm store whose data a VALU instruction writes too early and fails the build on it.
+#define APE_STORE_TAIL "\n\ts_nop 1"

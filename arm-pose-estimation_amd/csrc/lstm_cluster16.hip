@@ -83,8 +83,8 @@ __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 r
 }
 template <bool WT>
 __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
-    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
-    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" APE_STORE_TAIL :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" APE_STORE_TAIL :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 // (the flag looks: LDS-DMA into the wave's landing zone, async_look.h -- no destination register)
 

@@ -78,9 +78,9 @@ __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
 #if !defined(APE_UP128_ASSERT)
 #error "UP128_PLAIN_STORES rebuilds round 4's faulty hand-over: for the asserting diagnostic build (tests/tools/assert_up128.py) only"
 #endif
-    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen" APE_STORE_TAIL :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 #else
-    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen sc1" APE_STORE_TAIL :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 #endif
 }
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes from the buffer to 1 KiB of LDS at the wave-uniform byte address `lds_addr`

@@ -79,8 +79,8 @@ __device__ __forceinline__ void span32(f32x16& acc, const float* __restrict__ sr
 // scalar registers in a kernel that already spills them); `sc1` = write-through form for clusters that span XCDs
 template <bool WT>
 __device__ __forceinline__ void store_16(u32x4 v, unsigned voff, u32x4 rsrc) {
-    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
-    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    if constexpr (WT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" APE_STORE_TAIL :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" APE_STORE_TAIL :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"

@@ -151,3 +151,52 @@ def test_bank_routes_under_uneven_load(norm_stats, streamer, name, S, n_mc, rout
     streamer.drain()
     assert lib.ape_debug_set_bank_masks(bank._handle, None) == 0
     _no_abort(m)
+
+
+def test_fresh_banks_layer0_sequence_under_uneven_load(streamer):
+    """the layer-0 form of lstm_upper32.hip publishes every step's slices into the sequence launch B reads: fresh banks (first launches on
+    untouched buffers), push and step back to back with no host synchronisation in between, copies beside them -- and EVERY word of the
+    sequence against a float64 layer 0 in numpy.  (Round 5: once in ~2000 such frames sixteen lanes of one wave published the integer
+    slice epoch in place of a hidden value -- an asm store's data registers re-used inside its two wait states, async_look.h; the static
+    scan of tests/test_asm_hazards.py is the guard, this is the observation it was found by.)"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import nn_models
+    from wear_mocap_ape_amd.streams import StreamBank
+    lib = _hip.lib()
+    assert hasattr(lib, "ape_debug_bank_buffer"), "this file runs on the test-hooks library (APE_HIP_LIB)"
+    lib.ape_debug_bank_buffer.restype = C.c_int
+    lib.ape_debug_bank_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    cfg = orc.MODEL_CONFIGS["watch"]
+    T, I, O, H, S, n_mc = cfg["T"], cfg["I"], cfg["O"], cfg["H"], 41, 60
+    tiles = (S + 31) // 32
+    rng = np.random.default_rng(41)
+    sg = lambda v: 1.0 / (1.0 + np.exp(-v))
+    for bank_no in range(120):
+        sd = orc.make_state_dict(I, H, cfg["L"], O, int(rng.integers(100)))
+        m = nn_models.DropoutLSTM(I, H, cfg["L"], O, dropout=0.2, device=0); m.load_state_dict(sd); m.set_body(orc.DEFAULT_BODY)
+        bank = StreamBank(m, S, T, smooth=2, normalize=False, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=bank_no)
+        w_ih, w_hh = sd["lstm.weight_ih_l0"].astype(np.float64), sd["lstm.weight_hh_l0"].astype(np.float64)
+        b = sd["lstm.bias_ih_l0"].astype(np.float64) + sd["lstm.bias_hh_l0"].astype(np.float64)
+        hist = None
+        for f in range(2):
+            xx = rng.normal(size=(S, I)).astype(np.float32)
+            streamer.burst(8)
+            bank.push_features(torch.from_numpy(xx).cuda())
+            bank.step()
+            assert m.last_kernel() == "ape_lstm_upper32", m.last_kernel()
+            hist = np.repeat(xx[:, None], T, axis=1) if hist is None else np.concatenate([hist[:, 1:], xx[:, None]], axis=1)
+            got = np.empty(tiles * T * 8192, dtype=np.float32); n = C.c_size_t(0)
+            assert lib.ape_debug_bank_buffer(bank._handle, 2, got.ctypes.data_as(C.c_void_p), got.nbytes, C.byref(n)) == 0 and n.value == got.nbytes
+            h = np.zeros((S, H)); c = np.zeros_like(h); want = np.zeros((tiles * 32, T, H))
+            for t in range(T):
+                pre = hist[:, t].astype(np.float64) @ w_ih.T + h @ w_hh.T + b
+                c = sg(pre[:, H:2 * H]) * c + sg(pre[:, :H]) * np.tanh(pre[:, 2 * H:3 * H])
+                h = sg(pre[:, 3 * H:]) * np.tanh(c)
+                want[:S, t] = h
+            want = want.reshape(tiles, 32, T, 32, 8).transpose(0, 2, 3, 1, 4)           # [tile][step][k-block][row][8 units]
+            d = np.abs(got.reshape(want.shape) - want)
+            d[1, :, :, S - 32:] = 0.0                                                      # rows past the bank: computed, never read
+            assert d.max() < 2e-6, (bank_no, f, float(d.max()), np.argwhere(d > 2e-6)[:8].tolist())
+        _no_abort(m)
+        del bank, m
+    streamer.drain()

@@ -5,6 +5,7 @@ import ctypes as C, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
 import torch
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _load; _load.start()      # APE_SOAK_LOAD=1: beside device copies on a second stream
 from oracle import ape_oracle as orc
 from wear_mocap_ape_amd import _hip
 from wear_mocap_ape_amd.estimate import nn_models

@@ -6,6 +6,7 @@ import ctypes as C, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/arm-pose-estimation_amd")
 import torch
+import os as _os; sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _load; _load.start()      # APE_SOAK_LOAD=1: beside device copies on a second stream
 from oracle import ape_oracle as orc
 from wear_mocap_ape_amd import _hip
 from wear_mocap_ape_amd.estimate import nn_models
@@ -54,6 +55,7 @@ while time.time() - t0 < budget:
                 shadow[s].push(xx[s]); hist.append(np.vstack(shadow[s].rows).astype(np.float32))
             x = torch.from_numpy(np.repeat(np.stack(hist), k, axis=0)).cuda()
             y = torch.empty((S * k, O), dtype=torch.float32, device="cuda")
+            if _os.environ.get("APE_SOAK_SYNC_UPLOAD") == "1": torch.cuda.synchronize()      # (experiment: is the recomputation's input there?)
             drop = n_mc > 0 and cfg["L"] > 1
             # the shared-layer-0 routes draw the batch-tile kernel's masks (rows counted over the whole bank)
             if S * k >= 8192 or (name != "uarm" and S * k >= 2048 and n_mc >= 2): m.set_kernel("tile16")
@@ -62,6 +64,23 @@ while time.time() - t0 < budget:
             torch.cuda.synchronize(); m.set_kernel("auto")
             calls += 1
             y = y.cpu().numpy().astype(np.float64)
+            if hasattr(lib, "ape_debug_bank_targets") and n_mc > 0:      # (test-hooks library: the bank's own NN targets beside the recomputed ones)
+                lib.ape_debug_bank_targets.restype, lib.ape_debug_bank_targets.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+                yb = np.empty((S * k, O), dtype=np.float32)
+                if lib.ape_debug_bank_targets(bank._handle, yb.ctypes.data_as(C.c_void_p)) == 0:
+                    dd = np.abs(yb - y).max(axis=1)
+                    if dd.max() > 5e-6:
+                        print(f"  [targets] {name} S={S} n_mc={n_mc} frame {f}: bank targets vs recomputed rows differ in {int((dd > 5e-6).sum())} rows "
+                              f"(max {dd.max():.2e}), streams {sorted(set(int(r) // k for r in np.nonzero(dd > 5e-6)[0]))[:16]}", flush=True)
+                        # which side moves?  the recomputation once more, on both kernels, with the device drained in front
+                        for kern2 in ("tile16", "auto"):
+                            m.set_kernel(kern2); torch.cuda.synchronize()
+                            y2 = torch.empty((S * k, O), dtype=torch.float32, device="cuda")
+                            _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), S * k, T, _hip.FLAG_DROPOUT_PHILOX if drop else 0,
+                                                            None, 0.2 if drop else 0.0, seed + calls - 1, C.c_void_p(y2.data_ptr()), None), "fwd")
+                            torch.cuda.synchronize(); y2 = y2.cpu().numpy()
+                            print(f"            again on {kern2} [{m.last_kernel()}]: |again - first recomputation| {np.abs(y2 - y).max():.2e}, |again - bank| {np.abs(y2 - yb).max():.2e}", flush=True)
+                        m.set_kernel("auto")
             check = range(S) if S <= 64 else list(range(0, S, 50))
             for s in range(S):
                 samples[s] = y[s * k:(s + 1) * k]

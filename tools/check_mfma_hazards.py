@@ -13,6 +13,12 @@ free to COPY the destination registers (a phi move at a branch merge did) or, wh
 of that wait: the copy then holds what the registers held before, and a late-landing load clobbers the re-user's data.  The scan walks
 the code from every such load (following branches, up to the first `s_waitcnt vmcnt(0)` on each path) and reports any instruction that
 reads or writes a destination register.
+A fifth pattern, found in round 5 (lstm_upper32.hip, layer-0 form: beside a memory-bound neighbour one frame in ~2000 of a fresh bank had
+the integer 2 or 4 -- the slice epoch -- in word 0 of sixteen lanes of one wave's published slice): a vector-memory STORE of more than 64
+bits issued inside an asm statement, its data registers written by a VALU instruction fewer than 2 wait states later (there: the epoch's
+`v_add_u32 v2, 1, v51` right behind an untaken branch, v[2:5] being the store's data).  The store reads its data late (gfx940 and later: 2
+wait states; none if a buffer store's soffset is an SGPR -- LLVM's GCNHazardRecognizer, VMEM store-data hazard); hipcc pads the stores it
+emits itself, an asm statement is opaque to it.
     tools/check_mfma_hazards.py file.hip [extra hipcc flags]     exit code 1 when a hazard is found"""
 import re, subprocess, sys, tempfile
 
@@ -152,6 +158,43 @@ def scan_async_asm_loads(path, limit=6000):
                 j += 1; left -= 1
     return sorted(bad)
 
+def scan_asm_wide_stores(path, need=2):
+    """asm-issued stores of more than 64 bits (a buffer store only with a literal soffset): a VALU write of a data register within `need`
+    wait states behind it, on any path (an s_nop k counts k + 1, any other instruction 1)"""
+    ins, labels, in_asm = [], {}, False
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"): in_asm = True; continue
+        if t.startswith(";;#ASMEND"): in_asm = False; continue
+        c = t.split(";")[0].strip()
+        if c.endswith(":") and not t.startswith(";"):
+            labels[c[:-1]] = len(ins); continue
+        if not t or t.startswith((";", ".", "//")): continue
+        ins.append((n, c, in_asm))
+    bad = set()
+    for i, (n, t, a) in enumerate(ins):
+        m = re.match(r"(buffer|global|flat|scratch)_store_dwordx[34]\b", t)
+        if not a or not m: continue
+        ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+        if m.group(1) == "buffer" and len(ops) > 3 and re.match(r"s\d+|s\[|m0|ttmp", ops[3].split()[0]): continue      # soffset in a register: no hazard
+        data = regs(ops[0])
+        stack, seen = [(i + 1, 0)], set()
+        while stack:
+            j, states = stack.pop()
+            while states < need and j < len(ins) and (j, states) not in seen:
+                seen.add((j, states))
+                qn, qt, _ = ins[j]
+                if qt.startswith(("s_endpgm", "s_setpc")): break
+                if qt.startswith("s_branch"):
+                    j = labels.get(qt.split()[1], len(ins)); states += 1; continue
+                if qt.startswith("s_cbranch"):
+                    stack.append((labels.get(qt.split()[1], len(ins)), states + 1))
+                elif qt.startswith("v_") and " " in qt and regs(qt.split(None, 1)[1].split(",")[0].strip()) & data:
+                    bad.add((n, t, qn, qt, states))
+                states += (int(qt.split()[1]) + 1) if qt.startswith("s_nop") else 1
+                j += 1
+    return sorted(bad)
+
 if __name__ == "__main__":
     src = sys.argv[1]
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
@@ -162,10 +205,13 @@ if __name__ == "__main__":
         early = scan_early_reads(f.name) if asm_mfma else []
         sg = scan_sgpr_into_asm_vmem(f.name)
         al = scan_async_asm_loads(f.name)
+        ws = scan_asm_wide_stores(f.name)
     for pn, pt, n, t in bad: print(f"{src}: line {pn}: {pt}   ->   line {n}: {t}")
     for n, t, qn, qt in early: print(f"{src}: line {n}: {t}   read early by   line {qn}: {qt}")
     for pn, pt, n, t, st in sg: print(f"{src}: line {pn}: {pt}   ->   asm line {n}: {t}   ({st} wait states, 5 needed)")
     for n, t, qn, qt in al: print(f"{src}: asm load line {n}: {t}   destination touched in front of its wait by   line {qn}: {qt}")
+    for n, t, qn, qt, st in ws: print(f"{src}: asm store line {n}: {t}   data register written {st} wait state(s) later (2 needed) by   line {qn}: {qt}")
     print(f"{src}: {len(bad)} VALU-write -> MFMA SrcA/SrcB adjacencies, {len(early)} early reads of an MFMA result, "
-          f"{len(sg)} VALU-written SGPRs read early by an asm vector-memory instruction, {len(al)} touches of an in-flight asm load's destination")
-    sys.exit(1 if bad or early or sg or al else 0)
+          f"{len(sg)} VALU-written SGPRs read early by an asm vector-memory instruction, {len(al)} touches of an in-flight asm load's destination, "
+          f"{len(ws)} VALU writes of a wide asm store's data inside its 2 wait states")
+    sys.exit(1 if bad or early or sg or al or ws else 0)
