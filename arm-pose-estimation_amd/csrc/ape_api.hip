@@ -346,6 +346,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         for (int l = 0; l < L && e == hipSuccess && !imupose; ++l)
             e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
+        if (e == hipSuccess && H == 128 && L == 3) e = ape_prepare_lstm_cluster(H, 1, m->KX);       // layer 0 alone: launch A of the 3 x 128 bank
         if (e == hipSuccess && !imupose) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
         if (e == hipSuccess && !imupose) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
         // latency kernel with H/8 members (every CU of a 32-CU XCD at H = 256): only where an XCD has that many CUs
@@ -1623,6 +1624,31 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
             u.T = b->T; u.O = O; u.n_tiles = (b->S + 31) / 32;
             u.flags = diag_wt;
             e = ape_launch_lstm_lower32(u, xq, f16v2_capacity(m->n_cus), (hipStream_t)stream);
+            if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
+        } else if (b->up128 && coop && m->cluster_ok && ape_cluster_supported(H, 1, m->KX) && b->S >= 128 &&
+                   (b->S + 31) / 32 <= cluster_capacity(m->n_cus, H)) {
+            // launch A of the 3 x 128 bank on the first-generation cluster kernel's one-layer form (lstm_cluster.hip <128, 1, 64, 2>): 32
+            // streams per eight-member cluster, every step's output -> [S,T,H] as the batch-tile launch below writes it.  (Round 5:
+            // 1024 streams are 64 tiles of the batch-tile kernel -- a quarter of the chip for 54 us; here every CU holds 16 units of a
+            // cluster.)  Fewer than 128 streams stay below: the rendezvous costs more than the idle CUs.
+            ClusterParams c{};
+            c.x = b->xring; c.x_row_stride = (size_t)b->n_mc * b->T * I;
+            c.y = nullptr; c.hseq = m->hseq_ws;
+            c.wcl[0] = m->wcl[0]; c.bias[0] = m->bias[0];
+            c.w_out = m->w_out; c.b_out = m->b_out;
+            c.xx_m = m->stats; c.xx_s = m->stats + I; c.xx_r = m->stats + 2 * I + 2 * O;
+            c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+            c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+            c.ticket = c.status - 4; c.done = c.ticket + 1;
+            c.B = b->S; c.T = b->T; c.I = I; c.O = O; c.x_ring = x_ring;
+            c.flags = (flags & APE_FLAG_NORMALIZE_INPUT) | diag_wt;
+            c.dbg_wg = m->dbg_wg; c.xcc_slots = m->xcc_slots;
+            int clusters = (b->S + 31) / 32;
+            if (m->gen1_classes && !(diag_wt & APE_FLAG_NO_XCD_CLASSES)) {
+                const int c8 = (clusters + 7) / 8 * 8;
+                if (c8 <= cluster_capacity(m->n_cus, H)) { clusters = c8; c.flags |= APE_FLAG_XCD_CLASSES; }
+            }
+            e = ape_launch_lstm_cluster(H, 1, m->KX, 2, false, clusters, c, (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
         } else {
         // launch A: layer 0 alone over the S windows (first copy of every stream's ring), all steps -> [S,T,H]

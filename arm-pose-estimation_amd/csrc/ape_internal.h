@@ -81,6 +81,8 @@ struct ClusterParams {
     float dropout_p;
     unsigned long long seed;
     float* hseq;                        // [B,T,H] every step's top-layer output (all-steps mode), or nullptr
+    size_t x_row_stride;                // first-generation f32 kernel: floats between consecutive rows of x (0: T * I; a Monte-Carlo bank's ring
+                                        // keeps n_mc window slots per stream and layer 0 reads the first of each)
     int row_base;                       // first-generation kernel, Philox dropout: global index of this launch's row 0 in the caller's batch
                                         // (the counters name GLOBAL rows: the samples of a call do not depend on how it is split over launches)
     unsigned long long* dbg_wg;         // diagnostic builds only: 8 words per workgroup (ticket, XCC, clocks)

@@ -280,11 +280,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     constexpr int RPE = 256 / KX;                 // rows between a thread's consecutive elements
     const int xk = tid % KX, xrow = tid / KX;
     const int rows_here = bcast_x ? MR : max(0, min(MR, p.B - row0));      // (whole clusters past the batch: class-mode grids are rounded up)
+    // (xrs: floats between rows -- T * I, or the caller's stride when the rows are the first window slots of a Monte-Carlo bank's ring;
+    //  a row's T * I floats are all that is ever addressed, the descriptor's length only has to be no shorter)
+    const unsigned xrs = p.x_row_stride != 0 ? (unsigned)p.x_row_stride : (unsigned)(T * I);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x) + (bcast_x ? (size_t)0 : (size_t)row0 * T * I), 0,
-        (int)((size_t)(bcast_x ? 1 : rows_here) * T * I * sizeof(float)), 0x00020000);
-    const unsigned x_off0 = (xk < I) ? (unsigned)(((bcast_x ? 0 : xrow) * T * I + xk) * sizeof(float)) : 0x80000000u;
-    const unsigned x_estride = bcast_x ? 0u : (unsigned)(RPE * T * I * sizeof(float));
+        const_cast<float*>(p.x) + (bcast_x ? (size_t)0 : (size_t)row0 * xrs), 0,
+        (int)(bcast_x ? (size_t)T * I * sizeof(float) : ((size_t)(rows_here > 0 ? rows_here - 1 : 0) * xrs + (rows_here > 0 ? (size_t)T * I : 0)) * sizeof(float)), 0x00020000);
+    const unsigned x_off0 = (xk < I) ? (unsigned)(((bcast_x ? 0u : (unsigned)xrow * xrs) + (unsigned)xk) * sizeof(float)) : 0x80000000u;
+    const unsigned x_estride = bcast_x ? 0u : (unsigned)(RPE * xrs * sizeof(float));
     float xr[NE];
     auto fetch_x = [&](int t) {                    // t < T (the step offset is not range-checked)
         const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;      // windows kept as rings
@@ -468,13 +471,15 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                         if (q * CPB + j < NGH) commit_piece(l, q * CPB + j, gv);
                 }
                 if (q == QF) raise_pending();
-                if (q == QP) { peeked = peek_flags(ln, (unsigned)tn); peek_pending = true; }
-                if (q == Q0) {
+                // (L == 1, the layer-0 form of a Monte-Carlo bank's launch A: the slices the next section reads are the ones THIS section
+                //  publishes at its end -- nothing to look at or gather under its MFMAs; the blocking exchange sits behind the publish)
+                if (L > 1 && q == QP) { peeked = peek_flags(ln, (unsigned)tn); peek_pending = true; }
+                if (L > 1 && q == Q0) {
                     if (peek_pending) { peek_wait(peeked); peek_pending = false; }
                     ready = pre && (diag_noex || __all((int)(peeked >= (unsigned)tn)) != 0);
                     goff = g_thread_off + (ready ? 0u : 0x80000000u);
                 }
-                if (q >= Q0 && q < Q0 + GBLK) {
+                if (L > 1 && q >= Q0 && q < Q0 + GBLK) {
 #pragma unroll
                     for (int j = 0; j < PPB; ++j)
                         if ((q - Q0) * PPB + j < NGH) issue_piece(ln, (tn - 1) & 1, (q - Q0) * PPB + j, goff, gv);
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
             if (pre && !ready) st_acc[l == 0 ? 0 : 11] += 1;    // diagnostic: how often the blocking path runs
 #endif
             if (peek_pending) { peek_wait(peeked); peek_pending = false; }     // (a short section: looked, never judged)
-            if (pre && !ready) {                         // first step of a layer, or a peer was late: blocking path
+            if (L > 1 && pre && !ready) {                // first step of a layer, or a peer was late: blocking path
                 wait_flags(ln, (unsigned)tn, peeked);
                 issue_gather(ln, (tn - 1) & 1, gv);
             }
@@ -596,7 +601,23 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 pend_epoch = (unsigned)(t + 1);
             }
             STAMP_END(6);                                // 6: publish store issue
-            if (last) {
+            if (L == 1) {
+                // one layer: publish -> own flag -> the peers' flags -> gather; a barrier (every wave is through its spans: hbuf[0] and
+                // xin have no reader left), commit + the next step's x, the end barrier
+                if (pre) {
+                    raise_pending();
+                    wait_flags(0, (unsigned)tn, 0u);
+                    issue_gather(0, (tn - 1) & 1, gv);
+                }
+                bar();
+                if (pre) commit_gather(0, gv);
+                if (ph + 1 < T) {
+                    stage_x();
+                    if (ph + 2 < T) fetch_x(ph + 2);
+                }
+                bar();
+                if (ctl[0] != 0) return;
+            } else if (last) {
                 if (pre && !new_done) commit_gather(ln, gv);      // blocking path / first step: every wave is past
                 STAMP_END(7);                                        // the input span (mid or odd-path barrier)
                 bar();                                   // end of phase: hbuf[0] and x of the next phase visible
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                 if (odd_path) bar();                     // x staged on the odd path must be visible to the next phase
             }
             if (pre) prefetched = true;
-            if (l == 0 && ph == 0 && T > 1) {            // x_1 (section 1, which stages x_{ph+1}, idles in phase 0)
+            if (L > 1 && l == 0 && ph == 0 && T > 1) {   // x_1 (section 1, which stages x_{ph+1}, idles in phase 0)
                 bar();
                 stage_x();
                 if (T > 2) fetch_x(2);
@@ -633,7 +654,11 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     raise_pending();
     // ---- head: each member finishes RPM = MR/GH (>= 1) of the cluster's windows and gathers only THOSE rows of
     //      h^{L-1}_{T-1} (GH x RPM x 4 sixteen-byte pieces = at most one per thread, not the whole 64 KB slice set)
-    {
+    //      (all-steps callers -- y == nullptr: the head runs over the sequence afterwards, or not at all -- skip it: nobody waits for
+    //       the last step's flags then, and the wait below keeps this wave's flag store out of the last workgroup's re-zeroing)
+    if (p.y == nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         constexpr int RPM = (MR + GH - 1) / GH;          // rows per member
         static_assert(GH * RPM * 4 <= 256, "one head piece per thread");
         // this thread's share of the head weights first: the loads fly while the last flags and slices arrive
@@ -736,7 +761,7 @@ hipError_t prepare() {
 // 128 + 128 weight registers per lane = the whole accumulator file, one or two row tiles, no dropout -- its Monte-Carlo
 // mode is the plain forward, nn_models.py:246-251)
 bool ape_cluster_supported(int H, int L, int KX) {
-    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && L == 3 && KX == 64);
+    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && (L == 3 || L == 1) && KX == 64);
 }
 
 #define APE_CL_DISPATCH(FN, ...)                                                     \
@@ -751,6 +776,8 @@ bool ape_cluster_supported(int H, int L, int KX) {
         if (nmt == 1) return dropout ? FN<128, 3, 64, 1, true>(__VA_ARGS__) : FN<128, 3, 64, 1, false>(__VA_ARGS__); \
         if (nmt == 2) return dropout ? FN<128, 3, 64, 2, true>(__VA_ARGS__) : FN<128, 3, 64, 2, false>(__VA_ARGS__); \
         if (nmt == 4 && !dropout) return FN<128, 3, 64, 4, false>(__VA_ARGS__);      \
+    } else if (H == 128 && L == 1 && KX == 64) {  /* layer 0 of the 3 x 128 model on its own: launch A of its Monte-Carlo bank */ \
+        if (nmt == 2 && !dropout) return FN<128, 1, 64, 2, false>(__VA_ARGS__);      \
     }                                                                                \
     return hipErrorInvalidValue;
 
@@ -759,6 +786,7 @@ hipError_t ape_prepare_lstm_cluster(int H, int L, int KX) {
         for (bool dropout : {false, true}) {
             if (dropout && nmt == 4) continue;
             if (KX == 256 && (dropout || nmt == 4)) continue;       // not built (LDS: 64 rows x 264 columns of x alone)
+            if (L == 1 && (dropout || nmt != 2)) continue;          // the layer-0 form: one instantiation
             hipError_t e = [&]() -> hipError_t { APE_CL_DISPATCH(prepare) }();
             if (e != hipSuccess) return e;
         }
