@@ -55,6 +55,9 @@ bank_uarm)
   python3 tools/summarize_prof.py r05_bank_uarm $P/trace $P/fetch $P/write "ape_lstm_upper128" 65536 51200 --model uarm --T 6 --pmc-dir $P/mfma --pmc-dir $P/wave \
     --source csrc/lstm_upper128.hip --lds 146448 --flop-per-launch 1.6121856e11 --peak-tflops 157.3 --skip-first 6 --min-us 600 \
     --note "Command (MI355X, one GPU): \`rocprofv3 --kernel-trace --stats -- python3 tests/tools/bank_trace.py 1024 50 30 auto check uarm\` = a stream bank of 1024 streams x 50 Monte-Carlo dropout samples on the upper-arm model (38 -> 3 x 128 -> 12; the defaults of watch_phone_uarm_nn.py:14-20), T = 6, 6 + 30 frames; one frame = feature builder, layer 0 once per stream, \`ape_mc_expand128_kernel\` (masked layer-0 output in fragment order + layer 1's keep bits), THIS kernel over the 51 200 sample rows (1600 tiles of 32 rows on 64 clusters of 4 workgroups, layers 1 and 2), head reduce, post kernel.  Algorithmic FLOP of the launch = 51 200 rows x (6 steps x 2 layers x 2 x 4H x (H + H) + 2 O H) = 161.2 GFLOP (the reference runs every step through both spans of both layers, nn_models.py:191-207); executed 11/12 of it (h_{-1} = 0: step 0 of a layer is its input span alone).  Recipe \`tools/prof_r05.sh bank_uarm\`."
+  python3 tools/summarize_prof.py r05_bank_uarm_l0 $P/trace $P/fetch $P/write "ape_lstm_cluster<128, 1, 64, 2, false>" 65536 1024 --model uarm --T 6 --pmc-dir $P/mfma --pmc-dir $P/wave \
+    --source csrc/lstm_cluster.hip --lds 30224 --flop-per-launch 1.044381696e9 --peak-tflops 157.3 --skip-first 6 \
+    --note "Launch A of the same frames (see r05_bank_uarm.md): layer 0 of the 3 x 128 model once per stream on the one-layer form of the first-generation cluster kernel, 1024 streams = 32 clusters of 8 workgroups (32 streams each), T = 6, every exchange exposed (one layer has nothing to overlap it with); algorithmic FLOP = 1024 x 6 x 2 x 4H x (I + H) with I = 38, H = 128.  Until round 5 this launch ran on \`ape_lstm_tile16<128,1,4>\` (64 workgroups, 54.5 us)."
   kernels > gpurun_out/prof_bank_uarm_kernels.txt
   ;;
 bank_watch)
