@@ -330,6 +330,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         // (second-generation kernel of the 3 x 128 model: one flag per (32-row cluster, layer, member, one of eight waves))
         if (ape_cluster16_supported(H, L, m->KX) && (size_t)f16v2_capacity(m->n_cus) * L * 64 > flag_words)
             flag_words = (size_t)f16v2_capacity(m->n_cus) * L * 64;
+        if (ape_upper32_supported(H, L, O) && (size_t)f16v2_capacity(m->n_cus) * 2 * 32 > flag_words)
+            flag_words = (size_t)f16v2_capacity(m->n_cus) * 2 * 32;      // (lstm_upper32.hip: one flag per (cluster, set, member wave))
         if (ape_upper128_supported(H, L, O) && !imupose) {
             const int c128 = (m->n_cus / 4) / 8 * 8;
             if (ape_upper128_flag_words(c128) > flag_words) flag_words = ape_upper128_flag_words(c128);
@@ -375,6 +377,14 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
                 m->up32_ok = true;
             }
         }
+        // ImuPoseLSTM (2 x 256 behind a 256-wide input layer): each layer is exactly one register image of lstm_upper32.hip's clusters
+        // (K = 256 + 256); from 1024 windows on the LSTM runs there, one layer per launch (lstm_forward_impl)
+        if (imupose && H == 256 && L == 2 && m->KX == 256 && ape_upper32_supported(H, L, O) && f16v2_capacity(m->n_cus) >= 8) {
+            for (int l = 0; l < L && e == hipSuccess; ++l)
+                e = plan((void**)&m->wcl32[l], (size_t)4 * H * (H + H) * sizeof(float));
+            if (e == hipSuccess) e = ape_prepare_lstm_upper32();
+            m->split32_ok = true;
+        }
         // the Monte-Carlo bank's weight-stationary route for the 3 x 128 model (lstm_upper128.hip): four-member clusters, whole classes of 8
         if (ape_upper128_supported(H, L, O) && (m->n_cus / 4) / 8 * 8 >= 8 && !imupose) {
             for (int l = 1; l < L && e == hipSuccess; ++l) e = plan((void**)&m->wup128[l], (size_t)4 * H * 2 * H * sizeof(float));
@@ -406,6 +416,9 @@ int ape_model_destroy(ape_model_t* m) {
     if (m->slab) (void)hipFree(m->slab);             // weights, packs, statistics, exchange buffers, flags: one allocation
     if (m->y_ws) (void)hipFree(m->y_ws);             // workspaces grow on demand and are their own allocations
     if (m->z_ws) (void)hipFree(m->z_ws);
+    if (m->zfrag_ws) (void)hipFree(m->zfrag_ws);
+    if (m->hfrag_ws) (void)hipFree(m->hfrag_ws);
+    if (m->ypart_ws) (void)hipFree(m->ypart_ws);
     if (m->hseq_ws) (void)hipFree(m->hseq_ws);
     delete m;
     return APE_OK;
@@ -613,7 +626,7 @@ int ape_model_load_weights(ape_model_t* m, const float* blob, size_t n_floats) {
                         }
             if (m->wcl16[l]) HIP_TRY(hipMemcpy(m->wcl16[l], ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         }
-        if (m->c32_ok) {
+        if (m->wcl32[l] != nullptr) {
             // second-generation f32 cluster kernel (v_mfma_f32_32x32x2_f32, weights = A operand): 8 members x 4 waves, a wave owns
             // 8 units = 32 columns ordered gate * 8 + unit.  [member][wave][i / 4][lane][i % 4] with register i = 4 kb + j of
             // lane (column m = lane & 31, half hh = lane >> 5) = Wcat[gate(m) * H + member*32 + wave*8 + (m & 7)][8 kb + 4 hh + j]
@@ -837,6 +850,53 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         if (e != hipSuccess) return fail(APE_ERR_HIP, "input-layer kernel launch failed: %s", hipGetErrorString(e));
         lstm_x = m->z_ws;
         flags &= ~(uint32_t)APE_FLAG_NORMALIZE_INPUT;        // done in front of the input layer
+        // From 1024 windows on (32 tiles of 32: every persistent cluster of lstm_upper32.hip has one) the LSTM runs one layer per launch
+        // on those clusters: layer 0 in the SEQ form with the wide input, layer 1 reading its sequence as is -- K = 512 per layer is the
+        // clusters' whole register image; the first-generation kernel's 16-member clusters re-read nothing either but spend 16 CUs on
+        // 32 rows.  Chunks of 4096 windows bound the workspaces.
+        if (m->split32_ok && B >= 1024 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32 &&
+            !m->replaying && !have_hs && !(flags & (APE_FLAG_ALL_STEPS | APE_FLAG_BROADCAST_X)) && x_ring == 0 && T >= 1 &&
+            (size_t)128 * T * 32768 < ((size_t)1 << 32)) {
+            const int chunk = 4096;
+            const int tiles_max = ((B < chunk ? B : chunk) + 31) / 32;
+            if ((size_t)tiles_max > m->split_tiles_cap || (size_t)T > m->split_steps_cap) {
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing((hipStream_t)stream, &st);
+                if (st != hipStreamCaptureStatusNone)
+                    return fail(APE_ERR_CAPACITY, "lstm_forward: the layer workspaces (%d tiles x %d steps) cannot grow during stream capture", tiles_max, T);
+                HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+                if (m->zfrag_ws) { HIP_TRY(hipFree(m->zfrag_ws)); m->zfrag_ws = nullptr; }
+                if (m->hfrag_ws) { HIP_TRY(hipFree(m->hfrag_ws)); m->hfrag_ws = nullptr; }
+                if (m->ypart_ws) { HIP_TRY(hipFree(m->ypart_ws)); m->ypart_ws = nullptr; }
+                m->split_tiles_cap = m->split_steps_cap = 0;
+                const size_t tc = (size_t)tiles_max > m->split_tiles_cap ? (size_t)tiles_max : m->split_tiles_cap;
+                const size_t sc = (size_t)T;
+                HIP_TRY(hipMalloc((void**)&m->zfrag_ws, tc * sc * 32768));
+                HIP_TRY(hipMalloc((void**)&m->hfrag_ws, tc * sc * 32768));
+                HIP_TRY(hipMalloc((void**)&m->ypart_ws, ape_upper32_ypart_bytes((int)tc * 32)));
+                m->split_tiles_cap = tc; m->split_steps_cap = sc;
+            }
+            for (int b0 = 0; b0 < B; b0 += chunk) {
+                const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+                const int tiles = (nb + 31) / 32;
+                UpperParams u0{};
+                u0.xfrag = m->zfrag_ws; u0.xfrag_bytes = (size_t)tiles * T * 32768;
+                u0.w = m->wcl32[0]; u0.bias = m->bias[0]; u0.w_out = m->w_out;
+                u0.hx = m->hx; u0.hx_bytes = m->hx_bytes;
+                u0.xflags = m->xflags; u0.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u0.done = u0.status - 3;
+                u0.xcc_slots = m->xcc_slots; u0.dbg_wg = m->dbg_wg;
+                u0.hseq = m->hfrag_ws; u0.hseq_bytes = (size_t)tiles * T * 32768;
+                u0.T = T; u0.O = m->dims.output_size; u0.n_tiles = tiles; u0.flags = 0;
+                UpperParams u1 = u0;
+                u1.xfrag = m->hfrag_ws; u1.hseq = nullptr; u1.hseq_bytes = 0;
+                u1.w = m->wcl32[1]; u1.bias = m->bias[1]; u1.ypart = m->ypart_ws;
+                m->last_kernel = "ape_lstm_upper32";
+                hipError_t e2 = ape_launch_lstm_split32(m->z_ws + (size_t)b0 * T * H, nb, u0, u1, m->b_out,
+                                                        y_dev + (size_t)b0 * m->dims.output_size, f16v2_capacity(m->n_cus), (hipStream_t)stream);
+                if (e2 != hipSuccess) return fail(APE_ERR_HIP, "layer-split lstm launch failed: %s", hipGetErrorString(e2));
+            }
+            return APE_OK;
+        }
     }
     if (ape_lstm_tile16_smem_bytes(H, L, m->KX, m->dims.output_size, drop) > 160 * 1024)
         return fail(APE_ERR_UNSUPPORTED, "lstm_forward: H=%d L=%d with dropout exceeds the 160 KiB LDS of a CU", H, L);
@@ -2034,6 +2094,9 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
         return (m->f16_v2 && ape_cluster_f16v2_supported(m->dims.hidden_size, m->dims.num_layers, m->KX) &&
                 f16v2_capacity(m->n_cus) > 0 && B > 256) ? "ape_lstm_cluster_f16v2" : "ape_lstm_cluster_f16";
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
+    // ImuPoseLSTM from 1024 windows on: one layer per launch on lstm_upper32.hip's persistent clusters (lstm_forward_impl)
+    if (m->split32_ok && B >= 1024 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32)
+        return "ape_lstm_upper32<32, true> + <32, false>";
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {
         if (2LL * tile16_wave_rows(m->n_cus) * auto_tile16_waves(&m->dims, m->n_cus, B, T, false, gen2_of(m), m->wide_cluster) > B) return m->kernel_name.c_str();

@@ -324,6 +324,10 @@ size_t ape_lower32_xfrag_bytes(int streams, int T);
 size_t ape_lower32_hseq_bytes(int streams, int T);
 hipError_t ape_launch_lstm_lower32(const UpperParams& p, const XFragParams& xq, int max_clusters, hipStream_t stream);
 hipError_t ape_prepare_lstm_upper32();
+// ImuPoseLSTM's 2 x 256 LSTM behind its input layer, one layer per launch: z [B * T][256] row-major -> p0.xfrag (fragment order) ->
+// layer 0 (every step to p0.hseq) -> layer 1 reading p1.xfrag == p0.hseq -> head partials -> y [B,O]
+hipError_t ape_launch_lstm_split32(const float* z, int B, const UpperParams& p0, const UpperParams& p1, const float* b_out, float* y,
+                                   int max_clusters, hipStream_t stream);
 hipError_t ape_launch_lstm_upper32(const UpperParams& p, const ExpandParams& q, const float* b_out, float* y, int max_clusters,
                                    hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 bool ape_mc_small_supported(int H, int L, int KX);

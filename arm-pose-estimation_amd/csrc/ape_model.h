@@ -76,6 +76,11 @@ struct ape_model {
     bool upper_ok = false;          // layers 1.. can run on their own over a shared layer-0 sequence (stream bank, MC mode)
     bool up32_ok = false;           // ... and on the weight-stationary upper-layer kernel (lstm_upper32.hip: 2 x 256 models)
     bool up128_ok = false;          // ... or on lstm_upper128.hip (the 3 x 128 model: layers 1 and 2 in four-member clusters)
+    bool split32_ok = false;        // ImuPoseLSTM: the 2 x 256 LSTM behind the input layer, one layer per launch on lstm_upper32.hip's persistent clusters
+    float* zfrag_ws = nullptr;      // ... its workspaces: the input layer's activations in fragment order [tiles][T][32 KB],
+    float* hfrag_ws = nullptr;      //     layer 0's output sequence (same shape, layer 1's input),
+    float* ypart_ws = nullptr;      //     head partial sums [tiles * 32][8][16]
+    size_t split_tiles_cap = 0, split_steps_cap = 0;      // tiles x steps the first two hold
     float* wup128[APE_MAX_LAYERS] = {nullptr, nullptr, nullptr};   // its register image of layers 1, 2
     float* hx = nullptr;           // exchange slices
     size_t hx_bytes = 0;

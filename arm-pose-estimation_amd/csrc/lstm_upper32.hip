@@ -558,6 +558,32 @@ __global__ __launch_bounds__(256) void ape_x_frag_kernel(const XFragParams q) {
     }
 }
 
+// ---- a 256-wide input in fragment order: [tile][step][k-block 32][window 32][8] from the row-major [B * T][256] activations of
+// ImuPoseLSTM's input layer (nn_models.py:242; row b * T + t).  One workgroup per (tile of 32 windows, step): the 32 rows are read
+// whole (1 KiB each), turned through LDS, and leave as 1-KiB k-blocks; windows past the batch are zero.
+constexpr int ZS = 8 * 32 + 8;           // LDS stride of a k-block (floats), as XS below
+
+__global__ __launch_bounds__(256) void ape_z_frag_kernel(const float* __restrict__ z, float* __restrict__ zfrag, int B, int T) {
+    __shared__ __attribute__((aligned(16))) float sl[32 * ZS];
+    const unsigned tile = blockIdx.x / (unsigned)T, t = blockIdx.x - tile * (unsigned)T;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = threadIdx.x + 256 * e;                    // float4 index: row idx / 64, columns 4 (idx % 64) ..
+        const int row = idx >> 6, k = (idx & 63) * 4;
+        const long long b = (long long)tile * 32 + row;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (b < B) v = *reinterpret_cast<const f32x4*>(z + ((size_t)b * T + t) * 256 + k);
+        *reinterpret_cast<f32x4*>(sl + (k >> 3) * ZS + row * 8 + (k & 7)) = v;
+    }
+    __syncthreads();
+    f32x4* dst = reinterpret_cast<f32x4*>(zfrag + ((size_t)tile * T + t) * 8192);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = threadIdx.x + 256 * e;                    // float4 index: k-block idx / 64, inside it idx % 64
+        dst[idx] = *reinterpret_cast<const f32x4*>(sl + (idx >> 6) * ZS + (idx & 63) * 4);
+    }
+}
+
 // ---- the masked input of launch B, in the fragment order the kernel above copies ------------------------------------------------
 // Sample row r (row_base + its index in this chunk) is sample r % n_mc of stream r / n_mc; its input at step t is that stream's
 // layer-0 output h0[stream][t][unit] under the inter-layer dropout mask (nn.LSTM dropout, nn_models.py:169-174), drawn with the
@@ -634,7 +660,31 @@ hipError_t ape_prepare_lstm_upper32() {
     static_assert(smem_upper() <= APE_LDS_BYTES, "LDS layout exceeds a CU");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_upper32<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
+}
+
+// A two-layer 256-unit LSTM with a 256-wide input (ImuPoseLSTM behind its input layer), one layer per launch on the persistent clusters:
+// (1) the row-major activations -> fragment order; (2) layer 0 in the SEQ form with the wide input (<32, true>): every step's slices go to
+// p0.hseq in exactly the order (3) layer 1 (<32, false>) copies its input tiles from -- no builder in between (eval mode: no mask); head
+// partials + reduce as in the bank.  p1.xfrag must be p0.hseq.
+hipError_t ape_launch_lstm_split32(const float* z, int B, const UpperParams& p0, const UpperParams& p1, const float* b_out, float* y,
+                                   int max_clusters, hipStream_t stream) {
+    if (p0.n_tiles < 1 || p0.n_tiles != p1.n_tiles || max_clusters < 8 || p1.O > PO || p1.xfrag != p0.hseq) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ape_z_frag_kernel, dim3(p0.n_tiles * p0.T), dim3(256), 0, stream, z, const_cast<float*>(p0.xfrag), B, p0.T);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int clusters = (p0.n_tiles + 7) / 8 * 8;
+    if (clusters > max_clusters) clusters = max_clusters;
+    hipLaunchKernelGGL((ape_lstm_upper32<32, true>), dim3(clusters * GH), dim3(256), smem_upper(), stream, p0);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ape_lstm_upper32<32, false>), dim3(clusters * GH), dim3(256), smem_upper(), stream, p1);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ape_head_reduce_kernel, dim3((B * PO + 255) / 256), dim3(256), 0, stream, p1.ypart, b_out, y, B, p1.O);
+    return hipGetLastError();
 }
 
 // layer 0 of the S streams of a Monte-Carlo bank, every step's output in fragment order (p.hseq): the input tiles first
