@@ -886,7 +886,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 u0.xflags = m->xflags; u0.status = m->xflags + m->xflag_bytes / sizeof(unsigned); u0.done = u0.status - 3;
                 u0.xcc_slots = m->xcc_slots; u0.dbg_wg = m->dbg_wg;
                 u0.hseq = m->hfrag_ws; u0.hseq_bytes = (size_t)tiles * T * 32768;
-                u0.T = T; u0.O = m->dims.output_size; u0.n_tiles = tiles; u0.flags = 0;
+                u0.T = T; u0.O = m->dims.output_size; u0.n_tiles = tiles; u0.flags = flags & APE_FLAG_ALT_FORM;      // (selector: one-tile clusters on the blocking form, for A/B)
                 UpperParams u1 = u0;
                 u1.xfrag = m->hfrag_ws; u1.hseq = nullptr; u1.hseq_bytes = 0;
                 u1.w = m->wcl32[1]; u1.bias = m->bias[1]; u1.ypart = m->ypart_ws;

@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     //  section out of the loop, runs out of scalar registers and parks them in VGPR lanes -- a v_readlane in front of every copy)
     auto opaque = [](unsigned v) -> unsigned { asm volatile("" : "+s"(v)); return v; };
     const unsigned wave_kib = (unsigned)(wave * 1024);
-    auto issue_h_piece = [&](int s, unsigned epoch, int tile, int t, int k) {
-        const unsigned dst = opaque(hb_lds + wave_kib) + (unsigned)s * SET_BYTES + (unsigned)(k * 4096);
+    auto issue_h_piece = [&](int buf, int s, unsigned epoch, int tile, int t, int k) {      // -> hb[buf]; `s` names the set's exchange slots
+        const unsigned dst = opaque(hb_lds + wave_kib) + (unsigned)buf * SET_BYTES + (unsigned)(k * 4096);
         if constexpr (SEQ) {
             dma_1k(dst, dma_voff, hx_desc, (unsigned)(((size_t)tile * T + (t - 1)) * SET_BYTES) + (unsigned)(wave * 1024 + k * 4096));
         } else {
@@ -322,17 +322,37 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     //   [head partial store, last step only]  publish store (1; a store to nowhere on a last step)
     // so at the top of a section everything but the youngest entry is waited for (`vmcnt(1)`), and a few k-blocks in the
     // store itself has drained and its flag goes up.
-    auto section = [&](auto set_tag, auto first_tag) -> bool {
+    // SOLO (round 5; the wide-input forms only): a cluster that owns ONE tile has no other set to hide its exchange behind -- every step paid
+    // store -> acknowledge -> flag -> look -> gather in the open (2.6 us of 9.4 per step: ImuPoseLSTM at 1024 windows, one tile per cluster
+    // and layer).  With a 32-block input span in front of the recurrent one the section hides it itself, as lstm_cluster32.hip's layer 1
+    // does (MODE 3): the flag owed goes up at block QF, the look at the OWN set's flags and the gather of h_{t-1} ride
+    // under the input span (which does not read them), one barrier between the spans; the next step's input tile is copied under the
+    // same span.  LDS buffers alternate by step parity (the idle set's are free): what a section copies into was last read one section
+    // earlier, behind this section's top barrier -- no barrier at the end.
+    auto section = [&](auto set_tag, auto first_tag, auto solo_tag) -> bool {
         constexpr int s = decltype(set_tag)::value, o = s ^ 1;
         constexpr bool first = decltype(first_tag)::value;          // step 0 of a tile: no recurrent span (h_{-1} = 0)
+        constexpr bool solo = decltype(solo_tag)::value;
+        static_assert(!solo || (KXB >= 28 && s == 0), "the solo form needs the long input span");
         const int t = step_of[s], tile = tile_of[s];
         const bool last = t == T - 1;
+        const int bx = solo ? (t & 1) : s, bh = bx;                // LDS buffers of this section's input tile / gathered slices
 #ifdef APE_CLUSTER_STAMPS
         dg_sections += 1;
         dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- S0 ------------------------------------------------------------------------------------------------------------------
         if (ab_nobar) {
+        } else if (solo) {
+            if (prex[s]) {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the input tile copied under the section in front; only its publish store is younger
+            } else {                                               // the tile's first section
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_pending();
+#pragma unroll
+                for (int k = 0; k < NXD; ++k) issue_x_piece(bx, tile, t, k);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else if ((prex[s] || ab_nox) && (first || preh[s] || ab_noex)) {
             asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // the prefetched copies; only the publish store is younger
         } else {
@@ -348,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             if (!first && !ab_noex) {
                 wait_flags(s, pub[s]);
 #pragma unroll
-                for (int k = 0; k < NDMA; ++k) issue_h_piece(s, pub[s], tile, t, k);
+                for (int k = 0; k < NDMA; ++k) issue_h_piece(s, s, pub[s], tile, t, k);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -361,9 +381,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         const int abort_word = ctl[0];
         // the other set's next section: (tile_of[o], step_of[o]); it needs its input tile, and from step 1 on the slices it
         // published last (epoch pub[o])
-        const bool o_act = tile_of[o] >= 0 && !ab_nox;
-        const bool o_h = tile_of[o] >= 0 && step_of[o] >= 1 && !ab_noex;
-        unsigned peek = pub[o];
+        const bool o_act = !solo && tile_of[o] >= 0 && !ab_nox;
+        const bool o_h = !solo && tile_of[o] >= 0 && step_of[o] >= 1 && !ab_noex;
+        unsigned peek = solo ? pub[s] : pub[o];
         bool go = false;
         // hooks in the MFMA stream (k-block q of the section, a constant after unrolling):
         //   QF        the flag owed for the publish store of the section in front (drained by now)
@@ -372,10 +392,26 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         //   QJ .. +7  one piece of the other set's gather per block
         constexpr int QF = 3, QX = 4;
         constexpr int QP = first ? 16 : 28, QJ = first ? 20 : 32;
+        //   SOLO, all inside the input span:  QF as above   QX .. +7 the NEXT step's input tile   SP look at the own set's flags   SJ judge,
+        //   SJ .. +7 the gather of h_{t-1}
+        constexpr int SP = 14, SJ = 18;
         auto mid = [&](int q) {
             if (q == QF) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
+            }
+            if constexpr (solo) {
+                if (q >= QX && q < QX + NXD && !last && !ab_nox) issue_x_piece(bx ^ 1, tile, t + 1, q - QX);
+                if constexpr (!first) {
+                    if (q == SP) look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(s * NFL * sizeof(unsigned)));
+                    if (q == SJ - 1) {
+                        look_landed();
+                        peek = *look_mine;
+                    }
+                    if (q == SJ) go = !ab_noex && __all((int)(peek >= pub[s])) != 0;
+                    if (q >= SJ && q < SJ + NDMA && go) issue_h_piece(bh, s, pub[s], tile, t, q - SJ);
+                }
+                return;
             }
             if (q >= QX && q < QX + NXD && o_act) issue_x_piece(o, tile_of[o], step_of[o], q - QX);
             if (q == QP) look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(o * NFL * sizeof(unsigned)));     // (always: no branch)
@@ -384,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
                 peek = *look_mine;
             }
             if (q == QJ) go = o_h && __all((int)(peek >= pub[o])) != 0;
-            if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, pub[o], tile_of[o], step_of[o], q - QJ);
+            if (q >= QJ && q < QJ + NDMA && go) issue_h_piece(o, o, pub[o], tile_of[o], step_of[o], q - QJ);
         };
         UP_STAMP(dg_top)
         // ---- stacked-gate product: one dependent chain of 32x32x2 MFMAs ---------------------------------------------------------
@@ -395,8 +431,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             acc[4 * gate] = bv[0]; acc[4 * gate + 1] = bv[1]; acc[4 * gate + 2] = bv[2]; acc[4 * gate + 3] = bv[3];
         }
         if (!ab_nomfma) {
-            span32<KXB, NW>(acc, xb + s * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
-            if constexpr (!first) span32<BH, NW>(acc, hb + s * HL + frag, MR * 8, w, 4 * KXB, [&](int q) { mid(KXB + q); });
+            span32<KXB, NW>(acc, xb + bx * HL + frag, MR * 8, w, 0, [&](int q) { mid(q); });
+            if constexpr (solo && !first) {
+                // the slices h_{t-1}: on their way since block SJ, or -- a peer was late -- fetched now; one barrier and every wave sees them
+                if (!go && !ab_noex) {
+                    wait_flags(s, pub[s]);
+#pragma unroll
+                    for (int k = 0; k < NDMA; ++k) issue_h_piece(bh, s, pub[s], tile, t, k);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!ab_nobar) bar();
+            }
+            if constexpr (!first) span32<BH, NW>(acc, hb + bh * HL + frag, MR * 8, w, 4 * KXB, [&](int q) { mid(KXB + q); });
         }
         // (a section shorter than the hook schedule -- step 0 of the narrow-input form is 4 k-blocks -- runs the rest of it here)
         {
@@ -408,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         //  must be through with them first.  `tile_of[o] < 0` is state, not a flag judgement: uniform over the workgroup, so the
         //  extra barrier pairs up.  With both sets active the copies into this set's buffers are issued from the other set's
         //  section, behind ITS top barrier.)
-        if (tile_of[o] < 0 && !ab_nobar) bar();
+        if (!solo && tile_of[o] < 0 && !ab_nobar) bar();
         mfma_drain(acc);
         UP_STAMP(dg_chain)
         // ---- gates + cell update, lane-local: registers 4 gate + j = gate of unit 4 hh + j, window n ---------------------------
@@ -435,9 +481,13 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
             const f32x2 h = ov * (2.0f * rcp_2(1.0f + exp2_2(-2.885390081777927f * c)) - 1.0f);
             hnew[j] = h[0]; hnew[j + 1] = h[1];
         }
-        if (abort_word != 0) return false;                        // (a wave of this workgroup gave up in a blocking wait)
-        prex[o] = o_act;
-        preh[o] = go;
+        if (abort_word != 0 || (solo && ctl[0] != 0)) return false;      // (a wave of this workgroup gave up in a blocking wait)
+        if constexpr (solo) {
+            prex[s] = !last && !ab_nox;
+        } else {
+            prex[o] = o_act;
+            preh[o] = go;
+        }
         if (!SEQ && last) {
             // ---- head: partial y over this wave's 8 units = four more MFMAs, the fresh h values are the activation fragment ----
             f32x16 ya;
@@ -499,14 +549,25 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
     };
 
     bool ok = true;
+    // (a cluster with ONE tile in all -- the launch has no more tiles than clusters -- runs the solo form, where the input span is long
+    //  enough to hide the exchange: the 256-wide inputs)
+    const bool solo_cluster = KXB >= 28 && tile_of[1] < 0 && tile_of[0] >= 0 && tile_of[0] + 2 * NC >= p.n_tiles && !(p.flags & APE_FLAG_ALT_FORM);
+    if constexpr (KXB >= 28) {
+        if (solo_cluster) {
+#pragma unroll 1
+            while (ok && tile_of[0] >= 0)
+                ok = step_of[0] == 0 ? section(std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{})
+                                     : section(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+        }
+    }
 #pragma unroll 1
     while (ok && (tile_of[0] >= 0 || tile_of[1] >= 0)) {
         if (tile_of[0] >= 0)
-            ok = step_of[0] == 0 ? section(std::integral_constant<int, 0>{}, std::true_type{})
-                                 : section(std::integral_constant<int, 0>{}, std::false_type{});
+            ok = step_of[0] == 0 ? section(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{})
+                                 : section(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
         if (ok && tile_of[1] >= 0)
-            ok = step_of[1] == 0 ? section(std::integral_constant<int, 1>{}, std::true_type{})
-                                 : section(std::integral_constant<int, 1>{}, std::false_type{});
+            ok = step_of[1] == 0 ? section(std::integral_constant<int, 1>{}, std::true_type{}, std::false_type{})
+                                 : section(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
     }
     if (!ok) return;
     // (a flag still owed here is awaited by nobody -- the section behind a publish always raises it, and a set's last section

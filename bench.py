@@ -631,7 +631,7 @@ def other_paths():
         m.check()
         out["imupose_lstm"] = {"windows": B, "frames": T, "us_per_call": us, "windows_per_s": B / us * 1e6,
                                "tflops": m.flops_per_window(T) * B / us / 1e6, "kernel": m.kernel_name(B, T),
-                               "profile": "profiles/r05_imupose_cluster.md"}
+                               "profile": "profiles/r05_imupose_split_l0.md, profiles/r05_imupose_split_l1.md"}
         del m, x, y
     except Exception as exc:
         out["imupose_lstm"] = {"error": str(exc)[:200]}

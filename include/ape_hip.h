@@ -118,7 +118,8 @@ enum { APE_PRECISION_F32 = 0, APE_PRECISION_F16 = 1, APE_PRECISION_F16_GEN1 = 2 
                                                block-index classes (one XCD each) */
 #define APE_FLAG_ALT_FORM        0x01000000u /* the alternative decomposition where a kernel has two: the latency kernel's H/16-member form,
                                                lstm_cluster16's one-workgroup-per-CU form, the fp16 kernel's 16-unit-member form (two
-                                               workgroups per CU; measured slower) */
+                                               workgroups per CU; measured slower), ImuPoseLSTM's one-tile clusters on the
+                                               blocking exchange instead of the gather under the input span (same bits) */
 
 typedef struct ape_model ape_model_t;
 

@@ -200,3 +200,33 @@ def test_fresh_banks_layer0_sequence_under_uneven_load(streamer):
         _no_abort(m)
         del bank, m
     streamer.drain()
+
+
+@pytest.mark.parametrize("B,T", [(1024, 9), (1500, 5), (2090, 4)])
+def test_imupose_layer_split_under_uneven_load(streamer, B, T):
+    """ImuPoseLSTM from 1024 windows on: one layer per launch on lstm_upper32.hip's clusters -- one tile per cluster (the solo form: the
+    own gather under the input span), a mix of one- and two-tile clusters, two tiles everywhere + a ragged one; every window against the
+    oracle while the copies run, and once more on the blocking form of the one-tile clusters (ALT_FORM), bit for bit the same arithmetic"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import nn_models
+    sd = orc.make_imupose_state_dict(22, 14, 21)
+    m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0)
+    m.load_state_dict(sd)
+    x = np.random.default_rng(B + T).normal(size=(B, T, 22)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    ref = orc.imupose_forward(sd, x)[:, -1]
+    lib = _hip.lib()
+    ys = {}
+    for flags in (0, _hip.FLAG_ALT_FORM):
+        y = torch.empty((B, 14), dtype=torch.float32, device="cuda")
+        worst = 0.0
+        for rep in range(4):
+            streamer.burst()
+            _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(xt.data_ptr()), B, T, flags, None, 0.0, 0, C.c_void_p(y.data_ptr()), None), "fwd")
+            assert m.last_kernel() == "ape_lstm_upper32", m.last_kernel()
+            worst = max(worst, float(np.abs(y.cpu().numpy() - ref).max()))
+        assert worst < 2e-6, (B, T, flags, worst)
+        ys[flags] = y.cpu().numpy()
+    streamer.drain()
+    _no_abort(m)
+    assert np.array_equal(ys[0], ys[_hip.FLAG_ALT_FORM])
