@@ -17,3 +17,5 @@ run watch 700 8 f16 cluster $N 16
 run pocket 200 6 f16_gen1 cluster $N 16
 run pocket 4 6 f32 auto $N 4
 run pocket 1 6 f32 auto $N 4
+python tests/tools/uneven_imupose.py 1024 9 $N 8 2>&1 | grep -v "^launch\|amdgpu.ids" | tail -1
+python tests/tools/uneven_imupose.py 1500 5 $N 8 2>&1 | grep -v "^launch\|amdgpu.ids" | tail -1
