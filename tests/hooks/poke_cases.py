@@ -65,6 +65,48 @@ def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
         assert np.array_equal(m(x, last_step_only=True, normalize_input=True).numpy(), good)
 
 
+def test_aborted_imupose_layer_split_is_reissued():
+    """ImuPoseLSTM's layer-split route (two launches of lstm_upper32.hip per call, round 5) with the state an aborted launch leaves behind: the
+    host-output call is re-issued on the batch-tile kernel, the strict check of a device-output call raises and resets, recover() re-issues
+    in place; afterwards the handle gives the route's own bits again"""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.estimate import nn_models
+    sd = orc.make_imupose_state_dict(22, 14, 4)
+    m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0)
+    m.load_state_dict(sd)
+    poke = _poke(_hip.lib())
+    B, T = 1024, 5
+    assert "ape_lstm_upper32<32, true>" in m.kernel_name(B, T)
+    x = torch.from_numpy(np.random.default_rng(2).normal(size=(B, T, 22)).astype(np.float32))
+    good = m(x, last_step_only=True).numpy().copy()
+    assert m.last_kernel() == "ape_lstm_upper32"
+    tile = m.set_kernel("tile16")(x, last_step_only=True).numpy().copy()
+    m.set_kernel("auto")
+    assert np.abs(tile - good).max() < 2e-6
+    assert np.abs(good[:, 0] - orc.imupose_forward(sd, x.numpy())[:, -1]).max() < 2e-6
+    reissued = aborted = lost = 0
+    for which, value in ((0, 1), (6, 100000)):
+        assert poke(m.handle, which, value) == 0
+        out = m(x, last_step_only=True).numpy()
+        reissued += 1; aborted += 1
+        assert np.array_equal(out, tile), "the re-issue runs on the batch-tile kernel"
+        assert m.stats() == {"aborted_checks": aborted, "reissued_calls": reissued, "lost_calls": lost}
+        assert np.array_equal(m(x, last_step_only=True).numpy(), good)
+        assert poke(m.handle, which, value) == 0
+        m(x.cuda(), last_step_only=True)
+        with pytest.raises(UserWarning, match="aborted"):
+            m.check()
+        m.check()
+        aborted += 1; lost += 1
+        assert poke(m.handle, which, value) == 0
+        yd = m(x.cuda(), last_step_only=True)
+        m.recover()
+        reissued += 1; aborted += 1
+        assert np.array_equal(yd.cpu().numpy(), tile)
+        assert m.stats() == {"aborted_checks": aborted, "reissued_calls": reissued, "lost_calls": lost}
+        assert np.array_equal(m(x, last_step_only=True).numpy(), good)
+
+
 @pytest.mark.parametrize("name,S,n_mc,route", [("pocket", 330, 25, "ape_lstm_upper32"), ("uarm", 170, 50, "ape_lstm_upper128")])
 def test_aborted_infer_and_bank_step_are_reissued(norm_stats, name, S, n_mc, route):
     """ape_infer (LSTM + post-filter) and a Monte-Carlo stream-bank step behind an aborted launch: recover re-issues both; a bank
