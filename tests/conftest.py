@@ -48,3 +48,15 @@ def norm_stats():
     import json
     raw = json.loads((GOLDEN / "norm_stats.json").read_text())
     return {k: {kk: np.array(vv) if kk[:2] in ("xx", "yy") else vv for kk, vv in v.items()} for k, v in raw.items()}
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _memory_bound_neighbour():
+    """APE_SOAK_LOAD=1 python -m pytest tests -m gpu ...: the whole GPU suite beside a queue of 256 MiB device copies on a second stream for
+    the life of the session (tests/tools/_load.py) -- every parity assertion then holds under a loaded memory side, the condition that
+    exposed the two inline-asm faults of round 5.  Timing assertions are not meant for this mode.  Off by default."""
+    if os.environ.get("APE_SOAK_LOAD") == "1" and _has_gpu():
+        sys.path.insert(0, str(REPO / "tests" / "tools"))
+        import _load
+        _load.start()
+    yield
