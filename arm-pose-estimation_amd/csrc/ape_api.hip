@@ -850,11 +850,11 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         if (e != hipSuccess) return fail(APE_ERR_HIP, "input-layer kernel launch failed: %s", hipGetErrorString(e));
         lstm_x = m->z_ws;
         flags &= ~(uint32_t)APE_FLAG_NORMALIZE_INPUT;        // done in front of the input layer
-        // From 1024 windows on (32 tiles of 32: every persistent cluster of lstm_upper32.hip has one) the LSTM runs one layer per launch
-        // on those clusters: layer 0 in the SEQ form with the wide input, layer 1 reading its sequence as is -- K = 512 per layer is the
+        // Above 512 windows (where the first-generation kernel needs a second launch: 1480 us for 513 .. 1024 windows x 64 steps against
+        // 1020-1060 here) the LSTM runs one layer per launch on the persistent clusters of lstm_upper32.hip: layer 0 in the SEQ form with the wide input, layer 1 reading its sequence as is -- K = 512 per layer is the
         // clusters' whole register image; the first-generation kernel's 16-member clusters re-read nothing either but spend 16 CUs on
         // 32 rows.  Chunks of 4096 windows bound the workspaces.
-        if (m->split32_ok && B >= 1024 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32 &&
+        if (m->split32_ok && B > 512 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32 &&
             !m->replaying && !have_hs && !(flags & (APE_FLAG_ALL_STEPS | APE_FLAG_BROADCAST_X)) && x_ring == 0 && T >= 1 &&
             (size_t)128 * T * 32768 < ((size_t)1 << 32)) {
             const int chunk = 4096;
@@ -2094,8 +2094,8 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
         return (m->f16_v2 && ape_cluster_f16v2_supported(m->dims.hidden_size, m->dims.num_layers, m->KX) &&
                 f16v2_capacity(m->n_cus) > 0 && B > 256) ? "ape_lstm_cluster_f16v2" : "ape_lstm_cluster_f16";
     if (!m->cluster_ok || m->kernel_choice == APE_KERNEL_TILE16) return m->kernel_name.c_str();
-    // ImuPoseLSTM from 1024 windows on: one layer per launch on lstm_upper32.hip's persistent clusters (lstm_forward_impl)
-    if (m->split32_ok && B >= 1024 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32)
+    // ImuPoseLSTM above 512 windows: one layer per launch on lstm_upper32.hip's persistent clusters (lstm_forward_impl)
+    if (m->split32_ok && B > 512 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32)
         return "ape_lstm_upper32<32, true> + <32, false>";
     // under AUTO the kernel that takes the larger part of an eval-mode batch of this shape
     if (m->kernel_choice == APE_KERNEL_AUTO && B > 4 && T >= 1) {

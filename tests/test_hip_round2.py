@@ -374,15 +374,16 @@ def test_imupose_on_the_cluster_kernel():
     m = nn_models.ImuPoseLSTM(22, 256, 2, 14, device=0)
     m.load_state_dict(sd)
     rng = np.random.default_rng(5)
-    # (round 5: from 1024 windows on the LSTM runs one layer per launch on lstm_upper32.hip's persistent clusters -- 32 tiles on 32
-    #  clusters, a ragged 33rd tile, two tiles per cluster + a ragged one, and two chunks of the 4096-window workspace)
-    for B, T in ((5, 6), (16, 6), (40, 9), (300, 6), (1023, 5), (1024, 12), (1056, 5), (2090, 4), (4200, 3)):
+    # (round 5: above 512 windows -- where the old kernel needs a second launch -- the LSTM runs one layer per launch on lstm_upper32.hip's
+    #  persistent clusters: fewer tiles than clusters, 32 tiles on 32 clusters, a ragged 33rd tile, two tiles per cluster + a ragged one,
+    #  and two chunks of the 4096-window workspace)
+    for B, T in ((5, 6), (16, 6), (40, 9), (300, 6), (512, 5), (513, 5), (700, 7), (1024, 12), (1056, 5), (2090, 4), (4200, 3)):
         x = rng.normal(size=(B, T, 22)).astype(np.float32)
         xt = torch.from_numpy(x).cuda()
-        want = "ape_lstm_upper32<32, true>" if B >= 1024 else "ape_lstm_cluster<256, 2, 256"
+        want = "ape_lstm_upper32<32, true>" if B > 512 else "ape_lstm_cluster<256, 2, 256"
         assert want in m.set_kernel("auto").kernel_name(B, T)
         y_cl = m.set_kernel("auto")(xt, last_step_only=True).cpu().numpy()[:, 0]
-        assert m.last_kernel() == ("ape_lstm_upper32" if B >= 1024 else "ape_lstm_cluster"), m.last_kernel()
+        assert m.last_kernel() == ("ape_lstm_upper32" if B > 512 else "ape_lstm_cluster"), m.last_kernel()
         y_t16 = m.set_kernel("tile16")(xt, last_step_only=True).cpu().numpy()[:, 0]
         assert np.abs(y_cl - y_t16).max() < 2e-6, (B, T, float(np.abs(y_cl - y_t16).max()))
         sub = rng.choice(B, size=min(B, 24), replace=False)
