@@ -491,22 +491,14 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
                 for (int k = 0; k < NDMA; ++k) issue_piece(COLD, l, t - 1, k);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-#ifdef C32_TOPWAIT0
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
                 asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the prefetched copy; only the publish store is younger
-#endif
             }
         }
         prefetched = false;
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c1 = ST ? now() : 0ull;
 #endif
-#ifdef C32_M3_TOPBAR
-        bar();
-#else
         if constexpr (MODE != 3) bar();
-#endif
 #ifdef APE_CLUSTER_STAMPS
         const unsigned long long c2 = ST ? now() : 0ull;
 #endif
@@ -556,11 +548,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             // x of the next layer-0 step: registers -> LDS (layer 0's readers of xin finished before this section's barrier), and
             // the fetch of the step after it EARLY in the section: issued at its end the loads were the youngest entries but one of
             // the memory queue, and the counted wait at the top of the next section sat out their whole latency (13 us per launch)
-#ifdef C32_M3_QX4
-            if (l == L - 1 && q == QF + 1 && (ST || ph + 1 < T)) {
-#else
             if (l == L - 1 && q == ((MODE == 3) ? BH + 1 : QF + 1) && (ST || ph + 1 < T)) {
-#endif
                 HK_BEGIN();
                 stage_x();
                 if (ST || ph + 2 < T) fetch_x(ph + 2);

@@ -324,12 +324,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
     const unsigned pub_off = (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
     const float keep = 1.0f / (1.0f - p.dropout_p);
     const unsigned xf_rec = xf_desc[2], hx_rec = hx_desc[2];
-#ifdef UP128_DUMP
-    // (experiment: what nobody will read goes to a real slice of the cluster's own behind the exchange slices instead of out of range)
-    const unsigned NOWHERE = (unsigned)(((size_t)NC * 2 * 3 * 2 + cluster) * SET_BYTES) + (unsigned)((((member * 4 + wave) * MR + n) * 8 + 4 * hh) * sizeof(float));
-#else
     constexpr unsigned NOWHERE = 0x80000000u;                     // a store offset beyond the exchange buffer: dropped by the bounds check
-#endif
 
     // the sixteen 1-KiB pieces (per wave) of the operands of set s's NEXT section, piece i = 0 .. 15:
     //   0..3   layer 1's input: the pre-laid tile-step of p.xfrag                              (if the section has a layer-1 part)
@@ -390,11 +385,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper128(const Upper128Params
 #endif
         // ---- top: this section's operands
         if (pre[s]) {
-#ifdef UP128_TOPWAIT0
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // the prefetched copies (+ a head partial store); only the publish stores are younger
-#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             raise_pending();
@@ -709,7 +700,7 @@ bool ape_upper128_supported(int H, int L, int O) { return H == UH && L == 3 && O
 size_t ape_upper128_xfrag_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * SET_BYTES; }
 size_t ape_upper128_maskbits_bytes(int rows, int T) { return (size_t)((rows + MR - 1) / MR) * T * UH * sizeof(unsigned); }
 size_t ape_upper128_ypart_bytes(int rows) { return (size_t)((rows + MR - 1) / MR) * MR * GH * PO * sizeof(float); }
-size_t ape_upper128_hx_bytes(int clusters) { return (size_t)clusters * (2 * 3 * 2 + 1) * SET_BYTES; }     // (+ one slice per cluster: UP128_DUMP)
+size_t ape_upper128_hx_bytes(int clusters) { return (size_t)clusters * (2 * 3 * 2) * SET_BYTES; }
 size_t ape_upper128_flag_words(int clusters) { return (size_t)clusters * 2 * 2 * NFL; }
 
 hipError_t ape_prepare_lstm_upper128() {
