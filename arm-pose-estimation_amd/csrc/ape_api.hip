@@ -378,7 +378,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
             }
         }
         // ImuPoseLSTM (2 x 256 behind a 256-wide input layer): each layer is exactly one register image of lstm_upper32.hip's clusters
-        // (K = 256 + 256); from 1024 windows on the LSTM runs there, one layer per launch (lstm_forward_impl)
+        // (K = 256 + 256); above 512 windows the LSTM runs there, one layer per launch (lstm_forward_impl)
         if (imupose && H == 256 && L == 2 && m->KX == 256 && ape_upper32_supported(H, L, O) && f16v2_capacity(m->n_cus) >= 8) {
             for (int l = 0; l < L && e == hipSuccess; ++l)
                 e = plan((void**)&m->wcl32[l], (size_t)4 * H * (H + H) * sizeof(float));
@@ -851,9 +851,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         lstm_x = m->z_ws;
         flags &= ~(uint32_t)APE_FLAG_NORMALIZE_INPUT;        // done in front of the input layer
         // Above 512 windows (where the first-generation kernel needs a second launch: 1480 us for 513 .. 1024 windows x 64 steps against
-        // 1020-1060 here) the LSTM runs one layer per launch on the persistent clusters of lstm_upper32.hip: layer 0 in the SEQ form with the wide input, layer 1 reading its sequence as is -- K = 512 per layer is the
-        // clusters' whole register image; the first-generation kernel's 16-member clusters re-read nothing either but spend 16 CUs on
-        // 32 rows.  Chunks of 4096 windows bound the workspaces.
+        // 1020-1060 here) the LSTM runs one layer per launch on the persistent clusters of lstm_upper32.hip: layer 0 in the SEQ form
+        // with the wide input, layer 1 reading its sequence as is -- K = 512 per layer is the clusters' whole register image; the
+        // first-generation kernel's 16-member clusters re-read nothing either but spend 16 CUs on 32 rows.
+        // Chunks of 4096 windows bound the workspaces.
         if (m->split32_ok && B > 512 && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32 &&
             !m->replaying && !have_hs && !(flags & (APE_FLAG_ALL_STEPS | APE_FLAG_BROADCAST_X)) && x_ring == 0 && T >= 1 &&
             (size_t)128 * T * 32768 < ((size_t)1 << 32)) {
@@ -868,9 +869,10 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 if (m->zfrag_ws) { HIP_TRY(hipFree(m->zfrag_ws)); m->zfrag_ws = nullptr; }
                 if (m->hfrag_ws) { HIP_TRY(hipFree(m->hfrag_ws)); m->hfrag_ws = nullptr; }
                 if (m->ypart_ws) { HIP_TRY(hipFree(m->ypart_ws)); m->ypart_ws = nullptr; }
-                m->split_tiles_cap = m->split_steps_cap = 0;
+                // (both dimensions only ever grow: a caller alternating between many short and few long windows does not reallocate)
                 const size_t tc = (size_t)tiles_max > m->split_tiles_cap ? (size_t)tiles_max : m->split_tiles_cap;
-                const size_t sc = (size_t)T;
+                const size_t sc = (size_t)T > m->split_steps_cap ? (size_t)T : m->split_steps_cap;
+                m->split_tiles_cap = m->split_steps_cap = 0;
                 HIP_TRY(hipMalloc((void**)&m->zfrag_ws, tc * sc * 32768));
                 HIP_TRY(hipMalloc((void**)&m->hfrag_ws, tc * sc * 32768));
                 HIP_TRY(hipMalloc((void**)&m->ypart_ws, ape_upper32_ypart_bytes((int)tc * 32)));

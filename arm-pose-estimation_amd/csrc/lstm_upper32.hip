@@ -394,9 +394,19 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_upper32(const UpperParams p) 
         constexpr int QP = first ? 16 : 28, QJ = first ? 20 : 32;
         //   SOLO, all inside the input span:  QF as above   QX .. +7 the NEXT step's input tile   SP look at the own set's flags   SJ judge,
         //   SJ .. +7 the gather of h_{t-1}
-        constexpr int SP = 14, SJ = 18;
+#ifndef UP32_SQF
+#define UP32_SQF 3
+#endif
+#ifndef UP32_SP
+#define UP32_SP 14
+#endif
+#ifndef UP32_SJ
+#define UP32_SJ 18
+#endif
+        constexpr int SP = UP32_SP, SJ = UP32_SJ;
+        static_assert(!solo || (UP32_SQF < SP && SP + 2 <= SJ && SJ + NDMA <= KXB), "solo hook schedule");
         auto mid = [&](int q) {
-            if (q == QF) {
+            if (q == (solo ? UP32_SQF : QF)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 raise_pending();
             }
