@@ -1433,6 +1433,14 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
 // The pre-laid input is T x 1 KiB per sample row of a 2 x 256 model (lstm_upper32.hip), T x 512 B of the 3 x 128 model
 // (lstm_upper128.hip); it and -- 2 x 256 models -- launch A's sequence and input tiles sit behind ONE 32-bit buffer descriptor each, so
 // a bank that outgrows 2 GiB of any of them is chunked (launch B) or keeps the batch-tile route (launch A: 65 536 streams of 64 steps).
+// Sample rows from which a Monte-Carlo bank of a 2 x 256 model takes the weight-stationary route (layer 0 once per stream, the layer above
+// over the sample rows, both on lstm_upper32.hip): above 512 -- where the fused first-generation dropout kernel needs a second launch.
+// (Until round 5: 2048, two tiles per cluster -- a cluster with ONE tile paid its exchange in the open; with the SOLO form it does not.
+//  Measured, pocket, T = 6, frame of all streams: 21 x 25 rows 159 -> 117 us, 41 x 25 221 -> 160, 80 x 25 290 -> 168, 34 x 60 318 -> 167;
+//  up to 512 rows the one fused launch stays ahead: 20 x 25 97.5 against 116.)
+#ifndef APE_BANK_SHARE_MIN_ROWS
+#define APE_BANK_SHARE_MIN_ROWS 513
+#endif
 static bool bank_chunk_plan(bool up128, int S, int T, int n_mc, long long* chunk_rows) {
     const long long total = (long long)S * n_mc;
     const long long max_chunk = ((2047ll << 20) / ((long long)T * (up128 ? 512 : 1024))) / 1024 * 1024;
@@ -1468,14 +1476,14 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     // stream): worth its extra launch from two batch-tile waves of sample rows on.  The [S,T,H] sequence lives in the
     // model's all-steps workspace, sized here so that the step itself never allocates.
     ape_model* m = b->model;
-    // (on the weight-stationary route -- lstm_upper32.hip, both launches -- the sharing pays from 2048 sample rows on: two
-    //  32-row tiles per cluster, against four 512-row launches of the fused first-generation dropout kernel)
+    // (on the weight-stationary route -- lstm_upper32.hip, both launches -- the sharing pays from APE_BANK_SHARE_MIN_ROWS sample rows on;
+    //  the 3 x 128 model's route, lstm_upper128.hip, has no one-tile form and keeps 2048: two 32-row tiles per cluster)
     const long long sample_rows = (long long)b->S * n_mc;
     const bool can_up128 = m->up128_ok && m->c32_on;
     const bool can_up32 = (m->up32_ok && m->c32_on && f16v2_capacity(m->n_cus) >= 8) || can_up128;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
                    dropout_p > 0.0f && n_mc >= 2 &&
-                   (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= 2048));
+                   (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= (can_up128 ? 2048 : APE_BANK_SHARE_MIN_ROWS)));
     if (b->xfrag) { (void)hipFree(b->xfrag); b->xfrag = nullptr; }
     if (b->ypart) { (void)hipFree(b->ypart); b->ypart = nullptr; }
     if (b->xfrag0) { (void)hipFree(b->xfrag0); b->xfrag0 = nullptr; }

@@ -500,7 +500,7 @@ def stream_bank_numbers(model, stats, cases=None):
 def dispatch_boundaries(n_iter=30):
     """APE_KERNEL_AUTO at its dispatch boundaries, on THIS box: at each threshold of the plan (csrc/ape_api.hip: 512 / 513 eval rows for
     the second-generation kernels, windows of 11 / 12 steps for the 3 x 128 model, 4 / 5 rows and 128 / 129 samples for the latency
-    kernels, 2047 / 2048 sample rows for the bank's weight-stationary route, 3 / 4 clusters for the first generation's XCD classes)
+    kernels, 512 / 513 sample rows for the bank's weight-stationary route, 3 / 4 clusters for the first generation's XCD classes)
     AUTO and every kernel the public switch can force are timed on the same inputs (HIP events, median of n_iter launches after a
     warm-up); `auto_over_best` = AUTO's time over the fastest candidate's -- 1.00 means AUTO picked the fastest there."""
     from wear_mocap_ape_amd import _hip
@@ -561,8 +561,9 @@ def dispatch_boundaries(n_iter=30):
         for B in (96, 128):
             forward_case(f"pocket_dropout_B{B}_T6_clusters{B // 32}", "pocket", B, 6, True, False,
                          ("auto", ("auto", _hip.FLAG_NO_XCD_CLASSES), "tile16"))
-        # Monte-Carlo bank, 2047 | 2048 sample rows: fused first-generation launches | layer 0 shared + ape_lstm_upper32
-        for S, n_mc in ((89, 23), (128, 16)):
+        # Monte-Carlo bank, 512 | 513 sample rows: one fused first-generation launch | layer 0 shared + ape_lstm_upper32 (one-tile clusters on
+        # the SOLO form: the threshold was 2048 until round 5)
+        for S, n_mc in ((32, 16), (27, 19)):
             ent = {"candidates_us": {}, "kernels": {}}
             m = models["pocket"]
             rows = [torch.from_numpy(rng.normal(size=(S, 55)).astype(np.float32)).cuda() for _ in range(4)]

@@ -463,14 +463,17 @@ def test_two_estimator_threads_on_the_latency_kernel(norm_stats):
 
 # ---------------- Monte-Carlo bank on the weight-stationary route (lstm_upper32.hip), shapes the other tests do not reach -----------
 @pytest.mark.parametrize("name,S,n_mc,T", [("pocket", 83, 25, 1), ("watch", 83, 25, 2), ("pocket", 350, 7, 3), ("pocket", 41, 60, 6),
-                                            ("watch", 1100, 2, 8)])
+                                            ("watch", 1100, 2, 8),
+                                            # round 5: the route from 513 sample rows on -- fewer tiles than clusters (every cluster on the
+                                            # SOLO form), one-step windows there, a mix of one- and two-tile clusters
+                                            ("pocket", 21, 25, 6), ("pocket", 27, 19, 1), ("watch", 60, 25, 8), ("pocket", 9, 60, 6)])
 def test_mc_bank_cluster_route_against_batch_tile_route(golden, norm_stats, name, S, n_mc, T):
     """layer 0 once per stream + the layer above over the sample rows, both on the persistent cluster kernels (AUTO), against the
     same bank on the batch-tile kernels ('auto_gen1': same Philox counters, so the same dropout masks): window lengths 1 .. 8, sample
-    rows from 2048 on (the route's threshold), ragged last tiles, streams that straddle tiles, n_mc = 2 .. 60, several frames so
+    rows from 513 on (the route's threshold), ragged last tiles, streams that straddle tiles, n_mc = 2 .. 60, several frames so
     that the window rings wrap.  Every stacked row's hand / elbow position to 5e-6 (float32 summation order), messages to 5e-5."""
     from wear_mocap_ape_amd.streams import StreamBank
-    assert S * n_mc >= 2048
+    assert S * n_mc > 512
     stats = norm_stats[name]
     cfg = orc.MODEL_CONFIGS[name]
     feats = _synthetic_windows(stats, S, T + 3, cfg["I"], 77)

@@ -318,7 +318,7 @@ def test_auto_dispatch_names_the_planned_kernel_at_every_boundary():
     assert k["uarm_eval_B1024_T11"] == "ape_lstm_cluster" and k["uarm_eval_B1024_T12"] == "ape_lstm_cluster16"
     assert k["pocket_eval_B4_T6"] == "ape_lstm_cluster_small" and k["pocket_eval_B5_T6"] == "ape_lstm_cluster"
     assert k["pocket_mc_one_window_n128_T6"] == "ape_lstm_mc_small" and k["pocket_mc_one_window_n129_T6"] == "ape_lstm_cluster"
-    assert k["pocket_mc_bank_2047_sample_rows_T6"] == "ape_lstm_cluster" and k["pocket_mc_bank_2048_sample_rows_T6"] == "ape_lstm_upper32"
+    assert k["pocket_mc_bank_512_sample_rows_T6"] == "ape_lstm_cluster" and k["pocket_mc_bank_513_sample_rows_T6"] == "ape_lstm_upper32"
 
 
 def test_undeclared_flag_bits_are_refused(norm_stats):
