@@ -348,7 +348,8 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         for (int l = 0; l < L && e == hipSuccess && !imupose; ++l)
             e = plan(&m->wcl16[l], (size_t)4 * H * ((l == 0 ? m->KX : H) + H) * sizeof(_Float16));
         if (e == hipSuccess) e = ape_prepare_lstm_cluster(H, L, m->KX);
-        if (e == hipSuccess && H == 128 && L == 3) e = ape_prepare_lstm_cluster(H, 1, m->KX);       // layer 0 alone: launch A of the 3 x 128 bank
+        if (e == hipSuccess && ((H == 128 && L == 3) || (H == 256 && L == 2 && m->KX == 32)))
+            e = ape_prepare_lstm_cluster(H, 1, m->KX);       // layer 0 alone: launch A of a Monte-Carlo bank
         if (e == hipSuccess && !imupose) e = ape_prepare_lstm_cluster_f16(H, L, m->KX);
         if (e == hipSuccess && !imupose) e = ape_prepare_lstm_cluster_f16v2(H, L, m->KX);
         // latency kernel with H/8 members (every CU of a 32-CU XCD at H = 256): only where an XCD has that many CUs
@@ -1438,6 +1439,13 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
 // (Until round 5: 2048, two tiles per cluster -- a cluster with ONE tile paid its exchange in the open; with the SOLO form it does not.
 //  Measured, pocket, T = 6, frame of all streams: 21 x 25 rows 159 -> 117 us, 41 x 25 221 -> 160, 80 x 25 290 -> 168, 34 x 60 318 -> 167;
 //  up to 512 rows the one fused launch stays ahead: 20 x 25 97.5 against 116.)
+#ifndef APE_BANK_A_ONE_LAYER_MAX_STREAMS
+// 2 x 256 banks: launch A on the first-generation kernel's one-layer form up to this many streams (three any-placement clusters of 32;
+// from four clusters on that kernel forms XCD classes and the rendezvous eats the gain).  Measured, pocket, T = 6, frame of all streams,
+// one-layer form against the SEQ form of lstm_upper32.hip: 21 x 25 108.1 / 118.7 us, 41 x 25 155.3 / 165.7, 64 x 25 157.2 / 165.2,
+// 80 x 25 173.0 / 178.7 -- 100 x 25 220.3 / 215.8, 200 x 25 341.5 / 338.3, 512 x 25 767.4 / 748.4.
+#define APE_BANK_A_ONE_LAYER_MAX_STREAMS 96
+#endif
 #ifndef APE_BANK_SHARE_MIN_ROWS
 #define APE_BANK_SHARE_MIN_ROWS 513
 #endif
@@ -1677,7 +1685,36 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         const bool coop = !m->replaying && m->kernel_choice == APE_KERNEL_AUTO && m->c32_on && m->precision == APE_PRECISION_F32;
         const bool cluster_route = b->up32 && coop;
         hipError_t e = hipSuccess;
-        if (cluster_route) {
+        // launch A on the first-generation cluster kernel's one-layer form (lstm_cluster.hip <H, 1, KX, 2>): 32 streams per cluster of H / 16
+        // members, every step's output -> [S,T,H] in the model's sequence workspace, as the batch-tile launch writes it
+        auto launch_a_one_layer = [&]() -> hipError_t {
+            ClusterParams c{};
+            c.x = b->xring; c.x_row_stride = (size_t)b->n_mc * b->T * I;
+            c.y = nullptr; c.hseq = m->hseq_ws;
+            c.wcl[0] = m->wcl[0]; c.bias[0] = m->bias[0];
+            c.w_out = m->w_out; c.b_out = m->b_out;
+            c.xx_m = m->stats; c.xx_s = m->stats + I; c.xx_r = m->stats + 2 * I + 2 * O;
+            c.hx = m->hx; c.hx_bytes = m->hx_bytes;
+            c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+            c.ticket = c.status - 4; c.done = c.ticket + 1;
+            c.B = b->S; c.T = b->T; c.I = I; c.O = O; c.x_ring = x_ring;
+            c.flags = (flags & APE_FLAG_NORMALIZE_INPUT) | diag_wt;
+            c.dbg_wg = m->dbg_wg; c.xcc_slots = m->xcc_slots;
+            int clusters = (b->S + 31) / 32;
+            if (m->gen1_classes && !(diag_wt & APE_FLAG_NO_XCD_CLASSES)) {
+                const int c8 = (clusters + 7) / 8 * 8;
+                if (clusters >= 4 && c8 <= cluster_capacity(m->n_cus, H)) { clusters = c8; c.flags |= APE_FLAG_XCD_CLASSES; }
+            }
+            return ape_launch_lstm_cluster(H, 1, m->KX, 2, false, clusters, c, (hipStream_t)stream);
+        };
+        const bool a_one_layer_fits = m->cluster_ok && ape_cluster_supported(H, 1, m->KX) && (b->S + 31) / 32 <= cluster_capacity(m->n_cus, H);
+        // (2 x 256 models, small banks: the one-layer form's 16-member clusters have half the matrix work per CU and step of the 8-member
+        //  SEQ form below and the same exposed exchange; APE_BANK_A_ONE_LAYER_MAX_STREAMS above)
+        const bool a_on_gen1 = cluster_route && a_one_layer_fits && b->S <= APE_BANK_A_ONE_LAYER_MAX_STREAMS;
+        if (a_on_gen1) {
+            e = launch_a_one_layer();
+            if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
+        } else if (cluster_route) {
             // launch A on the weight-stationary structure (lstm_upper32.hip, SEQ form): S streams in tiles of 32 on the clusters,
             // every step's output in the fragment order launch B's input builder reads
             XFragParams xq{};
@@ -1695,30 +1732,11 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
             u.flags = diag_wt;
             e = ape_launch_lstm_lower32(u, xq, f16v2_capacity(m->n_cus), (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
-        } else if (b->up128 && coop && m->cluster_ok && ape_cluster_supported(H, 1, m->KX) && b->S >= 128 &&
-                   (b->S + 31) / 32 <= cluster_capacity(m->n_cus, H)) {
-            // launch A of the 3 x 128 bank on the first-generation cluster kernel's one-layer form (lstm_cluster.hip <128, 1, 64, 2>): 32
-            // streams per eight-member cluster, every step's output -> [S,T,H] as the batch-tile launch below writes it.  (Round 5:
-            // 1024 streams are 64 tiles of the batch-tile kernel -- a quarter of the chip for 54 us; here every CU holds 16 units of a
-            // cluster.)  Fewer than 128 streams stay below: the rendezvous costs more than the idle CUs.
-            ClusterParams c{};
-            c.x = b->xring; c.x_row_stride = (size_t)b->n_mc * b->T * I;
-            c.y = nullptr; c.hseq = m->hseq_ws;
-            c.wcl[0] = m->wcl[0]; c.bias[0] = m->bias[0];
-            c.w_out = m->w_out; c.b_out = m->b_out;
-            c.xx_m = m->stats; c.xx_s = m->stats + I; c.xx_r = m->stats + 2 * I + 2 * O;
-            c.hx = m->hx; c.hx_bytes = m->hx_bytes;
-            c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
-            c.ticket = c.status - 4; c.done = c.ticket + 1;
-            c.B = b->S; c.T = b->T; c.I = I; c.O = O; c.x_ring = x_ring;
-            c.flags = (flags & APE_FLAG_NORMALIZE_INPUT) | diag_wt;
-            c.dbg_wg = m->dbg_wg; c.xcc_slots = m->xcc_slots;
-            int clusters = (b->S + 31) / 32;
-            if (m->gen1_classes && !(diag_wt & APE_FLAG_NO_XCD_CLASSES)) {
-                const int c8 = (clusters + 7) / 8 * 8;
-                if (c8 <= cluster_capacity(m->n_cus, H)) { clusters = c8; c.flags |= APE_FLAG_XCD_CLASSES; }
-            }
-            e = ape_launch_lstm_cluster(H, 1, m->KX, 2, false, clusters, c, (hipStream_t)stream);
+        } else if (b->up128 && coop && a_one_layer_fits && b->S >= 128) {
+            // launch A of the 3 x 128 bank on the one-layer form (round 5: 1024 streams are 64 tiles of the batch-tile kernel -- a quarter
+            // of the chip for 54 us; here every CU holds 16 units of a cluster: 30.8 us).  Fewer than 128 streams stay below: the rendezvous
+            // costs more than the idle CUs.
+            e = launch_a_one_layer();
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
         } else {
         // launch A: layer 0 alone over the S windows (first copy of every stream's ring), all steps -> [S,T,H]
@@ -1742,7 +1760,8 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
             for (long long r0 = 0; r0 < total; r0 += b->chunk_rows) {
                 const int rows = (int)((total - r0 < b->chunk_rows) ? total - r0 : b->chunk_rows);
                 ExpandParams xq{};
-                xq.hseq = b->hfrag; xq.hseq_frag = 1; xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
+                xq.hseq = a_on_gen1 ? m->hseq_ws : b->hfrag; xq.hseq_frag = a_on_gen1 ? 0 : 1;
+                xq.xfrag = b->xfrag; xq.row_base = r0; xq.rows = rows; xq.T = b->T; xq.n_mc = b->n_mc;
                 xq.layer = 0; xq.dropout_p = b->dropout_p; xq.seed = b->seed + b->mc_calls;
                 xq.masks = b->inj_masks; xq.masks_rows = total;
                 UpperParams u{};

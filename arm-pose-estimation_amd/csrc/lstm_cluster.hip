@@ -761,7 +761,7 @@ hipError_t prepare() {
 // 128 + 128 weight registers per lane = the whole accumulator file, one or two row tiles, no dropout -- its Monte-Carlo
 // mode is the plain forward, nn_models.py:246-251)
 bool ape_cluster_supported(int H, int L, int KX) {
-    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && (L == 3 || L == 1) && KX == 64);
+    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && (L == 3 || L == 1) && KX == 64) || (H == 256 && L == 1 && KX == 32);
 }
 
 #define APE_CL_DISPATCH(FN, ...)                                                     \
@@ -778,6 +778,8 @@ bool ape_cluster_supported(int H, int L, int KX) {
         if (nmt == 4 && !dropout) return FN<128, 3, 64, 4, false>(__VA_ARGS__);      \
     } else if (H == 128 && L == 1 && KX == 64) {  /* layer 0 of the 3 x 128 model on its own: launch A of its Monte-Carlo bank */ \
         if (nmt == 2 && !dropout) return FN<128, 1, 64, 2, false>(__VA_ARGS__);      \
+    } else if (H == 256 && L == 1 && KX == 32) {  /* ... and of the 2 x 256 models, for banks of up to 512 streams */ \
+        if (nmt == 2 && !dropout) return FN<256, 1, 32, 2, false>(__VA_ARGS__);      \
     }                                                                                \
     return hipErrorInvalidValue;
 

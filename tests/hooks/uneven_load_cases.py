@@ -168,11 +168,11 @@ def test_fresh_banks_layer0_sequence_under_uneven_load(streamer):
     lib.ape_debug_bank_buffer.restype = C.c_int
     lib.ape_debug_bank_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     cfg = orc.MODEL_CONFIGS["watch"]
-    T, I, O, H, S, n_mc = cfg["T"], cfg["I"], cfg["O"], cfg["H"], 41, 60
+    T, I, O, H, S, n_mc = cfg["T"], cfg["I"], cfg["O"], cfg["H"], 130, 20      # (above 96 streams: launch A on the SEQ form of lstm_upper32.hip)
     tiles = (S + 31) // 32
     rng = np.random.default_rng(41)
     sg = lambda v: 1.0 / (1.0 + np.exp(-v))
-    for bank_no in range(120):
+    for bank_no in range(100):
         sd = orc.make_state_dict(I, H, cfg["L"], O, int(rng.integers(100)))
         m = nn_models.DropoutLSTM(I, H, cfg["L"], O, dropout=0.2, device=0); m.load_state_dict(sd); m.set_body(orc.DEFAULT_BODY)
         bank = StreamBank(m, S, T, smooth=2, normalize=False, dtype=torch.float64, monte_carlo_samples=n_mc, dropout=0.2, seed=bank_no)
@@ -196,7 +196,7 @@ def test_fresh_banks_layer0_sequence_under_uneven_load(streamer):
                 want[:S, t] = h
             want = want.reshape(tiles, 32, T, 32, 8).transpose(0, 2, 3, 1, 4)           # [tile][step][k-block][row][8 units]
             d = np.abs(got.reshape(want.shape) - want)
-            d[1, :, :, S - 32:] = 0.0                                                      # rows past the bank: computed, never read
+            d[tiles - 1, :, :, S - 32 * (tiles - 1):] = 0.0                                # rows past the bank: computed, never read
             assert d.max() < 2e-6, (bank_no, f, float(d.max()), np.argwhere(d > 2e-6)[:8].tolist())
         _no_abort(m)
         del bank, m

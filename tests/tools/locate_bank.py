@@ -17,7 +17,9 @@ from wear_mocap_ape_amd.streams import StreamBank
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 name = sys.argv[2] if len(sys.argv) > 2 else "watch"
-S, smooth, n_mc, frames = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((3, 41), (4, 2), (5, 60), (6, 4)))
+S, smooth, n_mc, frames = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((3, 130), (4, 2), (5, 20), (6, 4)))
+# (banks of up to 96 streams run launch A on the first-generation kernel's one-layer form since the end of round 5: their layer-0 sequence
+#  is row-major in the model's workspace, not in the buffer read back below -- the read-back part of this tool is for S > 96)
 SYNC_PUSH = os.environ.get("LOCATE_SYNC_PUSH") == "1"          # (experiment: a host synchronisation between push and step)
 cfg = orc.MODEL_CONFIGS[name]
 T, I, O, H = cfg["T"], cfg["I"], cfg["O"], cfg["H"]
