@@ -91,6 +91,11 @@ imupose)
   python3 tools/summarize_prof.py r05_imupose_split_l0 $P/trace $P/fetch $P/write "ape_lstm_upper32<32, true>" 65536 1024 --model imupose --T 64 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_upper32.hip --lds 144944 --flop-per-launch 6.8719476736e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "ImuPoseLSTM (nn_models.py:210-249: Linear 22 -> 256 + ReLU, 2 x 256 LSTM with a 256-wide layer-0 input, Linear 256 -> 14), 1024 windows x 64 frames, round 5: ONE LAYER PER LAUNCH on the persistent 32-row clusters of lstm_upper32.hip -- this is layer 0 in the SEQ form with the wide input (32 tiles on 32 clusters, one tile each: the solo form, own gather under the input span; every step's slices to the sequence layer 1 reads).  Algorithmic FLOP of the launch = 1024 x 64 x 2 x 4H x (256 + 256); \`python3 tests/tools/time_imupose.py\`; recipe \`tools/prof_r05.sh imupose\`.  The first-generation kernel's profile of the same model (two launches of 512 windows, 734.7 us each) is profiles/r05_imupose_cluster.md."
   python3 tools/summarize_prof.py r05_imupose_split_l1 $P/trace $P/fetch $P/write "ape_lstm_upper32<32, false>" 65536 1024 --model imupose --T 64 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_upper32.hip --lds 144944 --flop-per-launch 6.8726816768e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "Layer 1 of the same calls (see r05_imupose_split_l0.md): reads layer 0's sequence as its input tiles, head partials on the last step.  Algorithmic FLOP = 1024 x (64 x 2 x 4H x (256 + 256) + 2 x 14 x 256)."
   ;;
+imupose_gen1)
+  # the first-generation kernel on the same model (what served it until round 5; still serves it up to 512 windows): forced by set_kernel('cluster')
+  passes python3 tests/tools/time_imupose.py 1024 64 cluster
+  python3 tools/summarize_prof.py r05_imupose_cluster $P/trace $P/fetch $P/write "ape_lstm_cluster<256, 2, 256, 2, false>" 65536 512 --model imupose --T 64 --pmc-dir $P/mfma --pmc-dir $P/wave --source csrc/lstm_cluster.hip --flop-per-launch 6.8723671040e10 --peak-tflops 157.3 --skip-first 10 --min-us 300 --note "ImuPoseLSTM (nn_models.py:210-249), 1024 windows x 64 frames as TWO launches of 512 windows (16 clusters x 16 members x 32 rows) of the first-generation kernel, forced by \`set_kernel('cluster')\` (AUTO runs this shape on the layer-split route since round 5: r05_imupose_split_l0.md); algorithmic FLOP of one launch = 512 x (64 x 2 x 4H x (512 + 512) + 2 x 14 x 256); \`python3 tests/tools/time_imupose.py 1024 64 cluster\`; recipe \`tools/prof_r05.sh imupose_gen1\`."
+  ;;
 esac
 cp profiles/r05_*.md gpurun_out/ 2>/dev/null || true
 cp profiles/traffic_latest.json gpurun_out/traffic_latest.json
