@@ -1439,6 +1439,12 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
 // (Until round 5: 2048, two tiles per cluster -- a cluster with ONE tile paid its exchange in the open; with the SOLO form it does not.
 //  Measured, pocket, T = 6, frame of all streams: 21 x 25 rows 159 -> 117 us, 41 x 25 221 -> 160, 80 x 25 290 -> 168, 34 x 60 318 -> 167;
 //  up to 512 rows the one fused launch stays ahead: 20 x 25 97.5 against 116.)
+#ifndef APE_BANK_SHARE_MIN_ROWS_128
+// the 3 x 128 model's route (lstm_upper128.hip; no one-tile form, every exchange of a one-tile cluster is exposed): from where the fused
+// first-generation dropout kernel needs a THIRD launch.  Measured, T = 6, frame of all streams, fused launches / this route: 11 x 50 rows
+// 125.4 / 137.9 us -- 21 x 50 213.8 / 141.6, 30 x 50 213.8 / 146.1, 40 x 50 215.8 / 150.2, 64 x 25 179.9 / 147.2 (2048 until round 5)
+#define APE_BANK_SHARE_MIN_ROWS_128 1025
+#endif
 #ifndef APE_BANK_A_ONE_LAYER_MAX_STREAMS
 // 2 x 256 banks: launch A on the first-generation kernel's one-layer form up to this many streams (three any-placement clusters of 32;
 // from four clusters on that kernel forms XCD classes and the rendezvous eats the gain).  Measured, pocket, T = 6, frame of all streams,
@@ -1485,13 +1491,13 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     // model's all-steps workspace, sized here so that the step itself never allocates.
     ape_model* m = b->model;
     // (on the weight-stationary route -- lstm_upper32.hip, both launches -- the sharing pays from APE_BANK_SHARE_MIN_ROWS sample rows on;
-    //  the 3 x 128 model's route, lstm_upper128.hip, has no one-tile form and keeps 2048: two 32-row tiles per cluster)
+    //  the 3 x 128 model's route, lstm_upper128.hip, from APE_BANK_SHARE_MIN_ROWS_128)
     const long long sample_rows = (long long)b->S * n_mc;
     const bool can_up128 = m->up128_ok && m->c32_on;
     const bool can_up32 = (m->up32_ok && m->c32_on && f16v2_capacity(m->n_cus) >= 8) || can_up128;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
                    dropout_p > 0.0f && n_mc >= 2 &&
-                   (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= (can_up128 ? 2048 : APE_BANK_SHARE_MIN_ROWS)));
+                   (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= (can_up128 ? APE_BANK_SHARE_MIN_ROWS_128 : APE_BANK_SHARE_MIN_ROWS)));
     if (b->xfrag) { (void)hipFree(b->xfrag); b->xfrag = nullptr; }
     if (b->ypart) { (void)hipFree(b->ypart); b->ypart = nullptr; }
     if (b->xfrag0) { (void)hipFree(b->xfrag0); b->xfrag0 = nullptr; }

@@ -429,7 +429,11 @@ def test_recover_replays_only_into_memory_the_mirror_still_owns(norm_stats):
 @pytest.mark.parametrize("name,S,n_mc,T,route", [("pocket", 330, 25, 6, "ape_lstm_upper32"), ("watch", 90, 25, 8, "ape_lstm_upper32"),
                                                   ("pocket", 3, 25, 6, "ape_lstm_mc_small"), ("uarm", 1, 50, 6, "ape_lstm_mc_small"),
                                                   ("pocket", 40, 7, 6, "ape_lstm_cluster"), ("uarm", 170, 50, 6, "ape_lstm_upper128"),
-                                                  ("uarm", 45, 50, 6, "ape_lstm_upper128")])
+                                                  ("uarm", 45, 50, 6, "ape_lstm_upper128"),
+                                                  # round 5: the routes' new thresholds -- one-tile clusters (SOLO form, launch A on the
+                                                  # one-layer cluster form), the 3 x 128 route from 1025 sample rows, the fused launches below
+                                                  ("pocket", 21, 25, 6, "ape_lstm_upper32"), ("watch", 60, 25, 8, "ape_lstm_upper32"),
+                                                  ("uarm", 21, 50, 6, "ape_lstm_upper128"), ("uarm", 20, 50, 6, "ape_lstm_cluster")])
 def test_bank_routes_under_injected_masks_against_the_oracle(norm_stats, name, S, n_mc, T, route):
     """the bank's weight-stationary Monte-Carlo route (layer 0 once per stream, `ape_mc_expand_kernel`,
     `ape_lstm_upper32`) was pinned to the oracle only through the batch-tile route under the same Philox counters.  The test-hooks

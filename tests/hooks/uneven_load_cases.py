@@ -109,7 +109,8 @@ def test_mlp_pipeline_under_uneven_load(streamer):
 
 @pytest.mark.parametrize("name,S,n_mc,route", [("pocket", 170, 25, "ape_lstm_upper32"), ("watch", 100, 25, "ape_lstm_upper32"),
                                                ("pocket", 30, 25, "ape_lstm_upper32"), ("watch", 50, 25, "ape_lstm_upper32"),      # (one-tile clusters: SOLO form)
-                                               ("uarm", 100, 50, "ape_lstm_upper128"), ("uarm", 160, 25, "ape_lstm_upper128"), ("pocket", 1, 25, "ape_lstm_mc_small")])
+                                               ("uarm", 100, 50, "ape_lstm_upper128"), ("uarm", 160, 25, "ape_lstm_upper128"), ("uarm", 30, 50, "ape_lstm_upper128"),
+                                               ("pocket", 1, 25, "ape_lstm_mc_small")])
 def test_bank_routes_under_uneven_load(norm_stats, streamer, name, S, n_mc, route):
     """the Monte-Carlo banks' weight-stationary routes (and the one-stream latency kernel) with injected masks: every sample row of every
     frame against the oracle's masked cell loop while the copies run"""
