@@ -1738,10 +1738,10 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
             u.flags = diag_wt;
             e = ape_launch_lstm_lower32(u, xq, f16v2_capacity(m->n_cus), (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
-        } else if (b->up128 && coop && a_one_layer_fits && b->S >= 128) {
+        } else if (b->up128 && coop && a_one_layer_fits) {
             // launch A of the 3 x 128 bank on the one-layer form (round 5: 1024 streams are 64 tiles of the batch-tile kernel -- a quarter
-            // of the chip for 54 us; here every CU holds 16 units of a cluster: 30.8 us).  Fewer than 128 streams stay below: the rendezvous
-            // costs more than the idle CUs.
+            // of the chip for 54 us; here every CU holds 16 units of a cluster: 30.8 us).  Every bank size that fits the chip's clusters:
+            // 21 x 50 rows 141.6 -> 121.0 us per frame, 100 x 25 188.1 -> 164.5, 127 x 25 190.2 -> 166.4 against the batch-tile launch.
             e = launch_a_one_layer();
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
         } else {
