@@ -420,7 +420,9 @@ def stream_bank_numbers(model, stats, cases=None):
     out = {}
     if cases is None:
         cases = [("S1024_mc1", "pocket", 1024, None, 1, 100), ("S1024_mc25", "pocket", 1024, 25, 1, 30), ("S8192_mc25", "pocket", 8192, 25, 1, 8),
-                 ("uarm_S1024_mc50_T6", "uarm", 1024, 50, 1, 12), ("watch_S1024_mc25_T8", "watch", 1024, 25, 10, 20)]
+                 ("uarm_S1024_mc50_T6", "uarm", 1024, 50, 1, 12), ("watch_S1024_mc25_T8", "watch", 1024, 25, 10, 20),
+                 # small banks (round 5: the weight-stationary routes from 513 / 1025 sample rows on, one-tile clusters)
+                 ("S41_mc25", "pocket", 41, 25, 1, 200), ("uarm_S21_mc50_T6", "uarm", 21, 50, 1, 200)]
     shapes = {"pocket": (POCKET, 6, _hip.PARSE_WATCH_PHONE_POCKET, None),
               "uarm": (UARM, 6, _hip.PARSE_WATCH_PHONE_UARM, (NNS_INPUTS.WATCH_PHONE_CAL_ALL, NNS_TARGETS.ORI_CAL_LARM_UARM)),
               "watch": (WATCH, 8, _hip.PARSE_WATCH_ONLY, (NNS_INPUTS.WATCH_ONLY_CAL, NNS_TARGETS.ORI_CAL_LARM_UARM))}
