@@ -377,7 +377,7 @@ def test_imupose_on_the_cluster_kernel():
     # (round 5: above 512 windows -- where the old kernel needs a second launch -- the LSTM runs one layer per launch on lstm_upper32.hip's
     #  persistent clusters: fewer tiles than clusters, 32 tiles on 32 clusters, a ragged 33rd tile, two tiles per cluster + a ragged one,
     #  and two chunks of the 4096-window workspace)
-    for B, T in ((5, 6), (16, 6), (40, 9), (300, 6), (512, 5), (513, 5), (700, 7), (1024, 12), (1056, 5), (2090, 4), (4200, 3)):
+    for B, T in ((5, 6), (16, 6), (40, 9), (300, 6), (512, 5), (513, 5), (600, 1), (700, 7), (1024, 2), (1024, 12), (1056, 5), (2090, 4), (4200, 3)):
         x = rng.normal(size=(B, T, 22)).astype(np.float32)
         xt = torch.from_numpy(x).cuda()
         want = "ape_lstm_upper32<32, true>" if B > 512 else "ape_lstm_cluster<256, 2, 256"
