@@ -1439,6 +1439,12 @@ int ape_streams_create(ape_model_t* m, int32_t n_streams, int32_t seq_len, int32
 // (Until round 5: 2048, two tiles per cluster -- a cluster with ONE tile paid its exchange in the open; with the SOLO form it does not.
 //  Measured, pocket, T = 6, frame of all streams: 21 x 25 rows 159 -> 117 us, 41 x 25 221 -> 160, 80 x 25 290 -> 168, 34 x 60 318 -> 167;
 //  up to 512 rows the one fused launch stays ahead: 20 x 25 97.5 against 116.)
+// ---- which route a Monte-Carlo bank takes, as pure arithmetic on (model shape, CU count, bank size): used by ape_streams_set_mc /
+// streams_step_impl and, for the CPU tests of the thresholds, by ape_debug_bank_route ---------------------------------------------------
+enum { BANK_FUSED = 0, BANK_SHARED_TILE16 = 1, BANK_UPPER32 = 2, BANK_UPPER128 = 3 };              // route of the layers above layer 0
+enum { BANK_A_NONE = 0, BANK_A_TILE16 = 1, BANK_A_SEQ32 = 2, BANK_A_ONE_LAYER = 3 };                // kernel of launch A (layer 0 once per stream)
+static bool bank_shares_layer0(long long sample_rows, int n_cus, bool can_up32, bool can_up128);
+static int bank_launch_a_form(int route, int H, int KX, int n_cus, int S, bool cluster_ok);
 #ifndef APE_BANK_SHARE_MIN_ROWS_128
 // the 3 x 128 model's route (lstm_upper128.hip; no one-tile form, every exchange of a one-tile cluster is exposed): from where the fused
 // first-generation dropout kernel needs a THIRD launch.  Measured, T = 6, frame of all streams, fused launches / this route: 11 x 50 rows
@@ -1465,6 +1471,19 @@ static bool bank_chunk_plan(bool up128, int S, int T, int n_mc, long long* chunk
     if (chunk > total) chunk = (total + 31) / 32 * 32;
     *chunk_rows = chunk;
     return true;
+}
+
+static bool bank_shares_layer0(long long sample_rows, int n_cus, bool can_up32, bool can_up128) {
+    return sample_rows >= 2LL * tile16_wave_rows(n_cus) ||
+           (can_up32 && sample_rows >= (can_up128 ? APE_BANK_SHARE_MIN_ROWS_128 : APE_BANK_SHARE_MIN_ROWS));
+}
+// launch A of a bank on `route` (a cooperative step on a healthy model; a replay or a forced kernel takes the batch-tile launch)
+static int bank_launch_a_form(int route, int H, int KX, int n_cus, int S, bool cluster_ok) {
+    if (route == BANK_FUSED) return BANK_A_NONE;
+    const bool one_layer_fits = cluster_ok && ape_cluster_supported(H, 1, KX) && (S + 31) / 32 <= cluster_capacity(n_cus, H);
+    if (route == BANK_UPPER32) return (one_layer_fits && S <= APE_BANK_A_ONE_LAYER_MAX_STREAMS) ? BANK_A_ONE_LAYER : BANK_A_SEQ32;
+    if (route == BANK_UPPER128) return one_layer_fits ? BANK_A_ONE_LAYER : BANK_A_TILE16;
+    return BANK_A_TILE16;
 }
 
 int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t seed) {
@@ -1497,7 +1516,7 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
     const bool can_up32 = (m->up32_ok && m->c32_on && f16v2_capacity(m->n_cus) >= 8) || can_up128;
     b->shared_l0 = m->upper_ok && m->kernel_choice == APE_KERNEL_AUTO && m->precision == APE_PRECISION_F32 &&
                    dropout_p > 0.0f && n_mc >= 2 &&
-                   (sample_rows >= 2LL * tile16_wave_rows(m->n_cus) || (can_up32 && sample_rows >= (can_up128 ? APE_BANK_SHARE_MIN_ROWS_128 : APE_BANK_SHARE_MIN_ROWS)));
+                   bank_shares_layer0(sample_rows, m->n_cus, can_up32, can_up128);
     if (b->xfrag) { (void)hipFree(b->xfrag); b->xfrag = nullptr; }
     if (b->ypart) { (void)hipFree(b->ypart); b->ypart = nullptr; }
     if (b->xfrag0) { (void)hipFree(b->xfrag0); b->xfrag0 = nullptr; }
@@ -1713,10 +1732,11 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
             }
             return ape_launch_lstm_cluster(H, 1, m->KX, 2, false, clusters, c, (hipStream_t)stream);
         };
-        const bool a_one_layer_fits = m->cluster_ok && ape_cluster_supported(H, 1, m->KX) && (b->S + 31) / 32 <= cluster_capacity(m->n_cus, H);
+        const int a_form = !coop ? BANK_A_TILE16
+                                 : bank_launch_a_form(b->up32 ? BANK_UPPER32 : b->up128 ? BANK_UPPER128 : BANK_SHARED_TILE16, H, m->KX, m->n_cus, b->S, m->cluster_ok);
         // (2 x 256 models, small banks: the one-layer form's 16-member clusters have half the matrix work per CU and step of the 8-member
         //  SEQ form below and the same exposed exchange; APE_BANK_A_ONE_LAYER_MAX_STREAMS above)
-        const bool a_on_gen1 = cluster_route && a_one_layer_fits && b->S <= APE_BANK_A_ONE_LAYER_MAX_STREAMS;
+        const bool a_on_gen1 = cluster_route && a_form == BANK_A_ONE_LAYER;
         if (a_on_gen1) {
             e = launch_a_one_layer();
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
@@ -1738,7 +1758,7 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
             u.flags = diag_wt;
             e = ape_launch_lstm_lower32(u, xq, f16v2_capacity(m->n_cus), (hipStream_t)stream);
             if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step: layer-0 cluster launch failed: %s", hipGetErrorString(e));
-        } else if (b->up128 && coop && a_one_layer_fits) {
+        } else if (b->up128 && a_form == BANK_A_ONE_LAYER) {
             // launch A of the 3 x 128 bank on the one-layer form (round 5: 1024 streams are 64 tiles of the batch-tile kernel -- a quarter
             // of the chip for 54 us; here every CU holds 16 units of a cluster: 30.8 us).  Every bank size that fits the chip's clusters:
             // 21 x 50 rows 141.6 -> 121.0 us per frame, 100 x 25 188.1 -> 164.5, 127 x 25 190.2 -> 166.4 against the batch-tile launch.
@@ -2109,6 +2129,26 @@ int ape_debug_bank_chunks(int up128, int S, int T, int n_mc, long long out[3]) {
     out[0] = bank_chunk_plan(up128 != 0, S, T, n_mc, &chunk) ? 1 : 0;
     out[1] = chunk;
     out[2] = out[0] ? ((long long)S * n_mc + chunk - 1) / chunk : 0;
+    return APE_OK;
+}
+
+// the route ape_streams_set_mc plans for a Monte-Carlo bank of S streams x n_mc samples on a healthy model under APE_KERNEL_AUTO, float32,
+// dropout on (pure host arithmetic, for the CPU tests): out = {layer 0 shared 0/1, route BANK_*, launch A's kernel BANK_A_*, chunk rows}
+int ape_debug_bank_route(const ape_dims_t* dims, int n_cus, int S, int T, int n_mc, long long out[4]) {
+    if (!dims || !out || n_cus < 1 || S < 1 || T < 1 || n_mc < 1) return APE_ERR_INVALID_ARG;
+    const int H = dims->hidden_size, L = dims->num_layers, O = dims->output_size, KX = padded_input(dims->input_size);
+    const bool lstm = dims->model_kind == APE_MODEL_LSTM;
+    const bool cluster_ok = lstm && ape_cluster_supported(H, L, KX) && cluster_capacity(n_cus, H) >= 1;
+    const bool upper_ok = lstm && ((H == 256 && L == 2) || (H == 128 && L == 3));
+    const bool up32_ok = cluster_ok && ape_cluster32_supported(H, L, KX) && f16v2_capacity(n_cus) > 0 && ape_upper32_supported(H, L, O);
+    const bool up128_ok = cluster_ok && ape_upper128_supported(H, L, O) && (n_cus / 4) / 8 * 8 >= 8;
+    const bool can_up128 = up128_ok, can_up32 = (up32_ok && f16v2_capacity(n_cus) >= 8) || can_up128;
+    const long long rows = (long long)S * n_mc;
+    const bool shared = upper_ok && n_mc >= 2 && bank_shares_layer0(rows, n_cus, can_up32, can_up128);
+    long long chunk = 0;
+    int route = BANK_FUSED;
+    if (shared) route = (can_up32 && bank_chunk_plan(can_up128, S, T, n_mc, &chunk)) ? (can_up128 ? BANK_UPPER128 : BANK_UPPER32) : BANK_SHARED_TILE16;
+    out[0] = shared ? 1 : 0; out[1] = route; out[2] = bank_launch_a_form(route, H, KX, n_cus, S, cluster_ok); out[3] = chunk;
     return APE_OK;
 }
 

@@ -130,3 +130,45 @@ def test_bank_chunk_plan_keeps_every_32_bit_descriptor_under_2_gib():
     fits, chunk, n = plan(1, 100, 6, 21)                           # 2100 rows: one ragged chunk, rounded to whole 32-row tiles
     assert (fits, chunk, n) == (1, 2112, 1)
     assert plan(0, 2 ** 20, 6, 4096)[0] == 0                       # 2^32 sample rows: beyond the input builder's 32-bit row index
+
+
+def _bank_route(dims, n_cus, S, T, n_mc):
+    from wear_mocap_ape_amd import _hip
+    lib = _hip.lib()
+    lib.ape_debug_bank_route.restype = C.c_int
+    lib.ape_debug_bank_route.argtypes = [C.POINTER(_hip.ApeDims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong * 4)]
+    out = (C.c_longlong * 4)()
+    assert lib.ape_debug_bank_route(C.byref(dims), n_cus, S, T, n_mc, C.byref(out)) == 0
+    return dict(shared=out[0], route=("fused", "tile16", "upper32", "upper128")[out[1]],
+                launch_a=("none", "tile16", "seq32", "one_layer")[out[2]], chunk=out[3])
+
+
+def test_bank_routes_follow_the_thresholds():
+    """where a Monte-Carlo bank's layers run (`ape_streams_set_mc`, pure host arithmetic in `ape_debug_bank_route`): the thresholds round 5
+    moved -- 2 x 256 models from 513 sample rows (the fused dropout kernel's second launch), the 3 x 128 model from 1025 (its third), launch A
+    on the one-layer cluster form for small banks -- and what a device with fewer CUs does"""
+    from wear_mocap_ape_amd import _hip
+    pocket = _hip.ApeDims(22, 256, 2, 14, 0, 0, _hip.MODEL_LSTM)
+    watch = _hip.ApeDims(20, 256, 2, 12, 1, 0, _hip.MODEL_LSTM)
+    uarm = _hip.ApeDims(38, 128, 3, 12, 1, 0, _hip.MODEL_LSTM)
+    r = lambda d, S, n, T=6, cus=256: _bank_route(d, cus, S, T, n)
+    # 2 x 256: 512 | 513 sample rows; launch A on the one-layer form up to 96 streams, the SEQ form of lstm_upper32.hip above
+    assert r(pocket, 32, 16) == dict(shared=0, route="fused", launch_a="none", chunk=0)
+    assert r(pocket, 27, 19) == dict(shared=1, route="upper32", launch_a="one_layer", chunk=544)
+    assert r(pocket, 96, 25)["launch_a"] == "one_layer" and r(pocket, 97, 25)["launch_a"] == "seq32"
+    assert r(pocket, 1024, 25) == dict(shared=1, route="upper32", launch_a="seq32", chunk=25600)
+    assert r(watch, 41, 25, T=8)["route"] == "upper32" and r(watch, 20, 25, T=8)["route"] == "fused"
+    assert r(pocket, 600, 1)["shared"] == 0                                 # eval mode / one sample: nothing to share
+    # very large banks: chunks of equal size under 2 GiB of expanded input
+    big = r(pocket, 8192, 60)
+    assert big["route"] == "upper32" and big["chunk"] % 1024 == 0 and big["chunk"] * 6 * 1024 * 4 < (1 << 31) * 4
+    # 3 x 128: 1000 | 1050 sample rows; launch A on the one-layer form while 32 eight-member clusters hold the streams
+    assert r(uarm, 20, 50)["route"] == "fused" and r(uarm, 21, 50) == dict(shared=1, route="upper128", launch_a="one_layer", chunk=1056)
+    assert r(uarm, 1024, 50)["launch_a"] == "one_layer" and r(uarm, 1025, 50)["launch_a"] == "tile16"
+    # a quarter of the chip (64 CUs): 8 thirty-two-row clusters are still there; an eighth (32 CUs): the weight-stationary routes are gone and
+    # the sharing starts at two batch-tile waves (2 x 512 rows)
+    assert r(pocket, 41, 25, cus=64)["route"] == "upper32"
+    assert r(pocket, 41, 25, cus=32) == dict(shared=1, route="tile16", launch_a="tile16", chunk=0)
+    assert r(pocket, 40, 25, cus=32)["shared"] == 0
+    # other regressors have no bank route of their own
+    assert r(_hip.ApeDims(22, 256, 2, 14, 0, 0, _hip.MODEL_IMUPOSE), 100, 25)["shared"] == 0
