@@ -125,3 +125,24 @@ def test_the_checker_sees_an_in_flight_asm_load_touched(tmp_path):
 """)
     hits = chk.scan_async_asm_loads(str(f))
     assert len(hits) == 1 and hits[0][3].startswith("v_mov_b64 v[40:41]"), hits
+
+
+def test_every_wide_asm_store_carries_its_wait_states():
+    """by construction, not by the luck of a schedule (round 5, async_look.h): every asm statement of the kernels that issues a store of more
+    than 64 bits either ends in APE_STORE_TAIL (two wait states inside the statement) or takes its soffset from a scalar register (no
+    store-data hazard then); the scan of the compiled code above is the second line of defence"""
+    import re
+    offenders = []
+    for fn in sorted(os.listdir(CSRC)):
+        if not fn.endswith((".hip", ".h")): continue
+        src = open(os.path.join(CSRC, fn)).read()
+        for m in re.finditer(r'asm\s+volatile\s*\(\s*((?:"[^"]*"|\s|APE_STORE_TAIL|#OFF)+)', src):
+            text = m.group(1)
+            if not re.search(r"(buffer|global|flat|scratch)_store_dwordx[34]", text): continue
+            literal_soffset = re.search(r"buffer_store_dwordx[34]\s+%\d+,\s*%\d+,\s*%\d+,\s*0\b", text) is not None or "global_store" in text or "flat_store" in text
+            if literal_soffset and "APE_STORE_TAIL" not in text:
+                offenders.append((fn, src[:m.start()].count("\n") + 1))
+    assert not offenders, offenders
+    # ... and the check sees what it should: the helpers of the three kernels that publish through asm stores
+    tails = sum(open(os.path.join(CSRC, f)).read().count("APE_STORE_TAIL ::") for f in ("lstm_upper32.hip", "lstm_cluster16.hip", "lstm_upper128.hip"))
+    assert tails == 6, tails
