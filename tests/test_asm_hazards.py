@@ -146,3 +146,21 @@ def test_every_wide_asm_store_carries_its_wait_states():
     # ... and the check sees what it should: the helpers of the three kernels that publish through asm stores
     tails = sum(open(os.path.join(CSRC, f)).read().count("APE_STORE_TAIL ::") for f in ("lstm_upper32.hip", "lstm_cluster16.hip", "lstm_upper128.hip"))
     assert tails == 6, tails
+
+
+def test_no_asm_load_lands_in_a_compiler_allocated_register():
+    """by construction (round 5, async_look.h): a vector-memory load issued inside an asm statement lands in LDS (LDS-DMA), never in a register
+    the compiler allocated ("=v") -- hipcc is free to copy or re-use such a register before the statement that waits for the load -- unless the
+    SAME statement ends in the wait (the latency kernels' granule polls, lstm_latency_common.h)"""
+    import re
+    offenders = []
+    for fn in sorted(os.listdir(CSRC)):
+        if not fn.endswith((".hip", ".h")): continue
+        src = open(os.path.join(CSRC, fn)).read()
+        for m in re.finditer(r'asm\s+volatile\s*\(\s*((?:"[^"]*"|\s)+):\s*([^:;]*)', src):
+            text, outputs = m.group(1), m.group(2)
+            loads = re.findall(r"(?:buffer|global|flat|scratch)_load_\w+[^\\\"]*", text)
+            waited_inside = re.search(r"_load_\w+(?:(?!_load_).)*s_waitcnt vmcnt\(0\)\s*\"?\s*$", text.strip(), flags=re.S) is not None
+            if any(" lds" not in ld for ld in loads) and re.search(r'"=&?v"', outputs) and not waited_inside:
+                offenders.append((fn, src[:m.start()].count("\n") + 1))
+    assert not offenders, offenders
