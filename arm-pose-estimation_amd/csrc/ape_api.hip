@@ -115,14 +115,28 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // `gen2`: the second-generation kernel the model and the call are eligible for -- 32: lstm_cluster32.hip (2 x 256), 16:
 // lstm_cluster16.hip (3 x 128: a launch costs 24.6 + 6.6 T against the first generation's 15.5 + 7.5 T at 513 .. 1024 rows -- with
 // its XCD-local clusters; 15.1 + 7.75 T before them --, so it serves windows of 12 steps and more), 0: none
-enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3, PLAN_C16 = 4 };
-static int rest_kernel(int rest, int T, int gen2) {
+// (round 6) 48 = 16 + the level-synchronous kernel for short windows, lstm_level16.hip: T + 2 hand-overs per launch instead of a
+// three-layer pipeline with four fill / drain phases; it serves windows below lstm_cluster16.hip's 12 steps from APE_LV16_MIN_ROWS rows on
+enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3, PLAN_C16 = 4, PLAN_LV16 = 5 };
+#define APE_LV16_MIN_ROWS 513        // (512 rows: the first generation's 16-row clusters still fill the chip, 42 us against 49)
+#define APE_LV16_MAX_T 48           // (1024 rows: 170.6 / 222.2 / 327.8 us at 24 / 32 / 48 steps against lstm_cluster16.hip's 179.5 / 231.7 / 339.8; a tie at 64)
+#define APE_LV16_COST_US0 14.0      // a launch of up to 1024 rows: microseconds = US0 + US_T x T (measured)
+#define APE_LV16_COST_US_T 5.5
+static int rest_kernel(int rest, int T, int gen2, int n_cus) {
     if (rest <= 0) return PLAN_NONE;
     if (gen2 == 32 && rest > 512) return PLAN_C32;
-    if (gen2 == 16 && rest > 512 && T >= 12) return PLAN_C16;
+    static const int c16_min_t = getenv("APE_C16_MIN_T") ? atoi(getenv("APE_C16_MIN_T")) : 12;      // (diagnostic overrides for A/B runs)
+    static const int lv16_max_t = getenv("APE_LV16_MAX_T") ? atoi(getenv("APE_LV16_MAX_T")) : APE_LV16_MAX_T;
+    static const int lv16_min_rows = getenv("APE_LV16_MIN_ROWS") ? atoi(getenv("APE_LV16_MIN_ROWS")) : APE_LV16_MIN_ROWS;
+    // (ONE launch only: its workgroups take a CU's whole LDS, so a second launch cannot start under the first one's tail as the first
+    //  generation's do -- 2048 x 6: 108 us in two launches against 100)
+    if (gen2 == 48 && rest >= lv16_min_rows && rest <= 32 * ape_level16_max_clusters(n_cus) && T <= lv16_max_t) return PLAN_LV16;
+    if ((gen2 == 16 || gen2 == 48) && rest > 512 && T >= c16_min_t) return PLAN_C16;
     return PLAN_GEN1;
 }
-static int gen2_of(const ape_model* m) { return (m->c32_ok && m->c32_on) ? 32 : (m->c16_ok && m->c32_on) ? 16 : 0; }
+static int gen2_of(const ape_model* m) {
+    return (m->c32_ok && m->c32_on) ? 32 : (m->c16_ok && m->c32_on) ? (m->lv16_ok ? 48 : 16) : 0;
+}
 
 static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bool cdrop, int gen2 = 0, bool wide = false) {
     const int wave = tile16_wave_rows(n_cus), rpl = cluster_rows_per_launch(n_cus, dims->hidden_size, cdrop || wide);
@@ -138,9 +152,13 @@ static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bo
     auto cost = [&](int w) {
         const int rest = B - wave * w;
         if (rest <= 0) return w * t16;
-        const int k = rest_kernel(rest, T, (!cdrop && !wide && rpl2 > 0) ? gen2 : 0);
+        const int k = rest_kernel(rest, T, (!cdrop && !wide && rpl2 > 0) ? gen2 : 0, n_cus);
         if (k == PLAN_C32) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (16.0 + 12.4 * T);
         if (k == PLAN_C16) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (24.6 + 6.6 * T);
+        if (k == PLAN_LV16) {
+            const int rpl3 = 32 * ape_level16_max_clusters(n_cus);
+            return w * t16 + (double)((rest + rpl3 - 1) / rpl3) * (APE_LV16_COST_US0 + APE_LV16_COST_US_T * T);
+        }
         return w * t16 + (double)((rest + rpl - 1) / rpl) * tcl1;
     };
     int best = 0;
@@ -384,7 +402,7 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
             for (int l = 0; l < L && e == hipSuccess; ++l)
                 e = plan((void**)&m->wcl32[l], (size_t)4 * H * (H + H) * sizeof(float));
             if (e == hipSuccess) e = ape_prepare_lstm_upper32();
-            m->split32_ok = true;
+            m->split32_ok = (e == hipSuccess);
         }
         // the Monte-Carlo bank's weight-stationary route for the 3 x 128 model (lstm_upper128.hip): four-member clusters, whole classes of 8
         if (ape_upper128_supported(H, L, O) && (m->n_cus / 4) / 8 * 8 >= 8 && !imupose) {
@@ -395,6 +413,13 @@ int ape_model_create(const ape_dims_t* dims, ape_model_t** out) {
         if (ape_cluster16_supported(H, L, m->KX) && f16v2_capacity(m->n_cus) > 0 && !imupose) {
             if (e == hipSuccess) e = ape_prepare_lstm_cluster16(H, L, m->KX);
             m->c16_ok = true;
+            // short windows: the level-synchronous kernel, if the device holds two of its workgroups per CU (else the first generation serves them)
+            if (e == hipSuccess && ape_level16_supported(H, L, m->KX) && ape_level16_max_clusters(m->n_cus) > 0) {
+                m->gx16_bytes = ape_level16_gx_bytes(m->n_cus);
+                e = plan((void**)&m->gx16, 256 + m->gx16_bytes);
+                if (e == hipSuccess) e = ape_prepare_lstm_level16(H, L, m->KX);
+                m->lv16_ok = (e == hipSuccess);
+            }
         }
         if (e != hipSuccess) {
             ape_model_destroy(m);
@@ -967,7 +992,7 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
         const int rows_per_launch = 16 * nmt * cluster_capacity(m->n_cus, H);
         const bool small = !f16 && !cdrop && !all_steps && B <= 4 && T + L <= 4096 && m->small_batch_path && !m->wide_cluster;   // latency path: VALU GEMV, one exchange per phase
         const int small_uw = (flags & APE_FLAG_ALT_FORM) ? 4 : m->small_uw;
-        const int rest_plan = (f16 || small) ? PLAN_NONE : rest_kernel(B - n16, T, (!cdrop && !drop && !all_steps) ? gen2_of(m) : 0);
+        const int rest_plan = (f16 || small) ? PLAN_NONE : rest_kernel(B - n16, T, (!cdrop && !drop && !all_steps) ? gen2_of(m) : 0, m->n_cus);
         if (rest_plan == PLAN_C32) {
             // second-generation f32 kernel: 8-member clusters of 32 windows, 32x32x2 MFMA chain (lstm_cluster32.hip)
             const int rpl2 = 32 * f16v2_capacity(m->n_cus);
@@ -1015,6 +1040,31 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 m->last_kernel = "ape_lstm_cluster16";
                 hipError_t e = ape_launch_lstm_cluster16(H, L, m->KX, nb, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster16 lstm launch failed: %s", hipGetErrorString(e));
+            }
+            return APE_OK;
+        }
+        if (rest_plan == PLAN_LV16) {
+            // short windows of the 3 x 128 model: level-synchronous 16-window clusters, two workgroups per CU (lstm_level16.hip)
+            const int rpl3 = 32 * ape_level16_max_clusters(m->n_cus);
+            for (int b0 = n16; b0 < B; b0 += rpl3) {
+                const int nb = (B - b0 < rpl3) ? B - b0 : rpl3;
+                ClusterParams c{};
+                c.x = (flags & APE_FLAG_BROADCAST_X) ? x_dev : x_dev + (size_t)b0 * T * m->dims.input_size;
+                c.y = y_dev + (size_t)b0 * m->dims.output_size;
+                for (int l = 0; l < L; ++l) { c.wcl[l] = m->wcl[l]; c.bias[l] = m->bias[l]; }
+                c.w_out = m->w_out; c.b_out = m->b_out;
+                c.xx_m = m->stats; c.xx_s = m->stats + m->dims.input_size;
+                c.xx_r = m->stats + 2 * m->dims.input_size + 2 * m->dims.output_size;
+                c.hx = reinterpret_cast<float*>(m->gx16 + 256); c.hx_bytes = m->gx16_bytes; c.seq = reinterpret_cast<unsigned*>(m->gx16);
+                c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
+                c.ticket = c.status - 4; c.done = c.status - 3;
+                c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
+                c.flags = flags; c.x_ring = x_ring;
+                c.xcc_slots = m->xcc_slots;
+                c.dbg_wg = m->dbg_wg;
+                m->last_kernel = "ape_lstm_level16";
+                hipError_t e = ape_launch_lstm_level16(H, L, m->KX, nb, c, (hipStream_t)stream);
+                if (e != hipSuccess) return fail(APE_ERR_HIP, "level16 lstm launch failed: %s", hipGetErrorString(e));
             }
             return APE_OK;
         }
@@ -1272,6 +1322,7 @@ static int check_and_reset(ape_model_t* m) {
         HIP_TRY(hipMemset(m->xcc_slots, 0, APE_XCC_WORDS * sizeof(unsigned)));
         HIP_TRY(hipMemset(m->hxs, 0, 256 + m->hxs_bytes));     // the aborted launch's granules carry tags the next launch would await
         if (m->gxm) HIP_TRY(hipMemset(m->gxm, 0, 256 + 8 * m->gxm_cluster_bytes + 8 * 64 * 8));
+        if (m->gx16) HIP_TRY(hipMemset(m->gx16, 0, 256 + m->gx16_bytes));
         HIP_TRY(hipDeviceSynchronize());
         return fail(APE_ERR_HIP, "cluster kernel launch aborted (status %u: %s); outputs of every launch on this model "
                     "since the last successful check are invalid; the model is usable again", st,
@@ -1480,7 +1531,7 @@ static bool bank_shares_layer0(long long sample_rows, int n_cus, bool can_up32, 
 // launch A of a bank on `route` (a cooperative step on a healthy model; a replay or a forced kernel takes the batch-tile launch)
 static int bank_launch_a_form(int route, int H, int KX, int n_cus, int S, bool cluster_ok) {
     if (route == BANK_FUSED) return BANK_A_NONE;
-    const bool one_layer_fits = cluster_ok && ape_cluster_supported(H, 1, KX) && (S + 31) / 32 <= cluster_capacity(n_cus, H);
+    const bool one_layer_fits = cluster_ok && ape_cluster_layer0_supported(H, KX) && (S + 31) / 32 <= cluster_capacity(n_cus, H);
     if (route == BANK_UPPER32) return (one_layer_fits && S <= APE_BANK_A_ONE_LAYER_MAX_STREAMS) ? BANK_A_ONE_LAYER : BANK_A_SEQ32;
     if (route == BANK_UPPER128) return one_layer_fits ? BANK_A_ONE_LAYER : BANK_A_TILE16;
     return BANK_A_TILE16;
@@ -2099,7 +2150,8 @@ int ape_debug_plan2(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, 
     if (cap < 1) { out[0] = B; out[1] = out[2] = out[3] = 0; return APE_OK; }
     const bool g2 = c32 != 0 && !cdrop && f16v2_capacity(n_cus) > 0;
     const int gen2 = !g2 ? 0 : ape_cluster32_supported(H, dims->num_layers, padded_input(dims->input_size)) ? 32
-                     : ape_cluster16_supported(H, dims->num_layers, padded_input(dims->input_size)) ? 16 : 0;
+                     : ape_cluster16_supported(H, dims->num_layers, padded_input(dims->input_size))
+                           ? ((ape_level16_supported(H, dims->num_layers, padded_input(dims->input_size)) && ape_level16_max_clusters(n_cus) > 0) ? 48 : 16) : 0;
     long long n16 = 0;
     if (B > 4) n16 = (long long)tile16_wave_rows(n_cus) * auto_tile16_waves(dims, n_cus, B, T, cdrop != 0, gen2);
     if (n16 > B) n16 = B;
@@ -2107,12 +2159,17 @@ int ape_debug_plan2(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, 
     const int rest = B - (int)n16;
     out[1] = out[2] = out[3] = 0;
     if (rest > 0) {
-        out[5] = (B <= 4 && !cdrop) ? PLAN_SMALL : rest_kernel(rest, T, gen2);
+        out[5] = (B <= 4 && !cdrop) ? PLAN_SMALL : rest_kernel(rest, T, gen2, n_cus);
         if (out[5] == PLAN_C32 || out[5] == PLAN_C16) {
             const int rpl2 = 32 * f16v2_capacity(n_cus);
             out[1] = 2;
             out[3] = (rest + rpl2 - 1) / rpl2;
             out[2] = ((rest < rpl2 ? rest : rpl2) + 31) / 32;
+        } else if (out[5] == PLAN_LV16) {
+            const int rpl3 = 32 * ape_level16_max_clusters(n_cus);
+            out[1] = 2;
+            out[3] = (rest + rpl3 - 1) / rpl3;
+            out[2] = ((rest < rpl3 ? rest : rpl3) + 31) / 32;
         } else {
             const int nmt = cluster_nmt(n_cus, H, rest, cdrop != 0), rpl = 16 * nmt * cap;
             out[1] = nmt;
@@ -2178,7 +2235,11 @@ const char* ape_lstm_kernel_name(const ape_model_t* m, int32_t B, int32_t T) {
     }
     if (m->c32_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512)      // (two instantiations: lstm_cluster32.hip on ENDS)
         return T <= APE_C32_ENDS_MAX_T ? "ape_lstm_cluster32<256, 2, 32, true>" : "ape_lstm_cluster32<256, 2, 32, false>";
-    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32 && B > 512 && T >= 12) return "ape_lstm_cluster16<128, 3, 64, 2>";
+    if (m->c16_ok && m->c32_on && m->precision == APE_PRECISION_F32) {
+        const int k = rest_kernel(B, T, gen2_of(m), m->n_cus);
+        if (k == PLAN_LV16) return "ape_lstm_level16<128, 3, 64>";
+        if (k == PLAN_C16) return "ape_lstm_cluster16<128, 3, 64, 2>";
+    }
     return m->cluster_name.c_str();
 }
 

@@ -304,6 +304,7 @@ hipError_t ape_prepare_lstm_tile16(int H, int L, size_t smem_bytes);
 hipError_t ape_prepare_lstm_tile16_wide(size_t smem_bytes);
 hipError_t ape_prepare_lstm_tile16_upper(int H, int L, size_t smem_bytes);   // layers 1.. of a model on their own: <256,1,wide>, <128,2,wide>
 bool ape_cluster_supported(int H, int L, int KX);
+bool ape_cluster_layer0_supported(int H, int KX);
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster(int H, int L, int KX, int nmt, bool dropout, int clusters, const ClusterParams& p,
                                    hipStream_t stream);
@@ -317,6 +318,12 @@ hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const C
 bool ape_cluster16_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster16(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster16(int H, int L, int KX, int rows, const ClusterParams& p, hipStream_t stream);
+// level-synchronous kernel for short windows of the 3 x 128 model (lstm_level16.hip: 16-window clusters, two workgroups per CU)
+bool ape_level16_supported(int H, int L, int KX);
+int ape_level16_max_clusters(int n_cus);
+size_t ape_level16_gx_bytes(int n_cus);
+hipError_t ape_prepare_lstm_level16(int H, int L, int KX);
+hipError_t ape_launch_lstm_level16(int H, int L, int KX, int rows, const ClusterParams& p, hipStream_t stream);
 bool ape_upper32_supported(int H, int L, int O);
 size_t ape_upper32_xfrag_bytes(int rows, int T);
 size_t ape_upper32_ypart_bytes(int rows);

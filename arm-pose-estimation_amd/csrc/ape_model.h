@@ -69,6 +69,9 @@ struct ape_model {
     bool c32_on = true;             // ... and is not switched off (APE_KERNEL_CLUSTER_GEN1)
     bool gen1_classes = true;       // first-generation f32 kernel: XCD-class cluster formation where the grid allows it
     bool c16_ok = false;            // lstm_cluster16.hip covers this model (3 x 128) on this device (switched with c32_on)
+    bool lv16_ok = false;           // ... and lstm_level16.hip its short windows (switched with c32_on too)
+    char* gx16 = nullptr;           // ... [256 B: launch number][granules {h, tag}: cluster, row tile, parity, layer]
+    size_t gx16_bytes = 0;
     int precision = APE_PRECISION_F32;
     bool wide_cluster = false;      // ImuPoseLSTM: the f32 first-generation cluster kernel with a 256-wide layer-0 input, nothing else
     bool small_batch_path = true;   // B <= 4 on the VALU/shuffle variant of the cluster kernel

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     float* dbuf = own + NV * MR * SO;             // [L-1][MR][SH] gathered MASKED h (DROP only)
     unsigned* look_s = reinterpret_cast<unsigned*>(dbuf + (DROP ? (L - 1) * MR * SH : 0));   // [wave 4][64]: landing zones of the flag looks (async_look.h)
     int* ctl = reinterpret_cast<int*>(look_s + 4 * 64);         // [0] abort flag, [1] arrival ticket, [2] last-out
+    unsigned* arrive = reinterpret_cast<unsigned*>(ctl + 4);    // [L]: publishes of layer l whose stores have drained, over this member's four waves
     // A launch that finds the sticky status word set -- an earlier launch on this model aborted and skipped its
     // self-cleaning, so tickets, flags and counters are stale -- leaves without touching anything (status 2 tells
     // ape_model_check that later launches ran into it), and so does a workgroup whose ticket lies outside the grid.
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     unsigned* const class_ticket = p.xcc_slots + 64;
     unsigned* const xcc_words = p.xcc_slots + 64 + 8 * 16;
     const int cls = blockIdx.x & 7;
+    if (threadIdx.x < L) arrive[threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
         ctl[0] = 0;
         ctl[1] = -1;
@@ -379,13 +381,20 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     // The flag a wave owes for the slice it stored last: raised once those stores have drained -- a few k-blocks
     // into the NEXT section's MFMAs (the write-through latency hides there), or at the latest before this wave
     // blocks on anybody else's flag.
-    int pend_idx = -1;
+    // Raised per MEMBER (round 6): every wave arrives on the layer's LDS counter once its own stores have drained, and the last of the four
+    // stores the member's four flag words in ONE instruction.  32 .. 64 waves each storing its own word of the same one or two cache lines
+    // at about the same time complete one after the other on the memory side; the last of them became visible microseconds after it was
+    // issued (measured on lstm_cluster16.hip's final gather: 3 .. 7 us, profiles/r06_flag_serialisation.md).
+    int pend_idx = -1;                      // layer of the pending publish
     unsigned pend_epoch = 0u;
     auto raise_pending = [&]() {
         if (pend_idx < 0) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's slice stores are complete
-        if (!diag_noex && lane == 0)
-            __hip_atomic_store(myflags + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned prev = 0u;
+        if (lane == 0) prev = __hip_atomic_fetch_add(arrive + pend_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (!diag_noex && prev + 1u == 4u * pend_epoch && lane < 4)
+            __hip_atomic_store(myflags + pend_idx * NFL + member * 4 + lane, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_idx = -1;
     };
 
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
                     if (p.hseq != nullptr && l == L - 1 && v == 0 && row0 + row < p.B)
                         *reinterpret_cast<f32x4*>(p.hseq + ((size_t)(row0 + row) * T + t) * H + member * 16 + 4 * wave) = hv;
                 }
-                pend_idx = l * NFL + member * 4 + wave;
+                pend_idx = l;
                 pend_epoch = (unsigned)(t + 1);
             }
             STAMP_END(6);                                // 6: publish store issue
@@ -656,7 +665,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster(const ClusterParams p
     //      h^{L-1}_{T-1} (GH x RPM x 4 sixteen-byte pieces = at most one per thread, not the whole 64 KB slice set)
     //      (all-steps callers -- y == nullptr: the head runs over the sequence afterwards, or not at all -- skip it: nobody waits for
     //       the last step's flags then, and the wait below keeps this wave's flag store out of the last workgroup's re-zeroing)
-    if (p.y == nullptr) {
+    //      (only the one-layer form, launch A of a bank, takes the short cut: the all-steps launches of whole models keep the wait for the
+    //       last step's flags in front of the departure counter, as before round 5 -- ADVICE r05)
+    if (L == 1 && p.y == nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         constexpr int RPM = (MR + GH - 1) / GH;          // rows per member
@@ -737,7 +748,7 @@ template <int H, int L, int KX, int NMT, bool DROP>
 size_t smem_bytes() {
     constexpr int MR = 16 * NMT, NV = DROP ? 2 : 1;
     return ((size_t)L * MR * (H + 8) + (size_t)MR * (KX + 8) + (size_t)NV * MR * 20 +
-            (size_t)(DROP ? (L - 1) * MR * (H + 8) : 0) + 4 * 64 + 4) * sizeof(float);
+            (size_t)(DROP ? (L - 1) * MR * (H + 8) : 0) + 4 * 64 + 4 + 4) * sizeof(float);
 }
 
 template <int H, int L, int KX, int NMT, bool DROP>
@@ -761,8 +772,12 @@ hipError_t prepare() {
 // 128 + 128 weight registers per lane = the whole accumulator file, one or two row tiles, no dropout -- its Monte-Carlo
 // mode is the plain forward, nn_models.py:246-251)
 bool ape_cluster_supported(int H, int L, int KX) {
-    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && (L == 3 || L == 1) && KX == 64) || (H == 256 && L == 1 && KX == 32);
+    return (H == 256 && L == 2 && (KX == 32 || KX == 256)) || (H == 128 && L == 3 && KX == 64);
 }
+// layer 0 of a deployed shape on its own (launch A of a Monte-Carlo bank): ONE instantiation each, no dropout, two row tiles.  Not a
+// model shape: a user-built one-layer LSTM of these widths is served by the batch-tile kernel (the full-model predicate
+// must not answer for it, or ape_model_create takes the whole cluster set-up for a model it has no instantiations for)
+bool ape_cluster_layer0_supported(int H, int KX) { return (H == 128 && KX == 64) || (H == 256 && KX == 32); }
 
 #define APE_CL_DISPATCH(FN, ...)                                                     \
     if (H == 256 && L == 2 && KX == 32) {                                            \
@@ -784,6 +799,7 @@ bool ape_cluster_supported(int H, int L, int KX) {
     return hipErrorInvalidValue;
 
 hipError_t ape_prepare_lstm_cluster(int H, int L, int KX) {
+    if (L == 1 ? !ape_cluster_layer0_supported(H, KX) : !ape_cluster_supported(H, L, KX)) return hipErrorInvalidValue;
     for (int nmt : {1, 2, 4})
         for (bool dropout : {false, true}) {
             if (dropout && nmt == 4) continue;

@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef APE_CLUSTER_STAMPS
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     // eight waves, two per SIMD: unit group ug (4 hidden units = 16 tile columns) x row tile rt (16 windows).  A wave cannot issue anything
     // while its own MFMA occupies the matrix core (tools/experiments/mfma_chain_rate.hip: one v_fma between two MFMAs costs 12 cycles), so
     // the waves (ug, 0) and (ug, 1), which hold the same weights, take turns there: one's cell update, exchange and operand fetches run
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     f32x4* bias_s = reinterpret_cast<f32x4*>(patch + 4 * MR * 4);     // [wave 4][L][g 4]: start values of unit g's four gates
     unsigned* look_s = reinterpret_cast<unsigned*>(bias_s + 4 * L * 4);   // [wave NWV][64]: landing zones of the flag looks (async_look.h)
     int* ctl = reinterpret_cast<int*>(look_s + NWV * 64);             // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    unsigned* arrive = reinterpret_cast<unsigned*>(ctl + 4);          // [L]: publishes of layer l whose stores have drained, all waves of this member
     auto hb = [&](int l, int par) -> float* { return hbase + (l < L - 1 ? 2 * l + par : 2 * (L - 1)) * HL; };
 
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xFu;
+    if (tid < L) arrive[tid] = 0u;
     if (tid == 0) {
         ctl[0] = 0;
         ctl[1] = -1;
@@ -295,11 +300,19 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
         const unsigned buf = (unsigned)(l < L - 1 ? 2 * l + (step & 1) : 2 * (L - 1));
         dma_1k(opaque(hbase_lds + wave_kib) + buf * SET_BYTES + (unsigned)(k * NWV * 1024), dma_voff, hx_desc, src);
     };
-    int pend_idx = -1;
+    // The flag of a publish is raised per MEMBER, by the last of its waves whose store has drained (an arrival counter per layer in LDS), as
+    // ONE store instruction over the member's NWV flag words: 64 waves each storing its own word of the same two cache lines at about the
+    // same time serialise on the memory side -- write-through stores to one line complete one after the other -- and the last of them became
+    // visible 3 .. 7 us after it was issued (round 6, `profiles/r06_flag_serialisation.md`: the final gather of this kernel waited that long)
+    int pend_idx = -1;                      // layer of the pending publish
     unsigned pend_epoch = 0u;
     auto raise_pending = [&]() {
         if (pend_idx < 0) return;
-        if (lane == 0) __hip_atomic_store(flags_of + pend_idx, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned prev = 0u;
+        if (lane == 0) prev = __hip_atomic_fetch_add(arrive + pend_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev + 1u == (unsigned)NWV * pend_epoch && lane < NWV)
+            __hip_atomic_store(flags_of + pend_idx * NFL + member * NWV + lane, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_idx = -1;
     };
     auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -324,6 +337,15 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return c;
     };
+#endif
+#ifdef APE_CLUSTER_STAMPS
+    // timeline of cluster 0 / member 0 / wave 0 (100 MHz counter): [0] kernel entry, [1] prologue done, [2 + 3 ph + l] end of section (ph, l),
+    // then final publish, final gather, head, exit (tests/tools/timeline_uarm16.py)
+    unsigned long long tl[64];
+    int tl_n = 0;
+    auto tl_mark = [&]() { if (tl_n < 64) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); };
+    tl[tl_n++] = tl_entry;
+    tl_mark();
 #endif
     f32x4 pa = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                    // drained accumulator of the section in front
     auto section = [&](auto steady_tag, auto layer_tag, const int ph) -> bool {
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
             if (in_l2) store_16<false>(hv, off, hx_desc);
             else store_16<true>(hv, off, hx_desc);
             if (pactive) {
-                pend_idx = lp * NFL + member * NWV + wave;
+                pend_idx = lp;
                 pend_epoch = (unsigned)(tp + 1);
             }
         };
@@ -503,10 +525,19 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     for (int ph = 0; ph < P && ok; ++ph) {
         const bool st = ph >= L && ph <= T - 3;
         ok = st ? section(std::true_type{}, std::integral_constant<int, 0>{}, ph) : section(std::false_type{}, std::integral_constant<int, 0>{}, ph);
+#ifdef APE_CLUSTER_STAMPS
+        tl_mark();
+#endif
         if (!ok) break;
         ok = st ? section(std::true_type{}, std::integral_constant<int, 1>{}, ph) : section(std::false_type{}, std::integral_constant<int, 1>{}, ph);
+#ifdef APE_CLUSTER_STAMPS
+        tl_mark();
+#endif
         if (!ok) break;
         ok = st ? section(std::true_type{}, std::integral_constant<int, 2>{}, ph) : section(std::false_type{}, std::integral_constant<int, 2>{}, ph);
+#ifdef APE_CLUSTER_STAMPS
+        tl_mark();
+#endif
     }
     if (!ok) return;
 #ifdef APE_CLUSTER_STAMPS
@@ -525,22 +556,41 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
         const unsigned off = (lane < 16) ? hx_base(L - 1, (T - 1) & 1) + (unsigned)(((member * 4 + ug) * MR + rt * 16 + lane) * 16) : 0x80000000u;
         if (in_l2) store_16<false>(hv, off, hx_desc);
         else store_16<true>(hv, off, hx_desc);
-        pend_idx = (L - 1) * NFL + member * NWV + wave;
+        pend_idx = L - 1;
         pend_epoch = (unsigned)T;
     }
+#ifdef APE_CLUSTER_STAMPS
+    tl_mark();
+#endif
     // ---- final gather: h^{L-1}_{T-1} of every member ----------------------------------------------------------------------------
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         raise_pending();
+#ifdef APE_CLUSTER_STAMPS
+        tl_mark();
+        if (p.dbg_wg != nullptr && lane == 0 && cluster == 0) {       // when did every member wave of cluster 0 raise its last flag, and enter?
+            p.dbg_wg[256 + member * 8 + wave] = __builtin_amdgcn_s_memrealtime();
+            if (wave == 0) p.dbg_wg[320 + member] = tl_entry;
+        }
+#endif
         if (!prefetched) {
             wait_flags(L - 1, (unsigned)T);
+#ifdef APE_CLUSTER_STAMPS
+            tl_mark();
+#endif
 #pragma unroll
             for (int k = 0; k < NDMA; ++k) issue_piece(L - 1, T - 1, k);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef APE_CLUSTER_STAMPS
+        tl_mark();
+#endif
         bar();
         if (ctl[0] != 0) return;
     }
+#ifdef APE_CLUSTER_STAMPS
+    tl_mark();
+#endif
     // ---- head: member m finishes windows (MR / GH) m .. of the cluster's 32; 4 lanes per (window, target) ----------------------------
     {
         constexpr int RPM = MR / GH;
@@ -566,6 +616,13 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
             if (p.y != nullptr && live && part == 0 && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
         }
     }
+#ifdef APE_CLUSTER_STAMPS
+    tl_mark();
+    if (p.dbg_wg != nullptr && tid == 0 && cluster == 0 && member == 0) {
+        p.dbg_wg[128] = (unsigned long long)tl_n;
+        for (int i = 0; i < tl_n; ++i) p.dbg_wg[129 + i] = tl[i];
+    }
+#endif
     // ---- self-cleaning -----------------------------------------------------------------------------------------------------------------
     __syncthreads();
     if (tid == 0)
@@ -582,7 +639,7 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
 
 template <int H, int L, int KX, int RT>
 constexpr size_t smem16() {
-    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 256 * RT + (size_t)(KX / 16) * 256 * RT + 4 * RT * 64) * sizeof(float) + (size_t)4 * L * 4 * 16 + (size_t)4 * RT * 64 * sizeof(unsigned) + 16;
+    return ((size_t)(2 * (L - 1) + 1) * (H / 16) * 256 * RT + (size_t)(KX / 16) * 256 * RT + 4 * RT * 64) * sizeof(float) + (size_t)4 * L * 4 * 16 + (size_t)4 * RT * 64 * sizeof(unsigned) + 16 + 16;
 }
 
 }  // namespace

@@ -719,8 +719,18 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     if (!ok) return;
     // ---- final gather: h^{L-1}_{T-1} of every member (a section of layer L-1 "on step T": S0 only) -------------------------------
     {
+        // the last step's flags go up per MEMBER: every wave has drained its store in front of the barrier, wave 0 stores the member's four
+        // words in one instruction.  (Round 6: a cluster's 32 per-wave flag stores to one cache line, all issued at about the same time,
+        // complete one after the other on the memory side -- the last one turned visible 3 .. 7 us after its issue, measured on
+        // lstm_cluster16.hip's final gather, profiles/r06_flag_serialisation.md.  In the sections the looks are asynchronous and the
+        // stores spread out; here every wave of the cluster is waiting for exactly these words.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        raise_pending();
+        bar();
+        if (pend_idx >= 0) {
+            if (wave == 0 && lane < 4)
+                __hip_atomic_store(flags_of + (pend_idx - wave) + lane, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend_idx = -1;
+        }
         if (!prefetched) {
             wait_flags(L - 1, (unsigned)T);
 #pragma unroll

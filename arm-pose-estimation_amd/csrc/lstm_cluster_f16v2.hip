@@ -350,6 +350,15 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
             // its time to leave the CU, and the peers look at these words early to prefetch (measured: 252 vs 289 us)
             __hip_atomic_store(f, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // (pend_set stays: the waves of a member may take different paths to the barrier, and behind it wave 0 raises for all of them)
+    };
+    // the same behind the section's barrier, in front of which EVERY wave of the member has drained its store: wave 0 raises the member's
+    // four words in one store instruction (round 6: the 32 per-wave flag stores of a cluster to one cache line complete one after the other
+    // on the memory side -- lstm_cluster16.hip, profiles/r06_flag_serialisation.md; a quarter of the stores here)
+    auto raise_member = [&]() {
+        if (pend_set < 0) return;
+        if (wave == 0 && lane < 4)
+            __hip_atomic_store(flags_of + pend_set * NFL + member * 4 + lane, pend_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_set = -1;
     };
     // workgroup barrier that waits for this wave's LDS traffic only (not for the publish store or a DMA in flight)
@@ -379,16 +388,17 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                 issue_gather(s, (ph - 1) & 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the prefetched copy; only the publish store is younger
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetched copy AND this wave's publish store (raise_member below)
             }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         prefetched = false;
         V2_STAMP(1);                                              // 1: wait for the gather
         bar();
         V2_STAMP(3);                                              // 3: barrier
         if (!ST && ph == P) {                                     // gather-only tail (no per-set register state is needed any more)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            raise_pending();
+            raise_member();
             return ctl[0] == 0;
         }
         // the flag owed for the OTHER set's publish store, issued at the end of the section in front: right behind the
@@ -396,8 +406,7 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
         // here 244 us; after the layer-0 MFMAs (the store certainly drained, nothing waits) 252 us; after layer 0's gate
         // math 292 us -- the later the flag, the more gathers miss their prefetch and fall back to the blocking form
         if (F16_RAISE_AT == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!d_noex) raise_pending();
+            if (!d_noex) raise_member();
         }
         const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
         // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
