@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "arm-pose-estimation_amd", "csrc")
 
 
-@pytest.mark.parametrize("name", ["lstm_cluster16.hip", "lstm_cluster32.hip", "lstm_upper32.hip", "lstm_cluster_f16v2.hip", "lstm_mc_small.hip",
+@pytest.mark.parametrize("name", ["lstm_cluster16.hip", "lstm_level16.hip", "lstm_cluster32.hip", "lstm_upper32.hip", "lstm_cluster_f16v2.hip", "lstm_mc_small.hip",
                                   "lstm_cluster_small.hip", "lstm_upper128.hip", "lstm_cluster.hip", "mlp_pipe.hip"])
 def test_no_unguarded_adjacency_around_asm_mfmas(name):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py"), name], cwd=CSRC, capture_output=True, text=True)
@@ -21,6 +21,8 @@ def test_no_unguarded_adjacency_around_asm_mfmas(name):
     assert "0 VALU-written SGPRs read early by an asm vector-memory instruction" in r.stdout
     assert "0 touches of an in-flight asm load's destination" in r.stdout
     assert "0 VALU writes of a wide asm store's data inside its 2 wait states" in r.stdout
+    assert "0 compiler reads of an asm-written M0" in r.stdout
+    assert "0 transcendental results read by the next instruction inside an asm statement" in r.stdout
 
 
 def test_the_checker_sees_both_patterns(tmp_path):
@@ -34,15 +36,31 @@ def test_the_checker_sees_both_patterns(tmp_path):
 	v_mfma_f32_16x16x4_f32 v[118:121], v53, v125, v[118:121]
 	s_cbranch_vccnz .LBB0_2
 	s_nop 0
-.LBB0_2:
+.LBB0_2:                                ;   in Loop: Header=BB0_1 Depth=1
 	v_mov_b32_e32 v141, v121
 	s_nop 15
 	v_mov_b32_e32 v140, v120
 	s_endpgm
 """)
+    # (the label carries the trailing comment hipcc gives every label inside a loop: that form blinded the branch-following passes for two
+    #  rounds, VERDICT r05 -- every fragment of this file uses it now)
     assert len(chk.scan(str(f))) == 1
     early = chk.scan_early_reads(str(f))
     assert len(early) == 1 and early[0][3].startswith("v_mov_b32_e32 v141")
+    # the same read reached only THROUGH a taken branch into a commented in-loop label
+    f2 = tmp_path / "k2.s"
+    f2.write_text("""
+	v_mfma_f32_16x16x4_f32 v[118:121], v53, v125, v[118:121]
+	s_cbranch_scc1 .LBB0_7
+	s_nop 15
+	s_branch .LBB0_8
+.LBB0_7:                                ;   in Loop: Header=BB0_3 Depth=2
+	v_mov_b32_e32 v141, v121
+.LBB0_8:                                ;   in Loop: Header=BB0_3 Depth=2
+	s_endpgm
+""")
+    early2 = chk.scan_early_reads(str(f2))
+    assert len(early2) == 1 and early2[0][3].startswith("v_mov_b32_e32 v141"), early2
     # round 4: a spilled buffer descriptor reloaded by v_readlane_b32 right in front of an asm load (5 wait states needed)
     g = tmp_path / "g.s"
     g.write_text("""
@@ -60,9 +78,15 @@ def test_the_checker_sees_both_patterns(tmp_path):
 	v_readlane_b32 s60, v161, 4
 	s_nop 4
 	buffer_store_dwordx2 v[96:97], v70, s[60:63], 0 offen
+	v_readlane_b32 s64, v161, 4
+.LBB2_9:                                ;   in Loop: Header=BB2_4 Depth=1
+	;;#ASMSTART
+	buffer_load_dwordx4 v[74:77], v78, s[64:67], 0 offen sc1
+	;;#ASMEND
 """)
     hits = chk.scan_sgpr_into_asm_vmem(str(g))
-    assert len(hits) == 2 and all("s[48:51]" in h[3] for h in hits)      # the padded load and the compiler's own store are fine
+    # the padded load and the compiler's own store are fine; a (commented, in-loop) label ends the straight-line look-back
+    assert len(hits) == 2 and all("s[48:51]" in h[3] for h in hits)
 
 
 def test_the_checker_sees_the_store_data_pattern(tmp_path):
@@ -163,4 +187,80 @@ def test_no_asm_load_lands_in_a_compiler_allocated_register():
             waited_inside = re.search(r"_load_\w+(?:(?!_load_).)*s_waitcnt vmcnt\(0\)\s*\"?\s*$", text.strip(), flags=re.S) is not None
             if any(" lds" not in ld for ld in loads) and re.search(r'"=&?v"', outputs) and not waited_inside:
                 offenders.append((fn, src[:m.start()].count("\n") + 1))
+    assert not offenders, offenders
+
+
+def test_the_uneven_load_case_list_matches_the_child_file():
+    """tests/test_hip_round5.py names every case of tests/hooks/uneven_load_cases.py statically (its collection must not need a GPU); this
+    keeps the list honest on the CPU: the child file's collected ids are exactly the parent's list"""
+    import re
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "hooks", "uneven_load_cases.py"), "--collect-only", "-q",
+                        "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True)
+    child = {ln.split("::", 1)[1].strip() for ln in r.stdout.splitlines() if "::" in ln}
+    src = open(os.path.join(ROOT, "tests", "test_hip_round5.py")).read()
+    listed = set(re.findall(r'^    "(test_[^"]+)",$', src, re.M))
+    assert child and child == listed, sorted(child ^ listed)
+
+
+def test_the_checker_sees_a_compiler_read_of_an_asm_written_m0(tmp_path):
+    """round 6: the LDS-DMA statements write M0 inside the asm; a compiler-emitted reader of M0 behind one of them, with no
+    compiler write of M0 in between, is reported -- explicit operands and the implicit readers (register-relative moves, its own LDS-DMA)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_mfma_hazards as chk
+    f = tmp_path / "m.s"
+    f.write_text("""
+	s_mov_b32 m0, s9
+	v_movrels_b32_e32 v4, v10
+	;;#ASMSTART
+	s_mov_b32 m0, s40
+	s_nop 0
+	buffer_load_dwordx4 v1, s[20:23], s33 offen sc1 lds
+	;;#ASMEND
+.LBB3_5:                                ;   in Loop: Header=BB3_2 Depth=1
+	v_movrels_b32_e32 v5, v10
+	s_add_u32 s3, m0, 4
+	s_mov_b32 m0, s9
+	v_movrels_b32_e32 v6, v10
+	s_endpgm
+""")
+    hits = chk.scan_m0_after_asm(str(f))
+    assert len(hits) == 2 and hits[0][3].startswith("v_movrels_b32_e32 v5") and hits[1][3].startswith("s_add_u32 s3, m0"), hits
+
+
+def test_the_checker_sees_a_transcendental_result_read_inside_asm(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_mfma_hazards as chk
+    f = tmp_path / "t.s"
+    f.write_text("""
+	v_exp_f32_e32 v7, v3
+	;;#ASMSTART
+	v_max_f32 v9, v9, v7
+	;;#ASMEND
+	v_rcp_f32_e32 v8, v3
+	s_nop 0
+.LBB5_2:                                ;   in Loop: Header=BB5_1 Depth=1
+	;;#ASMSTART
+	v_max_f32 v9, v9, v8
+	;;#ASMEND
+	v_exp_f32_e32 v7, v3
+	v_max_f32_e32 v9, v9, v7
+	s_endpgm
+""")
+    hits = chk.scan_trans_into_asm_valu(str(f))
+    assert len(hits) == 1 and hits[0][1].startswith("v_exp_f32_e32 v7") and hits[0][3].startswith("v_max_f32 v9, v9, v7"), hits
+
+
+def test_no_per_element_bit_cast_of_a_vector_in_an_array():
+    """round 6 (lstm_level16.hip): hipcc 7.2 folded `__builtin_bit_cast(float, v[q][0])` / `(.., v[q][2])` of an asm statement's vector
+    outputs into a splat of element 0 (`ds_write2_b32 .., v62, v62`: both windows of a granule pair took the first one's value; every
+    output off by 1e-2).  No scan of the compiled code names that; the source form is kept out instead: elements of a vector that lives in an
+    array are moved as the words they are, or the whole vector is cast at once (lstm_cluster16.hip already notes the same folding on loads)."""
+    import re
+    offenders = []
+    for fn in sorted(os.listdir(CSRC)):
+        if not fn.endswith((".hip", ".h")): continue
+        for n, line in enumerate(open(os.path.join(CSRC, fn)), 1):
+            if line.lstrip().startswith("//"): continue
+            if re.search(r"__builtin_bit_cast\(\s*(float|unsigned|int)\s*,\s*[A-Za-z_][A-Za-z_0-9]*\[[^\]]+\]\[[^\]]+\]\s*\)", line):
+                offenders.append(f"{fn}:{n}: {line.strip()[:120]}")
     assert not offenders, offenders

@@ -19,6 +19,15 @@ bits issued inside an asm statement, its data registers written by a VALU instru
 `v_add_u32 v2, 1, v51` right behind an untaken branch, v[2:5] being the store's data).  The store reads its data late (gfx940 and later: 2
 wait states; none if a buffer store's soffset is an SGPR -- LLVM's GCNHazardRecognizer, VMEM store-data hazard); hipcc pads the stores it
 emits itself, an asm statement is opaque to it.
+A sixth pattern, named by the round-5 code review before it was ever seen (round 6): the LDS-DMA statements write M0 inside the asm
+(`s_mov_b32 m0, %0`) and hipcc does not know -- listing "m0" as a clobber changes no code and draws a "reserved register" warning.  A
+compiler-emitted instruction that READS M0 (s_movrel / v_movrel indexing, its own `buffer_load ... lds`, s_sendmsg, ds_gws, an explicit m0
+operand) while the last writer of M0 in layout order was an asm statement would use the asm's LDS address as its index.  The kernels give the
+compiler no reason to use M0 (no dynamically indexed register arrays in the loops that hold the DMA statements); the scan makes that a
+checked fact of every build.
+A seventh, from the same table: gfx940 and later need one wait state between a transcendental VALU instruction
+(v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos) and a non-transcendental VALU instruction that reads its result; hipcc pads its own
+consumers, not a VALU instruction inside an asm statement (the packed multiply / max of mlp_pipe.hip, the permlane swaps, an MFMA).
     tools/check_mfma_hazards.py file.hip [extra hipcc flags]     exit code 1 when a hazard is found"""
 import re, subprocess, sys, tempfile
 
@@ -195,6 +204,55 @@ def scan_asm_wide_stores(path, need=2):
                 j += 1
     return sorted(bad)
 
+TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
+
+def scan_trans_into_asm_valu(path):
+    """a VALU instruction INSIDE an asm statement that reads, as the very next instruction, the result of a transcendental one"""
+    ins, in_asm = [], False
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"): in_asm = True; continue
+        if t.startswith(";;#ASMEND"): in_asm = False; continue
+        c = t.split(";")[0].strip()
+        if not c or c.startswith((".", "//")) or c.endswith(":"): continue
+        ins.append((n, c, in_asm))
+    bad = []
+    for i in range(1, len(ins)):
+        n, t, a = ins[i]
+        pn, pt, _ = ins[i - 1]
+        if not a or not t.startswith("v_") or " " not in t or not pt.startswith(TRANS) or " " not in pt: continue
+        dst = regs(pt.split(None, 1)[1].split(",")[0].strip())
+        srcs = set()
+        for o in t.split(None, 1)[1].split(",")[1:]: srcs |= regs(o.strip().split(" ")[0])
+        if t.startswith(("v_mfma", "v_smfmac")): srcs |= regs(t.split(None, 1)[1].split(",")[0].strip())
+        if dst & srcs: bad.append((pn, pt, n, t))
+    return bad
+
+M0_IMPLICIT = ("s_movrel", "v_movrel", "s_sendmsg", "ds_gws", "v_interp", "ds_append", "ds_consume", "ds_ordered_count")
+
+def scan_m0_after_asm(path):
+    """a compiler-emitted instruction that reads M0 -- explicitly, or implicitly (M0_IMPLICIT, its own LDS-DMA loads) -- while the last write
+    of M0 in layout order came from inside an asm statement (labels and branches do not reset the state: conservative)"""
+    ins, in_asm = [], False
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"): in_asm = True; continue
+        if t.startswith(";;#ASMEND"): in_asm = False; continue
+        c = t.split(";")[0].strip()
+        if not c or c.startswith((".", "//")) or c.endswith(":"): continue
+        ins.append((n, c, in_asm))
+    bad, writer = [], None
+    for n, t, a in ins:
+        parts = t.split(None, 1)
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        toks = re.findall(r"[A-Za-z_][A-Za-z_0-9]*", parts[1]) if len(parts) > 1 else []
+        writes = bool(ops) and ops[0] == "m0" and parts[0].startswith("s_")
+        reads = ("m0" in toks[1:] if writes else "m0" in toks) or parts[0].startswith(M0_IMPLICIT) or \
+                (parts[0].startswith(("buffer_load", "global_load")) and (t.endswith(" lds") or " lds " in t or parts[0].startswith("global_load_lds")))
+        if not a and reads and writer is not None and writer[0]: bad.append((writer[1], writer[2], n, t))
+        if writes: writer = (a, n, t)
+    return bad
+
 if __name__ == "__main__":
     src = sys.argv[1]
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
@@ -206,12 +264,17 @@ if __name__ == "__main__":
         sg = scan_sgpr_into_asm_vmem(f.name)
         al = scan_async_asm_loads(f.name)
         ws = scan_asm_wide_stores(f.name)
+        m0 = scan_m0_after_asm(f.name)
+        tr = scan_trans_into_asm_valu(f.name)
     for pn, pt, n, t in bad: print(f"{src}: line {pn}: {pt}   ->   line {n}: {t}")
     for n, t, qn, qt in early: print(f"{src}: line {n}: {t}   read early by   line {qn}: {qt}")
     for pn, pt, n, t, st in sg: print(f"{src}: line {pn}: {pt}   ->   asm line {n}: {t}   ({st} wait states, 5 needed)")
     for n, t, qn, qt in al: print(f"{src}: asm load line {n}: {t}   destination touched in front of its wait by   line {qn}: {qt}")
     for n, t, qn, qt, st in ws: print(f"{src}: asm store line {n}: {t}   data register written {st} wait state(s) later (2 needed) by   line {qn}: {qt}")
+    for pn, pt, n, t in tr: print(f"{src}: line {pn}: {pt}   ->   asm line {n}: {t}   (a transcendental's result needs one wait state)")
+    for wn, wt, n, t in m0: print(f"{src}: asm line {wn}: {wt}   wrote M0, read by the compiler's   line {n}: {t}")
     print(f"{src}: {len(bad)} VALU-write -> MFMA SrcA/SrcB adjacencies, {len(early)} early reads of an MFMA result, "
           f"{len(sg)} VALU-written SGPRs read early by an asm vector-memory instruction, {len(al)} touches of an in-flight asm load's destination, "
-          f"{len(ws)} VALU writes of a wide asm store's data inside its 2 wait states")
-    sys.exit(1 if bad or early or sg or al or ws else 0)
+          f"{len(ws)} VALU writes of a wide asm store's data inside its 2 wait states, {len(m0)} compiler reads of an asm-written M0, "
+          f"{len(tr)} transcendental results read by the next instruction inside an asm statement")
+    sys.exit(1 if bad or early or sg or al or ws or m0 or tr else 0)
