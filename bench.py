@@ -594,6 +594,85 @@ def dispatch_boundaries(n_iter=30):
     return out
 
 
+def beside_neighbour(model, x, n_launch=40):
+    """what the write-through hand-over's bytes cost when the memory side is busy.  Two weight-stationary kernels --
+    `ape_lstm_cluster32` on the headline shape (306 MB of counter traffic per launch for 5.8 MB of algorithmic bytes) and the upper-arm bank's
+    `ape_lstm_upper128` (1.03 GB per launch) -- timed ALONE and BESIDE a queue of 256 MiB device-to-device copies on a second stream (the
+    uneven-load tests' streamer), and the copies' achieved rate alone and beside each kernel.  One measurement each, HIP events."""
+    from wear_mocap_ape_amd import _hip
+    from wear_mocap_ape_amd.streams import StreamBank
+    from wear_mocap_ape_amd.utility.names import NNS_INPUTS, NNS_TARGETS
+    out = {}
+    try:
+        lib = _hip.lib()
+        side = torch.cuda.Stream()
+        src = torch.full((64 << 20,), 1.0, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(src)
+        copy_bytes = 2.0 * src.numel() * 4              # read + write
+
+        def copies(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(side):
+                a.record(side)
+                for _ in range(n):
+                    dst.copy_(src, non_blocking=True)
+                b.record(side)
+            return a, b
+
+        a, b = copies(20)
+        b.synchronize()
+        out["copies_alone_GBps"] = 20 * copy_bytes / (a.elapsed_time(b) * 1e-3) / 1e9
+
+        def beside(step, n, copies_per_burst):
+            """`step()` n times alone, then n times while a burst of copies runs; per-launch microseconds both ways and the burst's rate"""
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2 * n)]
+            for i in range(n):
+                ev[i][0].record(); step(); ev[i][1].record()
+            torch.cuda.synchronize()
+            ca, cb = copies(copies_per_burst)
+            for i in range(n, 2 * n):
+                ev[i][0].record(); step(); ev[i][1].record()
+            torch.cuda.synchronize()
+            alone = float(np.median([p.elapsed_time(q) for p, q in ev[:n]])) * 1e3
+            # only the launches that ended before the burst did ran beside it
+            burst_ms = ca.elapsed_time(cb)
+            t_in = [ca.elapsed_time(q) for p, q in ev[n:]]
+            inside = [p.elapsed_time(q) * 1e3 for (p, q), t in zip(ev[n:], t_in) if t < burst_ms]
+            return alone, (float(np.median(inside)) if inside else None), len(inside), copies_per_burst * copy_bytes / (burst_ms * 1e-3) / 1e9
+
+        B, T = x.shape[0], x.shape[1]
+        y = torch.empty((B, POCKET["O"]), dtype=torch.float32, device=x.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        step = lambda: _hip.check(lib.ape_lstm_forward(model.handle, C.c_void_p(x.data_ptr()), B, T, _hip.FLAG_NORMALIZE_INPUT, None, 0.0, 0,
+                                                       C.c_void_p(y.data_ptr()), st), "ape_lstm_forward")
+        al, be, n_in, rate = beside(step, n_launch, 450)
+        model.check()
+        out["ape_lstm_cluster32_1024x64"] = {"us_alone": al, "us_beside_copies": be, "launches_beside": n_in, "slowdown": (be / al) if be else None,
+                                             "copies_GBps_beside": rate}
+        um = _bank_model(UARM, (NNS_INPUTS.WATCH_PHONE_CAL_ALL, NNS_TARGETS.ORI_CAL_LARM_UARM))
+        width = _hip.PARSE_SHAPES[_hip.PARSE_WATCH_PHONE_UARM][0]
+        rows = torch.from_numpy(np.random.default_rng(5).normal(size=(1024, width)).astype(np.float32)).cuda()
+        bank = StreamBank(um, 1024, 6, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=50, dropout=0.2)
+
+        def frame():
+            bank.push_rows(rows, _hip.PARSE_WATCH_PHONE_UARM)
+            bank.step_datagrams()
+        for _ in range(8):
+            frame()
+        al, be, n_in, rate = beside(frame, 12, 240)
+        um.check()
+        out["uarm_bank_frame_S1024_mc50"] = {"us_alone": al, "us_beside_copies": be, "frames_beside": n_in, "slowdown": (be / al) if be else None,
+                                             "copies_GBps_beside": rate, "dominant_kernel": "ape_lstm_upper128 (1.03 GB of counter traffic per launch)"}
+        out["note"] = ("copies: 256 MiB device-to-device on a second stream, rate = bytes read + written over the burst's elapsed time; "
+                       "`beside` = median over the launches that ended inside the burst")
+    except Exception as exc:                # reported, never fatal for the headline line
+        out["error"] = str(exc)[:300]
+    return out
+
+
 def other_paths():
     """the SURVEY 8 'next' rows beside the headline, each one measurement (HIP events) on synthetic inputs with seeded random
     weights: the MLP regressor and ImuPoseLSTM (f3) and the ensemble Kalman estimator (f4 tail, parity unpinned)"""
@@ -828,6 +907,10 @@ def compact_line(out):
     line["roofline"] = {k: _r(rf[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "traffic_stale",
                                                   "kernel", "kernel_ms", "flop_per_launch", "hbm_algorithmic_bytes_per_launch",
                                                   "hbm_frac") if k in rf}
+    bn = rf.get("beside_memory_bound_neighbour") or {}
+    if bn and "error" not in bn:
+        line["roofline"]["slowdown_beside_copies"] = {"cluster32": _r(g(bn, "ape_lstm_cluster32_1024x64", "slowdown"), 3),
+                                                      "uarm_bank_frame": _r(g(bn, "uarm_bank_frame_S1024_mc50", "slowdown"), 3)}
     cs = out.get("cold_start") or {}
     line["cold_start_ms"] = [_r(cs.get("first_step_ms")), _r(cs.get("mean_of_first_10_steps_ms"))]
     cb = out.get("cpu_baseline")
@@ -1162,6 +1245,7 @@ def main():
             out["stream_bank_T6"] = stream_bank_numbers(model, stats)
             out["other_paths"] = other_paths()
             out["dispatch_boundaries"] = dispatch_boundaries()
+            out["roofline"]["beside_memory_bound_neighbour"] = beside_neighbour(model, x)
             out["fp16_config4"] = fp16_config4(data_stats.get_norm_stats(NNS_INPUTS.WATCH_ONLY_CAL,
                                                                          NNS_TARGETS.ORI_CAL_LARM_UARM))
             if not args.no_cpu_baseline:
