@@ -378,6 +378,10 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     bool prefetched = false;
     auto section = [&](auto steady_tag, const int ph, const int s) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 2 <= ph <= T - 3, every condition below holds
+        // (Round 6, measured and dropped: the next step's x staged HERE, in front of the wait for the gather, instead of between the layers'
+        //  MFMAs -- 238.8 against 236.1 us.  The slab's registers come from compiler-issued loads, and hipcc's own `s_waitcnt vmcnt(n)` in front of
+        //  their first use counts only the vector-memory operations it knows: the asm-issued look and gather behind them are not in its count,
+        //  so it waits for them too and nothing overlaps.)
         // ---- S0: this set's slices of the last phase into LDS ------------------------------------------------------------
         if (ST || ph > 0) {
             if (!prefetched && !d_noex) {                         // first phases, a late peer, the final gathers

@@ -5,7 +5,7 @@
 // lstm_cluster.hip / lstm_cluster16.hip software-pipeline the three layers (phase p: layer l on step p - l) and hide a section's hand-over
 // behind the two other sections of the phase.  At T = 6 that pipeline is eight phases of which four are fill / drain: their hand-overs
 // have nothing to hide behind, the idle sections still pay their barriers and waits, and both row tiles of a CU wait at the same time
-// (lstm_cluster16.hip's timeline at 1024 x 6: 58 us in the kernel for 26 us of matrix work, profiles/r06_uarm_T6.md).  This kernel turns
+// (lstm_cluster16.hip's timeline at 1024 x 6: 58 us in the kernel for 26 us of matrix work, profiles/r06_uarm_T6_timelines.md).  This kernel turns
 // the decomposition around:
 //   * LEVEL-synchronous: level k = every (layer l, step k - l) that exists, computed back to back from the slices of level k - 1 --
 //     ONE hand-over per level (T + 2 of them), no idle sections, no hooks inside the MFMA spans, every wait a plain blocking one;

@@ -164,6 +164,12 @@ class Estimator:
         return self._device_frame
 
     use_device_frame = True    # False: processing_loop runs the staged methods (parse -> predict -> message) like the reference
+    # True: with add_mc_samples the message is ONE float array of 25 + 6 N values instead of the reference's Python list of them
+    # (estimator.py:131-137).  Everything the reference does with the message takes either (`struct.pack('f' * len(msg), *msg)`,
+    # stream/publisher/pose_est_udp.py:47; np.array(msg)); building the list is the largest host cost of a Monte-Carlo frame -- 1825 floats
+    # at 60 samples x smooth 5: ~20 us of a 58 us frame, and most of its p99 (bench.py batch1.estimator_loop).  Opt-in: the default keeps
+    # the reference's type.
+    msg_as_array = False
 
     def process_row(self, row):
         """one iteration of the consumer loop (estimator.py:174-177): raw message -> the message put on the queue"""
@@ -176,6 +182,8 @@ class Estimator:
         if not self._add_mc_samples:
             return self._last_msg.copy()
         # list of 25 floats followed, for N > 1 stacked rows, by every row's hand and elbow xyz (estimator.py:131-137)
+        if self.msg_as_array:
+            return out.copy() if out.shape[0] > 31 else self._last_msg.copy()
         return out.tolist() if out.shape[0] > 31 else out[:25].tolist()
 
     @staticmethod

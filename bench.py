@@ -335,10 +335,13 @@ def estimator_loop(sd, n_frames=1000):
         rows = [array("f", r.tolist()) for r in g["rows"]]
         for mc, smooth in ((1, 1), (25, 1), (60, 5)):
             ent = {}
-            for form in ("device_frame", "staged"):
+            for form in ("device_frame", "device_frame_array", "staged"):
+                if form == "device_frame_array" and mc == 1:
+                    continue                    # (25 values: nothing to save)
                 est = WatchPhonePocketNN(model_hash=h, smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
-                est.use_device_frame = form == "device_frame"
-                n = n_frames if form == "device_frame" else max(200, n_frames // 4)
+                est.use_device_frame = form != "staged"
+                est.msg_as_array = form == "device_frame_array"      # opt-in: the message as one float array instead of a list (estimator.py)
+                n = n_frames if form != "staged" else max(200, n_frames // 4)
                 for i in range(30):
                     msg = est.process_row(rows[i % len(rows)])
                 us = np.empty(n)
@@ -360,6 +363,8 @@ def estimator_loop(sd, n_frames=1000):
                     ent[form]["split_p50_us"] = {"parse_row_to_xx": float(np.median(tt[:, 0]) * 1e6),
                                                  "add_xx_to_row_hist_and_make_prediction": float(np.median(tt[:, 1]) * 1e6),
                                                  "msg_from_pred": float(np.median(tt[:, 2]) * 1e6)}
+                elif form == "device_frame_array":
+                    ent[form]["p99_over_p50"] = ent[form]["p99_us"] / ent[form]["p50_us"]
                 else:
                     ent[form]["aborted_checks"] = est._hip_model().stats()["aborted_checks"]
                     # where a frame's wall time goes, frame by frame (ape_streams_frame_stats, ABI 7): inside the C call -- launch calls,
@@ -934,7 +939,9 @@ def compact_line(out):
         line["batch1"] = {"p50_us": _r(b1["p50_us"]), "p99_us": _r(b1["p99_us"]), "frames_per_s": _r(b1["frames_per_s"]),
                           "cpu_frames_per_s": _r(b1.get("cpu_frames_per_s")),
                           "estimator_loop_p50_p99_us": {k: [_r(g(v, "device_frame", "p50_us")), _r(g(v, "device_frame", "p99_us"))]
-                                                        for k, v in el.items() if isinstance(v, dict) and "device_frame" in v}}
+                                                        for k, v in el.items() if isinstance(v, dict) and "device_frame" in v},
+                          "estimator_loop_array_msg_p50_p99_us": {k: [_r(g(v, "device_frame_array", "p50_us")), _r(g(v, "device_frame_array", "p99_us"))]
+                                                                  for k, v in el.items() if isinstance(v, dict) and "device_frame_array" in v}}
     sb = out.get("stream_bank_T6")
     if sb:
         line["bank_frame_ms"] = {k: _r(v.get("ms_per_frame_of_all_streams")) for k, v in sb.items() if isinstance(v, dict)}

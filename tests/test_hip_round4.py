@@ -66,6 +66,17 @@ def test_consumer_loop_on_the_device_frame_replays_reference_traces(golden, tmp_
         est2 = cls(model_hash=h, smooth=smooth, add_mc_samples=False, monte_carlo_samples=mc)
         out = est2.process_row(array("f", g["rows"][0].tolist()))
         assert isinstance(out, np.ndarray) and out.shape == (25,) and np.abs(out - g[f"msg_{tag}"][0][:25]).max() < TOL_MSG_LOOP
+        # opt-in (round 6): the same message as ONE float array instead of a list -- what the reference's publisher packs either way
+        # (struct.pack('f' * len(msg), *msg), stream/publisher/pose_est_udp.py:47): same values, same length, same bytes on the wire
+        import struct
+        est4 = cls(model_hash=h, smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
+        est4.msg_as_array = True
+        est.reset()
+        for f, row32 in enumerate(g["rows"][:6]):
+            a = est.process_row(array("f", row32.tolist()))
+            b = est4.process_row(array("f", row32.tolist()))
+            assert isinstance(b, np.ndarray) and b.ndim == 1 and len(b) == len(a) and np.array_equal(np.asarray(a, dtype=b.dtype), b)
+            assert struct.pack("f" * len(a), *a) == struct.pack("f" * len(b), *b)
         # the staged methods (reference semantics, host histories) stay available and agree
         est3 = cls(model_hash=h, smooth=smooth, add_mc_samples=True, monte_carlo_samples=mc)
         est3.use_device_frame = False

@@ -33,8 +33,8 @@ case $1 in
 cluster32)
   passes python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline
   python3 tools/summarize_prof.py r06_cluster32 $P/trace $P/fetch $P/write "ape_lstm_cluster32<256, 2, 32, false>" 65536 1024 --model pocket --T 64 --pmc-dir $P/mfma --pmc-dir $P/wave \
-    --source csrc/lstm_cluster32.hip --lds 137232 --flop-per-launch 1.06039345152e11 --peak-tflops 157.3 --skip-first 60 --min-us 600 \
-    --note "Command (MI355X, one GPU): \`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline\` (40 pre-roll + 20 warm-up + 100 timed steps of the 1024 x 64 shape; the f32 leg of \`fp16_config4\` and the \`beside_memory_bound_neighbour\` launches follow -- the latter beside device copies, which is why the mean is taken over the first 160 launches only: --skip-first 60 of them); counters from separate \`--kernel-trace --pmc\` passes of the same command (FETCH_SIZE; WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY); recipe \`tools/prof_r06.sh cluster32\`.  Round 6 changed one thing in this kernel: the LAST step's flags go up per member (one store instruction behind a barrier)."
+    --source csrc/lstm_cluster32.hip --lds 137232 --flop-per-launch 1.06039345152e11 --peak-tflops 157.3 --skip-first 60 --count 100 --min-us 600 \
+    --note "Command (MI355X, one GPU): \`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline\` (40 pre-roll + 20 warm-up + 100 TIMED steps of the 1024 x 64 shape = launches 61..160, the ones summarised here; the f32 leg of \`fp16_config4\` and the \`beside_memory_bound_neighbour\` launches follow, the latter beside device copies); counters from separate \`--kernel-trace --pmc\` passes of the same command (FETCH_SIZE; WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY); recipe \`tools/prof_r06.sh cluster32\`.  Round 6 changed one thing in this kernel: the LAST step's flags go up per member (one store instruction behind a barrier)."
   python3 tools/summarize_prof.py r06_cluster32_T6 $P/trace $P/fetch $P/write "ape_lstm_cluster32<256, 2, 32, true>" 65536 1024 --model pocket --T 6 --pmc-dir $P/mfma --pmc-dir $P/wave \
     --source csrc/lstm_cluster32.hip --lds 137232 --flop-per-launch 9.94784051e9 --peak-tflops 157.3 --skip-first 10 \
     --note "The short-window instantiation (end forms) in the same bench.py command: the 1024-stream eval bank's LSTM launch (\`stream_bank_T6.S1024_mc1\`, T = 6) and the dispatch-boundary legs at 513 rows.  Round 6: the last step's flags per member -- 87.6 -> 83-86 us."

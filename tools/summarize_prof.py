@@ -40,6 +40,7 @@ ap.add_argument("--peak-tflops", type=float)
 ap.add_argument("--note", default="")
 ap.add_argument("--wg-threads", type=int, default=256)
 ap.add_argument("--skip-first", type=int, default=0, help="leave the first N matching launches out of the duration mean (clock ramp)")
+ap.add_argument("--count", type=int, default=0, help="only this many launches behind --skip-first (later launches of the command run under other conditions)")
 ap.add_argument("--min-us", type=float, default=0.0, help="only launches at least this long (the same instantiation also serves shorter windows)")
 ap.add_argument("--model", default=None, help="pocket | watch | uarm | ff | imupose: part of the traffic entry's key (the same kernel serves several models)")
 ap.add_argument("--T", type=int, default=None, help="window length of the profiled launches: part of the traffic entry's key")
@@ -78,6 +79,8 @@ tr = sorted((r for r in trace if mine(r)), key=lambda r: int(r["Start_Timestamp"
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
 dur = [d for d in dur if d >= args.min_us]
 steady = dur[args.skip_first:] if len(dur) > args.skip_first else dur
+if args.count:
+    steady = steady[:args.count]
 allk = {}
 for r in trace:
     allk.setdefault((r["Kernel_Name"], int(r["Grid_Size"])), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -143,7 +146,7 @@ except Exception:
     pass
 lines += ["| quantity | value |", "|---|---|", f"| launches in trace | {len(dur)} |"]
 if dur:
-    lines.append(f"| mean / min / max duration (us), launches {args.skip_first + 1}.. | {mean_us:.1f} / {min(steady):.1f} / {max(steady):.1f} |")
+    lines.append(f"| mean / min / max duration (us), launches {args.skip_first + 1}..{args.skip_first + len(steady) if args.count else ''} | {mean_us:.1f} / {min(steady):.1f} / {max(steady):.1f} |")
     if args.skip_first:
         lines.append(f"| mean of the first {args.skip_first} launches (clock ramp, us) | {statistics.mean(dur[:args.skip_first]):.1f} |")
 if res:
