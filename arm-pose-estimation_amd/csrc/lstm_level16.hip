@@ -209,6 +209,10 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_level16(const ClusterParams p
         }
     };
     fetch_x(0);
+    // the launch number of this model's level kernel (bumped by the last workgroup out): the upper bits of every tag.  Loaded in FRONT of the
+    // weights: the vector-memory counter is in issue order, so a value loaded behind them would be waited for behind all 44 weight loads --
+    // and level 0 needs only the first four of those
+    const unsigned seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu;
 
     // ---- weights: registers for the whole launch (both agents hold the member's slices); host layout of the first generation
     //      (ape_api.hip, wcl): [member][wave][register / 4][lane][4], register 4 q + j of lane (row c = lane & 15 = unit * 4 + gate,
@@ -255,8 +259,6 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_level16(const ClusterParams p
     const int tile = cluster * NA + agent;
     auto gx_base = [&](int par, int l) -> unsigned { return (unsigned)((((size_t)tile * 2 + par) * L + l) * GSET_BYTES); };
     const __amdgpu_buffer_rsrc_t gx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)p.hx_bytes, 0x00020000);
-    // the launch number of this model's level kernel (bumped by the last workgroup out): the upper bits of every tag
-    const unsigned seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu;
     const unsigned pub_off = (unsigned)(((member * 4 + ug) * 64 + lane) * 8);
     // sweep: thread tid_a takes pairs tid_a + 256 q (q = 0..3) of a set = granules 2 tid_a + 512 q (+ 1): producer member 2 q + (tid_a >> 7),
     // unit group (tid_a >> 5) & 3, unit (tid_a & 31) >> 3, windows 2 (tid_a & 7) (+ 1) -> LDS [member][unit group][window][unit]
