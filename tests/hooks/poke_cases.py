@@ -19,7 +19,7 @@ def _poke(lib):
     return lib.ape_debug_poke
 
 
-@pytest.mark.parametrize("name,B", [("pocket", 1), ("pocket", 64), ("pocket", 1024), ("uarm", 1024)])
+@pytest.mark.parametrize("name,B", [("pocket", 1), ("pocket", 64), ("pocket", 1024), ("uarm", 1024), ("uarm", 1000)])
 def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
     """state an aborted launch leaves behind (sticky status word set, tickets consumed): the next call on that handle must never
     return garbage silently.  Host outputs: the Python mirror recovers (ape_model_recover re-issues the call on the batch-tile
@@ -30,6 +30,7 @@ def test_aborted_cluster_launch_is_reissued_or_reported(norm_stats, name, B):
     poke = _poke(_hip.lib())
     T = cfg["T"] if B < 1024 else 64
     if B == 1024: assert m.kernel_name(B, T) == {"pocket": "ape_lstm_cluster32<256, 2, 32, false>", "uarm": "ape_lstm_cluster16<128, 3, 64, 2>"}[name]
+    if B == 1000: assert m.kernel_name(B, T) == "ape_lstm_level16<128, 3, 64>"      # (round 6: tagged granules, no flags -- the same status / ticket protocol)
     x = torch.from_numpy(_synthetic_windows(norm_stats[name], B, T, cfg["I"], 3))
     good = m(x, last_step_only=True, normalize_input=True).numpy().copy()
     m.set_kernel("tile16")
