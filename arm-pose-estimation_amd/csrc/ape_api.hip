@@ -1059,7 +1059,9 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.xflags = m->xflags; c.status = m->xflags + m->xflag_bytes / sizeof(unsigned);
                 c.ticket = c.status - 4; c.done = c.status - 3;
                 c.B = nb; c.T = T; c.I = m->dims.input_size; c.O = m->dims.output_size;
-                c.flags = flags; c.x_ring = x_ring;
+                c.flags = flags & ~APE_FLAG_LV16_SINGLE; c.x_ring = x_ring;
+                // up to 16 rows per cluster of the device: one row tile per cluster, so that the rows spread over every CU
+                if (nb <= 16 * ape_level16_max_clusters(m->n_cus)) c.flags |= APE_FLAG_LV16_SINGLE;
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
                 m->last_kernel = "ape_lstm_level16";
@@ -2167,9 +2169,10 @@ int ape_debug_plan2(const ape_dims_t* dims, int n_cus, int B, int T, int cdrop, 
             out[2] = ((rest < rpl2 ? rest : rpl2) + 31) / 32;
         } else if (out[5] == PLAN_LV16) {
             const int rpl3 = 32 * ape_level16_max_clusters(n_cus);
-            out[1] = 2;
+            const bool single = rest <= rpl3 / 2;                 // one row tile per cluster (APE_FLAG_LV16_SINGLE)
+            out[1] = single ? 1 : 2;
             out[3] = (rest + rpl3 - 1) / rpl3;
-            out[2] = ((rest < rpl3 ? rest : rpl3) + 31) / 32;
+            out[2] = single ? (rest + 15) / 16 : ((rest < rpl3 ? rest : rpl3) + 31) / 32;
         } else {
             const int nmt = cluster_nmt(n_cus, H, rest, cdrop != 0), rpl = 16 * nmt * cap;
             out[1] = nmt;

@@ -21,6 +21,7 @@
 #define APE_DIAG_NO_BARRIER  0x00100000u   // upper-layer kernel: no workgroup barrier at a section's top
 
 #define APE_FLAG_XCD_CLASSES 0x00800000u   // internal (set by the launcher): the first-generation kernel forms its clusters within block-index classes
+#define APE_FLAG_LV16_SINGLE 0x00800000u   // internal (set by the launcher, lstm_level16.hip only -- the same bit means nothing else there): one row tile per cluster
 
 // Hand-over form of a flag-based kernel, in one place: plain (write-back) payload stores ONLY when the caller opted in with
 // APE_FLAG_IN_XCD_PLAIN AND the cluster verified at run time that all its members share an XCD (`same_xcd`); otherwise write-through.

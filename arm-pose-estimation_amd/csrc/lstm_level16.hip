@@ -161,12 +161,16 @@ __global__ __launch_bounds__(512, 1) void ape_lstm_level16(const ClusterParams p
     if (ctl[1] < 0) return;
     const int ticket = __builtin_amdgcn_readfirstlane(ctl[1]);
     const int cluster = (ticket / GH) * 8 + cls, member = ticket % GH;
-    const int row0 = cluster * (NA * MR) + agent * MR;
+    // one-agent form (the launcher's choice for up to 16 x max_clusters rows): a cluster owns ONE row tile, agent 1 of every workgroup is idle,
+    // so that 512 rows still spread over every CU (32 clusters) -- with nobody to alternate with, a level costs its matrix work plus its
+    // hand-over, which is still less than the first generation's pipeline at these sizes
+    const bool single = (p.flags & APE_FLAG_LV16_SINGLE) != 0;
+    const int row0 = single ? cluster * MR : cluster * (NA * MR) + agent * MR;
 
     // ---- x: thread -> NE (window, column) elements of the agent's step slab, all with the same column ----------------------------------
     constexpr int NE = (MR * KX) / NTA;
     const int xk = tid_a % KX, xrow = tid_a / KX;
-    const int rows_here = bcast_x ? MR : max(0, min(MR, p.B - row0));
+    const int rows_here = (single && agent != 0) ? 0 : (bcast_x ? MR : max(0, min(MR, p.B - row0)));
     const unsigned long long x_addr = reinterpret_cast<unsigned long long>(p.x + (bcast_x ? (size_t)0 : (size_t)row0 * T * I));
     // (per-agent descriptor: its words differ between the two halves of the workgroup, uniform within a wave)
     const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)x_addr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(x_addr >> 32));
@@ -538,10 +542,12 @@ hipError_t ape_prepare_lstm_level16(int H, int L, int KX) {
                                (int)smem_level16<128, 3, 64>());
 }
 
-// `rows` windows, at most 32 x ape_level16_max_clusters(n_cus); the grid is rounded up to whole block-index classes (8 clusters x 8 members)
+// `rows` windows, at most 32 x ape_level16_max_clusters(n_cus) (16 x with APE_FLAG_LV16_SINGLE in p.flags: one row tile per cluster); the grid is
+// rounded up to whole block-index classes (8 clusters x 8 members)
 hipError_t ape_launch_lstm_level16(int H, int L, int KX, int rows, const ClusterParams& p, hipStream_t stream) {
     if (!ape_level16_supported(H, L, KX)) return hipErrorInvalidValue;
-    const int grid_clusters = ((rows + 31) / 32 + 7) / 8 * 8;
+    const bool single = (p.flags & APE_FLAG_LV16_SINGLE) != 0;
+    const int grid_clusters = single ? ((rows + 15) / 16 + 7) / 8 * 8 : ((rows + 31) / 32 + 7) / 8 * 8;
     constexpr size_t smem = smem_level16<128, 3, 64>();
     hipLaunchKernelGGL((ape_lstm_level16<128, 3, 64>), dim3(grid_clusters * 8), dim3(512), smem, stream, p);
     return hipGetLastError();
