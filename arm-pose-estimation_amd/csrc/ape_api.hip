@@ -115,13 +115,20 @@ static int cluster_rows_per_launch(int n_cus, int H, bool cdrop) { return 16 * (
 // `gen2`: the second-generation kernel the model and the call are eligible for -- 32: lstm_cluster32.hip (2 x 256), 16:
 // lstm_cluster16.hip (3 x 128: a launch costs 24.6 + 6.6 T against the first generation's 15.5 + 7.5 T at 513 .. 1024 rows -- with
 // its XCD-local clusters; 15.1 + 7.75 T before them --, so it serves windows of 12 steps and more), 0: none
-// (round 6) 48 = 16 + the level-synchronous kernel for short windows, lstm_level16.hip: T + 2 hand-overs per launch instead of a
-// three-layer pipeline with four fill / drain phases; it serves windows below lstm_cluster16.hip's 12 steps from APE_LV16_MIN_ROWS rows on
+// (round 6) 48 = 16 + the level-synchronous kernel lstm_level16.hip: T + 2 hand-overs per launch instead of a three-layer pipeline with four
+// fill / drain phases.  It serves ONE launch's worth of rows: 5 .. 512 with one row tile per cluster at every window length, 513 .. 1024 with
+// two row tiles per cluster (two agents per workgroup) up to 48 steps; lstm_cluster16.hip keeps the longer windows and the larger batches
 enum { PLAN_NONE = 0, PLAN_GEN1 = 1, PLAN_C32 = 2, PLAN_SMALL = 3, PLAN_C16 = 4, PLAN_LV16 = 5 };
-#define APE_LV16_MIN_ROWS 513        // (512 rows: the first generation's 16-row clusters still fill the chip, 42 us against 49)
-#define APE_LV16_MAX_T 48           // (1024 rows: 170.6 / 222.2 / 327.8 us at 24 / 32 / 48 steps against lstm_cluster16.hip's 179.5 / 231.7 / 339.8; a tie at 64)
+#define APE_LV16_MIN_ROWS 5          // (up to 4 rows: the latency kernel)
+#define APE_LV16_MAX_T 48           // two row tiles per cluster, 513 .. 1024 rows: 170.6 / 222.2 / 327.8 us at 24 / 32 / 48 steps against
+                                    // lstm_cluster16.hip's 179.5 / 231.7 / 339.8; a tie at 64
+#define APE_LV16_MAX_T_SINGLE 4000  // one row tile per cluster, up to 512 rows: faster than the first generation at every window measured
+                                    // (512 rows: 40.0 / 66.9 / 123.2 / 231.5 / 304.9 us at 6 / 12 / 24 / 48 / 64 steps against 42.8 / 70.4 / 129.7 /
+                                    // 245.3 / 323.2; 5 rows: 34.3 against 42.8); a level's tag holds 12 bits of step count
 #define APE_LV16_COST_US0 14.0      // a launch of up to 1024 rows: microseconds = US0 + US_T x T (measured)
-#define APE_LV16_COST_US_T 5.5
+#define APE_LV16_COST_US_T 6.8
+#define APE_LV16_COST1_US0 13.0     // ... of up to 512 rows (one row tile per cluster)
+#define APE_LV16_COST1_US_T 4.5
 static int rest_kernel(int rest, int T, int gen2, int n_cus) {
     if (rest <= 0) return PLAN_NONE;
     if (gen2 == 32 && rest > 512) return PLAN_C32;
@@ -130,7 +137,10 @@ static int rest_kernel(int rest, int T, int gen2, int n_cus) {
     static const int lv16_min_rows = getenv("APE_LV16_MIN_ROWS") ? atoi(getenv("APE_LV16_MIN_ROWS")) : APE_LV16_MIN_ROWS;
     // (ONE launch only: its workgroups take a CU's whole LDS, so a second launch cannot start under the first one's tail as the first
     //  generation's do -- 2048 x 6: 108 us in two launches against 100)
-    if (gen2 == 48 && rest >= lv16_min_rows && rest <= 32 * ape_level16_max_clusters(n_cus) && T <= lv16_max_t) return PLAN_LV16;
+    if (gen2 == 48 && rest >= lv16_min_rows) {
+        if (rest <= 16 * ape_level16_max_clusters(n_cus) && T <= APE_LV16_MAX_T_SINGLE) return PLAN_LV16;       // one row tile per cluster
+        if (rest <= 32 * ape_level16_max_clusters(n_cus) && T <= lv16_max_t) return PLAN_LV16;
+    }
     if ((gen2 == 16 || gen2 == 48) && rest > 512 && T >= c16_min_t) return PLAN_C16;
     return PLAN_GEN1;
 }
@@ -156,8 +166,8 @@ static int auto_tile16_waves(const ape_dims_t* dims, int n_cus, int B, int T, bo
         if (k == PLAN_C32) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (16.0 + 12.4 * T);
         if (k == PLAN_C16) return w * t16 + (double)((rest + rpl2 - 1) / rpl2) * (24.6 + 6.6 * T);
         if (k == PLAN_LV16) {
-            const int rpl3 = 32 * ape_level16_max_clusters(n_cus);
-            return w * t16 + (double)((rest + rpl3 - 1) / rpl3) * (APE_LV16_COST_US0 + APE_LV16_COST_US_T * T);
+            if (rest <= 16 * ape_level16_max_clusters(n_cus)) return w * t16 + APE_LV16_COST1_US0 + APE_LV16_COST1_US_T * T;
+            return w * t16 + APE_LV16_COST_US0 + APE_LV16_COST_US_T * T;
         }
         return w * t16 + (double)((rest + rpl - 1) / rpl) * tcl1;
     };

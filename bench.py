@@ -506,7 +506,7 @@ def stream_bank_numbers(model, stats, cases=None):
 
 def dispatch_boundaries(n_iter=30):
     """APE_KERNEL_AUTO at its dispatch boundaries, on THIS box: at each threshold of the plan (csrc/ape_api.hip: 512 / 513 eval rows for
-    the second-generation kernels, windows of 48 / 49 steps and 512 / 513 rows for the 3 x 128 model, 4 / 5 rows and 128 / 129 samples for the latency
+    the second-generation kernels, windows of 48 / 49 steps, 4 / 5 and 1024 / 1025 rows for the 3 x 128 model, 4 / 5 rows and 128 / 129 samples for the latency
     kernels, 512 / 513 sample rows for the bank's weight-stationary route, 3 / 4 clusters for the first generation's XCD classes)
     AUTO and every kernel the public switch can force are timed on the same inputs (HIP events, median of n_iter launches after a
     warm-up); `auto_over_best` = AUTO's time over the fastest candidate's -- 1.00 means AUTO picked the fastest there."""
@@ -555,11 +555,12 @@ def dispatch_boundaries(n_iter=30):
         for B in (512, 513):
             for T in (6, 64):
                 forward_case(f"pocket_eval_B{B}_T{T}", "pocket", B, T, False, False, ("auto", "cluster_gen1", "tile16"))
-        # 3 x 128, 1024 rows, windows of 48 | 49 steps: ape_lstm_level16 (round 6) | ape_lstm_cluster16; 512 | 513 rows at the deployed 6 steps:
-        # first generation | ape_lstm_level16
+        # 3 x 128, 1024 rows, windows of 48 | 49 steps: ape_lstm_level16 (round 6) | ape_lstm_cluster16; at the deployed 6 steps 4 | 5 rows:
+        # latency kernel | ape_lstm_level16 (one row tile per cluster up to 512 rows, two above), 1024 | 1025 rows: one launch of it | two of the
+        # first generation
         for T in (48, 49):
             forward_case(f"uarm_eval_B1024_T{T}", "uarm", 1024, T, False, False, ("auto", "cluster_gen1", "tile16"))
-        for B in (512, 513):
+        for B in (4, 5, 512, 1024, 1025):
             forward_case(f"uarm_eval_B{B}_T6", "uarm", B, 6, False, False, ("auto", "cluster_gen1", "tile16"))
         # eval rows 4 | 5: latency kernel | first generation
         for B in (4, 5):

@@ -66,6 +66,7 @@ def _no_abort(m):
     ("uarm", 1024, 6, "f32", "auto", "ape_lstm_level16"),                # round 6: tagged granules polled by every wave, two agents per workgroup
     ("uarm", 700, 13, "f32", "auto", "ape_lstm_level16"),                # ... with row tiles and whole clusters past the end of the batch
     ("uarm", 530, 2, "f32", "auto", "ape_lstm_level16"),                 # ... and a window shorter than the model is deep
+    ("uarm", 300, 6, "f32", "auto", "ape_lstm_level16"),                 # ... one row tile per cluster (the idle agent of every workgroup), copies beside it
     ("watch", 700, 8, "f16", "cluster", "ape_lstm_cluster_f16v2"),
     ("watch", 1024, 64, "f16", "cluster", "ape_lstm_cluster_f16v2"),
     ("pocket", 200, 6, "f16_gen1", "cluster", "ape_lstm_cluster_f16"),

@@ -86,13 +86,14 @@ def test_first_generation_kernel_forms_xcd_local_clusters(norm_stats, name, B, T
     model.set_kernel("auto")
 
 
-@pytest.mark.parametrize("B,T", [(1024, 6), (513, 6), (600, 1), (700, 2), (1000, 3), (1024, 7), (1024, 8), (993, 11), (777, 48)])
+@pytest.mark.parametrize("B,T", [(1024, 6), (513, 6), (600, 1), (700, 2), (1000, 3), (1024, 7), (1024, 8), (993, 11), (777, 48),
+                                 (512, 6), (5, 6), (16, 3), (300, 1), (129, 70), (512, 64)])
 def test_uarm_level_synchronous_kernel_for_short_windows(norm_stats, B, T):
     """lstm_level16.hip (round 6: WatchPhoneUarmNN's 3 x 128 LSTM at its DEPLOYED window of 6 steps, watch_phone_uarm_nn.py:13-41,107-121 --
-    eval-mode batches of 513 .. 1024 rows with windows of up to 48 steps: one launch) against the float32 oracle (module tolerance 1e-6), the
+    eval-mode calls that fit ONE launch: 513 .. 1024 rows with windows of up to 48 steps on two row tiles per cluster = two agents per workgroup,
+    5 .. 512 rows at every window length on one row tile per cluster) against the float32 oracle (module tolerance 1e-6), the
     first-generation cluster kernel and the batch-tile kernel (other summation orders only): windows shorter than the model is deep
-    (T = 1, 2: levels where layers are still missing), windows either side of the 7 steps up to which every x slab is staged in the
-    prologue, ragged batches (a last cluster with rows past the batch, whole row tiles and clusters that own none), the raw-window route with the float64 z-score, and run-to-run determinism."""
+    (T = 1, 2: levels where layers are still missing), long windows on the one-tile form, ragged batches (a last cluster with rows past the batch, whole row tiles and clusters that own none), the raw-window route with the float64 z-score, and run-to-run determinism."""
     name = "uarm"
     st = norm_stats[name]
     model, sd, cfg = make_model(name, 5, st)

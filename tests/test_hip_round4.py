@@ -327,7 +327,8 @@ def test_auto_dispatch_names_the_planned_kernel_at_every_boundary():
     k = {key: v["kernels"]["auto"] for key, v in d.items() if isinstance(v, dict)}
     assert k["pocket_eval_B512_T64"] == "ape_lstm_cluster" and k["pocket_eval_B513_T64"] == "ape_lstm_cluster32"
     assert k["uarm_eval_B1024_T48"] == "ape_lstm_level16" and k["uarm_eval_B1024_T49"] == "ape_lstm_cluster16"
-    assert k["uarm_eval_B512_T6"] == "ape_lstm_cluster" and k["uarm_eval_B513_T6"] == "ape_lstm_level16"
+    assert k["uarm_eval_B4_T6"] == "ape_lstm_cluster_small" and k["uarm_eval_B5_T6"] == "ape_lstm_level16"
+    assert k["uarm_eval_B1024_T6"] == "ape_lstm_level16" and k["uarm_eval_B1025_T6"] == "ape_lstm_cluster"
     assert k["pocket_eval_B4_T6"] == "ape_lstm_cluster_small" and k["pocket_eval_B5_T6"] == "ape_lstm_cluster"
     assert k["pocket_mc_one_window_n128_T6"] == "ape_lstm_mc_small" and k["pocket_mc_one_window_n129_T6"] == "ape_lstm_cluster"
     assert k["pocket_mc_bank_512_sample_rows_T6"] == "ape_lstm_cluster" and k["pocket_mc_bank_513_sample_rows_T6"] == "ape_lstm_upper32"

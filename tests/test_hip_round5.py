@@ -30,6 +30,7 @@ UNEVEN_LOAD_CASES = [
     "test_lstm_kernels_under_uneven_load[uarm-1024-6-f32-auto-ape_lstm_level16]",
     "test_lstm_kernels_under_uneven_load[uarm-700-13-f32-auto-ape_lstm_level16]",
     "test_lstm_kernels_under_uneven_load[uarm-530-2-f32-auto-ape_lstm_level16]",
+    "test_lstm_kernels_under_uneven_load[uarm-300-6-f32-auto-ape_lstm_level16]",
     "test_lstm_kernels_under_uneven_load[watch-700-8-f16-cluster-ape_lstm_cluster_f16v2]",
     "test_lstm_kernels_under_uneven_load[watch-1024-64-f16-cluster-ape_lstm_cluster_f16v2]",
     "test_lstm_kernels_under_uneven_load[pocket-200-6-f16_gen1-cluster-ape_lstm_cluster_f16]",

@@ -39,15 +39,15 @@ def test_one_layer_models_of_the_layer0_widths_are_created_and_run(I, H, O):
 
 
 def test_level16_serves_the_upper_arm_estimators_eval_windows(norm_stats):
-    """the route a caller of `Estimator.infer_windows` / the eval bank takes at the deployed shape: 1024 windows x 6 steps of the 3 x 128 model go
-    to `ape_lstm_level16` under AUTO, 512 and 1025 do not, `cluster_gen1` switches it off with the other second-generation kernels -- and all
+    """the route a caller of `Estimator.infer_windows` / the eval bank takes at the deployed shape: 1024, 512 and 40 windows x 6 steps of the 3 x 128 model go
+    to `ape_lstm_level16` under AUTO (two row tiles per cluster / one), 1025 do not, `cluster_gen1` switches it off with the other second-generation kernels -- and all
     of them agree with the oracle; two calls on two model handles interleaved on one stream keep their launch numbers apart (the tags of
     one handle's granules mean nothing to the other's buffer)."""
     from tests.test_hip_parity import make_model, _synthetic_windows
     st = norm_stats["uarm"]
     m, sd, cfg = make_model("uarm", 9, st)
     m2, sd2, _ = make_model("uarm", 10, st)
-    for B, want in ((1024, "ape_lstm_level16"), (512, "ape_lstm_cluster"), (1025, "ape_lstm_cluster")):
+    for B, want in ((1024, "ape_lstm_level16"), (512, "ape_lstm_level16"), (40, "ape_lstm_level16"), (1025, "ape_lstm_cluster")):
         x = _synthetic_windows(st, B, 6, cfg["I"], B)
         xn = ((x.astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
         xd = torch.from_numpy(x).cuda()

@@ -74,16 +74,19 @@ def test_split_with_the_second_generation_kernel():
     assert _plan2(pocket, 256, 1, 6)["kernel"] == SMALL and _plan2(pocket, 256, 5, 6)["kernel"] == GEN1
     assert _plan2(pocket, 256, 1024, 64, cdrop=1)["kernel"] == GEN1
     # the 3 x 128 model has its own second-generation kernels: above 512 rows lstm_cluster16.hip for windows of 12 steps and more, and --
-    # round 6 -- lstm_level16.hip for windows of up to 48 steps when ONE launch of it holds the rest (513 .. 1024 rows on 256 CUs)
+    # round 6 -- lstm_level16.hip wherever ONE launch of it holds the rest: 5 .. 512 rows at every window length (one row tile per cluster),
+    # 513 .. 1024 rows up to 48 steps (two row tiles per cluster) on 256 CUs
     assert _plan2(uarm, 256, 1024, 64) == dict(n16=0, nmt=2, clusters=32, launches=1, capacity=32, kernel=C16)
     assert _plan2(uarm, 256, 1024, 6) == dict(n16=0, nmt=2, clusters=32, launches=1, capacity=32, kernel=LV16)
-    assert _plan2(uarm, 256, 513, 6)["kernel"] == LV16 and _plan2(uarm, 256, 513, 6)["clusters"] == 17
-    assert _plan2(uarm, 256, 512, 6)["kernel"] == GEN1 and _plan2(uarm, 256, 512, 64)["kernel"] == GEN1
+    assert _plan2(uarm, 256, 513, 6) == dict(n16=0, nmt=2, clusters=17, launches=1, capacity=32, kernel=LV16)
+    assert _plan2(uarm, 256, 512, 6) == dict(n16=0, nmt=1, clusters=32, launches=1, capacity=32, kernel=LV16)
+    assert _plan2(uarm, 256, 5, 6) == dict(n16=0, nmt=1, clusters=1, launches=1, capacity=32, kernel=LV16)
+    assert _plan2(uarm, 256, 4, 6)["kernel"] == SMALL and _plan2(uarm, 256, 300, 200)["kernel"] == LV16
     assert _plan2(uarm, 256, 1024, 48)["kernel"] == LV16 and _plan2(uarm, 256, 1024, 49)["kernel"] == C16
     assert _plan2(uarm, 256, 1025, 6)["kernel"] == GEN1 and _plan2(uarm, 256, 1025, 12)["kernel"] == C16      # two launches: not its case
-    assert _plan2(uarm, 256, 1024, 6, cdrop=1)["kernel"] == GEN1 and _plan2(uarm, 256, 1024, 64, cdrop=1)["kernel"] == GEN1
-    assert _plan2(uarm, 256, 1024, 64, c32=0)["kernel"] == GEN1 and _plan2(uarm, 256, 1024, 6, c32=0)["kernel"] == GEN1
-    assert _plan2(uarm, 64, 300, 6)["kernel"] == GEN1 and _plan2(uarm, 64, 600, 6)["kernel"] in (GEN1, 0)        # 64 CUs: one launch holds 256 rows
+    assert _plan2(uarm, 256, 1024, 6, cdrop=1)["kernel"] == GEN1 and _plan2(uarm, 256, 300, 6, cdrop=1)["kernel"] == GEN1
+    assert _plan2(uarm, 256, 1024, 64, c32=0)["kernel"] == GEN1 and _plan2(uarm, 256, 300, 6, c32=0)["kernel"] == GEN1
+    assert _plan2(uarm, 64, 128, 6)["kernel"] == LV16 and _plan2(uarm, 64, 256, 6)["kernel"] == LV16 and _plan2(uarm, 64, 300, 6)["kernel"] == GEN1   # 64 CUs: 8 clusters
     # round 2's test case: 4396 rows x 64 frames stay on the cluster kernel altogether (five launches of it are priced below a
     # batch-tile wave + one more launch) ...
     p = _plan2(pocket, 256, 4396, 64)
