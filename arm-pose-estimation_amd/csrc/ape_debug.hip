@@ -7,7 +7,8 @@ extern "C" {
 
 // internal (not in the public header): overwrite one control word of the cluster kernels -- 0 status, 1 ticket,
 // 2 departure counter, 3 launch number of the latency kernel, 4 / 5 status word / a class ticket of the MLP pipeline, 6 the class-0 ticket of
-// the cluster kernels that form their clusters within block-index classes, 7 the launch number of the Monte-Carlo latency kernel -- so that tests
+// the cluster kernels that form their clusters within block-index classes, 7 the launch number of the Monte-Carlo latency kernel, 8 the launch
+// number of the level-synchronous kernel (lstm_level16.hip) -- so that tests
 // can stage the state an aborted launch leaves behind
 int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
     if (m && m->ffp_ok && (which == 4 || which == 5)) {          // the MLP pipeline's status word / first class ticket
@@ -26,6 +27,12 @@ int ape_debug_poke(ape_model_t* m, int which, unsigned value) {
         APE_DBG_TRY(hipSetDevice(m->dims.device));
         APE_DBG_TRY(hipDeviceSynchronize());
         APE_DBG_TRY(hipMemcpy(m->gxm, &value, sizeof(value), hipMemcpyHostToDevice));
+        return APE_OK;
+    }
+    if (m && m->lv16_ok && which == 8) {         // the level-synchronous kernel's launch number (upper bits of its granule tags)
+        APE_DBG_TRY(hipSetDevice(m->dims.device));
+        APE_DBG_TRY(hipDeviceSynchronize());
+        APE_DBG_TRY(hipMemcpy(m->gx16, &value, sizeof(value), hipMemcpyHostToDevice));
         return APE_OK;
     }
     if (!m || !m->cluster_ok || which < 0 || which > 3) return APE_ERR_INVALID_ARG;

@@ -249,6 +249,28 @@ def test_latency_kernel_launch_number_wrap():
     model.check()
 
 
+def test_level_kernel_launch_number_wrap(norm_stats):
+    """lstm_level16.hip's granule tags = (20-bit launch number << 12) | level, the number kept on the device and bumped by the last workgroup
+    out; at the wrap that workgroup zeroes the granule buffer (tag 0 is never awaited), so a tag of 2^20 launches ago cannot pass for a
+    fresh one: launches across the wrap -- both forms, one and two row tiles per cluster -- give the same bits as before it"""
+    from wear_mocap_ape_amd import _hip
+    st = norm_stats["uarm"]
+    model, sd, cfg = make_model("uarm", 14, st)
+    poke = _poke(_hip.lib())
+    xs = [torch.from_numpy(_synthetic_windows(st, B, T, cfg["I"], B)).cuda() for B, T in ((1024, 6), (40, 6), (700, 3), (512, 9))]
+    before = []
+    for x in xs:
+        before.append(model(x, last_step_only=True, normalize_input=True).cpu().numpy())
+        assert model.last_kernel() == "ape_lstm_level16"
+        xn = ((x.cpu().numpy().astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
+        assert np.abs(before[-1][:, 0] - orc.lstm_forward(sd, xn)[:, -1]).max() < 1e-6
+    assert poke(model.handle, 8, 0xFFFFD) == 0
+    for rep in range(2):                            # launches 0xFFFFD, E, F (wrap: granules zeroed), 0, 1, 2, ...
+        for b, x in zip(before, xs):
+            assert np.array_equal(model(x, last_step_only=True, normalize_input=True).cpu().numpy(), b)
+    model.check()
+
+
 @pytest.mark.parametrize("name,S,n_mc", [("pocket", 330, 25), ("uarm", 170, 50)])
 def test_mc_bank_in_several_chunks(norm_stats, name, S, n_mc):
     """the weight-stationary route handles the sample rows in chunks (one launch each, <= 2 GiB of pre-laid input): a bank cut
