@@ -1,6 +1,6 @@
-// Weight-stationary cluster LSTM kernel for SHORT windows of the 3 x 128 upper-arm regressor (WatchPhoneUarmNN: I = 38, H = 128, L = 3,
-// deployed sequence_len 6; reference estimate/watch_phone_uarm_nn.py:13-41,107-121, nn_models.py:160-189), exact float32, eval mode,
-// last-step output.  Round 6.
+// Weight-stationary cluster LSTM kernel for the calls of the 3 x 128 upper-arm regressor that fit ONE launch -- its deployed short window
+// first (WatchPhoneUarmNN: I = 38, H = 128, L = 3, sequence_len 6; reference estimate/watch_phone_uarm_nn.py:13-41,107-121,
+// nn_models.py:160-189) --, exact float32, eval mode, last-step output.  Round 6.
 //
 // lstm_cluster.hip / lstm_cluster16.hip software-pipeline the three layers (phase p: layer l on step p - l) and hide a section's hand-over
 // behind the two other sections of the phase.  At T = 6 that pipeline is eight phases of which four are fill / drain: their hand-overs
@@ -23,10 +23,12 @@
 //     this one 54); double-buffered by level parity on both sides.  The only atomicity assumed is a naturally aligned 8-byte store's;
 //   * valid under ANY placement (write-through stores, L1-bypassing loads); the clusters still form within block-index classes
 //     (blockIdx % 8 = XCD under round-robin dispatch) for speed, nothing relies on it, there is no plain-store variant and no rendezvous;
-//   * a row tile past the end of the batch computes nothing and waits for nobody;
+//   * a row tile past the end of the batch computes nothing and waits for nobody; up to 512 rows the launcher asks for ONE row tile per
+//     cluster (APE_FLAG_LV16_SINGLE: agent 1 of every workgroup idle) so that the rows spread over every CU -- nobody alternates then, a level
+//     costs its matrix work plus its hand-over, and that still beats the first generation's pipeline from 5 rows on at every window length;
 //   * bounded spins (every wait, LDS ones included, ends when anybody in the workgroup has given up), sticky status word; nothing to clean
 //     but the class tickets: the launch number goes up by one, the next launch awaits other tags.
-// Measured at 1024 x 6: 54-55 us against the first generation's 61.5; a level costs the two agents' matrix work plus
+// Measured at 1024 x 6: 54-55 us against the first generation's 61.5, at 512 x 6 40.0 against 42.8; a level costs the two agents' matrix work plus
 // ~1 us -- beside a partner's dependent MFMA chain the other wave's compares and LDS writes hardly issue, so the end of a hand-over waits
 // for the partner's level to end (sub-stamps in the diagnostic build).
 // Inline asm: the MFMAs (weights of the upper layers are AGPR operands; a level-section's last MFMA carries its drain) and the polling
