@@ -303,7 +303,10 @@ __global__ __launch_bounds__(256 * RT, 3 - RT) void ape_lstm_cluster16(const Clu
     // The flag of a publish is raised per MEMBER, by the last of its waves whose store has drained (an arrival counter per layer in LDS), as
     // ONE store instruction over the member's NWV flag words: 64 waves each storing its own word of the same two cache lines at about the
     // same time serialise on the memory side -- write-through stores to one line complete one after the other -- and the last of them became
-    // visible 3 .. 7 us after it was issued (round 6, `profiles/r06_flag_serialisation.md`: the final gather of this kernel waited that long)
+    // visible 3 .. 7 us after it was issued (round 6, `profiles/r06_flag_serialisation.md`: the final gather of this kernel waited that long).
+    // No wave can wait for a flag that needs its own arrival's siblings stuck behind it: a blocking wait (`wait_flags`, in front of a section's
+    // barrier) is for a slice set published a phase ago, whose raise -- in front of the barrier of the section after its publish at the
+    // latest -- every wave of the member has passed; the final gather's waves all reach their raise without a barrier in between.
     int pend_idx = -1;                      // layer of the pending publish
     unsigned pend_epoch = 0u;
     auto raise_pending = [&]() {

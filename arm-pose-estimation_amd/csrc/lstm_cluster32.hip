@@ -723,7 +723,12 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         // words in one instruction.  (Round 6: a cluster's 32 per-wave flag stores to one cache line, all issued at about the same time,
         // complete one after the other on the memory side -- the last one turned visible 3 .. 7 us after its issue, measured on
         // lstm_cluster16.hip's final gather, profiles/r06_flag_serialisation.md.  In the sections the looks are asynchronous and the
-        // stores spread out; here every wave of the cluster is waiting for exactly these words.)
+        // stores spread out; here every wave of the cluster is waiting for exactly these words.  The arrival-counter form of the other
+        // kernels -- the last of a member's waves to drain raises for all four -- was tried in the sections of the short-window instantiation
+        // and DEADLOCKS here: with two layers (and MODE 3's own gather) a wave on the blocking path waits, in front of the section's barrier, for
+        // flags that include its OWN member's newest ones, which then need the arrival of waves that wait for it behind that barrier.  In
+        // lstm_cluster.hip / lstm_cluster16.hip a blocking wait is only ever for flags at least a section older than the member's own pending
+        // raise, and every wave of the member has passed that raise.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar();
         if (pend_idx >= 0) {
