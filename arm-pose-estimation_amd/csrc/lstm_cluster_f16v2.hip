@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     f32x4* bias_s = reinterpret_cast<f32x4*>(own + 4 * L * SR * UPW);   // [wave 4][L][NTW][lane 64]: the accumulators' start values
     unsigned* look_s = reinterpret_cast<unsigned*>(bias_s + 4 * L * NTW * 64);   // [wave 4][64]: landing zones of the flag looks (async_look.h)
     int* ctl = reinterpret_cast<int*>(look_s + 4 * 64);             // [0] abort, [1] class ticket, [2] last-out, [3] same XCD
+    float* xraw = reinterpret_cast<float*>(ctl + 4);                // [NS][2 parity][SR * KX] raw float32 step slabs (UPW == 8: fetched by LDS-DMA)
 
     // control words (all zero between launches): [8 class tickets, one per 64-byte line][n_wg XCD words][done]
     unsigned* const class_ticket = p.xcc_slots + 64;
@@ -202,6 +203,9 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     // unit of (tile t, lane group g): member*32 + wave*8 + t*4 + g
     // (b_ih + b_hh, f32) of this lane's four gates per (layer, tile): the accumulators start from it; kept in LDS, not in
     // 16 registers -- the register file is the weight store
+    // (round 6: ... and in registers too in the form with one wave per SIMD -- 328 of its 512 are in use --: the start values used to come out of
+    //  LDS at the head of each layer's span, an exposed LDS latency in front of the first MFMA, twice a section)
+    f32x4 bias_r[L][NTW];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
 #pragma unroll
             for (int k = 0; k < 4; ++k) bv[k] = p.bias[l][k * H + member * (4 * UPW) + wave * UPW + t * 4 + g];
             bias_s[((wave * L + l) * NTW + t) * 64 + lane] = bv;
+            bias_r[l][t] = bv;
         }
     // per-set register state is kept as "this section's set" / "the other set" and swapped at the end of every section,
     // so the section body exists once per kind (no unrolling over the sets, no dynamically indexed register arrays)
@@ -284,11 +289,43 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
             xin[((s * 2 + (t & 1)) * SR + row) * SX + xk] = (_Float16)xf;
         }
     };
-    fetch_x(xr, 0, 0);
-    fetch_x(xr_o, 1, 0);
-    stage_x(xr, 0, 0);
-    stage_x(xr_o, 1, 0);
-    if (T > 1) { fetch_x(xr, 0, 1); fetch_x(xr_o, 1, 1); }
+    // Round 6, the eight-unit form: a step slab travels global -> LDS as RAW float32 by LDS-DMA (two instructions per wave: element tid + 256 e
+    // lands at its own index, fetched and later read by the same thread) and is z-scored from there at the TOP of the set's next section, in
+    // front of the wait for the gathered slices -- ~0.15 us of float64 arithmetic per section that used to sit between the layers' MFMAs.
+    // (With the slab in REGISTERS that did not work: hipcc's `s_waitcnt` in front of the first use of a compiler-issued load does not count
+    //  the asm-issued look and gather behind it and waits for them too.  An LDS-DMA has no destination register and is waited for by a
+    //  counted `vmcnt` written here.)
+    const ape_desc_t x_desc = ape_make_desc(reinterpret_cast<const void*>(((unsigned long long)x_hi << 32) | x_lo), (unsigned)x_bytes);
+    const unsigned xraw_lds = (unsigned)reinterpret_cast<unsigned long long>(xraw) + (unsigned)(wave * 256);
+    auto dma_x = [&](int s, int t) {
+        const int slot = (t + p.x_ring >= T) ? t + p.x_ring - T : t + p.x_ring;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int row = s * SR + (tid + 256 * e) / KX;
+            const unsigned off = (xk < I && row < rows_here) ? x_off[e] + (unsigned)(s * SR) * x_rowbytes : 0x80000000u;      // (past the descriptor: 0)
+            look_issue(xraw_lds + (unsigned)(((s * 2 + (t & 1)) * SR * KX + 256 * e) * sizeof(float)), off, x_desc, (unsigned)(slot * I * sizeof(float)));
+        }
+    };
+    auto stage_x_lds = [&](int s, int t) {
+        float src[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) src[e] = xraw[(s * 2 + (t & 1)) * SR * KX + tid + 256 * e];
+        stage_x(src, s, t);
+    };
+    if constexpr (UPW == 8) {
+        dma_x(0, 0);
+        dma_x(1, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_x_lds(0, 0);
+        stage_x_lds(1, 0);
+        if (T > 1) { dma_x(0, 1); dma_x(1, 1); }
+    } else {
+        fetch_x(xr, 0, 0);
+        fetch_x(xr_o, 1, 0);
+        stage_x(xr, 0, 0);
+        stage_x(xr_o, 1, 0);
+        if (T > 1) { fetch_x(xr, 0, 1); fetch_x(xr_o, 1, 1); }
+    }
 
     // ---- do all members of this cluster really share an XCD? ------------------------------------------------------
     if (wave == 0) {
@@ -378,10 +415,20 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
     bool prefetched = false;
     auto section = [&](auto steady_tag, const int ph, const int s) -> bool {
         constexpr bool ST = decltype(steady_tag)::value;          // steady state: 2 <= ph <= T - 3, every condition below holds
-        // (Round 6, measured and dropped: the next step's x staged HERE, in front of the wait for the gather, instead of between the layers'
-        //  MFMAs -- 238.8 against 236.1 us.  The slab's registers come from compiler-issued loads, and hipcc's own `s_waitcnt vmcnt(n)` in front of
-        //  their first use counts only the vector-memory operations it knows: the asm-issued look and gather behind them are not in its count,
-        //  so it waits for them too and nothing overlaps.)
+        // x of this set's next step: raw slab (LDS, fetched by this set's section in front) -> z-score -> the other parity buffer of xin (its
+        // readers are two sections back).  In FRONT of the wait for the gather.  Behind the slab's two DMAs (issued by this set's section in
+        // front, i.e. the section before last) every section issues at least a look and a publish store, and the section in front its own two
+        // slab DMAs first: at least SIX younger operations, whatever was prefetched -- so with six left in flight the slab has landed by
+        // construction, while the youngest six of the usual case (look, four gather DMAs, publish store) may still be travelling.
+        // (From REGISTERS this was measured and lost, 238.8 against 236.1 us: hipcc's own wait in front of the first use of a compiler-issued
+        //  load does not count the asm-issued look and gather behind it, so it waited for them too.)
+        if constexpr (UPW == 8) {
+            if ((ST || ph + 1 < T) && !d_nox) {
+                if (ST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                stage_x_lds(s, ph + 1);
+            }
+        }
         // ---- S0: this set's slices of the last phase into LDS ------------------------------------------------------------
         if (ST || ph > 0) {
             if (!prefetched && !d_noex) {                         // first phases, a late peer, the final gathers
@@ -415,12 +462,12 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
         const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
         // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
         // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
-        f32x4 ax[QX], a0r[QH], a1i[QH], a1r[QH];
+        // (round 6: h^0 of the set's last phase is BOTH layer 0's recurrent operand and layer 1's input -- read once, kept through layer 0's
+        //  gate math: the second read of the same 8 fragments cost every wave 8 of its 25 ds_read_b128 per section, 32 KB of LDS traffic per CU)
+        f32x4 ax[QX], a0r[QH], a1r[QH];
         const _Float16* hset = hbuf + s * L * HL + g * 128 + r * 8;
-        if (ST || ph < T) {
-            load_frags<QX>(ax, xin + ((s * 2 + (ph & 1)) * SR + r) * SX + 8 * g, 32);
-            if (ST || ph > 0) load_frags<QH>(a0r, hset, 512);
-        }
+        if (ST || ph < T) load_frags<QX>(ax, xin + ((s * 2 + (ph & 1)) * SR + r) * SX + 8 * g, 32);
+        if (ST || ph > 0) load_frags<QH>(a0r, hset, 512);
         V2_STAMP(7);                                              // 7: fragment read issue
         // the next section: the other set, in this phase (s = 0) or the next (s = 1); it needs epoch `want`
         const int sn = s ^ 1, phn = ph + s;
@@ -436,13 +483,13 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
             f32x4 acc[NTW];
             if (active) {
 #pragma unroll
-                for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias_s[((wave * L + l) * NTW + tt) * 64 + lane];
+                for (int tt = 0; tt < NTW; ++tt) acc[tt] = (UPW == 8) ? bias_r[l][tt] : bias_s[((wave * L + l) * NTW + tt) * 64 + lane];
                 if (d_nomfma) {
                 } else if (l == 0) {
                     span<NTW, QX, NB0>(acc, ax, w0, 0);
                     if (ST || t > 0) span<NTW, QH, NB0>(acc, a0r, w0, QX);
                 } else {
-                    span<NTW, QH, NB1>(acc, a1i, w1, 0);
+                    span<NTW, QH, NB1>(acc, a0r, w1, 0);
                     if (F16_LOOK_AT == 3) {                           // (sweep position: between layer 1's two spans)
                         look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
                         peeked = true;
@@ -461,12 +508,15 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                 peeked = true;
             }
             if (l == 0) {
-                if (ST || ph >= 1) load_frags<QH>(a1i, hset, 512);
                 if (ST || ph > 1) load_frags<QH>(a1r, hset + HL, 512);
                 // x of the next step: registers -> the other parity buffer (its readers are two sections back), next fetch
                 if ((ST || ph + 1 < T) && !d_nox) {
-                    stage_x(xr, s, ph + 1);
-                    if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
+                    if constexpr (UPW == 8) {
+                        if (ST || ph + 2 < T) dma_x(s, ph + 2);
+                    } else {
+                        stage_x(xr, s, ph + 1);
+                        if (ST || ph + 2 < T) fetch_x(xr, s, ph + 2);
+                    }
                 }
             } else if (!peeked) {
                 // [B0] look at the flags the next section needs (if the section has not issued it yet: F16_LOOK_AT, or a layer-1 part that did not run); the load flies under the gate math below.  Issued as LDS-DMA into the wave's
@@ -592,7 +642,7 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
 template <int H, int L, int KX, int UPW>
 constexpr size_t smem_bytes() {
     return ((size_t)2 * L * 16 * H + (size_t)2 * 2 * 16 * (KX + 16) + (size_t)4 * L * 16 * UPW) * sizeof(_Float16) +
-           (size_t)4 * L * (UPW / 4) * 64 * 16 + (size_t)4 * 64 * sizeof(unsigned) + 16;
+           (size_t)4 * L * (UPW / 4) * 64 * 16 + (size_t)4 * 64 * sizeof(unsigned) + 16 + (UPW == 8 ? (size_t)2 * 2 * 16 * KX * sizeof(float) : 0);
 }
 
 }  // namespace
