@@ -865,7 +865,7 @@ def fp16_config4(stats_watch, n_iter=20):
                          # write-through) -- C + E binds, DESIGN.md 4.11
                          "latency_floor_us": 2 * (T_FRAMES + 2) * (1132 + 905 + 88 + 482) / 2310.0,
                          "frac_of_latency_floor": 2 * (T_FRAMES + 2) * (1132 + 905 + 88 + 482) / 2310.0 / (out["f16"] * 1e3),
-                         "hand_over": "write-through (sc1) stores: the default since round 5; APE_FLAG_IN_XCD_PLAIN measures ~8 % faster",
+                         "hand_over": "write-through (sc1) stores: the default since round 5",
                          "note": "latency-bound, not matrix-bound: per layer-step a wave has 2 x 16 f16 MFMAs (~0.5K cycles) "
                                  "between two cluster-wide exchanges of h; the f16 dense MFMA peak is the stated roofline, "
                                  "latency_floor_us = sections x (MFMA spans + gates + one in-XCD hop) the one that binds"}}
