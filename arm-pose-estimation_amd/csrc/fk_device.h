@@ -4,6 +4,7 @@
 // a * b + c, like numpy: contraction is off inside every function, whatever the including translation unit does.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "angle_device.h"
 
 namespace ape_fkdev {
 
@@ -65,8 +66,8 @@ __device__ inline Quat six_drr_to_quat(const double* s) {
 
 __device__ __forceinline__ Quat hips_quat(double sn, double cs) {   // transformations.py:177-179
 #pragma clang fp contract(off)
-    const double half = 0.5 * atan2(sn, cs);
-    return Quat{cos(half), 0.0, sin(half), 0.0};
+    const ape_angledev::CS h = ape_angledev::half_of_atan2(sn, cs);   // (cos, sin) of atan2(sn, cs) / 2, without the angle
+    return Quat{h.c, 0.0, h.s, 0.0};
 }
 
 }  // namespace ape_fkdev

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/ape_hip.h"
+#include "angle_device.h"
 
 namespace ape_parsedev {
 
@@ -26,13 +27,18 @@ __device__ __forceinline__ Q qinv(const Q q) {
 }
 // android (X east, Y north, Z up) -> global (X right, Y up, Z forward): [-w, x, z, y]
 __device__ __forceinline__ Q no_north(const Q q) { return Q{-q.w, q.x, q.z, q.y}; }
-// azimuth of q * (0,0,1): atan2(x, z) of the rotated forward axis
-__device__ __forceinline__ double y_rot_of(const Q q) {
+// q * (0,0,1): the rotated forward axis; its azimuth is atan2(x, z)
+__device__ __forceinline__ Q fwd_of(const Q q) {
 #pragma clang fp contract(off)
-    const Q t = qmul(qmul(q, Q{0.0, 0.0, 0.0, 1.0}), qconj(q));
-    return atan2(t.x, t.z);
+    return qmul(qmul(q, Q{0.0, 0.0, 0.0, 1.0}), qconj(q));
 }
-__device__ __forceinline__ Q y_quat(double a) { return Q{cos(0.5 * a), 0.0, sin(0.5 * a), 0.0}; }
+// the y rotation by MINUS the azimuth of q's forward axis (reduce_global_quat_to_y_rot -> euler_to_quat(0, -a, 0)): angle_device.h
+__device__ __forceinline__ Q north_of(const Q q) {
+#pragma clang fp contract(off)
+    const Q t = fwd_of(q);
+    const ape_angledev::CS h = ape_angledev::half_of_atan2(t.x, t.z);
+    return Q{h.c, 0.0, -h.s, 0.0};
+}
 __device__ __forceinline__ Q rd(const float* row, int i) {
 #pragma clang fp contract(off)
     return Q{(double)row[i], (double)row[i + 1], (double)row[i + 2], (double)row[i + 3]};
@@ -69,7 +75,7 @@ __device__ inline void parse_row(const float* row, int width, int kind, double* 
     for (int i = 0; i < 13; ++i) xx[o++] = (double)row[sw_sensor_col(i)];
     const double r_pres = (double)row[19] - (double)row[cl.init_pres];
     const Q sw_fwd = rd(row, cl.fwd), sw_rot = rd(row, cl.rot);
-    Q north = y_quat(-y_rot_of(no_north(sw_fwd)));
+    Q north = north_of(no_north(sw_fwd));
     if (kind == APE_PARSE_WATCH_PHONE_UARM) {
         // north incl. the left-hand calibration turn; watch / phone offsets to the calibration pose
         north = qmul(Q{0.7071068, 0.0, -0.7071068, 0.0}, north);
@@ -88,9 +94,10 @@ __device__ inline void parse_row(const float* row, int width, int kind, double* 
         if (kind == APE_PARSE_WATCH_PHONE_POCKET) {
             const Q ph_rot_g = qmul(north, no_north(rd(row, cl.ph_rot)));
             const Q ph_fwd_g = qmul(north, no_north(rd(row, cl.ph_fwd)));
-            const double hy = y_rot_of(qmul(ph_rot_g, qinv(ph_fwd_g)));
-            xx[o++] = sin(hy);
-            xx[o++] = cos(hy);
+            const Q t = fwd_of(qmul(ph_rot_g, qinv(ph_fwd_g)));
+            const ape_angledev::CS a = ape_angledev::of_atan2(t.x, t.z);
+            xx[o++] = a.s;
+            xx[o++] = a.c;
         }
     }
 }

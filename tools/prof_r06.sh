@@ -59,6 +59,15 @@ bank_uarm)
     --note "Launch A of the same frames: layer 0 of the 3 x 128 model once per stream on the one-layer form of the first-generation cluster kernel (round 6: flags per member through an LDS arrival counter)."
   kernels > gpurun_out/prof_r06_bank_uarm_kernels.txt
   ;;
+bank_eval)    # the eval bank's frame (feature builder + LSTM + post-filter), per model: kernel trace only
+  for m in pocket watch uarm; do
+    WHAT=bank_eval_$m
+    rm -rf $P/trace
+    trace python3 tests/tools/bank_trace.py 1024 0 200 auto check $m
+    cat gpurun_out/prof_$WHAT.out | grep -v amdgpu.ids > gpurun_out/prof_r06_${WHAT}_kernels.txt
+    kernels >> gpurun_out/prof_r06_${WHAT}_kernels.txt
+  done
+  ;;
 esac
 cp profiles/r06_*.md gpurun_out/ 2>/dev/null || true
 cp profiles/traffic_latest.json gpurun_out/traffic_latest.json
