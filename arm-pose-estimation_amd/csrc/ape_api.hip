@@ -802,11 +802,7 @@ static int mc_small_launch(ape_model_t* m, const float* x, size_t x_stream_strid
 // x_ring: time step t of every window lives in slot (t + x_ring) mod T (0 = the linear layout of the public entry)
 static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int32_t T, uint32_t flags,
                              const float* masks_dev, float dropout_p, uint64_t seed, float* y_dev, void* stream,
-                             int x_ring, const float* h0_dev = nullptr, const float* c0_dev = nullptr, FkTail* fk = nullptr,
-                             const StreamPostParams* post = nullptr, bool* post_done = nullptr) {
-    // post / post_done (ape_streams_step): the bank's post-filter, offered to the launch; *post_done says whether the launch took it
-    // into its tail (one launch of ape_lstm_cluster32's short-window instantiation over all the rows) or the caller still has to run it
-    if (post_done) *post_done = false;
+                             int x_ring, const float* h0_dev = nullptr, const float* c0_dev = nullptr, FkTail* fk = nullptr) {
     if (!m || !x_dev || !y_dev) return fail(APE_ERR_INVALID_ARG, "lstm_forward: NULL argument");
     if (B < 1 || T < 1) return fail(APE_ERR_INVALID_ARG, "lstm_forward: B=%d T=%d must be >= 1", B, T);
     flags &= ~(uint32_t)APE_FLAG_XCD_CLASSES;            // (the launcher's own bit)
@@ -1027,12 +1023,8 @@ static int lstm_forward_impl(ape_model_t* m, const float* x_dev, int32_t B, int3
                 c.xcc_slots = m->xcc_slots;
                 c.dbg_wg = m->dbg_wg;
                 m->last_kernel = "ape_lstm_cluster32";
-                const bool with_post = post != nullptr && post_done != nullptr && n16 == 0 && nb == B && post->S == B && post->O == c.O &&
-                                       ape_cluster32_post_supported(T, *post);
-                hipError_t e = with_post ? ape_launch_lstm_cluster32_post(H, L, m->KX, (nb + 31) / 32, c, *post, (hipStream_t)stream)
-                                         : ape_launch_lstm_cluster32(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
+                hipError_t e = ape_launch_lstm_cluster32(H, L, m->KX, (nb + 31) / 32, c, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(APE_ERR_HIP, "cluster32 lstm launch failed: %s", hipGetErrorString(e));
-                if (with_post) *post_done = true;
             }
             return APE_OK;
         }
@@ -1772,7 +1764,6 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         q.part = b->post_part; q.part_cnt = b->post_cnt;
         return q;
     };
-    bool post_in_tail = false;
     if (b->shared_l0) {
         if (!m->has_weights) return fail(APE_ERR_NOT_READY, "streams_step: weights not loaded");
         if ((size_t)b->S * b->T > m->hseq_cap) return fail(APE_ERR_CAPACITY, "streams_step: the layer-0 sequence workspace is gone");
@@ -1946,25 +1937,16 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
         hipEvent_t ev_a, ev_z;
         prof_pair(&ev_a, &ev_z);
         if (ev_a) (void)hipEventRecord(ev_a, (hipStream_t)stream);
-        // a deterministic bank without stacking: the post-filter is offered to the regressor's launch (ape_lstm_cluster32's short-window
-        // instantiation runs it in its tail for the four streams a member finishes: one kernel less per step, round 6); a profiled
-        // step keeps the kernels apart, so that the pair of events brackets the regressor alone as it always did
-        const StreamPostParams q0 = post_params();
-        static const bool post_apart = getenv("APE_BANK_POST_APART") != nullptr;        // (diagnostic override for A/B runs)
-        const bool offer = !drop && q0.smooth == 1 && q0.n_mc == 1 && b->S >= 8 && !b->prof_on && !post_apart;
         if (int rc = lstm_forward_impl(m, b->xring, b->S * b->n_mc, b->T,
                                        flags | diag_wt | (!drop ? 0u : b->inj_masks ? APE_FLAG_DROPOUT_MASKS : APE_FLAG_DROPOUT_PHILOX),
-                                       drop ? b->inj_masks : nullptr, drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring,
-                                       nullptr, nullptr, nullptr, offer ? &q0 : nullptr, offer ? &post_in_tail : nullptr))
+                                       drop ? b->inj_masks : nullptr, drop ? b->dropout_p : 0.0f, b->seed + b->mc_calls, b->y_new, stream, x_ring))
             return rc;
         if (ev_z) (void)hipEventRecord(ev_z, (hipStream_t)stream);
         ++b->mc_calls;
     }
-    if (!post_in_tail) {
-        StreamPostParams q = post_params();
-        hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
-    }
+    StreamPostParams q = post_params();
+    hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
     ++b->steps;
     journal_add(m, je);
     return APE_OK;

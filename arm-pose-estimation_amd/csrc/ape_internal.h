@@ -315,9 +315,6 @@ hipError_t ape_launch_lstm_cluster_f16(int H, int L, int KX, int nmt, int cluste
 bool ape_cluster32_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster32(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream);
-// ... with a deterministic stream bank's post-filter (stream_post_device.h) in the launch's tail: one kernel less per step
-bool ape_cluster32_post_supported(int T, const StreamPostParams& q);
-hipError_t ape_launch_lstm_cluster32_post(int H, int L, int KX, int clusters, const ClusterParams& p, const StreamPostParams& q, hipStream_t stream);
 // second generation for 16-unit members (lstm_cluster16.hip: the 3 x 128 upper-arm model; first-generation register image wcl)
 bool ape_cluster16_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster16(int H, int L, int KX);

@@ -34,7 +34,6 @@
 
 #include "ape_internal.h"
 #include "async_look.h"
-#include "stream_post_device.h"
 #include "../../include/ape_hip.h"
 
 namespace {
@@ -128,18 +127,8 @@ __device__ __forceinline__ void dma_1k(unsigned lds_addr, unsigned voff, u32x4 r
 #ifndef C32_QPD
 #define C32_QPD 0
 #endif
-// Post (round 6): an empty pack, or ONE C32Post<TMsg> = the parameters of a stream bank's post-filter that runs in the TAIL of this launch -- a
-// member finishes four windows in the head; where those are the bank's streams (deterministic bank: one row per stream, no stacking) its
-// four waves are the four role waves of stream_post_lanes for them, and the step's third kernel (5.5 us for 1024 streams, of which a
-// dependent load -> float64 chain -> store of any size costs ~4) is gone.  (A pack, not a second kernel around a shared body: with an
-// empty pack the kernels' names, signatures and object code are what they were.)
-template <typename TMsg> struct C32Post { typedef TMsg msg_t; StreamPostParams q; };
-template <typename A> __device__ __forceinline__ const A& c32_first(const A& a) { return a; }
-
-template <int H, int L, int KX, bool ENDS, typename... Post>
-__global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams p, const Post... post) {
-    constexpr bool POST = sizeof...(Post) == 1;
-    static_assert(sizeof...(Post) <= 1 && (!POST || ENDS), "the post-filter rides in the short-window instantiation");
+template <int H, int L, int KX, bool ENDS>
+__global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams p) {
     constexpr int UPW = 8;                  // hidden units per wave (x 4 gates = the 32 columns of its tile)
     constexpr int GH = H / (4 * UPW);       // members per cluster
     constexpr int MR = 32;                  // windows per cluster (one 32-row tile)
@@ -776,13 +765,8 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
     }
 #endif
     // ---- head: member m finishes windows 4m .. 4m+3 of the cluster's 32 ----------------------------------------------------------------
-    constexpr int RPM = MR / GH;
-    float* y_tail = nullptr;                                     // POST: the member's four prediction rows, for the post-filter below
-    if constexpr (POST) {
-        __shared__ float y_tail_s[RPM * 24];
-        y_tail = y_tail_s;
-    }
     {
+        constexpr int RPM = MR / GH;
         // (window, target) dot products over H, 4 lanes each (k-blocks interleaved by 4), combined by lane shuffles
         const int part = tid & 3;
         for (int oi = tid >> 2; oi < ((RPM * O + 63) / 64) * 64; oi += 64) {
@@ -806,18 +790,9 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
             s_acc += __shfl_xor(s_acc, 1, 64);
             s_acc += __shfl_xor(s_acc, 2, 64);
             if (p.y != nullptr && live && part == 0 && b < p.B) p.y[(size_t)b * O + o] = s_acc + p.b_out[o];
-            if constexpr (POST) {
-                if (live && part == 0) y_tail[rr * O + o] = s_acc + p.b_out[o];
-            }
         }
     }
     C32_TL(5);
-    // ---- the bank's post-filter for this member's four streams (de-normalise, forward kinematics, message; stream_post_device.h) ----
-    if constexpr (POST) {
-        const auto& pa = c32_first(post...);
-        __syncthreads();
-        ape_postdev::stream_post_lanes<typename std::remove_reference_t<decltype(pa)>::msg_t, RPM>(pa.q, row0 + member * RPM, y_tail);
-    }
     // ---- self-cleaning: the last workgroup out re-zeroes every polled word ------------------------------------------
     __syncthreads();
     if (tid == 0)
@@ -829,12 +804,6 @@ __global__ __launch_bounds__(256, 1) void ape_lstm_cluster32(const ClusterParams
         for (int i = tid; i < (int)gridDim.x; i += 256) __hip_atomic_store(xcc_words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 8) __hip_atomic_store(class_ticket + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (host frames: the sticky status word, behind every workgroup's outputs -- a launch that gave up never gets here and the host
-        //  keeps its sentinel)
-        if constexpr (POST) {
-            const StreamPostParams& q = c32_first(post...).q;
-            if (tid == 0 && q.status_out != nullptr) *q.status_out = __hip_atomic_load(q.status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -852,13 +821,8 @@ hipError_t ape_prepare_lstm_cluster32(int H, int L, int KX) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    // (these two hold ~1.5 KB of static LDS for the post-filter beside the dynamic layout: the limit asked for is the layout itself)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, true, C32Post<float>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes32());
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, true, C32Post<double>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes32());
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ape_lstm_cluster32<256, 2, 32, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, APE_LDS_BYTES);
 }
 
 // `clusters` = 32-window clusters needed; the grid is rounded up to whole block-index classes (8 clusters), the extra
@@ -869,20 +833,5 @@ hipError_t ape_launch_lstm_cluster32(int H, int L, int KX, int clusters, const C
     constexpr size_t smem = smem_bytes32();
     if (p.T <= APE_C32_ENDS_MAX_T) hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32, true>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
     else hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32, false>), dim3(grid_clusters * 8), dim3(256), smem, stream, p);
-    return hipGetLastError();
-}
-
-// Can this launch carry the bank's post-filter in its tail?  One row per stream and no stacking (the lanes form of the post-filter), a window
-// the short-window instantiation covers, at most 20 targets (y_tail), no per-stream completion words (small host frames: their own kernel).
-bool ape_cluster32_post_supported(int T, const StreamPostParams& q) {
-    return T <= APE_C32_ENDS_MAX_T && q.smooth == 1 && q.n_mc == 1 && q.O <= 20 && q.done_out == nullptr && q.part == nullptr;
-}
-
-hipError_t ape_launch_lstm_cluster32_post(int H, int L, int KX, int clusters, const ClusterParams& p, const StreamPostParams& q, hipStream_t stream) {
-    if (!ape_cluster32_supported(H, L, KX) || !ape_cluster32_post_supported(p.T, q) || q.S != p.B || q.O != p.O) return hipErrorInvalidValue;
-    const int grid_clusters = (clusters + 7) / 8 * 8;
-    constexpr size_t smem = smem_bytes32();
-    if (q.msg_dtype == APE_F32) hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32, true, C32Post<float>>), dim3(grid_clusters * 8), dim3(256), smem, stream, p, C32Post<float>{q});
-    else hipLaunchKernelGGL((ape_lstm_cluster32<256, 2, 32, true, C32Post<double>>), dim3(grid_clusters * 8), dim3(256), smem, stream, p, C32Post<double>{q});
     return hipGetLastError();
 }

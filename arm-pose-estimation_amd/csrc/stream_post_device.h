@@ -274,25 +274,24 @@ __device__ inline void stream_post(const StreamPostParams& p, const int s, const
 // per workgroup, the four role waves as above.  stream_post() gives every stream a workgroup of its own whose waves then run with ONE
 // active lane -- 4096 waves at 1024 streams, four per SIMD, each a chain of ~500 float64 instructions: the kernel was bound by their
 // issue slots (13.6 us at 1024 streams against 6 us for one stream).  Same device functions in the same order: bit-identical outputs.
-// (NL lanes per role wave carry streams s0 .. s0 + NL - 1 and read their predictions from y_rows[lane * O ...]: 64 from the bank's y_new in
-//  the kernel of its own; 4 from LDS in the tail of ape_lstm_cluster32, where a cluster member finishes four windows -- lstm_cluster32.hip)
-template <typename TMsg, int NL>
-__device__ inline void stream_post_lanes(const StreamPostParams& p, const int s0, const float* y_rows) {
+template <typename TMsg>
+__device__ inline void stream_post_wide(const StreamPostParams& p, const int s0) {
 #pragma clang fp contract(off)
 
-    __shared__ double rot[NL][3][3];
-    __shared__ double e0w[NL][21];                          // est row of every stream (the N == 1 message is a copy of it)
+    __shared__ double rot[64][3][3];
+    __shared__ double e0w[64][21];                          // est row of every stream (the N == 1 message is a copy of it)
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int s = s0 + lane, O = p.O;
-    const bool act = lane < NL && s < p.S;
+    const bool act = s < p.S;
     const bool hips = p.layout != APE_LAYOUT_ORI_CAL_LARM_UARM;
     const bool full = p.layout == APE_LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS;
     const int qc[3] = {hips ? 9 : 6, hips ? 13 : 10, 17};
     const int c_in[3] = {full ? 3 : 0, full ? 12 : 6, full ? 18 : 12};
-    if (lane < NL)
-        for (int c = role; c < 21; c += 4) e0w[lane][c] = 0.0;
+    if (p.status_out != nullptr && s0 == 0 && threadIdx.x == 255)
+        *p.status_out = __hip_atomic_load(p.status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = role; c < 21; c += 4) e0w[lane][c] = 0.0;
     __syncthreads();
-    const float* src = y_rows + (size_t)(act ? lane : 0) * O;
+    const float* src = p.y_new + (size_t)(act ? s : 0) * O;
     auto load = [&](int c) -> double {
         double v = (double)src[c];
         if (p.yy_m) v = v * p.yy_s[c] + p.yy_m[c];          // estimator.py:108-109
@@ -363,13 +362,6 @@ __device__ inline void stream_post_lanes(const StreamPostParams& p, const int s0
         __syncthreads();
         if (role == 0 && act) __hip_atomic_store(p.done_out + s, p.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-
-template <typename TMsg>
-__device__ inline void stream_post_wide(const StreamPostParams& p, const int s0) {
-    if (p.status_out != nullptr && s0 == 0 && threadIdx.x == 255)
-        *p.status_out = __hip_atomic_load(p.status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stream_post_lanes<TMsg, 64>(p, s0, p.y_new + (size_t)(s0 < p.S ? s0 : 0) * p.O);
 }
 
 }  // namespace ape_postdev

@@ -1,5 +1,6 @@
-# A/B of the eval bank's frame with the post-filter in the regressor's tail (default) and as a kernel of its own (APE_BANK_POST_APART=1):
-# kernel trace of 200 frames of 1024 streams per model.  Run on the GPU box: bash tests/tools/exp_r06_post_in_tail.sh
+# A/B of the eval bank's frame with the post-filter in the regressor's tail and as a kernel of its own (APE_BANK_POST_APART=1): kernel trace of
+# 200 frames of 1024 streams per model.  The tail form exists at commit f3b941f only (measured slower, taken out: profiles/r06_post_in_tail.md);
+# check that commit out to run this.  On the GPU box: bash tests/tools/exp_r06_post_in_tail.sh
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
