@@ -4,9 +4,9 @@
 // (utility/transformations.py:200-207 reduce_global_quat_to_y_rot -> :152-174 euler_to_quat) and the hips quaternion of the
 // post-filter (:177-179) -- as  a = atan2(y, x);  (cos(a / 2), 0, sin(a / 2), 0),  and the pocket features as sin(a), cos(a)
 // (estimate/watch_phone_pocket_nn.py:88-93).  In float64 on the device atan2 -> cos -> sin is three software routines of a few
-// hundred dependent instructions each; a row of the feature builder is ONE such chain, so the chain's length is the kernel's
-// duration (round 6: 7.0 us for 1024 rows, of which the quaternion algebra is the small part).  The half-angle identities give the
-// same numbers from two square roots and three divisions:
+// hundred dependent instructions each; a row of the feature builder is ONE such chain, issued at an instruction per ~9 cycles, so the
+// chain's length is the kernel's duration whatever the grid (round 6, 1024 rows: pocket 7.1 -> 6.3 us, watch 5.3 -> 5.0, upper arm
+// 7.3 -> 6.9; profiles/r06_post_in_tail.md).  The half-angle identities give the same numbers from two square roots and three divisions:
 //     r = sqrt(x^2 + y^2), c = x / r, |s| = |y| / r;  big = sqrt((1 + |c|) / 2) >= 0.707, small = |s| / (2 big);
 //     c >= 0:  cos(a/2) = big,   |sin(a/2)| = small;     c < 0:  cos(a/2) = small, |sin(a/2)| = big;     sin(a/2) carries y's sign
 // (|a/2| <= pi/2, so the cosine is never negative; the division is always by the well-conditioned one of the pair).  Each result is

@@ -432,6 +432,61 @@ def gen_stream_traces():
     ref_nn.load_deployed_model_from_hash = real_loader
 
 
+def edge_forward_quats(rng):
+    """android-frame calibration quaternions whose azimuth (transformations.py:200-207) covers the circle and its corners: the global y
+    rotation by `a` is the android quaternion (-cos(a/2), 0, 0, sin(a/2)) (android_quat_to_global_no_north, :225-233)"""
+    ang = [0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, np.pi - 1e-6, -np.pi + 1e-6, 1e-7, -1e-7, 3.0, -3.0, 0.75 * np.pi, -0.75 * np.pi, 1e-3]
+    ang += list(np.linspace(-np.pi, np.pi, 25))
+    q = [np.array([-np.cos(0.5 * a), 0.0, 0.0, np.sin(0.5 * a)]) for a in ang]
+    q += [np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 0.0, -1.0]), np.array([-1.0, 0.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0, 0.0])]
+    r = rand_unit_quats(rng, 30)
+    q += list(r[:16])                                           # tilted calibration poses
+    q += list(r[16:20] * 1e-18) + list(r[20:24] * 1e15)         # un-normalised: the azimuth does not depend on the norm
+    q += list(r[24:30] * rng.uniform(0.2, 3.0, size=(6, 1)))
+    q += [np.zeros(4)]                                          # no calibration at all: atan2(0, 0)
+    return np.array(q)
+
+
+def gen_feature_edges():
+    """parse_row_to_xx of the three reference estimators on rows whose calibration quaternions sweep the azimuths (the recorded traces of
+    gen_stream_traces hold ONE forward quaternion each): fixture for the feature builder's angle arithmetic"""
+    from wear_mocap_ape.data_types import messaging
+    from wear_mocap_ape.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+    classes = {
+        "pocket": (WatchPhonePocketNN, messaging.WATCH_PHONE_IMU_LOOKUP),
+        "watch": (WatchOnlyNN, messaging.WATCH_ONLY_IMU_LOOKUP),
+        "uarm": (WatchPhoneUarmNN, messaging.WATCH_PHONE_IMU_LOOKUP),
+    }
+    real_loader = ref_nn.load_deployed_model_from_hash
+    blob = {}
+    for name, (cls, lookup) in classes.items():
+        def fake_load(hash_str, _name=name):
+            model, p, _ = ref_model(_name, 3, dropout=0.0)
+            return model, p
+        ref_nn.load_deployed_model_from_hash = fake_load
+        rng = np.random.default_rng(33)
+        fwd = edge_forward_quats(rng)
+        rows = synth_rows(rng, len(fwd), len(lookup), lookup)
+        rows[:, [lookup[f"sw_forward_{c}"] for c in "wxyz"]] = fwd.astype(np.float32)
+        if "ph_forward_w" in lookup:     # the phone's own calibration: the same sweep, in another order; three rows with rotation == calibration
+            ph = fwd[rng.permutation(len(fwd))].astype(np.float32)
+            rows[:, [lookup[f"ph_forward_{c}"] for c in "wxyz"]] = ph
+            rows[:3, [lookup[f"ph_rotvec_{c}"] for c in "wxyz"]] = ph[:3]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            est = cls(model_hash=HASHES[name], smooth=1, add_mc_samples=True, monte_carlo_samples=1)
+            xs = []
+            with np.errstate(all="ignore"):
+                for row32 in rows:
+                    xs.append(np.asarray(est.parse_row_to_xx(array("f", row32.tolist())), dtype=np.float64))
+        blob[f"rows_{name}"] = rows
+        blob[f"xx_{name}"] = np.array(xs)
+    ref_nn.load_deployed_model_from_hash = real_loader
+    np.savez_compressed(OUT / "feature_edges.npz", **blob)
+
+
 def gen_trace_mc_stats():
     """The reference ESTIMATORS in their Monte-Carlo mode, end to end: each class is built with its deployed dropout rate and
     4000 samples per frame, driven through the 20-row trace of `stream_trace_<name>.npz` exactly as `processing_loop` does
@@ -519,6 +574,10 @@ def main():
         gen_trace_mc_stats()
         print("wrote", OUT / "trace_mc_stats.npz")
         return
+    if sys.argv[1:] == ["feature_edges"]:    # add this one fixture without rewriting the others
+        gen_feature_edges()
+        print("wrote", OUT / "feature_edges.npz")
+        return
     if sys.argv[1:] == ["mc"]:
         gen_mc_stats()
         print("wrote", OUT / "mc_stats.npz")
@@ -538,6 +597,7 @@ def main():
     gen_fk(stats)
     gen_stream_traces()
     gen_trace_mc_stats()
+    gen_feature_edges()
     gen_csv_header()
     total = sum(f.stat().st_size for f in OUT.glob("*.np*")) + (OUT / "norm_stats.json").stat().st_size
     print("golden fixtures written to", OUT, f"({total / 1024:.0f} KiB)")

@@ -65,3 +65,33 @@ def test_level16_serves_the_upper_arm_estimators_eval_windows(norm_stats):
     m(torch.from_numpy(x).cuda(), last_step_only=True, normalize_input=True)
     assert m.last_kernel() == "ape_lstm_cluster"
     m.check()
+
+
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_feature_builder_over_the_azimuths(golden, tmp_path, monkeypatch, name):
+    """`ape_parse_rows` on `feature_edges.npz` -- the reference's own parse_row_to_xx outputs on 74 rows whose calibration quaternions sweep
+    the azimuth circle, its corners (0, +-pi, +-pi/2, pi - 1e-6, +-1e-7), tilted and un-normalised poses (1e-18 .. 1e15) and the zero
+    quaternion.  Round 6: the builder gets cos / sin of the azimuth and of half of it from half-angle identities instead of
+    atan2 -> cos / sin (csrc/angle_device.h); the recorded traces hold ONE calibration quaternion each, this fixture holds the circle.
+    float32 rows against the reference at 1e-6 (2e-6 upper arm: part of ITS quaternion math is float32), float64
+    rows against the host builder (the reference's formulas in float64; itself held to this fixture on the CPU) at 1e-12; NaN exactly
+    where the reference has NaN."""
+    from array import array
+    from tests.test_hip_parity import _deploy_dir
+    from wear_mocap_ape_amd import config
+    from wear_mocap_ape_amd.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape_amd.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+    g = golden("feature_edges.npz")
+    deploy, h = _deploy_dir(tmp_path, name, 3, dropout=0.0)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    est = {"pocket": WatchPhonePocketNN, "watch": WatchOnlyNN, "uarm": WatchPhoneUarmNN}[name](model_hash=h)
+    rows, ref = g[f"rows_{name}"], g[f"xx_{name}"]
+    xx = est.parse_rows(rows).cpu().numpy().astype(np.float64)
+    assert xx.shape == ref.shape and np.array_equal(np.isnan(xx), np.isnan(ref))
+    assert np.nanmax(np.abs(xx - ref)) < (2e-6 if name == "uarm" else 1e-6), np.nanmax(np.abs(xx - ref))
+    xx64 = est.parse_rows(rows, out_dtype=torch.float64).cpu().numpy()
+    with np.errstate(all="ignore"):
+        host = np.array([np.asarray(est.parse_row_to_xx(array("f", r.tolist())), dtype=np.float64) for r in rows])
+    assert np.array_equal(np.isnan(xx64), np.isnan(host))
+    assert np.nanmax(np.abs(xx64 - host)) < (1e-12 if name == "uarm" else 1e-6), np.nanmax(np.abs(xx64 - host))

@@ -174,6 +174,27 @@ def test_features_from_row(golden, name):
         assert np.abs(xx.astype(np.float64) - ref[f]).max() < tol, (f, np.abs(xx - ref[f]).max())
 
 
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_features_from_row_over_the_azimuths(golden, name):
+    """the same builder on `feature_edges.npz`: 74 rows whose calibration quaternions sweep the azimuth circle, its corners (0, +-pi, +-pi/2,
+    pi - 1e-6, +-1e-7), tilted and un-normalised poses (1e-18 .. 1e15) and no calibration at all (the zero quaternion: NaN where the
+    reference has NaN) -- the reference's own parse_row_to_xx outputs (tests/golden/gen_golden.py gen_feature_edges)"""
+    from wear_mocap_ape_amd.data_types import messaging
+    import wear_mocap_ape_amd.estimate.watch_only as wo
+    import wear_mocap_ape_amd.estimate.watch_phone_pocket_nn as wp
+    import wear_mocap_ape_amd.estimate.watch_phone_uarm_nn as wu
+    g = golden("feature_edges.npz")
+    fn, lookup = {"pocket": (wp.features_from_row, messaging.WATCH_PHONE_IMU_LOOKUP),
+                  "watch": (wo.features_from_row, messaging.WATCH_ONLY_IMU_LOOKUP),
+                  "uarm": (wu.features_from_row, messaging.WATCH_PHONE_IMU_LOOKUP)}[name]
+    rows, ref = g[f"rows_{name}"], g[f"xx_{name}"]
+    assert len(rows) == 74 and np.isnan(ref).sum() == {"pocket": 2, "watch": 0, "uarm": 12}[name]
+    with np.errstate(all="ignore"):
+        xx = np.array([np.asarray(fn(array("f", r.tolist()), lookup), dtype=np.float64) for r in rows])
+    assert np.array_equal(np.isnan(xx), np.isnan(ref))
+    assert np.nanmax(np.abs(xx - ref)) < (1e-12 if name == "uarm" else 1e-7), np.nanmax(np.abs(xx - ref))      # measured: 6.7e-16 / 0.0
+
+
 def build_c_caller(tmp_path):
     """gcc-compile tests/c_abi/demo.c (plain C, no Python, no torch) against include/ape_hip.h and libape_hip.so"""
     import subprocess
