@@ -1280,9 +1280,7 @@ int ape_model_recover(ape_model_t* m) {
     for (int i = 0; i < m->journal_n && ok; ++i) {
         const ApeJournalEntry& e = m->journal[i];
         if (e.kind != ApeJournalEntry::STEP) continue;
-        // (one row pushed AHEAD since: the alternate ring still holds the step's window -- replay_entry steps on that one)
-        const bool ahead = e.bank->frames == e.bank_frames + 1 && e.bank->xring_alt != nullptr && e.bank->alt_frames == e.bank_frames;
-        if ((e.bank->frames != e.bank_frames && !ahead) || e.bank->steps != e.bank_steps + 1) ok = false;
+        if (e.bank->frames != e.bank_frames || e.bank->steps != e.bank_steps + 1) ok = false;
         for (int j = i + 1; j < m->journal_n; ++j)
             if (m->journal[j].kind == ApeJournalEntry::STEP && m->journal[j].bank == e.bank) ok = false;
     }
@@ -1457,9 +1455,7 @@ static hipError_t bank_alloc(ape_streams* b) {
     if (b->xring) (void)hipFree(b->xring);
     if (b->yring) (void)hipFree(b->yring);
     if (b->y_new) (void)hipFree(b->y_new);
-    if (b->xring_alt) (void)hipFree(b->xring_alt);          // (ape_streams_push_rows_ahead allocates it again when it is wanted)
-    b->xring = b->yring = b->y_new = b->xring_alt = nullptr;
-    b->alt_frames = -1; b->staged = false;
+    b->xring = b->yring = b->y_new = nullptr;
     hipError_t e = hipMalloc((void**)&b->xring, R * b->T * I * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&b->yring, R * b->smooth * O * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&b->y_new, R * O * sizeof(float));
@@ -1630,11 +1626,6 @@ int ape_streams_set_mc(ape_streams_t* b, int32_t n_mc, float dropout_p, uint64_t
 
 int ape_streams_destroy(ape_streams_t* b) {
     if (!b) return APE_OK;
-    if (b->side) { (void)hipStreamSynchronize(b->side); (void)hipStreamDestroy(b->side); }
-    if (b->ev_staged) (void)hipEventDestroy(b->ev_staged);
-    if (b->ev_sync) (void)hipEventDestroy(b->ev_sync);
-    for (auto ev : b->ev_read) if (ev) (void)hipEventDestroy(ev);
-    if (b->xring_alt) (void)hipFree(b->xring_alt);
     if (b->xring) (void)hipFree(b->xring);
     if (b->yring) (void)hipFree(b->yring);
     if (b->y_new) (void)hipFree(b->y_new);
@@ -1664,20 +1655,11 @@ int ape_streams_destroy(ape_streams_t* b) {
 int ape_streams_reset(ape_streams_t* b) {
     if (!b) return fail(APE_ERR_INVALID_ARG, "streams_reset: NULL bank");
     b->frames = 0; b->steps = 0;
-    b->alt_frames = -1;            // (the next push is a cold start into `xring`; a push ahead in flight is waited for there: `staged` stays)
     return APE_OK;
 }
 
 // where the next row goes: one slot of each of the stream's n_mc windows (stride T*I apart), or -- first row after
 // a reset -- all n_mc*T slots, which are contiguous
-// a push ahead in flight on the bank's side stream: whatever the step's stream does next with the rings comes behind it
-static int join_staged(ape_streams* b, void* stream) {
-    if (!b->staged) return APE_OK;
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, b->ev_staged, 0));
-    b->staged = false;
-    return APE_OK;
-}
-
 static void next_slot(const ape_streams* b, size_t I, float** out, int* rep, size_t* rep_stride) {
     const bool cold = b->frames == 0;
     *out = b->xring + (cold ? 0 : (size_t)(b->frames % b->T) * I);
@@ -1696,7 +1678,6 @@ int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev,
     if (I != b->model->dims.input_size)
         return fail(APE_ERR_INVALID_ARG, "streams_push_rows: kind %d builds %d features, the model takes %d", kind, I,
                     b->model->dims.input_size);
-    if (int rc = join_staged(b, stream)) return rc;
     float* out; int rep; size_t rep_stride;
     next_slot(b, (size_t)I, &out, &rep, &rep_stride);
     hipError_t e = ape_launch_parse_rows(rows_dev, b->S, width, kind, out, APE_F32, I, (size_t)b->n_mc * b->T * I, rep,
@@ -1706,71 +1687,10 @@ int ape_streams_push_rows(ape_streams_t* b, int32_t kind, const float* rows_dev,
     return APE_OK;
 }
 
-// The next frame's rows while the newest step may still be running (deterministic banks; include/ape_hip.h).  The feature builder is
-// the one launch of a frame that does not depend on the frame in front: issued on the bank's side stream it runs beside the tail of the
-// regressor and the post-filter instead of in front of the next regressor launch (1024 streams, T = 6: 93.0 -> 87.4 us per frame with
-// a stand-in, tests/tools/exp_r06_parse_side_stream.py).  What it must not do is write the ring the step in flight reads -- the new row's slot is
-// that window's OLDEST row -- so the bank alternates between two rings: this launch writes the new slot and a copy of the previous
-// frame's slot (the one row the alternate ring lacks) into the alternate ring, and the two swap roles.  Ordering, all by events: the side
-// stream waits for the caller's `rows_ready` (if any), for the last step that read the alternate ring, and -- when the alternate ring
-// is stale (first use, cold start, in-order pushes in between) -- for a whole-ring copy on the step's stream; the next launch on the
-// step's stream that touches the rings waits for the side stream (join_staged).
-int ape_streams_push_rows_ahead(ape_streams_t* b, int32_t kind, const float* rows_dev, void* rows_ready, void* stream) {
-    if (!b || !rows_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_rows_ahead: NULL argument");
-    if (!b->xring) return fail(APE_ERR_NOT_READY, "streams_push_rows_ahead: the bank lost its rings in a failed ape_streams_set_mc");
-    // Monte-Carlo banks keep n_mc window copies per stream and spend a percent of their frame in the builder: in order, as always.
-    // So does a cold start (every slot of the window takes the row).
-    if (b->mc || b->n_mc != 1 || b->frames == 0) {
-        if (rows_ready) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)rows_ready, 0));
-        return ape_streams_push_rows(b, kind, rows_dev, stream);
-    }
-    int width, I;
-    const int big_endian = (kind & APE_PARSE_BIG_ENDIAN) ? 1 : 0;
-    kind &= ~APE_PARSE_BIG_ENDIAN;
-    if (!parse_kind_dims(kind, &width, &I)) return fail(APE_ERR_INVALID_ARG, "streams_push_rows_ahead: unknown kind %d", kind);
-    if (I != b->model->dims.input_size)
-        return fail(APE_ERR_INVALID_ARG, "streams_push_rows_ahead: kind %d builds %d features, the model takes %d", kind, I,
-                    b->model->dims.input_size);
-    HIP_TRY(hipSetDevice(b->model->dims.device));
-    const size_t ring_bytes = (size_t)b->S * b->T * I * sizeof(float);
-    if (!b->side) {
-        HIP_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming | hipEventDisableSystemFence));
-        HIP_TRY(hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming | hipEventDisableSystemFence));
-        for (auto& ev : b->ev_read) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));
-    }
-    if (!b->xring_alt) { HIP_TRY(hipMalloc((void**)&b->xring_alt, ring_bytes)); b->alt_frames = -1; }
-    // (two pushes ahead in a row: the first one's slot is the row this one carries over -- same side stream, already in order)
-    if (b->alt_frames != b->frames - 1) {
-        // the alternate ring does not hold the window that ended one frame ago: bring it up to the current one on the step's stream
-        // (behind every step that read it and every in-order push into the current ring), and let the side stream see that
-        if (int rc = join_staged(b, stream)) return rc;
-        HIP_TRY(hipMemcpyAsync(b->xring_alt, b->xring, ring_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        HIP_TRY(hipEventRecord(b->ev_sync, (hipStream_t)stream));
-        HIP_TRY(hipStreamWaitEvent(b->side, b->ev_sync, 0));
-    } else {
-        // steady alternation: the last step that read the alternate ring is two steps back
-        HIP_TRY(hipStreamWaitEvent(b->side, b->ev_read[b->ring_sel ^ 1], 0));
-    }
-    if (rows_ready) HIP_TRY(hipStreamWaitEvent(b->side, (hipEvent_t)rows_ready, 0));
-    const size_t slot_new = (size_t)(b->frames % b->T) * I, slot_prev = (size_t)((b->frames - 1) % b->T) * I;
-    hipError_t e = ape_launch_parse_rows(rows_dev, b->S, width, kind, b->xring_alt + slot_new, APE_F32, I, (size_t)b->T * I, 1, (size_t)b->T * I,
-                                         big_endian, b->side, b->xring + slot_prev, b->xring_alt + slot_prev);
-    if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_push_rows_ahead launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(b->ev_staged, b->side));
-    std::swap(b->xring, b->xring_alt);
-    b->ring_sel ^= 1;
-    b->alt_frames = b->frames;         // what is now the alternate ring holds the window of the frame in front, complete
-    b->staged = true;
-    ++b->frames;
-    return APE_OK;
-}
-
 int ape_streams_push_features(ape_streams_t* b, const float* xx_dev, void* stream) {
     if (!b || !xx_dev) return fail(APE_ERR_INVALID_ARG, "streams_push_features: NULL argument");
     if (!b->xring) return fail(APE_ERR_NOT_READY, "streams_push_features: the bank lost its rings in a failed ape_streams_set_mc");
     const int I = b->model->dims.input_size;
-    if (int rc = join_staged(b, stream)) return rc;
     float* out; int rep; size_t rep_stride;
     next_slot(b, (size_t)I, &out, &rep, &rep_stride);
     hipError_t e = ape_launch_ring_write(xx_dev, b->S, I, out, (size_t)b->n_mc * b->T * I, rep, rep_stride, (hipStream_t)stream);
@@ -1801,7 +1721,6 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
     if (!b->xring || !b->yring || !b->y_new)
         return fail(APE_ERR_NOT_READY, "streams_step: the bank lost its rings in a failed ape_streams_set_mc");
     if (b->frames == 0) return fail(APE_ERR_NOT_READY, "streams_step: no row pushed since the last reset");
-    if (int rc = join_staged(b, stream)) return rc;          // (a row pushed ahead on the side stream: the step comes behind it)
     // the exchange-form selectors of include/ape_hip.h travel to the frame's LSTM launches unchanged (same bits whichever is set)
     const uint32_t diag_wt = flags & (APE_FLAG_ANY_PLACEMENT | APE_FLAG_IN_XCD_PLAIN | APE_FLAG_NO_XCD_CLASSES);
     flags &= ~diag_wt;
@@ -2028,9 +1947,6 @@ static int streams_step_impl(ape_streams_t* b, uint32_t flags, void* msg_dev, vo
     StreamPostParams q = post_params();
     hipError_t e = ape_launch_stream_post(q, (hipStream_t)stream);
     if (e != hipSuccess) return fail(APE_ERR_HIP, "streams_step launch failed: %s", hipGetErrorString(e));
-    // (a later push ahead writes the ring this step read only behind this point)
-    static const bool exp_no_read = getenv("APE_EXP_AHEAD_NO_READ_EVENT") != nullptr;      // TIMING EXPERIMENT ONLY (unsafe): see exp_r06_parse_side_stream.py
-    if (b->side && !exp_no_read) HIP_TRY(hipEventRecord(b->ev_read[b->ring_sel], (hipStream_t)stream));
     ++b->steps;
     journal_add(m, je);
     return APE_OK;
@@ -2204,12 +2120,8 @@ static int replay_entry(ape_model_t* m, const ApeJournalEntry& e) {
             return ape_infer(m, (const float*)e.in0, e.B, e.T, e.flags, (float*)e.out0, e.out1, e.i2, e.stream);
         case ApeJournalEntry::STEP: {
             ape_streams* b = e.bank;
-            b->steps = e.bank_steps; b->mc_calls = e.bank_mc_calls;         // (frames unchanged, or one row pushed ahead: checked by the caller)
-            const bool ahead = b->frames == e.bank_frames + 1;
-            if (ahead) { std::swap(b->xring, b->xring_alt); b->frames = e.bank_frames; }
-            const int rc = ape_streams_step(b, e.flags, e.out0, e.out1, e.i2, e.stream);
-            if (ahead) { std::swap(b->xring, b->xring_alt); b->frames = e.bank_frames + 1; }
-            return rc;
+            b->steps = e.bank_steps; b->mc_calls = e.bank_mc_calls;         // (frames unchanged: checked by the caller)
+            return ape_streams_step(b, e.flags, e.out0, e.out1, e.i2, e.stream);
         }
     }
     return fail(APE_ERR_INVALID_ARG, "recover: unknown journal entry");

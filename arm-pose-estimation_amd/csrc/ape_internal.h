@@ -355,8 +355,7 @@ bool ape_cluster_f16v2_supported(int H, int L, int KX);
 hipError_t ape_prepare_lstm_cluster_f16v2(int H, int L, int KX);
 hipError_t ape_launch_lstm_cluster_f16v2(int H, int L, int KX, int clusters, const ClusterParams& p, hipStream_t stream, bool duo = false);
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
-                                 size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream,
-                                 const float* carry_src = nullptr, float* carry_dst = nullptr);
+                                 size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream);
 hipError_t ape_launch_ring_write(const float* xx, int N, int I, float* out, size_t out_stride, int rep,
                                  size_t rep_stride, hipStream_t stream);
 hipError_t ape_launch_stream_post(const StreamPostParams& p, hipStream_t stream);

@@ -119,17 +119,6 @@ struct ape_streams {
     float dropout_p = 0.0f;
     unsigned long long seed = 0, mc_calls = 0;
     float* xring = nullptr;      // [S,n_mc,T,I] feature rows, slot = frame mod T (a stream's n_mc windows are copies)
-    // ape_streams_push_rows_ahead (deterministic banks): a second ring, so that the NEXT frame's feature builder can run on a side stream
-    // beside the step that reads this one.  `xring` always names the ring that holds the newest complete window; a push ahead writes the
-    // new slot AND a copy of the previous frame's slot into `xring_alt`, then the two swap.
-    float* xring_alt = nullptr;
-    long long alt_frames = -1;   // `frames` value the alternate ring is complete for (-1: stale -- a whole-ring copy comes first)
-    int ring_sel = 0;            // which of the two event slots below belongs to `xring`
-    hipStream_t side = nullptr;
-    hipEvent_t ev_staged = nullptr;            // side stream: the pushed-ahead slot is in its ring
-    hipEvent_t ev_read[2] = {nullptr, nullptr};   // step's stream: the last step that read ring k has been issued up to here
-    hipEvent_t ev_sync = nullptr;              // step's stream: a whole-ring copy / an in-order push that the side stream must see
-    bool staged = false;         // a push ahead is in flight on the side stream: the next launch that touches the rings waits for it
     float* yring = nullptr;      // [S,smooth,n_mc,O] model outputs, slot = step mod smooth
     float* y_new = nullptr;      // [S,n_mc,O]
     double* post_part = nullptr; // split post-filter (stream_post_device.h): [S][chunks][21] partial sums + [S] tickets behind them, or

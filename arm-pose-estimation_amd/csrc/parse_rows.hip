@@ -32,15 +32,11 @@ constexpr int XW = 39;                          // feature row stride in LDS (od
 // plain [N,I] matrix; the stream bank (ape_streams_push_rows) points it at one slot of every stream's window ring
 // (out_stride = T*I) or, on a cold start, at all T of them (rep = T, rep_stride = I: estimator.py:96-97).
 // big_endian: the rows are the UDP payload as received (55 or 28 big-endian float32, stream_listener/imu.py:53).
-// carry_dst (ape_streams_push_rows_ahead: the bank alternates between two window rings so that this launch can run beside the step that
-// reads the other one): row n's I values at carry_src + n * out_stride -- the previous frame's slot in the ring being read -- are copied to
-// carry_dst + n * out_stride, the same slot of the ring being written; nullptr: nothing is carried.
 template <typename TOut>
 __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* __restrict__ rows, int N, int width,
                                                                   int kind, TOut* __restrict__ out, int I,
                                                                   size_t out_stride, int rep, size_t rep_stride,
-                                                                  int big_endian, const float* __restrict__ carry_src,
-                                                                  float* __restrict__ carry_dst) {
+                                                                  int big_endian) {
     __shared__ float slab[PR_ROWS * 57];        // row stride 57: odd -> conflict-free per-thread rows
     const int tid = threadIdx.x;
     const size_t r0 = (size_t)blockIdx.x * PR_ROWS;
@@ -63,25 +59,19 @@ __global__ __launch_bounds__(PR_BLOCK) void ape_parse_rows_kernel(const float* _
         const int rr = idx / per_row, rem = idx - rr * per_row, j = rem / I, i = rem - j * I;
         out[(r0 + rr) * out_stride + j * rep_stride + i] = (TOut)xout[rr * XW + i];
     }
-    if (carry_dst != nullptr)
-        for (int idx = tid; idx < n * I; idx += PR_BLOCK) {
-            const int rr = idx / I, i = idx - rr * I;
-            carry_dst[(r0 + rr) * out_stride + i] = carry_src[(r0 + rr) * out_stride + i];
-        }
 }
 
 }  // namespace
 
 hipError_t ape_launch_parse_rows(const float* rows, int N, int width, int kind, void* out, int out_dtype, int I,
-                                 size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream,
-                                 const float* carry_src, float* carry_dst) {
+                                 size_t out_stride, int rep, size_t rep_stride, int big_endian, hipStream_t stream) {
     const int grid = (N + PR_ROWS - 1) / PR_ROWS;
     if (out_dtype == APE_F32)
         hipLaunchKernelGGL(ape_parse_rows_kernel<float>, dim3(grid), dim3(PR_BLOCK), 0, stream, rows, N, width, kind,
-                           static_cast<float*>(out), I, out_stride, rep, rep_stride, big_endian, carry_src, carry_dst);
+                           static_cast<float*>(out), I, out_stride, rep, rep_stride, big_endian);
     else
         hipLaunchKernelGGL(ape_parse_rows_kernel<double>, dim3(grid), dim3(PR_BLOCK), 0, stream, rows, N, width, kind,
-                           static_cast<double*>(out), I, out_stride, rep, rep_stride, big_endian, carry_src, carry_dst);
+                           static_cast<double*>(out), I, out_stride, rep, rep_stride, big_endian);
     return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ MODEL_LSTM, MODEL_FF, MODEL_IMUPOSE = 0, 1, 2
 PARSE_WATCH_PHONE_POCKET, PARSE_WATCH_ONLY, PARSE_WATCH_ONLY_PHONE_MSG, PARSE_WATCH_PHONE_UARM = 0, 1, 2, 3
 PARSE_SHAPES = {0: (55, 22), 1: (28, 20), 2: (55, 20), 3: (55, 38)}
 PARSE_BIG_ENDIAN = 0x100          # OR-ed into a kind: rows are big-endian float32 (the UDP payload as received)
-ABI_VERSION = 8
+ABI_VERSION = 7
 
 EST_WIDTH = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 21, LAYOUT_ORI_CAL_LARM_UARM: 14, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 21}
 NUM_TARGETS = {LAYOUT_ORI_CAL_LARM_UARM_HIPS: 14, LAYOUT_ORI_CAL_LARM_UARM: 12, LAYOUT_ORI_POS_CAL_LARM_UARM_HIPS: 20}
@@ -77,7 +77,6 @@ SIGNATURES = {
     "ape_streams_set_mc": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_uint64]),
     "ape_streams_push_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ape_streams_push_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ape_streams_push_rows_ahead": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ape_streams_step": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ape_streams_frame_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
     "ape_streams_frame_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),

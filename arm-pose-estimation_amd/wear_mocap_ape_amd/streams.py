@@ -67,7 +67,7 @@ class StreamBank:
     """The per-frame step of many independent wearable streams with all state on the device: window rings,
     smoothing stacks, regressor, FK and messages (C ABI ``ape_streams_*``).  For every stream it does what one
     ``Estimator`` does per frame (estimator.py:93-137), so S estimator threads of the reference become three kernel
-    launches per frame (the first of them beside the frame in front where rows are pushed ``ahead``).  Rank-local: give each rank its ``shard_range`` of streams.
+    launches per frame.  Rank-local: give each rank its ``shard_range`` of streams.
 
     ``model`` is a HIP-backed ``DropoutLSTM`` (nn_models.py) with weights, norm stats and body set.
     ``monte_carlo_samples=None`` runs the regressor once per stream with deterministic weights; an integer n runs
@@ -133,24 +133,12 @@ class StreamBank:
                         "ape_streams_profile_read")
         return float(ms.value), int(n.value)
 
-    def push_rows(self, rows: torch.Tensor, kind: int, big_endian: bool = False, ahead: bool = False, ready: "torch.cuda.Event" = None):
-        """rows: float32 [S, 55|28] on the device -- one raw message per stream (data_types/messaging.py layouts).
-
-        ``ahead=True`` (``ape_streams_push_rows_ahead``): the row of the NEXT frame while the newest step may still be running -- the
-        feature builder runs on the bank's side stream beside that step instead of in front of the next one.  ``rows`` must be
-        complete when the call is made, or ``ready`` is an event recorded behind the work that produces it; it is not ordered behind
-        earlier work on the current stream, and the tensor must stay untouched until the next step has been issued."""
+    def push_rows(self, rows: torch.Tensor, kind: int, big_endian: bool = False):
+        """rows: float32 [S, 55|28] on the device -- one raw message per stream (data_types/messaging.py layouts)"""
         width = self._hip.PARSE_SHAPES[kind][0]
         if rows.dtype != torch.float32 or tuple(rows.shape) != (self._n, width) or not rows.is_cuda or not rows.is_contiguous():
             raise UserWarning(f"push_rows wants a contiguous float32 [{self._n},{width}] device tensor")
         k = kind | (self._hip.PARSE_BIG_ENDIAN if big_endian else 0)
-        if ahead:
-            ev = self._C.c_void_p(ready.cuda_event) if ready is not None else None
-            self._hip.check(self._hip.lib().ape_streams_push_rows_ahead(self._handle, k, self._C.c_void_p(rows.data_ptr()), ev,
-                                                                        self._stream()), "ape_streams_push_rows_ahead")
-            return
-        if ready is not None:
-            ready.wait(torch.cuda.current_stream(self._device))
         self._hip.check(self._hip.lib().ape_streams_push_rows(self._handle, k, self._C.c_void_p(rows.data_ptr()),
                                                               self._stream()), "ape_streams_push_rows")
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define APE_ABI_VERSION 8
+#define APE_ABI_VERSION 7
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -240,19 +240,6 @@ int ape_parse_rows(int32_t kind, const float* rows_dev, int32_t N, void* xx_dev,
  *   ape_streams_push_rows      rows_dev f32 [S,55|28] raw messages of `kind` (ape_parse_rows kinds, may carry
  *                              APE_PARSE_BIG_ENDIAN) -> features -> next slot of every stream's window ring
  *   ape_streams_push_features  xx_dev f32 [S,I]: the same for callers that build features themselves
- *   ape_streams_push_rows_ahead (ABI 8)  ape_streams_push_rows for the NEXT frame while the newest step may still be running: the
- *                              feature builder is the one launch of a frame that does not depend on the frame in front (Estimator.
- *                              parse_row_to_xx, estimator.py:174-175, against the window and the model of :93-120), so the bank issues
- *                              it on a side stream of its own, into the second of two window rings it alternates between, and
- *                              the next step waits for it.  Same values, same order of calls as ape_streams_push_rows (push, step,
- *                              push, step ...); `stream` is the stream of the bank's steps.  rows_dev must be COMPLETE when the
- *                              side stream gets to it: either it already is when the call is made (rows_ready = NULL), or
- *                              rows_ready is a hipEvent_t recorded behind the work that produces it.  It is NOT ordered behind
- *                              earlier work on `stream` -- that is the point -- and rows_dev must stay untouched until the next
- *                              step has been issued.  Deterministic banks (no ape_streams_set_mc); a Monte-Carlo bank, and any bank's
- *                              first row after a reset, take the in-order route (behind rows_ready).  An aborted step can be
- *                              re-issued by ape_model_recover until the row after the NEXT one is pushed (the alternate ring keeps
- *                              the aborted step's window).
  *   ape_streams_step           one prediction per stream from the current windows:
  *                              msg_dev  [S,25] of out_dtype, layout of compose_msg.py:72-78
  *                              tail_dev [S,smooth,6] of out_dtype or NULL: hand and elbow xyz of every smoothing row
@@ -280,7 +267,6 @@ int ape_streams_reset(ape_streams_t* bank);
 int ape_streams_set_mc(ape_streams_t* bank, int32_t n_mc, float dropout_p, uint64_t seed);
 int ape_streams_push_rows(ape_streams_t* bank, int32_t kind, const float* rows_dev, void* stream);
 int ape_streams_push_features(ape_streams_t* bank, const float* xx_dev, void* stream);
-int ape_streams_push_rows_ahead(ape_streams_t* bank, int32_t kind, const float* rows_dev, void* rows_ready, void* stream);
 int ape_streams_step(ape_streams_t* bank, uint32_t flags, void* msg_dev, void* tail_dev, int32_t out_dtype, void* stream);
 /* ONE iteration of Estimator.processing_loop (estimator.py:174-177: parse_row_to_xx -> add_xx_to_row_hist_and_make_prediction
  * -> msg_from_pred) for every stream of the bank, with HOST buffers (ABI 6): what the drop-in Estimator classes call per frame.

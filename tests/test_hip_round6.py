@@ -95,98 +95,3 @@ def test_feature_builder_over_the_azimuths(golden, tmp_path, monkeypatch, name):
         host = np.array([np.asarray(est.parse_row_to_xx(array("f", r.tolist())), dtype=np.float64) for r in rows])
     assert np.array_equal(np.isnan(xx64), np.isnan(host))
     assert np.nanmax(np.abs(xx64 - host)) < (1e-12 if name == "uarm" else 1e-6), np.nanmax(np.abs(xx64 - host))
-
-
-@pytest.mark.parametrize("name,S", [("pocket", 1024), ("pocket", 37), ("watch", 600), ("uarm", 1024), ("uarm", 9)])
-def test_rows_pushed_ahead_give_the_frames_of_rows_pushed_in_order(norm_stats, name, S):
-    """`ape_streams_push_rows_ahead` (ABI 8): the NEXT frame's feature builder on the bank's side stream, into the second of two window
-    rings, beside the step in flight.  Same calls in the same order as the in-order bank -- push, step, push, step -- so every frame's
-    datagrams must be BIT-equal to a bank fed in order, through: steady alternation, an in-order push in between (the alternate ring goes
-    stale: whole-ring copy), two pushes without a step, big-endian payloads, a reset (cold start: every slot takes the row), rows that
-    are still being produced on another stream when the call is made (`ready` event), and 60 more frames issued without a host-side
-    wait; the last frames against the oracle on sampled streams (window bookkeeping -> LSTM -> FK -> message, 5e-6).  A Monte-Carlo bank
-    takes the in-order route whatever the caller says: same samples as a bank fed in order."""
-    from tests.test_hip_parity import make_model
-    from wear_mocap_ape_amd import _hip
-    from wear_mocap_ape_amd.streams import StreamBank
-    st = norm_stats[name]
-    m, sd, cfg = make_model(name, 33, st)
-    body = orc.DEFAULT_BODY
-    m.set_body(body)
-    T, I = cfg["T"], cfg["I"]
-    kind = {"pocket": _hip.PARSE_WATCH_PHONE_POCKET, "watch": _hip.PARSE_WATCH_ONLY, "uarm": _hip.PARSE_WATCH_PHONE_UARM}[name]
-    width = _hip.PARSE_SHAPES[kind][0]
-    rng = np.random.default_rng(S + T)
-    n_frames = 100
-    rows = rng.normal(size=(n_frames, S, width)).astype(np.float32)
-    rows_dev = [torch.from_numpy(r).cuda() for r in rows]
-    rows_be = {f: torch.from_numpy(rows[f].astype(">f4").view(np.float32)).cuda() for f in (7, 8, 23)}
-    inorder, ahead = StreamBank(m, S, T, smooth=1, normalize=True), StreamBank(m, S, T, smooth=1, normalize=True)
-    side = torch.cuda.Stream()
-    outs_a, outs_b = [], []
-
-    def frame(f, how):
-        be = f in rows_be
-        r = rows_be[f] if be else rows_dev[f]
-        inorder.push_rows(r, kind, big_endian=be)
-        if how == "ahead":
-            ahead.push_rows(r, kind, big_endian=be, ahead=True)
-        elif how == "event":           # the rows arrive on another stream behind a long kernel: the event is all that orders them
-            late = torch.empty_like(rows_dev[f])
-            with torch.cuda.stream(side):
-                junk = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")
-                late.copy_(rows_dev[f] + 0.0 * junk[0, 0])
-                ev = torch.cuda.Event(); ev.record(side)
-            ahead.push_rows(late, kind, ahead=True, ready=ev)
-            frame.keep = (late, junk)
-        else:
-            ahead.push_rows(r, kind, big_endian=be)
-    for f in range(40):
-        if f == 20:
-            inorder.reset(); ahead.reset()
-        if f in (14, 15):              # two rows without a step in between (f = 14 is pushed, 15 is pushed, then one step)
-            frame(f, "ahead")
-            if f == 14:
-                continue
-        else:
-            frame(f, "inorder" if f in (0, 10, 11, 27) else "event" if f in (5, 30) else "ahead")
-        outs_a.append(inorder.step(with_tail=True)[0].cpu().numpy().copy())
-        outs_b.append(ahead.step(with_tail=True)[0].cpu().numpy().copy())
-        assert np.array_equal(outs_a[-1], outs_b[-1]), f
-    # no host-side wait between the frames: the events are all that orders the two streams
-    for f in range(40, n_frames):
-        ahead.push_rows(rows_dev[f], kind, ahead=True)
-        last = ahead.step()
-    got = last.cpu().numpy().copy()
-    for f in range(40, n_frames):
-        inorder.push_rows(rows_dev[f], kind)
-        want = inorder.step()
-    assert np.array_equal(got, want.cpu().numpy())
-    m.check()
-    # the oracle on sampled streams: the window of the last T frames
-    xx = np.stack([m_parse(kind, rows_dev[f], I) for f in range(n_frames - T, n_frames)], axis=1)      # [S,T,I]
-    sample = sorted(set([0, S - 1] + rng.integers(0, S, 12).tolist()))
-    xn = ((xx[sample].astype(np.float64) - st["xx_m"]) / st["xx_s"]).astype(np.float32)
-    pred = orc.lstm_forward(sd, xn)[:, -1].astype(np.float64) * st["yy_s"] + st["yy_m"]
-    for k, s in enumerate(sample):
-        ref = orc.msg_from_est(orc.arm_pose_from_targets(pred[k][None], body, cfg["layout"], "eigh"), body, cfg["layout"])
-        assert np.abs(got[s] - ref).max() < 5e-6, (s, np.abs(got[s] - ref).max())
-    # Monte-Carlo bank: in order whatever the caller asks for
-    if S <= 40:
-        mc_a = StreamBank(m, S, T, smooth=1, normalize=True, monte_carlo_samples=5, dropout=0.2, seed=4)
-        mc_b = StreamBank(m, S, T, smooth=1, normalize=True, monte_carlo_samples=5, dropout=0.2, seed=4)
-        for f in range(T + 2):
-            mc_a.push_rows(rows_dev[f], kind); mc_b.push_rows(rows_dev[f], kind, ahead=True)
-            assert np.array_equal(mc_a.step_datagrams().cpu().numpy(), mc_b.step_datagrams().cpu().numpy())
-        m.check()
-
-
-def m_parse(kind, rows_dev, I):
-    """features of raw rows through `ape_parse_rows` (held to the reference by the feature builder's own tests)"""
-    import ctypes as C
-    from wear_mocap_ape_amd import _hip
-    xx = torch.empty((rows_dev.shape[0], I), dtype=torch.float32, device="cuda")
-    _hip.check(_hip.lib().ape_parse_rows(kind, C.c_void_p(rows_dev.data_ptr()), rows_dev.shape[0], C.c_void_p(xx.data_ptr()), _hip.F32, None),
-               "ape_parse_rows")
-    torch.cuda.synchronize()
-    return xx.cpu().numpy()

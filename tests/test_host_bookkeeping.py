@@ -73,7 +73,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(raw, name), f"libape_hip.so does not export {name}"
     assert sorted(_hip.SIGNATURES) == declared   # the Python binding covers the same set
     lib = _hip.lib()
-    assert lib.ape_abi_version() == _hip.ABI_VERSION == 8
+    assert lib.ape_abi_version() == _hip.ABI_VERSION == 7
     assert not hasattr(raw, "ape_debug_poke"), "test hooks belong to lib/diag/libape_hip_testhooks.so only"
     assert lib.ape_device_count() >= 0
 

@@ -3,7 +3,8 @@ frame's feature builder runs on a second stream instead of in front of the regre
 race to construct): the main stream steps the bank (regressor + post-filter) on an unchanged ring, a side stream runs `ape_parse_rows` for
 1024 rows into a scratch matrix once per frame, issued right behind the step -- the upper bound of what such a pipeline can hide.
 python tests/tools/exp_r06_parse_side_stream.py [pocket|watch|uarm]
-(mode `ahead`: what was then built on it, ape_streams_push_rows_ahead)"""
+(mode `ahead`: what was then built on it, ape_streams_push_rows_ahead -- exists at commit 549884f only, measured slower and taken out:
+profiles/r06_post_in_tail.md section 3; on any other commit the mode is skipped)"""
 import ctypes as C
 import os
 import sys
@@ -62,5 +63,6 @@ def run(mode):
     return a.elapsed_time(b) / frames * 1e3
 
 
+modes = ("in_order", "no_builder", "side_stream") + (("ahead",) if hasattr(lib, "ape_streams_push_rows_ahead") else ())
 for rep in range(3):
-    print(f"{name} S={S} T={T}: " + "   ".join(f"{mode} {run(mode):.1f} us" for mode in ("in_order", "no_builder", "side_stream", "ahead")), flush=True)
+    print(f"{name} S={S} T={T}: " + "   ".join(f"{mode} {run(mode):.1f} us" for mode in modes), flush=True)
