@@ -95,3 +95,30 @@ def test_feature_builder_over_the_azimuths(golden, tmp_path, monkeypatch, name):
         host = np.array([np.asarray(est.parse_row_to_xx(array("f", r.tolist())), dtype=np.float64) for r in rows])
     assert np.array_equal(np.isnan(xx64), np.isnan(host))
     assert np.nanmax(np.abs(xx64 - host)) < (1e-12 if name == "uarm" else 1e-6), np.nanmax(np.abs(xx64 - host))
+
+
+@pytest.mark.parametrize("name", ["pocket", "watch", "uarm"])
+def test_feature_builder_on_random_messages(tmp_path, monkeypatch, name):
+    """20 000 random messages per estimator (every column standard normal: un-normalised rotation and calibration quaternions, azimuths all
+    round the circle, both branches of the half-angle pair) through `ape_parse_rows` in float64 against the host builder (the reference's
+    formulas in float64, itself held to the reference's outputs on `feature_edges.npz` and the recorded traces): 1e-12 for the upper-arm
+    estimator, whose host builder returns float64; 2e-6 for the two whose builders return float32 like the reference's."""
+    from array import array
+    from tests.test_hip_parity import _deploy_dir
+    from wear_mocap_ape_amd import config, _hip
+    from wear_mocap_ape_amd.estimate.watch_only import WatchOnlyNN
+    from wear_mocap_ape_amd.estimate.watch_phone_pocket_nn import WatchPhonePocketNN
+    from wear_mocap_ape_amd.estimate.watch_phone_uarm_nn import WatchPhoneUarmNN
+    deploy, h = _deploy_dir(tmp_path, name, 3, dropout=0.0)
+    monkeypatch.setitem(config.PATHS, "deploy", deploy)
+    est = {"pocket": WatchPhonePocketNN, "watch": WatchOnlyNN, "uarm": WatchPhoneUarmNN}[name](model_hash=h)
+    kind = {"pocket": _hip.PARSE_WATCH_PHONE_POCKET, "watch": _hip.PARSE_WATCH_ONLY, "uarm": _hip.PARSE_WATCH_PHONE_UARM}[name]
+    rng = np.random.default_rng(77)
+    rows = rng.normal(size=(20000, _hip.PARSE_SHAPES[kind][0])).astype(np.float32)
+    rows[::7] *= rng.uniform(1e-3, 1e3, size=(len(rows[::7]), 1)).astype(np.float32)
+    xx64 = est.parse_rows(rows, out_dtype=torch.float64).cpu().numpy()
+    host = np.array([np.asarray(est.parse_row_to_xx(array("f", r.tolist())), dtype=np.float64) for r in rows])
+    assert np.isfinite(xx64).all() and np.isfinite(host).all()
+    # (sensor columns are copied: exact; the 6D rotation and the yaw features are the arithmetic under test)
+    err = np.abs(xx64 - host) / np.maximum(1.0, np.abs(host))
+    assert err.max() < (1e-12 if name == "uarm" else 2e-6), (err.max(), np.unravel_index(err.argmax(), err.shape))
