@@ -122,3 +122,22 @@ def test_feature_builder_on_random_messages(tmp_path, monkeypatch, name):
     # (sensor columns are copied: exact; the 6D rotation and the yaw features are the arithmetic under test)
     err = np.abs(xx64 - host) / np.maximum(1.0, np.abs(host))
     assert err.max() < (1e-12 if name == "uarm" else 2e-6), (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("layout,O", [(0, 14), (2, 20)])
+def test_post_filter_on_random_targets_all_round_the_hips_circle(layout, O):
+    """`ape_fk` on 100 000 random prediction rows per hips-carrying target layout against the oracle (float64, 1e-11): the hips quaternion comes
+    from half-angle identities since round 6 (csrc/angle_device.h) and the goldens hold a few hundred rows; the (sin, cos) pairs here cover the
+    circle, tiny and large magnitudes included."""
+    from wear_mocap_ape_amd.estimate import _post
+    rng = np.random.default_rng(layout + 5)
+    N = 100000
+    preds = rng.normal(size=(N, O))
+    preds[::11, -2:] *= rng.uniform(1e-6, 1e6, size=(len(preds[::11]), 1))
+    preds[::13, -1] = -np.abs(preds[::13, -1])                 # cos < 0: the other branch of the half-angle pair
+    preds[::17, -2] *= 1e-9                                    # azimuths next to 0 and to +-pi
+    ctx = _post.context(layout)
+    est = _post.fk_rows(ctx.handle, layout, ctx.device, preds, orc.DEFAULT_BODY)
+    ref = orc.arm_pose_from_targets(preds, orc.DEFAULT_BODY, layout, "closed")
+    assert est.shape == ref.shape and np.isfinite(est).all()
+    assert np.abs(est - ref).max() < 1e-11, np.abs(est - ref).max()
