@@ -108,9 +108,6 @@ __device__ __forceinline__ void span(f32x4 (&acc)[NTW], const f32x4 (&a)[NQ], co
 // math, 2: behind layer 0's MFMAs, 3: between layer 1's two spans -- the default since round 5: the look now lands in LDS and is read back
 // from there, one LDS hop more than the register destination it had; swept under the write-through hand-over at 1024 x 64:
 // 0 241.3 us, 1 243.3, 2 288.0, 3 235.1; flag raise behind layer 0's MFMAs instead of behind the barrier 255.7)
-#ifndef F16_RAISE_AT
-#define F16_RAISE_AT 0
-#endif
 #ifndef F16_LOOK_AT
 #define F16_LOOK_AT 3
 #endif
@@ -456,9 +453,9 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
         // barrier, so that the peers' look at these words (after THEIR layer-1 MFMAs) finds it.  Measured on configs[4]:
         // here 244 us; after the layer-0 MFMAs (the store certainly drained, nothing waits) 252 us; after layer 0's gate
         // math 292 us -- the later the flag, the more gathers miss their prefetch and fall back to the blocking form
-        if (F16_RAISE_AT == 0) {
-            if (!d_noex) raise_member();
-        }
+        // (the sweep switch for the second position is gone: round 6's counted wait in front of the slab staging assumes THIS order of the
+        //  wave's vector-memory operations -- with the raise behind layer 0's MFMAs the re-sweep read 228 us and wrong values)
+        if (!d_noex) raise_member();
         const int abort_word = ctl[0];                            // read with the fragments, looked at before the publish
         // this section's activation fragments (both layers read the LDS state of the set's last phase only): layer 0's
         // now, layer 1's once layer 0's registers are free -- they land under the gate math of layer 0
@@ -499,10 +496,6 @@ __global__ __launch_bounds__(256, (UPW == 4 ? 2 : 1)) void ape_lstm_cluster_f16v
                 mfma_drain<NTW>(acc);
             }
             V2_STAMP(4);                                          // 4: MFMA spans (incl. the wait for the LDS reads feeding them)
-            if (l == 0 && F16_RAISE_AT == 1) {                    // (sweep position: the flag owed goes up behind layer 0's MFMAs)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!d_noex) raise_pending();
-            }
             if (l == 0 && F16_LOOK_AT == 2) {
                 look_issue(look_lds, look_voff, fl_desc, fl_off + (unsigned)(sn * NFL * sizeof(unsigned)));
                 peeked = true;
