@@ -525,15 +525,26 @@ def dispatch_boundaries(n_iter=30):
     lib = _hip.lib()
     out = {}
 
-    def timed(fn):
-        for _ in range(5):
-            fn()
-        us = []
-        for _ in range(n_iter):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); fn(); b.record(); b.synchronize()
-            us.append(a.elapsed_time(b) * 1e3)
-        return float(np.median(us))
+    def timed_together(cands):
+        """cands: [(tag, fn)] -> {tag: median us}.  The candidates of a case take turns, launch by launch (HIP events, host-synchronised), behind
+        un-timed rounds that last until the part's clocks have settled: timed one after the other, the candidate that went first behind the
+        set-up read up to 4 % slower than the SAME kernel timed second (round 6)."""
+        for _ in range(3):
+            for _, fn in cands:
+                fn()
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.03:
+            for _, fn in cands:
+                fn()
+            torch.cuda.synchronize()
+        us = {tag: [] for tag, _ in cands}
+        for it in range(n_iter):
+            # (the order rotates: a launch behind the batch-tile candidate, which streams the weights through every L2, starts ~2 us colder)
+            for tag, fn in cands[it % len(cands):] + cands[:it % len(cands)]:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); fn(); b.record(); b.synchronize()
+                us[tag].append(a.elapsed_time(b) * 1e3)
+        return {tag: float(np.median(v)) for tag, v in us.items()}
 
     try:
         models = {"pocket": _bank_model(POCKET, (NNS_INPUTS.WATCH_PHONE_CAL_HIP, NNS_TARGETS.ORI_CAL_LARM_UARM_HIPS)),
@@ -547,14 +558,18 @@ def dispatch_boundaries(n_iter=30):
             y = torch.empty((B, cfg["O"]), dtype=torch.float32, device="cuda")
             flags = (_hip.FLAG_DROPOUT_PHILOX if drop else 0) | (_hip.FLAG_BROADCAST_X if bcast else 0)
             ent = {"candidates_us": {}, "kernels": {}}
+            cands = []
             for k in kernels:
                 kk, fl = (k, flags) if isinstance(k, str) else (k[0], flags | k[1])
-                m.set_kernel(kk)
-                call = lambda: _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, fl, None, 0.2 if drop else 0.0, 7,
-                                                               C.c_void_p(y.data_ptr()), None), "fwd")
                 tag = kk if isinstance(k, str) else f"{kk}+0x{k[1]:x}"
-                ent["candidates_us"][tag] = timed(call)
-                ent["kernels"][tag] = m.last_kernel()
+
+                def call(kk=kk, fl=fl, tag=tag):
+                    m.set_kernel(kk)                    # (a host-side switch on the handle)
+                    _hip.check(lib.ape_lstm_forward(m.handle, C.c_void_p(x.data_ptr()), B, T, fl, None, 0.2 if drop else 0.0, 7,
+                                                    C.c_void_p(y.data_ptr()), None), "fwd")
+                    ent["kernels"][tag] = m.last_kernel()
+                cands.append((tag, call))
+            ent["candidates_us"] = timed_together(cands)
             m.set_kernel("auto")
             m.check()
             ent["auto_over_best"] = ent["candidates_us"]["auto"] / min(ent["candidates_us"].values())
@@ -587,19 +602,22 @@ def dispatch_boundaries(n_iter=30):
             ent = {"candidates_us": {}, "kernels": {}}
             m = models["pocket"]
             rows = [torch.from_numpy(rng.normal(size=(S, 55)).astype(np.float32)).cuda() for _ in range(4)]
+            cands, banks = [], []
             for k in ("auto", "auto_gen1"):
-                m.set_kernel(k)
+                m.set_kernel(k)                         # (a bank plans its route when it is put into Monte-Carlo mode, and steps under the same switch)
                 bank = StreamBank(m, S, 6, smooth=1, normalize=True, dtype=torch.float32, monte_carlo_samples=n_mc, dropout=0.2)
-                st = {"i": 0}
+                banks.append(bank)
 
-                def frame():
+                def frame(k=k, bank=bank, st={"i": 0}):
+                    m.set_kernel(k)
                     bank.push_rows(rows[st["i"] % 4], _hip.PARSE_WATCH_PHONE_POCKET)
                     bank.step_datagrams()
                     st["i"] += 1
-                ent["candidates_us"][k] = timed(frame)
-                ent["kernels"][k] = m.last_kernel()
-                m.check()
-                del bank
+                    ent["kernels"][k] = m.last_kernel()
+                cands.append((k, frame))
+            ent["candidates_us"] = timed_together(cands)
+            m.check()
+            del banks, cands
             m.set_kernel("auto")
             ent["auto_over_best"] = ent["candidates_us"]["auto"] / min(ent["candidates_us"].values())
             out[f"pocket_mc_bank_{S * n_mc}_sample_rows_T6"] = ent
